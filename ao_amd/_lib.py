@@ -1,0 +1,100 @@
+"""ctypes binding of ao_amd/lib/libptv2_hip.so (C ABI: include/ptv2_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing, fails to load,
+or a launcher returns a non-zero status, a RuntimeError is raised.  Nothing in
+this package computes on the CPU or through the oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptv2_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c_int, _c_size, _vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); pointers are passed as integers (tensor.data_ptr())
+_SIGNATURES = {
+    "ptv2_abi_version": (_c_int, []),
+    "ptv2_build_info": (ctypes.c_char_p, []),
+    "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),
+    "knn_query_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _vp]),
+    "farthest_point_sampling_hip_workspace_bytes": (_c_size, [_c_int] * 2),
+    "farthest_point_sampling_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_size, _vp]),
+    "grouping_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
+    "grouping_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
+    "interpolation_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
+    "interpolation_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
+    "subtraction_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
+    "subtraction_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
+    "aggregation_forward_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 6),
+    "aggregation_backward_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 9),
+    "attention_relation_step_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 7),
+    "attention_relation_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 10),
+    "attention_fusion_step_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),
+    "attention_fusion_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 9),
+}
+
+_ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace too small)",
+        3: "PTV2_ERR_LAUNCH (HIP launch failed)"}
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every .hip under ao_amd/csrc for gfx950 into ao_amd/lib/libptv2_hip.so (make + hipcc)."""
+    cmd = ["make", "-C", CSRC, "-j4", "all"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def register(signatures):
+    """Let other csrc units (gva, gridpool, ...) add their entry points to the binding table."""
+    _SIGNATURES.update(signatures)
+    if _lib is not None:
+        _bind(_lib, signatures)
+
+
+def _bind(lib, signatures):
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "ao_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ao_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        _bind(handle, _SIGNATURES)
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError("ao_amd: %s failed with status %d: %s" % (what, status, _ERR.get(status, "?")))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ao_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback" % t.device)
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,58 @@
+// ao_amd/csrc/common.h -- shared device/host helpers for libptv2_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptv2_hip.h"
+
+#define WAVE 64
+
+#define PTV2_CHECK_LAUNCH()                         \
+    do {                                            \
+        if (hipGetLastError() != hipSuccess) return PTV2_ERR_LAUNCH; \
+    } while (0)
+
+static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):
+// fma(dz,dz, fma(dx,dx, dy*dy)), q - p per component.  The only add that could be
+// contracted is already inside an explicit fma, so -ffp-contract cannot change it.
+__device__ __forceinline__ float ref_d2(float qx, float qy, float qz, float x, float y, float z) {
+    float dx = qx - x, dy = qy - y, dz = qz - z;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// First segment i with pt < offset[i] (the reference's get_bt_idx,
+// knn_query_cuda_kernel.cu:45-56), as a binary search; clamps to b-1.
+__device__ __forceinline__ int seg_of(int pt, const int *__restrict__ offset, int b) {
+    int lo = 0, hi = b - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (pt < offset[mid]) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Order-preserving float <-> int encoding for atomicMin/atomicMax on floats.
+__device__ __forceinline__ int f2ord(float f) {
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) {
+    return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m, WAVE);
+    hi = __shfl_xor(hi, m, WAVE);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Bijective XCD-aware remap of a 1-D block index (guide T1): blocks that share
+// `orig % 8` share an XCD (and its L2); give each such group a contiguous range
+// of logical tiles.  Speed only -- never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = orig & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (orig >> 3);
+}

@@ -1,0 +1,519 @@
+// ao_amd/csrc/knn.hip -- exact batched k-NN for gfx950 (MI355X).
+//
+// Replaces the reference's brute-force one-thread-per-query kernel
+// (libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104) with
+//
+//   1. a per-call uniform grid over each batch segment of xyz (counting sort by cell:
+//      bbox -> grid setup -> count+rank -> 2-launch exclusive scan -> scatter),
+//      everything on device, no host sync;
+//   2. a grid query: one lane per query, neighbour cells visited in Chebyshev rings,
+//      candidates read as float4 (x,y,z,id) from the cell-sorted copy, the KC = k+1
+//      best kept sorted in registers; a ring search stops when the KC-th best squared
+//      distance is provably smaller than anything outside the rings visited;
+//   3. tie detection: the reference result is "the k smallest, ascending" whenever the
+//      k+1 smallest squared distances of a query are pairwise distinct (SURVEY.md 8a,
+//      tests/test_oracle_ops.py::test_knn_tie_rule_is_sufficient).  Queries that fail that
+//      test are appended to a list and
+//   4. re-run by an exact emulation of the reference's max-heap (reheap :15-30,
+//      heap_sort :33-42, ascending index scan with strict `d2 < heap max` :88-97): one
+//      wavefront per query, 64 candidates per step filtered with a ballot against the
+//      current heap root, survivors pushed in index order.  Bit-identical by construction.
+//
+// Squared distances use the pinned rounding sequence ref_d2() (common.h).
+#include "common.h"
+
+namespace {
+
+struct SegGrid {
+    float minx, miny, minz, h, inv_h;
+    int gx, gy, gz, cell_base, n_pts, start;
+    int pad;
+};
+
+struct Workspace {
+    int *tie_count;      // [1]
+    int *bbox_lo;        // [3b] ordered-int encoded
+    int *bbox_hi;        // [3b]
+    SegGrid *seg;        // [b]
+    int *block_sums;     // [scan blocks]
+    int *cell_count;     // [ncell]
+    int *cell_start;     // [ncell + 1]
+    int *point_cell;     // [n]
+    int *point_rank;     // [n]
+    float4 *sorted;      // [n]
+    int *tie_list;       // [m]
+    size_t bytes;
+};
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+Workspace carve(void *base, int m, int n, int b) {
+    Workspace w;
+    size_t ncell = (size_t)n + b + 1;
+    size_t ncell_pad = (size_t)divup(ncell + 1, SCAN_TILE) * SCAN_TILE;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return r; };
+    w.tie_count = (int *)take(sizeof(int) * 4);
+    w.bbox_lo = (int *)take(sizeof(int) * 3 * b);
+    w.bbox_hi = (int *)take(sizeof(int) * 3 * b);
+    w.seg = (SegGrid *)take(sizeof(SegGrid) * b);
+    w.block_sums = (int *)take(sizeof(int) * (ncell_pad / SCAN_TILE + 1));
+    w.cell_count = (int *)take(sizeof(int) * ncell_pad);
+    w.cell_start = (int *)take(sizeof(int) * (ncell_pad + 1));
+    w.point_cell = (int *)take(sizeof(int) * n);
+    w.point_rank = (int *)take(sizeof(int) * n);
+    w.sorted = (float4 *)take(sizeof(float4) * n);
+    w.tie_list = (int *)take(sizeof(int) * (m > 0 ? m : 1));
+    w.bytes = off;
+    return w;
+}
+
+// ---------------------------------------------------------------- grid build --
+__global__ void knn_init_kernel(int *tie_count, int *bbox_lo, int *bbox_hi, int b, int *cell_count,
+                                int ncell_pad) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *tie_count = 0;
+    if (t < 3 * b) {
+        bbox_lo[t] = 0x7fffffff;
+        bbox_hi[t] = (int)0x80000000;
+    }
+    for (int i = t; i < ncell_pad; i += gridDim.x * blockDim.x) cell_count[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void knn_bbox_kernel(int n, const float *__restrict__ xyz,
+                                                       const int *__restrict__ offset, int b,
+                                                       int *bbox_lo, int *bbox_hi) {
+    __shared__ int s_lo[3], s_hi[3];
+    int t = blockIdx.x * 256 + threadIdx.x;
+    int first = blockIdx.x * 256, last = min(first + 255, n - 1);
+    int seg_first = seg_of(first, offset, b), seg_last = seg_of(last, offset, b);
+    bool valid = t < n;
+    float x = 0, y = 0, z = 0;
+    if (valid) {
+        x = xyz[3 * t];
+        y = xyz[3 * t + 1];
+        z = xyz[3 * t + 2];
+    }
+    if (seg_first == seg_last) {  // block lies in one segment: LDS reduce, 6 atomics per block
+        if (threadIdx.x < 3) {
+            s_lo[threadIdx.x] = 0x7fffffff;
+            s_hi[threadIdx.x] = (int)0x80000000;
+        }
+        __syncthreads();
+        float v[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int lo = valid ? f2ord(v[a]) : 0x7fffffff, hi = valid ? f2ord(v[a]) : (int)0x80000000;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                lo = min(lo, __shfl_xor(lo, o, WAVE));
+                hi = max(hi, __shfl_xor(hi, o, WAVE));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMin(&s_lo[a], lo);
+                atomicMax(&s_hi[a], hi);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            atomicMin(&bbox_lo[seg_first * 3 + threadIdx.x], s_lo[threadIdx.x]);
+            atomicMax(&bbox_hi[seg_first * 3 + threadIdx.x], s_hi[threadIdx.x]);
+        }
+    } else if (valid) {  // block straddles a segment boundary (at most b-1 such blocks)
+        int s = seg_of(t, offset, b);
+        atomicMin(&bbox_lo[s * 3 + 0], f2ord(x));
+        atomicMax(&bbox_hi[s * 3 + 0], f2ord(x));
+        atomicMin(&bbox_lo[s * 3 + 1], f2ord(y));
+        atomicMax(&bbox_hi[s * 3 + 1], f2ord(y));
+        atomicMin(&bbox_lo[s * 3 + 2], f2ord(z));
+        atomicMax(&bbox_hi[s * 3 + 2], f2ord(z));
+    }
+}
+
+// One thread per segment: choose the cell size so that cells <= points (then the cell tables
+// of all segments fit n + b + 1 entries and segment s owns [start_s + s, ...)).
+__global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, const int *bbox_lo,
+                                      const int *bbox_hi, SegGrid *seg, float occupancy) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b) return;
+    int start = s == 0 ? 0 : offset[s - 1];
+    int cnt = offset[s] - start;
+    SegGrid g;
+    g.start = start;
+    g.n_pts = cnt > 0 ? cnt : 0;
+    g.cell_base = start + s;
+    g.gx = g.gy = g.gz = 1;
+    g.minx = g.miny = g.minz = 0.f;
+    g.h = 1.f;
+    g.inv_h = 1.f;
+    g.pad = 0;
+    if (cnt > 0) {
+        float lo[3], ext[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = ord2f(bbox_lo[s * 3 + a]);
+            ext[a] = fmaxf(ord2f(bbox_hi[s * 3 + a]) - lo[a], 0.f);
+        }
+        float emax = fmaxf(fmaxf(ext[0], ext[1]), fmaxf(ext[2], 1e-12f));
+        // volume with degenerate axes floored at 1/64 of the largest extent (planar / linear clouds)
+        float vol = 1.f;
+        for (int a = 0; a < 3; ++a) vol *= fmaxf(ext[a], emax * (1.f / 64.f));
+        float h = cbrtf(vol * occupancy / (float)cnt);
+        h = fmaxf(h, emax * (1.f / 1000.f));
+        int gx, gy, gz;
+        for (int it = 0; it < 200; ++it) {
+            gx = (int)fminf(floorf(ext[0] / h) + 1.f, 1024.f);
+            gy = (int)fminf(floorf(ext[1] / h) + 1.f, 1024.f);
+            gz = (int)fminf(floorf(ext[2] / h) + 1.f, 1024.f);
+            if ((long long)gx * gy * gz <= (long long)cnt) break;
+            h *= 1.08f;
+        }
+        if ((long long)gx * gy * gz > (long long)cnt) { gx = gy = gz = 1; h = emax * 2.f + 1.f; }
+        g.gx = gx; g.gy = gy; g.gz = gz;
+        g.h = h;
+        g.inv_h = 1.f / h;
+        g.minx = lo[0]; g.miny = lo[1]; g.minz = lo[2];
+    }
+    seg[s] = g;
+}
+
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h, int g) {
+    float c = floorf((v - lo) * inv_h);
+    c = fminf(fmaxf(c, 0.f), (float)(g - 1));
+    return (int)c;
+}
+
+__global__ __launch_bounds__(256) void knn_cell_count_kernel(int n, const float *__restrict__ xyz,
+                                                             const int *__restrict__ offset, int b,
+                                                             const SegGrid *__restrict__ seg,
+                                                             int *cell_count, int *point_cell,
+                                                             int *point_rank) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int s = seg_of(t, offset, b);
+    SegGrid g = seg[s];
+    int cx = cell_coord(xyz[3 * t], g.minx, g.inv_h, g.gx);
+    int cy = cell_coord(xyz[3 * t + 1], g.miny, g.inv_h, g.gy);
+    int cz = cell_coord(xyz[3 * t + 2], g.minz, g.inv_h, g.gz);
+    int cell = g.cell_base + (cz * g.gy + cy) * g.gx + cx;
+    point_cell[t] = cell;
+    point_rank[t] = atomicAdd(&cell_count[cell], 1);
+}
+
+// exclusive scan over ncell_pad ints, phase 1: per-tile sums
+__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_reduce_kernel(const int *__restrict__ in,
+                                                                       int *block_sums) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    const int4 *p = (const int4 *)(in + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
+    int4 a = p[0], c = p[1];
+    int v = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < SCAN_THREADS / WAVE; ++i) t += s_w[i];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// phase 2: every tile re-derives its base from the tile sums before it, then scans itself
+__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_apply_kernel(const int *__restrict__ in,
+                                                                      const int *__restrict__ block_sums,
+                                                                      int *out, int ntiles) {
+    __shared__ int s_w[SCAN_THREADS / WAVE];
+    __shared__ int s_base;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) part += block_sums[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, WAVE);
+    if (lane == 0) s_w[wid] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < SCAN_THREADS / WAVE; ++i) t += s_w[i];
+        s_base = t;
+    }
+    __syncthreads();
+    int base = s_base;
+    __syncthreads();
+    const int4 *p = (const int4 *)(in + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
+    int4 a = p[0], c = p[1];
+    int v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { int x = v[i]; v[i] = tot; tot += x; }
+    int inc = tot;  // inclusive wave scan of per-thread totals
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        int y = __shfl_up(inc, o, WAVE);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) s_w[wid] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int i = 0; i < wid; ++i) wbase += s_w[i];
+    int tbase = base + wbase + inc - tot;
+    int4 *q = (int4 *)(out + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
+    q[0] = make_int4(tbase + v[0], tbase + v[1], tbase + v[2], tbase + v[3]);
+    q[1] = make_int4(tbase + v[4], tbase + v[5], tbase + v[6], tbase + v[7]);
+    if (blockIdx.x == ntiles - 1 && threadIdx.x == SCAN_THREADS - 1)
+        out[(size_t)ntiles * SCAN_TILE] = tbase + tot;
+}
+
+__global__ __launch_bounds__(256) void knn_scatter_kernel(int n, const float *__restrict__ xyz,
+                                                          const int *__restrict__ cell_start,
+                                                          const int *__restrict__ point_cell,
+                                                          const int *__restrict__ point_rank,
+                                                          float4 *sorted) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    int pos = cell_start[point_cell[t]] + point_rank[t];
+    sorted[pos] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], __int_as_float(t));
+}
+
+// ---------------------------------------------------------------- grid query --
+template <int KC>
+__device__ __forceinline__ void topk_insert(float (&bd)[KC], int (&bi)[KC], float d2, int id) {
+    // sorted ascending; new element goes after all entries <= d2 (stable)
+#pragma unroll
+    for (int j = KC - 1; j > 0; --j) {
+        bool shift = d2 < bd[j - 1];
+        bool here = !shift && d2 < bd[j];
+        float nd = shift ? bd[j - 1] : (here ? d2 : bd[j]);
+        int ni = shift ? bi[j - 1] : (here ? id : bi[j]);
+        bd[j] = nd;
+        bi[j] = ni;
+    }
+    if (d2 < bd[0]) { bd[0] = d2; bi[0] = id; }
+}
+
+template <int KC>
+__device__ __forceinline__ void scan_range(const float4 *__restrict__ sorted, int p0, int p1, float qx,
+                                           float qy, float qz, float (&bd)[KC], int (&bi)[KC]) {
+    for (int p = p0; p < p1; ++p) {
+        float4 c = sorted[p];
+        float d2 = ref_d2(qx, qy, qz, c.x, c.y, c.z);
+        if (d2 < bd[KC - 1]) topk_insert<KC>(bd, bi, d2, __float_as_int(c.w));
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void knn_grid_query_kernel(
+    int m, int k, const float4 *__restrict__ sorted, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int b,
+    const SegGrid *__restrict__ seg, const int *__restrict__ cell_start, int *__restrict__ idx,
+    float *__restrict__ dist2, int pad_with_start, int self_mode, int *tie_count, int *tie_list) {
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= m) return;
+    int qid, s;
+    float qx, qy, qz;
+    if (self_mode) {  // queries visited in cell order: neighbouring lanes share candidate cells
+        float4 p = sorted[t];
+        qx = p.x; qy = p.y; qz = p.z;
+        qid = __float_as_int(p.w);
+        s = seg_of(qid, offset, b);
+    } else {
+        qid = t;
+        qx = new_xyz[3 * t]; qy = new_xyz[3 * t + 1]; qz = new_xyz[3 * t + 2];
+        s = seg_of(t, new_offset, b);
+    }
+    const SegGrid g = seg[s];
+    float bd[KC];
+    int bi[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) { bd[j] = 1e10f; bi[j] = -1; }
+
+    if (g.n_pts > 0) {
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
+        const int cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
+        const int cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+        const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+        for (int R = 1;; ++R) {
+            const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
+            const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
+            const int xa = max(cx - R, 0), xb = min(cx + R, g.gx - 1);
+            for (int z = z0; z <= z1; ++z) {
+                for (int y = y0; y <= y1; ++y) {
+                    const int row = g.cell_base + (z * g.gy + y) * g.gx;
+                    const bool full = (R == 1) || (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
+                    if (full) {
+                        scan_range<KC>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, bd, bi);
+                    } else {
+                        if (cx - R >= 0)
+                            scan_range<KC>(sorted, cell_start[row + cx - R], cell_start[row + cx - R + 1], qx, qy, qz, bd, bi);
+                        if (cx + R <= g.gx - 1)
+                            scan_range<KC>(sorted, cell_start[row + cx + R], cell_start[row + cx + R + 1], qx, qy, qz, bd, bi);
+                    }
+                }
+            }
+            if (R >= rmax) break;  // whole segment scanned
+            // every unvisited point is farther than (R - eps) cells along some axis; eps covers the
+            // fp32 rounding of cell_coord() (|error| << 0.01 cell for grids <= 1024 per axis)
+            const float lim = ((float)R - 0.01f) * g.h;
+            if (bd[KC - 1] < lim * lim) break;
+        }
+    }
+
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j + 1 < KC; ++j)
+        if (j < k && bd[j] == bd[j + 1] && bd[j + 1] < 1e10f) tie = true;
+    if (tie) tie_list[atomicAdd(tie_count, 1)] = qid;
+
+    const int pad = pad_with_start ? g.start : -1;
+    int *orow = idx + (size_t)qid * k;
+    float *drow = dist2 + (size_t)qid * k;
+    if (k == KC - 1 && (KC - 1) % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < KC - 1; j += 4) {
+            int4 iv = make_int4(bd[j] < 1e10f ? bi[j] : pad, bd[j + 1] < 1e10f ? bi[j + 1] : pad,
+                                bd[j + 2] < 1e10f ? bi[j + 2] : pad, bd[j + 3] < 1e10f ? bi[j + 3] : pad);
+            *(int4 *)(orow + j) = iv;
+            *(float4 *)(drow + j) = make_float4(bd[j], bd[j + 1], bd[j + 2], bd[j + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KC - 1; ++j)
+            if (j < k) {
+                orow[j] = bd[j] < 1e10f ? bi[j] : pad;
+                drow[j] = bd[j];
+            }
+    }
+}
+
+// ------------------------------------------------- exact reference emulation --
+// One wavefront per listed query.  The heap lives in LDS; every lane executes the same
+// (wave-uniform) heap code, so LDS accesses are broadcasts and no lane diverges.
+constexpr int EX_WAVES = 4;
+
+__device__ __forceinline__ void ex_reheap(volatile float *hd, volatile int *hi, int k) {
+    int root = 0, child = 1;
+    while (child < k) {
+        if (child + 1 < k && hd[child + 1] > hd[child]) child++;
+        if (hd[root] > hd[child]) return;
+        float td = hd[root]; hd[root] = hd[child]; hd[child] = td;
+        int ti = hi[root]; hi[root] = hi[child]; hi[child] = ti;
+        root = child;
+        child = root * 2 + 1;
+    }
+}
+
+__global__ __launch_bounds__(EX_WAVES *WAVE) void knn_exact_kernel(
+    int m, int k, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int b, int *__restrict__ idx,
+    float *__restrict__ dist2, int pad_with_start, const int *__restrict__ tie_count,
+    const int *__restrict__ tie_list, int all_queries) {
+    __shared__ float s_d[EX_WAVES][128];
+    __shared__ int s_i[EX_WAVES][128];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    volatile float *hd = s_d[wid];
+    volatile int *hi = s_i[wid];
+    const int total = all_queries ? m : *tie_count;
+    const int nwaves = gridDim.x * EX_WAVES;
+    for (int w = blockIdx.x * EX_WAVES + wid; w < total; w += nwaves) {
+        const int q = all_queries ? w : tie_list[w];
+        const int s = seg_of(q, new_offset, b);
+        const int start = s == 0 ? 0 : offset[s - 1];
+        const int end = offset[s];
+        const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+        for (int j = lane; j < k; j += WAVE) {
+            hd[j] = 1e10f;
+            hi[j] = pad_with_start ? start : -1;
+        }
+        for (int base = start; base < end; base += WAVE) {
+            const int i = base + lane;
+            float d2 = 3.0e38f;
+            if (i < end) d2 = ref_d2(qx, qy, qz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+            unsigned long long mask = __ballot(d2 < hd[0]);  // root only ever decreases: safe prefilter
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float cd = __shfl(d2, l, WAVE);
+                if (cd < hd[0]) {  // knn_query_cuda_kernel.cu:93-97
+                    hd[0] = cd;
+                    hi[0] = base + l;
+                    ex_reheap(hd, hi, k);
+                }
+            }
+        }
+        for (int i = k - 1; i > 0; --i) {  // heap_sort (:33-42)
+            float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
+            int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+            ex_reheap(hd, hi, i);
+        }
+        for (int j = lane; j < k; j += WAVE) {
+            idx[(size_t)q * k + j] = hi[j];
+            dist2[(size_t)q * k + j] = hd[j];
+        }
+    }
+}
+
+template <int KC>
+void launch_query(hipStream_t st, int m, int k, const Workspace &w, const float *new_xyz,
+                  const int *offset, const int *new_offset, int b, int *idx, float *dist2,
+                  int pad_with_start, int self_mode) {
+    hipLaunchKernelGGL(knn_grid_query_kernel<KC>, dim3(divup(m, 256)), dim3(256), 0, st, m, k, w.sorted,
+                       new_xyz, offset, new_offset, b, w.seg, w.cell_start, idx, dist2, pad_with_start,
+                       self_mode, w.tie_count, w.tie_list);
+}
+
+}  // namespace
+
+extern "C" size_t knn_query_hip_workspace_bytes(int m, int n, int b) {
+    if (m < 0 || n < 0 || b < 1) return 0;
+    return carve(nullptr, m, n, b).bytes;
+}
+
+extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                                      const int *offset, const int *new_offset, int *idx, float *dist2,
+                                      int n, int b, int pad_with_start, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    if (nsample < 1 || nsample > 128 || m < 0 || n < 0 || b < 1) return PTV2_ERR_ARG;
+    if (m == 0) return PTV2_OK;
+    if (!xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PTV2_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int k = nsample;
+    if (k > 32 || n == 0) {  // large k: exact emulation for every query (heap does not fit registers)
+        hipLaunchKernelGGL(knn_exact_kernel, dim3(min(divup(m, EX_WAVES), 4096)), dim3(EX_WAVES * WAVE), 0, st, m,
+                           k, xyz, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, (const int *)nullptr,
+                           (const int *)nullptr, 1);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
+    Workspace w = carve(workspace, m, n, b);
+    if (!workspace || workspace_bytes < w.bytes) return PTV2_ERR_WORKSPACE;
+    const int ncell = n + b + 1;
+    const int ntiles = divup(ncell + 1, SCAN_TILE);
+    const int ncell_pad = ntiles * SCAN_TILE;
+    const int self_mode = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
+
+    hipLaunchKernelGGL(knn_init_kernel, dim3(min(divup(ncell_pad, 256), 1024)), dim3(256), 0, st, w.tie_count,
+                       w.bbox_lo, w.bbox_hi, b, w.cell_count, ncell_pad);
+    hipLaunchKernelGGL(knn_bbox_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.bbox_lo,
+                       w.bbox_hi);
+    hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(divup(b, 64)), dim3(64), 0, st, b, offset, w.bbox_lo, w.bbox_hi,
+                       w.seg, 2.0f);
+    hipLaunchKernelGGL(knn_cell_count_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.seg,
+                       w.cell_count, w.point_cell, w.point_rank);
+    hipLaunchKernelGGL(knn_scan_reduce_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, w.cell_count, w.block_sums);
+    hipLaunchKernelGGL(knn_scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, w.cell_count, w.block_sums,
+                       w.cell_start, ntiles);
+    hipLaunchKernelGGL(knn_scatter_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, w.cell_start, w.point_cell,
+                       w.point_rank, w.sorted);
+    if (k <= 1) launch_query<2>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    else if (k <= 3) launch_query<4>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    else if (k <= 8) launch_query<9>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    else if (k <= 16) launch_query<17>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    else launch_query<33>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    hipLaunchKernelGGL(knn_exact_kernel, dim3(512), dim3(EX_WAVES * WAVE), 0, st, m, k, xyz, new_xyz, offset,
+                       new_offset, b, idx, dist2, pad_with_start, (const int *)w.tie_count, (const int *)w.tie_list, 0);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -1,0 +1,62 @@
+"""Inverse-distance interpolation.  Mirrors libs/pointops/functions/interpolation.py:8-59."""
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+from .query import knn_query
+
+
+def interpolation_index_weight(xyz, new_xyz, offset, new_offset, k=3):
+    """k-NN of every new_xyz row among xyz + normalised inverse-distance weights (:13-16).
+    Index -1 (coarse segment shorter than k) wraps to the last row as torch indexing does (:21)."""
+    idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset)
+    dist_recip = 1.0 / (dist + 1e-8)
+    norm = torch.sum(dist_recip, dim=1, keepdim=True)
+    weight = (dist_recip / norm).contiguous()
+    idx = torch.where(idx < 0, idx + xyz.shape[0], idx).contiguous()
+    return idx, weight
+
+
+class _InterpolateRows(Function):
+    """output[n,:] = sum_i input[idx[n,i],:] * weight[n,i] with the scatter-add backward."""
+
+    @staticmethod
+    def forward(ctx, input, idx, weight):
+        _lib.require_cuda(input, idx, weight)
+        input = input.contiguous()
+        n, k = idx.shape
+        m, c = input.shape
+        output = torch.zeros((n, c), dtype=torch.float32, device=input.device)
+        rc = _lib.lib().interpolation_forward_hip_launcher(n, c, k, input.data_ptr(), idx.data_ptr(),
+                                                           weight.data_ptr(), output.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "interpolation_forward_hip_launcher")
+        ctx.m = m
+        ctx.save_for_backward(idx, weight)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        idx, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        n, c = grad_output.shape
+        grad_input = torch.zeros((ctx.m, c), dtype=torch.float32, device=grad_output.device)
+        rc = _lib.lib().interpolation_backward_hip_launcher(n, c, idx.shape[1], grad_output.data_ptr(), idx.data_ptr(),
+                                                            weight.data_ptr(), grad_input.data_ptr(),
+                                                            _lib.stream_ptr())
+        _lib.check(rc, "interpolation_backward_hip_launcher")
+        return grad_input, None, None
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """
+    input: coords: (m, 3), new_xyz: (n, 3), color: (m, c), offset: (b), new_offset: (b)
+    output: (n, c)
+    """
+    assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
+    idx, weight = interpolation_index_weight(xyz, new_xyz, offset, new_offset, k)
+    return _InterpolateRows.apply(feat, idx, weight)
+
+
+def interpolation2(xyz, new_xyz, input, offset, new_offset, k=3):
+    """The reference's autograd.Function spelling (:25-59); same computation."""
+    return interpolation(xyz, new_xyz, input, offset, new_offset, k)

@@ -1,0 +1,157 @@
+/*
+ * include/ptv2_hip.h -- C ABI of libptv2_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the reference's `pointops._C` extension
+ * (jihun1998/AO, libs/pointops/src).  Every entry point replaces one
+ * `extern "C" ..._cuda_launcher` of the reference (cited per function), keeps
+ * its argument order, and appends what a correct stream-ordered library needs:
+ *
+ *   - sizes the reference left implicit (n, b) where our kernels need them,
+ *   - a caller-owned scratch workspace (+ a *_workspace_bytes query) instead of
+ *     hidden allocations,
+ *   - `void *stream` (a hipStream_t; NULL = the legacy default stream the
+ *     reference launches on),
+ *   - an int status return (the reference returns void and never checks):
+ *       PTV2_OK, PTV2_ERR_ARG, PTV2_ERR_WORKSPACE, PTV2_ERR_LAUNCH.
+ *
+ * All pointers are device pointers unless stated.  fp32 data, int32 indices.
+ * Ownership: the caller owns every buffer; the library keeps no state between
+ * calls and is re-entrant across host threads.  Buffers marked [zeroed] must be
+ * zero-filled by the caller before the call (the reference has the same
+ * contract: libs/pointops/functions/interpolation.py:39, aggregation.py:20,
+ * grouping.py:31).
+ */
+#ifndef PTV2_HIP_H
+#define PTV2_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTV2_OK 0
+#define PTV2_ERR_ARG 1
+#define PTV2_ERR_WORKSPACE 2
+#define PTV2_ERR_LAUNCH 3
+
+/* Library / build identification (host only). */
+int ptv2_abi_version(void);
+const char *ptv2_build_info(void);
+
+/* ------------------------------------------------------------------ kNN --
+ * Replaces knn_query_cuda_launcher
+ *   (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13, kernel .cu:60-112)
+ * and, with pad_with_start=1, pointops2's knnquery_cuda_launcher
+ *   (libs/pointops2/src/knnquery/knnquery_cuda_kernel.cu:65-116).
+ * For each of the m rows of new_xyz: the nsample nearest rows of xyz inside the
+ * same batch segment, ascending squared distance; idx (m,nsample) int32,
+ * dist2 (m,nsample) fp32 SQUARED distances (the python wrapper takes the sqrt,
+ * libs/pointops/functions/query.py:24).  Missing neighbours: idx -1 (or the
+ * segment start when pad_with_start), dist2 1e10.  Results are bit-identical to
+ * the reference's heap algorithm, including its behaviour under tied distances.
+ * 1 <= nsample <= 128.  xyz (n,3), new_xyz (m,3), offset/new_offset (b) cumulative.
+ * new_xyz == xyz && new_offset == offset selects the self-query fast path.
+ */
+size_t knn_query_hip_workspace_bytes(int m, int n, int b);
+int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                           const int *offset, const int *new_offset, int *idx, float *dist2,
+                           int n, int b, int pad_with_start, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ FPS --
+ * Replaces farthest_point_sampling_cuda_launcher
+ *   (libs/pointops/src/sampling/sampling_cuda_kernel.h:13, kernel .cu:14-171);
+ * pointops2: furthestsampling_cuda_launcher (same kernel modulo names).
+ * b clouds; n_max = largest cloud size (selects the reference's block size B,
+ * cuda_utils.h:11-14, which defines its tie rule); tmp (n) fp32 must be
+ * pre-filled with 1e10 (sampling.py:19); idx (new_offset[b-1]) int32 out.
+ * n_total = total number of points (offset[b-1]), m_total = new_offset[b-1].
+ */
+size_t farthest_point_sampling_hip_workspace_bytes(int b, int n_total);
+int farthest_point_sampling_hip_launcher(int b, int n_max, const float *xyz, const int *offset,
+                                         const int *new_offset, float *tmp, int *idx,
+                                         int n_total, int m_total, void *workspace,
+                                         size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------- grouping --
+ * grouping_{forward,backward}_cuda_launcher
+ *   (libs/pointops/src/grouping/grouping_cuda_kernel.h:14-15, .cu:5-40).
+ * forward: output[m,s,:] = input[idx[m,s],:]   (idx < 0 -> zeros; the reference reads out of bounds)
+ * backward: grad_input[idx[m,s],:] += grad_output[m,s,:]     grad_input (n,c) [zeroed]
+ */
+int grouping_forward_hip_launcher(int m, int nsample, int c, const float *input, const int *idx,
+                                  float *output, void *stream);
+int grouping_backward_hip_launcher(int m, int nsample, int c, const float *grad_output,
+                                   const int *idx, float *grad_input, void *stream);
+
+/* -------------------------------------------------------- interpolation --
+ * interpolation_{forward,backward}_cuda_launcher
+ *   (libs/pointops/src/interpolation/interpolation_cuda_kernel.h, .cu:5-47).
+ * forward: output[n,:] += sum_i input[idx[n,i],:] * weight[n,i]     output (n,c) [zeroed]
+ * backward: grad_input[idx[n,i],:] += grad_output[n,:] * weight[n,i]  grad_input (m,c) [zeroed]
+ */
+int interpolation_forward_hip_launcher(int n, int c, int k, const float *input, const int *idx,
+                                       const float *weight, float *output, void *stream);
+int interpolation_backward_hip_launcher(int n, int c, int k, const float *grad_output,
+                                        const int *idx, const float *weight, float *grad_input,
+                                        void *stream);
+
+/* ---------------------------------------------------------- subtraction --
+ * subtraction_{forward,backward}_cuda_launcher
+ *   (libs/pointops/src/subtraction/subtraction_cuda_kernel.h, .cu:5-44).
+ * forward: output[n,s,:] = input1[n,:] - input2[idx[n,s],:]
+ * backward: grad_input1[n,:] += g ; grad_input2[idx[n,s],:] -= g      both (n,c) [zeroed]
+ */
+int subtraction_forward_hip_launcher(int n, int nsample, int c, const float *input1,
+                                     const float *input2, const int *idx, float *output,
+                                     void *stream);
+int subtraction_backward_hip_launcher(int n, int nsample, int c, const int *idx,
+                                      const float *grad_output, float *grad_input1,
+                                      float *grad_input2, void *stream);
+
+/* ---------------------------------------------------------- aggregation --
+ * aggregation_{forward,backward}_cuda_launcher
+ *   (libs/pointops/src/aggregation/aggregation_cuda_kernel.h, .cu:5-53).
+ * forward: output[n,c] += sum_s (input[idx[n,s],c] + position[n,s,c]) * weight[n,s,c % w_c]   [zeroed]
+ * backward: grad_input (n,c) [zeroed], grad_position (n,ns,c), grad_weight (n,ns,w_c) [zeroed]
+ */
+int aggregation_forward_hip_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                     const float *position, const float *weight, const int *idx,
+                                     float *output, void *stream);
+int aggregation_backward_hip_launcher(int n, int nsample, int c, int w_c, const float *input,
+                                      const float *position, const float *weight, const int *idx,
+                                      const float *grad_output, float *grad_input,
+                                      float *grad_position, float *grad_weight, void *stream);
+
+/* ------------------------------------------------------------ attention --
+ * attention_{relation,fusion}_step_{forward,backward}_cuda_launcher
+ *   (libs/pointops/src/attention/attention_cuda_kernel.h, .cu:9-147).
+ * relation fwd: output[r,g] += sum_c query[tgt[r],g,c] * key[ref[r],g,c] * weight[c]   (m,g) [zeroed]
+ * relation bwd: grad_query, grad_key (n,g,c) [zeroed], grad_weight (c) [zeroed]
+ * fusion fwd:   output[tgt[r],g,c] += weight[r,g] * value[ref[r],g,c]                (n,g,c) [zeroed]
+ * fusion bwd:   grad_weight (m,g) [zeroed], grad_value (n,g,c) [zeroed]
+ */
+int attention_relation_step_forward_hip_launcher(int m, int g, int c, const float *query,
+                                                 const float *key, const float *weight,
+                                                 const int *index_target, const int *index_refer,
+                                                 float *output, void *stream);
+int attention_relation_step_backward_hip_launcher(int m, int g, int c, const float *query,
+                                                  float *grad_query, const float *key,
+                                                  float *grad_key, const float *weight,
+                                                  float *grad_weight, const int *index_target,
+                                                  const int *index_refer, const float *grad_output,
+                                                  void *stream);
+int attention_fusion_step_forward_hip_launcher(int m, int g, int c, const float *weight,
+                                               const float *value, const int *index_target,
+                                               const int *index_refer, float *output, void *stream);
+int attention_fusion_step_backward_hip_launcher(int m, int g, int c, const float *weight,
+                                                float *grad_weight, const float *value,
+                                                float *grad_value, const int *index_target,
+                                                const int *index_refer, const float *grad_output,
+                                                void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTV2_HIP_H */

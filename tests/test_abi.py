@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol include/ptv2_hip.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ptv2_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_version|_info))\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ao_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_symbols()
+    assert len(names) >= 18, names
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), "missing export: " + n
+    missing = [n for n in names if n not in lib._SIGNATURES]
+    assert not missing, "declared in the header but not bound in ao_amd/_lib.py: %s" % missing
+    extra = [n for n in lib._SIGNATURES if n not in names]
+    assert not extra, "bound but not declared in include/ptv2_hip.h: %s" % extra
+
+
+def test_host_only_entry_points(lib):
+    L = lib.lib()
+    assert L.ptv2_abi_version() == 1
+    assert b"gfx950" in L.ptv2_build_info()
+    a = L.knn_query_hip_workspace_bytes(80000, 80000, 1)
+    b = L.knn_query_hip_workspace_bytes(240000, 240000, 3)
+    assert 0 < a < b < 64 << 20
+    assert L.knn_query_hip_workspace_bytes(10, 10, 0) == 0  # invalid b
+
+
+def test_ops_fail_loudly_without_gpu(lib):
+    import torch
+
+    from ao_amd import pointops
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    xyz = torch.zeros(8, 3)
+    off = torch.tensor([8], dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pointops.knn_query(2, xyz, off)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pointops.grouping(torch.zeros(8, 2, dtype=torch.int32), torch.zeros(8, 4), xyz)
