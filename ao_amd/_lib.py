@@ -35,7 +35,7 @@ _SIGNATURES = {
     "attention_relation_step_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 7),
     "attention_relation_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 10),
     "attention_fusion_step_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),
-    "attention_fusion_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 9),
+    "attention_fusion_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 8),
 }
 
 _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace too small)",

@@ -1,0 +1,100 @@
+"""Scene geometry for PT-v2m2: everything that depends only on (coord, offset).
+
+In the reference the geometric work is interleaved with the network: every BlockSequence calls
+knn_query (point_transformer_v2m2_base.py:223, recomputed in the decoder on identical coords),
+every GridPool voxelises + sorts (:244-269, with a host-sync python loop in offset2batch), every
+"interp" unpool runs a 3-NN (:311).  None of it depends on features or weights, so here it is
+computed ONCE per batch, up front, under no_grad: 1 + S self-kNNs, S grid poolings, S cross-kNNs
+for an S-stage model -- and handed to the layers as a `SceneGeometry`.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from .. import pointops
+from ..pointops.interpolation import interpolation_index_weight
+
+
+@dataclass
+class Level:
+    coord: torch.Tensor            # (N,3) fp32
+    offset: torch.Tensor           # (B,) int32 cumulative
+    knn: dict = field(default_factory=dict)  # K -> (N,K) int32 neighbour table of this level
+    # link to the next coarser level (filled for all but the last level)
+    cluster: Optional[torch.Tensor] = None   # (N,) int64: fine point -> coarse point
+    order: Optional[torch.Tensor] = None     # (N,) int64: fine points sorted by cluster (stable)
+    idx_ptr: Optional[torch.Tensor] = None   # (N'+1,) int64 CSR over `order`
+    # link from the next coarser level back to this one ("interp" unpooling)
+    up_idx: Optional[torch.Tensor] = None    # (N,3) int32 into the coarser level
+    up_weight: Optional[torch.Tensor] = None  # (N,3) fp32
+
+
+    def neighbours(self, k):
+        """Self k-NN table of this level; one kNN launch per distinct K, shared by every BlockSequence
+        that works at this resolution (encoder and decoder)."""
+        if k not in self.knn:
+            with torch.no_grad():
+                self.knn[k] = pointops.knn_query(k, self.coord, self.offset)[0]
+        return self.knn[k]
+
+
+@dataclass
+class SceneGeometry:
+    levels: List[Level] = field(default_factory=list)
+
+
+def offset2batch(offset):
+    off = offset.long()
+    counts = torch.diff(off, prepend=off.new_zeros(1))
+    return torch.repeat_interleave(torch.arange(off.numel(), device=off.device), counts)
+
+
+def voxel_cluster_ids(coord, offset, grid_size):
+    """Cluster id of GridPool (:246-259): per-cloud min-shifted coords, torch_cluster.grid_cluster
+    formula with the batch index as the most significant digit (oracle/ptv2_ref.py:voxel_grid)."""
+    batch = offset2batch(offset)
+    nb = offset.numel()
+    start = torch.full((nb, 3), float("inf"), device=coord.device, dtype=coord.dtype)
+    start = start.scatter_reduce(0, batch.view(-1, 1).expand(-1, 3), coord, "amin", include_self=True)
+    pos = coord - start[batch]
+    size = coord.new_tensor([grid_size, grid_size, grid_size])
+    num = (pos.max(0)[0] / size).long() + 1          # voxels per axis over the whole batch
+    cell = (pos / size.view(1, 3)).long()
+    stride_y, stride_z, stride_b = num[0], num[0] * num[1], num[0] * num[1] * num[2]
+    return cell[:, 0] + cell[:, 1] * stride_y + cell[:, 2] * stride_z + batch * stride_b, batch
+
+
+def grid_pool_geometry(coord, offset, grid_size):
+    """Coordinates-only half of GridPool.forward (:257-268).  Cluster means are accumulated in
+    ascending point order (as a stable sort + sequential segment sum does in the oracle)."""
+    key, batch = voxel_cluster_ids(coord, offset, grid_size)
+    _, cluster, counts = torch.unique(key, sorted=True, return_inverse=True, return_counts=True)
+    order = torch.sort(cluster, stable=True)[1]
+    idx_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, dim=0)])
+    new_coord = torch.segment_reduce(coord[order], "mean", offsets=idx_ptr, axis=0)
+    new_batch = batch[order[idx_ptr[:-1]]]
+    new_offset = torch.cumsum(new_batch.bincount(minlength=offset.numel()), dim=0).int()
+    return new_coord.contiguous(), new_offset, cluster, order, idx_ptr
+
+
+@torch.no_grad()
+def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
+    """neighbours[i] = iterable of K values needed at level i (level 0 = input resolution,
+    level i+1 = after grid_sizes[i])."""
+    offset = offset.int().contiguous()
+    coord = coord.contiguous()
+    geo = SceneGeometry()
+    cur = Level(coord=coord, offset=offset)
+    for i, ks in enumerate(neighbours):
+        for k in ks:
+            cur.neighbours(k)
+        geo.levels.append(cur)
+        if i == len(grid_sizes):
+            break
+        nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, grid_sizes[i])
+        cur.cluster, cur.order, cur.idx_ptr = cluster, order, idx_ptr
+        if interp:
+            cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
+        cur = Level(coord=nc, offset=noff)
+    return geo

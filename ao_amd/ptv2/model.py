@@ -1,0 +1,338 @@
+"""PT-v2m2 backbone on the MI355X ops.
+
+Same registry name ("PT-v2m2"), constructor kwargs, `forward(data_dict) -> seg_logits` contract and
+state_dict key layout as the reference
+(pointcept/models/point_transformer_v2/point_transformer_v2m2_base.py:447-576), so reference
+checkpoints load unchanged and the AO trainers can build it from their config.  What differs is
+the execution plan:
+
+  * all geometry (kNN tables, grid-pool clusters, interpolation indices/weights) is computed once
+    per batch up front (ao_amd/ptv2/geometry.py) instead of inside each layer;
+  * grouped vector attention runs through `ao_amd.ptv2.gva` (fused HIP kernels) -- the unfused
+    composition of gather ops below (`gva_unfused`) is kept as the in-framework statement of
+    the same math for debugging (AO_AMD_GVA=unfused);
+  * dense Linear layers stay on rocBLAS/hipBLASLt (MFMA) through torch.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import pointops
+from ..pointops.interpolation import _InterpolateRows
+from .geometry import build_geometry
+
+
+class PointBatchNorm(nn.Module):
+    """BatchNorm over the channel (last) axis of (N,C) or (N,L,C); statistics over all other axes
+    (reference :26-45 reaches the same statistics through two transposes)."""
+
+    def __init__(self, embed_channels):
+        super().__init__()
+        self.norm = nn.BatchNorm1d(embed_channels)
+
+    def forward(self, input):
+        if input.dim() == 2:
+            return self.norm(input)
+        if input.dim() == 3:
+            n, l, c = input.shape
+            return self.norm(input.reshape(n * l, c)).view(n, l, c)
+        raise NotImplementedError
+
+
+def _lin_bn_relu(cin, cout, bias):
+    return nn.Sequential(nn.Linear(cin, cout, bias=bias), PointBatchNorm(cout), nn.ReLU(inplace=True))
+
+
+class GroupedVectorAttention(nn.Module):
+    def __init__(self, embed_channels, groups, attn_drop_rate=0.0, qkv_bias=True, pe_multiplier=False,
+                 pe_bias=True):
+        super().__init__()
+        assert embed_channels % groups == 0
+        self.embed_channels, self.groups = embed_channels, groups
+        self.attn_drop_rate, self.qkv_bias = attn_drop_rate, qkv_bias
+        self.pe_multiplier, self.pe_bias = pe_multiplier, pe_bias
+        c, g = embed_channels, groups
+        self.linear_q = _lin_bn_relu(c, c, qkv_bias)
+        self.linear_k = _lin_bn_relu(c, c, qkv_bias)
+        self.linear_v = nn.Linear(c, c, bias=qkv_bias)
+        if pe_multiplier:
+            self.linear_p_multiplier = nn.Sequential(nn.Linear(3, c), PointBatchNorm(c), nn.ReLU(inplace=True),
+                                                     nn.Linear(c, c))
+        if pe_bias:
+            self.linear_p_bias = nn.Sequential(nn.Linear(3, c), PointBatchNorm(c), nn.ReLU(inplace=True),
+                                               nn.Linear(c, c))
+        self.weight_encoding = nn.Sequential(nn.Linear(c, g), PointBatchNorm(g), nn.ReLU(inplace=True),
+                                             nn.Linear(g, g))
+        self.softmax = nn.Softmax(dim=1)
+        self.attn_drop = nn.Dropout(attn_drop_rate)
+
+    def gva_unfused(self, query, key, value, coord, reference_index):
+        """The reference's op sequence (:109-128) on the HIP gather kernel."""
+        key = pointops.grouping(reference_index, key, coord, with_xyz=True)
+        value = pointops.grouping(reference_index, value, coord, with_xyz=False)
+        pos, key = key[:, :, 0:3], key[:, :, 3:]
+        relation_qk = key - query.unsqueeze(1)
+        if self.pe_multiplier:
+            relation_qk = relation_qk * self.linear_p_multiplier(pos)
+        if self.pe_bias:
+            peb = self.linear_p_bias(pos)
+            relation_qk = relation_qk + peb
+            value = value + peb
+        weight = self.weight_encoding(relation_qk)
+        weight = self.attn_drop(self.softmax(weight))
+        mask = torch.sign(reference_index + 1).to(weight.dtype)
+        weight = weight * mask.unsqueeze(-1)
+        n, ns, c = value.shape
+        value = value.view(n, ns, self.groups, c // self.groups)
+        return (value * weight.unsqueeze(-1)).sum(1).reshape(n, c)
+
+    def forward(self, feat, coord, reference_index):
+        query, key, value = self.linear_q(feat), self.linear_k(feat), self.linear_v(feat)
+        mode = os.environ.get("AO_AMD_GVA", "unfused")
+        fusable = self.pe_bias and not self.pe_multiplier and (self.attn_drop_rate == 0.0 or not self.training)
+        if mode == "fused" and fusable:
+            from . import gva
+
+            return gva.grouped_vector_attention(self, query, key, value, coord, reference_index)
+        return self.gva_unfused(query, key, value, coord, reference_index)
+
+
+class DropPath(nn.Module):
+    """Per-row stochastic depth (timm DropPath semantics, reference :19,160-162): each point's residual
+    branch is zeroed with probability p and the survivors are scaled by 1/(1-p)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = torch.empty((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device, dtype=x.dtype).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class Block(nn.Module):
+    def __init__(self, embed_channels, groups, qkv_bias=True, pe_multiplier=False, pe_bias=True,
+                 attn_drop_rate=0.0, drop_path_rate=0.0, enable_checkpoint=False):
+        super().__init__()
+        self.attn = GroupedVectorAttention(embed_channels, groups, attn_drop_rate, qkv_bias, pe_multiplier, pe_bias)
+        self.fc1 = nn.Linear(embed_channels, embed_channels, bias=False)
+        self.fc3 = nn.Linear(embed_channels, embed_channels, bias=False)
+        self.norm1 = PointBatchNorm(embed_channels)
+        self.norm2 = PointBatchNorm(embed_channels)
+        self.norm3 = PointBatchNorm(embed_channels)
+        self.act = nn.ReLU(inplace=True)
+        self.enable_checkpoint = enable_checkpoint
+        self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
+
+    def forward(self, points, reference_index):
+        coord, feat, offset = points
+        identity = feat
+        feat = self.act(self.norm1(self.fc1(feat)))
+        if self.enable_checkpoint and self.training:
+            feat = torch.utils.checkpoint.checkpoint(self.attn, feat, coord, reference_index, use_reentrant=False)
+        else:
+            feat = self.attn(feat, coord, reference_index)
+        feat = self.act(self.norm2(feat))
+        feat = self.norm3(self.fc3(feat))
+        feat = self.act(identity + self.drop_path(feat))
+        return [coord, feat, offset]
+
+
+class BlockSequence(nn.Module):
+    def __init__(self, depth, embed_channels, groups, neighbours=16, qkv_bias=True, pe_multiplier=False,
+                 pe_bias=True, attn_drop_rate=0.0, drop_path_rate=0.0, enable_checkpoint=False):
+        super().__init__()
+        if isinstance(drop_path_rate, (list, tuple)):
+            rates = list(drop_path_rate)
+            assert len(rates) == depth
+        elif isinstance(drop_path_rate, float):
+            rates = [drop_path_rate] * depth
+        else:
+            rates = [0.0] * depth
+        self.neighbours = neighbours
+        self.blocks = nn.ModuleList(
+            Block(embed_channels, groups, qkv_bias, pe_multiplier, pe_bias, attn_drop_rate, rates[i], enable_checkpoint)
+            for i in range(depth))
+
+    def forward(self, points, reference_index=None):
+        coord, feat, offset = points
+        if reference_index is None:  # stand-alone use: same call as the reference (:223)
+            reference_index, _ = pointops.knn_query(self.neighbours, coord, offset)
+        for block in self.blocks:
+            points = block(points, reference_index)
+        return points
+
+
+class _SegmentMax(torch.autograd.Function):
+    """Per-cluster channel max over CSR segments of `order` (torch_scatter.segment_csr(reduce="max"),
+    reference :266); the gradient goes to the arg-max row."""
+
+    @staticmethod
+    def forward(ctx, feat, cluster, n_out):
+        idx = cluster.view(-1, 1).expand(-1, feat.shape[1])
+        out = feat.new_full((n_out, feat.shape[1]), float("-inf")).scatter_reduce(0, idx, feat, "amax", include_self=True)
+        ctx.save_for_backward(feat, cluster, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        feat, cluster, out = ctx.saved_tensors
+        hit = feat == out[cluster]
+        # exactly one winner per (cluster, channel): the first row in point order among equal maxima
+        n = feat.shape[0]
+        rank = torch.arange(n, device=feat.device).view(-1, 1).expand_as(feat)
+        big = torch.full_like(rank, n)
+        first = torch.full((out.shape[0], feat.shape[1]), n, device=feat.device, dtype=rank.dtype)
+        first = first.scatter_reduce(0, cluster.view(-1, 1).expand_as(feat), torch.where(hit, rank, big), "amin",
+                                     include_self=True)
+        win = hit & (rank == first[cluster])
+        return torch.where(win, grad[cluster], torch.zeros_like(feat)), None, None
+
+
+class GridPool(nn.Module):
+    """Partition-based pooling (reference :229-269).  The clustering itself lives in geometry.py."""
+
+    def __init__(self, in_channels, out_channels, grid_size, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.grid_size = in_channels, out_channels, grid_size
+        self.fc = nn.Linear(in_channels, out_channels, bias=bias)
+        self.norm = PointBatchNorm(out_channels)
+        self.act = nn.ReLU(inplace=True)
+
+    def forward(self, feat, fine_level, coarse_level):
+        feat = self.act(self.norm(self.fc(feat)))
+        return _SegmentMax.apply(feat, fine_level.cluster, coarse_level.coord.shape[0])
+
+
+class UnpoolWithSkip(nn.Module):
+    """Map / interpolation unpooling with skip connection (reference :272-316)."""
+
+    def __init__(self, in_channels, skip_channels, out_channels, bias=True, skip=True, backend="map"):
+        super().__init__()
+        assert backend in ("map", "interp")
+        self.in_channels, self.skip_channels, self.out_channels = in_channels, skip_channels, out_channels
+        self.skip, self.backend = skip, backend
+        self.proj = _lin_bn_relu(in_channels, out_channels, bias)
+        self.proj_skip = _lin_bn_relu(skip_channels, out_channels, bias)
+
+    def forward(self, feat, skip_feat, fine_level):
+        feat = self.proj(feat)
+        if self.backend == "map" and fine_level.cluster is not None:
+            feat = feat[fine_level.cluster]
+        else:
+            feat = _InterpolateRows.apply(feat, fine_level.up_idx, fine_level.up_weight)
+        if self.skip:
+            feat = feat + self.proj_skip(skip_feat)
+        return feat
+
+
+class Encoder(nn.Module):
+    def __init__(self, depth, in_channels, embed_channels, groups, grid_size=None, neighbours=16, qkv_bias=True,
+                 pe_multiplier=False, pe_bias=True, attn_drop_rate=None, drop_path_rate=None, enable_checkpoint=False):
+        super().__init__()
+        self.down = GridPool(in_channels, embed_channels, grid_size)
+        self.blocks = BlockSequence(depth, embed_channels, groups, neighbours, qkv_bias, pe_multiplier, pe_bias,
+                                    attn_drop_rate if attn_drop_rate is not None else 0.0,
+                                    drop_path_rate if drop_path_rate is not None else 0.0, enable_checkpoint)
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels, skip_channels, embed_channels, groups, depth, neighbours=16, qkv_bias=True,
+                 pe_multiplier=False, pe_bias=True, attn_drop_rate=None, drop_path_rate=None, enable_checkpoint=False,
+                 unpool_backend="map"):
+        super().__init__()
+        self.up = UnpoolWithSkip(in_channels, skip_channels, embed_channels, backend=unpool_backend)
+        self.blocks = BlockSequence(depth, embed_channels, groups, neighbours, qkv_bias, pe_multiplier, pe_bias,
+                                    attn_drop_rate if attn_drop_rate is not None else 0.0,
+                                    drop_path_rate if drop_path_rate is not None else 0.0, enable_checkpoint)
+
+
+class GVAPatchEmbed(nn.Module):
+    def __init__(self, depth, in_channels, embed_channels, groups, neighbours=16, qkv_bias=True, pe_multiplier=False,
+                 pe_bias=True, attn_drop_rate=0.0, drop_path_rate=0.0, enable_checkpoint=False):
+        super().__init__()
+        self.in_channels, self.embed_channels = in_channels, embed_channels
+        self.proj = _lin_bn_relu(in_channels, embed_channels, False)
+        self.blocks = BlockSequence(depth, embed_channels, groups, neighbours, qkv_bias, pe_multiplier, pe_bias,
+                                    attn_drop_rate, drop_path_rate, enable_checkpoint)
+
+
+class PointTransformerV2(nn.Module):
+    """Registry name "PT-v2m2" (reference :447)."""
+
+    def __init__(self, in_channels, num_classes, patch_embed_depth=1, patch_embed_channels=48, patch_embed_groups=6,
+                 patch_embed_neighbours=8, enc_depths=(2, 2, 6, 2), enc_channels=(96, 192, 384, 512),
+                 enc_groups=(12, 24, 48, 64), enc_neighbours=(16, 16, 16, 16), dec_depths=(1, 1, 1, 1),
+                 dec_channels=(48, 96, 192, 384), dec_groups=(6, 12, 24, 48), dec_neighbours=(16, 16, 16, 16),
+                 grid_sizes=(0.06, 0.12, 0.24, 0.48), attn_qkv_bias=True, pe_multiplier=False, pe_bias=True,
+                 attn_drop_rate=0.0, drop_path_rate=0, enable_checkpoint=False, unpool_backend="map"):
+        super().__init__()
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.num_stages = len(enc_depths)
+        for seq in (dec_depths, enc_channels, dec_channels, enc_groups, dec_groups, enc_neighbours, dec_neighbours,
+                    grid_sizes):
+            assert len(seq) == self.num_stages
+        self.grid_sizes, self.unpool_backend = tuple(grid_sizes), unpool_backend
+        self.patch_embed = GVAPatchEmbed(patch_embed_depth, in_channels, patch_embed_channels, patch_embed_groups,
+                                         patch_embed_neighbours, attn_qkv_bias, pe_multiplier, pe_bias, attn_drop_rate,
+                                         enable_checkpoint=enable_checkpoint)
+        enc_dp = [x.item() for x in torch.linspace(0, drop_path_rate, sum(enc_depths))]
+        dec_dp = [x.item() for x in torch.linspace(0, drop_path_rate, sum(dec_depths))]
+        enc_channels = [patch_embed_channels] + list(enc_channels)
+        dec_channels = list(dec_channels) + [enc_channels[-1]]
+        self.enc_stages, self.dec_stages = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.num_stages):
+            self.enc_stages.append(Encoder(
+                enc_depths[i], enc_channels[i], enc_channels[i + 1], enc_groups[i], grid_sizes[i], enc_neighbours[i],
+                attn_qkv_bias, pe_multiplier, pe_bias, attn_drop_rate,
+                enc_dp[sum(enc_depths[:i]):sum(enc_depths[:i + 1])], enable_checkpoint))
+            self.dec_stages.append(Decoder(
+                dec_channels[i + 1], enc_channels[i], dec_channels[i], dec_groups[i], dec_depths[i], dec_neighbours[i],
+                attn_qkv_bias, pe_multiplier, pe_bias, attn_drop_rate,
+                dec_dp[sum(dec_depths[:i]):sum(dec_depths[:i + 1])], enable_checkpoint, unpool_backend))
+        self.seg_head = (nn.Sequential(nn.Linear(dec_channels[0], dec_channels[0]), PointBatchNorm(dec_channels[0]),
+                                       nn.ReLU(inplace=True), nn.Linear(dec_channels[0], num_classes))
+                         if num_classes > 0 else nn.Identity())
+
+    def geometry(self, coord, offset):
+        ks = [{self.patch_embed.blocks.neighbours, self.dec_stages[0].blocks.neighbours}]
+        for i in range(self.num_stages):
+            here = {self.enc_stages[i].blocks.neighbours}
+            if i + 1 < self.num_stages:
+                here.add(self.dec_stages[i + 1].blocks.neighbours)
+            ks.append(here)
+        return build_geometry(coord, offset, self.grid_sizes, ks, interp=self.unpool_backend == "interp")
+
+    def forward(self, data_dict, geometry=None):
+        coord, feat = data_dict["coord"], data_dict["feat"]
+        offset = data_dict["offset"].int()
+        geo = geometry if geometry is not None else self.geometry(coord, offset)
+        lv = geo.levels
+        pe = self.patch_embed
+        feat = pe.blocks([lv[0].coord, pe.proj(feat), lv[0].offset], lv[0].neighbours(pe.blocks.neighbours))[1]
+        skips = [feat]
+        for i, enc in enumerate(self.enc_stages):
+            feat = enc.down(feat, lv[i], lv[i + 1])
+            feat = enc.blocks([lv[i + 1].coord, feat, lv[i + 1].offset], lv[i + 1].neighbours(enc.blocks.neighbours))[1]
+            skips.append(feat)
+        feat = skips.pop()
+        for i in reversed(range(self.num_stages)):
+            dec = self.dec_stages[i]
+            feat = dec.up(feat, skips.pop(), lv[i])
+            feat = dec.blocks([lv[i].coord, feat, lv[i].offset], lv[i].neighbours(dec.blocks.neighbours))[1]
+        return self.seg_head(feat)
+
+
+MODEL_TYPE = "PT-v2m2"
+
+
+def build_from_cfg(cfg):
+    """cfg: the `backbone=dict(type="PT-v2m2", ...)` dict of the reference configs."""
+    cfg = dict(cfg)
+    assert cfg.pop("type", MODEL_TYPE) == MODEL_TYPE
+    return PointTransformerV2(**cfg)

@@ -61,3 +61,14 @@ def test_ops_fail_loudly_without_gpu(lib):
         pointops.knn_query(2, xyz, off)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pointops.grouping(torch.zeros(8, 2, dtype=torch.int32), torch.zeros(8, 4), xyz)
+
+
+def test_binding_arity_matches_header(lib):
+    """ctypes argtypes must have exactly one entry per parameter declared in the header."""
+    txt = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, params in re.findall(r"\b([a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", txt):
+        if name not in lib._SIGNATURES:
+            continue
+        params = params.strip()
+        count = 0 if params in ("", "void") else params.count(",") + 1
+        assert count == len(lib._SIGNATURES[name][1]), (name, count, len(lib._SIGNATURES[name][1]))

@@ -1,0 +1,131 @@
+"""GPU parity of the PT-v2m2 model (ao_amd/ptv2) against fixtures captured from the reference
+nn.Module (tests/golden/ptv2_*.npz, gva_block.npz) and against the CPU oracle at other sizes.
+Tolerance: fp32 features within 1e-4 (north_star); parameter gradients in relative L2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ptv2_ref as M
+from tests.test_oracle_model import assert_grad_close, block_state, digest
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ptv2():
+    assert torch.cuda.is_available()
+    import ao_amd.ptv2 as ptv2
+
+    return ptv2
+
+
+@pytest.fixture(params=["unfused", "fused"])
+def gva_mode(request, monkeypatch):
+    monkeypatch.setenv("AO_AMD_GVA", request.param)
+    if request.param == "fused":
+        pytest.importorskip("ao_amd.ptv2.gva")
+    return request.param
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_block_matches_reference_module(ptv2, golden, gva_mode, mode):
+    g = golden("gva_block.npz")
+    bst = block_state(int(g["state_seed"]))
+    assert digest(bst) == str(g["digest"])
+    blk = ptv2.Block(48, 6).cuda()
+    blk.load_state_dict(bst, strict=True)
+    blk.train(mode == "train")
+    xyz, idx = dev(g["xyz"]), dev(g["idx"])
+    feat = dev(g["feat"]).requires_grad_(True)
+    out = blk.attn(feat, xyz, idx)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["attn_out_" + mode], rtol=1e-4, atol=1e-4)
+    names = [n for n, _ in blk.attn.named_parameters()]
+    grads = torch.autograd.grad(out, [feat] + list(blk.attn.parameters()), dev(g["attn_gout"]))
+    np.testing.assert_allclose(grads[0].cpu().numpy(), g["attn_gfeat_" + mode], rtol=1e-3, atol=1e-4)
+    for n, gr in zip(names, grads[1:]):
+        ref = g["attn_g_%s_%s" % (mode, n)]
+        if mode == "train" and n.endswith(".0.bias"):  # exactly-zero true gradient (bias in front of a BN)
+            wref = g["attn_g_%s_%s" % (mode, n[:-4] + "weight")]
+            assert np.linalg.norm(gr.cpu().numpy()) <= 2e-3 * np.linalg.norm(wref) + 1e-4, n
+            continue
+        assert_grad_close(gr.cpu().numpy(), ref, n)
+    blk.load_state_dict(bst, strict=True)
+    _, y, _ = blk([xyz, feat, dev(g["offset"])], idx)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["block_out_" + mode], rtol=1e-4, atol=1e-4)
+    (gf,) = torch.autograd.grad(y, feat, dev(g["attn_gout"]))
+    np.testing.assert_allclose(gf.cpu().numpy(), g["block_gfeat_" + mode], rtol=1e-3, atol=1e-4)
+    if mode == "train":
+        sd = blk.state_dict()
+        for k in g.files:
+            if k.startswith("block_buf_"):
+                np.testing.assert_allclose(sd[k[len("block_buf_"):]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["s3dis", "scannet"])
+def test_full_model_matches_reference_module(ptv2, golden, gva_mode, tag):
+    g = golden("ptv2_%s.npz" % tag)
+    cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.0)
+    st0 = M.init_state(cfg, seed=int(g["state_seed"]))
+    assert digest(st0) == str(g["digest"])
+    model = ptv2.PointTransformerV2(**cfg).cuda()
+    data = dict(coord=dev(g["coord"]), feat=dev(g["feat"]), offset=dev(g["offset"]))
+    label = dev(g["label"])
+    for mode in ("train", "eval"):
+        model.load_state_dict(st0, strict=True)
+        model.train(mode == "train")
+        logits = model(data)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits_" + mode], rtol=1e-3, atol=2e-4)
+        loss = F.cross_entropy(logits, label, ignore_index=-1)
+        assert abs(float(loss) - float(g["loss_" + mode])) < 2e-5
+        if mode == "train":
+            watch = [k[len("grad_"):] for k in g.files if k.startswith("grad_")]
+            params = dict(model.named_parameters())
+            grads = torch.autograd.grad(loss, [params[w] for w in watch])
+            for w, gr in zip(watch, grads):
+                assert_grad_close(gr.cpu().numpy(), g["grad_" + w], w)
+
+
+def test_geometry_matches_oracle(ptv2):
+    """Pooled coordinates, clusters, offsets and kNN tables of every level equal the oracle's bit for bit."""
+    from ao_amd import synth
+    from oracle import pointops_ref as P
+
+    b = synth.scene_batch([3, 4], point_max=9000)
+    coord, offset = torch.from_numpy(b["coord"]), torch.from_numpy(b["offset"])
+    model = ptv2.PointTransformerV2(**ptv2.S3DIS_BACKBONE)
+    geo = model.geometry(coord.cuda(), offset.cuda())
+    c, o = coord, offset.long()
+    for i, gs in enumerate(ptv2.S3DIS_BACKBONE["grid_sizes"]):
+        lv = geo.levels[i]
+        assert torch.equal(lv.neighbours(16).cpu(), P.knn_query(16, c, o.int())[0])
+        nc, noff, cluster, order, idx_ptr = M.grid_pool_geometry(c, o, gs)
+        assert torch.equal(lv.cluster.cpu(), cluster)
+        assert torch.equal(geo.levels[i + 1].offset.cpu().long(), noff)
+        assert torch.equal(geo.levels[i + 1].coord.cpu(), nc), "pooled coordinates differ at level %d" % (i + 1)
+        ridx, rw = P.interpolation_weights(nc, c, noff.int(), o.int())
+        assert torch.equal(lv.up_idx.cpu(), ridx)
+        np.testing.assert_allclose(lv.up_weight.cpu().numpy(), rw.numpy(), rtol=1e-6, atol=1e-7)
+        c, o = nc, noff
+
+
+def test_train_step_runs_and_reduces_loss(ptv2):
+    from ao_amd import synth
+
+    torch.manual_seed(0)
+    b = synth.scene_batch([5], point_max=6000)
+    data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    seg = ptv2.DefaultSegmentor(ptv2.S3DIS_BACKBONE).cuda().train()
+    opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+    losses = []
+    for _ in range(8):
+        loss = seg(data)["loss"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
