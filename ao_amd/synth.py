@@ -85,12 +85,12 @@ def lattice_cloud(nx, ny, nz, step):
     return np.ascontiguousarray(g * step, dtype=np.float32)
 
 
-def scene_batch(seeds, point_max=80000, in_channels=6, num_classes=13, ignore_frac=0.1):
+def scene_batch(seeds, point_max=80000, in_channels=6, num_classes=13, ignore_frac=0.1, room=None):
     """Collated batch in the reference's offset format (pointcept/datasets/utils.py:14-40):
     dict(coord (N,3) f32, feat (N,in_channels) f32, segment (N,) i64, offset (B,) i32 cumulative)."""
     coords, feats, labels, counts = [], [], [], []
     for i, seed in enumerate(seeds):
-        c = room_scene(seed=seed, room=seed, point_max=point_max)
+        c = room_scene(seed=seed, room=seed if room is None else room, point_max=point_max)
         rng = np.random.default_rng(10_000 + seed)
         extra = rng.uniform(-1, 1, (c.shape[0], in_channels - 3)).astype(np.float32)
         lab = rng.integers(0, num_classes, c.shape[0]).astype(np.int64)

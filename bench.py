@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- points/sec, forward+backward+optimizer step, PT-v2m2 S3DIS config, synthetic scenes.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = one full training step of the hot path on one batch that is already resident in HBM:
+geometry (kNN tables, grid pooling, interpolation tables) + PT-v2m2 forward + cross-entropy +
+backward + AdamW.  One process per GPU; data parallel by scene (one scene per rank, weak scaling);
+gradients all-reduced by torch DDP over RCCL (backend "nccl" on ROCm).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (task section 4):
+  roofline      the dominant hand-written kernel, timed live with HIP events on the launch stream
+  cpu_baseline  the CPU oracle (oracle/ptv2_ref.py + C kNN) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=120000, help="points per scene (BASELINE.json configs[1]: ~120k)")
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--cpu-sample-points", type=int, default=12000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_batch(rank, scenes, points, device):
+    from ao_amd import synth
+
+    seeds = [rank * scenes + i for i in range(scenes)]
+    b = synth.scene_batch(seeds, point_max=points, room=1)
+    return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
+
+
+def algorithmic_step_bytes(levels, cfg):
+    """compulsory fp32 traffic of the fused blocks, fwd+bwd = 4*N*(6C+2K+6) per block."""
+    c0 = cfg["patch_embed_channels"]
+    per_level = [(cfg["patch_embed_depth"] + cfg["dec_depths"][0], c0, cfg["patch_embed_neighbours"])]
+    for i, d in enumerate(cfg["enc_depths"]):
+        extra = cfg["dec_depths"][i + 1] if i + 1 < len(cfg["dec_depths"]) else 0
+        per_level.append((d + extra, cfg["enc_channels"][i], cfg["enc_neighbours"][i]))
+    total = 0
+    for (nb, c, k), n in zip(per_level, levels):
+        total += nb * 4 * n * (6 * c + 2 * k + 6)
+    return total
+
+
+def cpu_baseline(cfg, sample_points):
+    """fwd+bwd+AdamW of the CPU oracle on a bounded crop of the same scene generator."""
+    from ao_amd import synth
+    from oracle import pointops_ref, ptv2_ref
+
+    pointops_ref.build()
+    torch.manual_seed(0)
+    b = synth.scene_batch([0], point_max=sample_points, room=1)
+    data = {k: torch.from_numpy(v) for k, v in b.items()}
+    model = ptv2_ref.RefModule(dict(cfg, drop_path_rate=0.0)).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        loss = torch.nn.functional.cross_entropy(model(data), data["segment"], ignore_index=-1)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return dict(value=sample_points / t, unit="points/s", cores=torch.get_num_threads(), kind="port",
+                sample="1 scene cropped to %d points, fwd+bwd+AdamW, median of 2 after 1 warm-up, %.1f s/step; "
+                       "torch-CPU restatement + C kNN (oracle/), drop_path 0" % (sample_points, t))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                         % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import ao_amd.ptv2 as ptv2
+    from ao_amd.profiling import clock
+
+    torch.manual_seed(4242)
+    cfg = dict(ptv2.S3DIS_BACKBONE)
+    seg = ptv2.DefaultSegmentor(cfg).to(device).train()
+    net = seg
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(seg, device_ids=[local_rank], broadcast_buffers=False,
+                                                        gradient_as_bucket_view=True)
+    opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+    data = make_batch(rank, args.scenes, args.points, device)
+    n_points = int(data["coord"].shape[0])
+    autocast = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" else None
+
+    def step():
+        if autocast is not None:
+            with autocast:
+                loss = net(data)["loss"]
+        else:
+            loss = net(data)["loss"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    clock.enabled = not args.no_roofline
+    clock.reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    clock.enabled = False
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    total_points = torch.tensor([n_points], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(total_points, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    points_per_step = float(total_points.item())
+
+    if rank == 0:
+        with torch.no_grad():
+            geo = seg.backbone.geometry(data["coord"], data["offset"])
+        levels = [int(lv.coord.shape[0]) for lv in geo.levels]
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "points/sec fwd+bwd PTv2m2 S3DIS", "value": points_per_step * args.steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "s3dis semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
+                                   "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.scenes, args.points),
+                       "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
+                       "parallelism": "dp%d" % world, "loss": float(loss)},
+        }
+        step_bytes = algorithmic_step_bytes(levels, cfg)
+        out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
+        out["config"]["step_frac_of_hbm_roofline"] = (step_bytes / (ms * 1e-3)) / (HBM_PEAK_GBS * 1e9)
+        if not args.no_roofline:
+            summ = clock.summary()
+            if summ:
+                name, rec = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+                achieved = rec["bytes_per_launch"] / (rec["avg_us"] * 1e-6) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_us": rec["avg_us"], "launches": rec["launches"],
+                                   "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
+                                   "all_kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
+                                                       "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
+                                                   for k, v in summ.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_points)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
