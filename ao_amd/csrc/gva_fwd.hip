@@ -1,0 +1,315 @@
+// ao_amd/csrc/gva_fwd.hip -- forward stages of the fused grouped vector attention (gfx950).
+// Math and notation: ao_amd/ptv2/gva.py (module docstring); reference op sequence:
+// pointcept/models/point_transformer_v2/point_transformer_v2m2_base.py:103-129.
+//
+//   gva_pos_stats       sum pos, sum pos pos^T over all N*K neighbour slots (BN_p closed form)
+//   gva_logits_forward  W1[n,s,:] = kW[idx] - qW[n] + ReLU(pos a^T + b) M + cW, plus per-channel
+//                       sum / sum-of-squares for BN_w.  One lane per neighbour slot, the G logits in
+//                       registers; a, b, M are wave-uniform operands (scalar loads, SGPR FMA sources).
+//                       HBM traffic per launch: idx + coord + kW/qW gathers in, W1 out -- the
+//                       (N,K,C) intermediate of the reference never exists.
+//   gva_aggregate_forward  per point (one wavefront): BN_w affine + ReLU + Linear(G,G) + softmax over
+//                       the K neighbours (K-lane shuffle groups) + mask, then with lanes over channels
+//                       out_v = sum_s w v[idx], A[g] = sum_s w[s,g] P[s,:], sw = sum_s w.
+#include "gva_common.h"
+
+namespace gva {
+
+// ------------------------------------------------------------------ pos stats --
+__global__ __launch_bounds__(TPB) void pos_stats_kernel(int n, int k, const float *__restrict__ coord,
+                                                        const int *__restrict__ idx, float *__restrict__ part) {
+    __shared__ float s_w[WPB][9];
+    const long long rows = (long long)n * k;
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows; row += (long long)gridDim.x * TPB) {
+        Rel r = rel_pos(coord, idx, row, (int)(row / k));
+        acc[0] += r.x; acc[1] += r.y; acc[2] += r.z;
+        acc[3] += r.x * r.x; acc[4] += r.x * r.y; acc[5] += r.x * r.z;
+        acc[6] += r.y * r.y; acc[7] += r.y * r.z; acc[8] += r.z * r.z;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        float v = wave_sum(acc[j]);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        float v = 0.f;
+        for (int w = 0; w < WPB; ++w) v += s_w[w][threadIdx.x];
+        part[blockIdx.x * 9 + threadIdx.x] = v;
+    }
+}
+
+__global__ void pos_stats_finalize_kernel(const float *__restrict__ part, int nblk, double *s1, double *s2) {
+    __shared__ double s[9];
+    if (threadIdx.x < 9) {
+        double acc = 0.0;
+        for (int b = 0; b < nblk; ++b) acc += (double)part[b * 9 + threadIdx.x];
+        s[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1[0] = s[0]; s1[1] = s[1]; s1[2] = s[2];
+        s2[0] = s[3]; s2[1] = s[4]; s2[2] = s[5];
+        s2[3] = s[4]; s2[4] = s[6]; s2[5] = s[7];
+        s2[6] = s[5]; s2[7] = s[7]; s2[8] = s[8];
+    }
+}
+
+// ------------------------------------------------------------- logits forward --
+template <int G>
+__global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, const float *__restrict__ kW,
+                                                         const float *__restrict__ qW, const float *__restrict__ a,
+                                                         const float *__restrict__ b, const float *__restrict__ M,
+                                                         const float *__restrict__ cW, const float *__restrict__ coord,
+                                                         const int *__restrict__ idx, float *__restrict__ W1,
+                                                         float *__restrict__ part) {
+    __shared__ float s_w[WPB][2 * G];
+    const long long rows = (long long)n * k;
+    float t1[G], t2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t1[g] = t2[g] = 0.f;
+    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows; row += (long long)gridDim.x * TPB) {
+        const int nn = (int)(row / k);
+        const Rel r = rel_pos(coord, idx, row, nn);
+        float acc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float kv = r.src >= 0 ? kW[(long long)r.src * G + g] : 0.f;
+            acc[g] = (kv - qW[(long long)nn * G + g]) + cW[g];
+        }
+        for (int ci = 0; ci < c; ++ci) {  // wave-uniform operands: a, b, M
+            const float p = pe_act(a[3 * ci], a[3 * ci + 1], a[3 * ci + 2], b[ci], r.x, r.y, r.z);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_fmaf(p, M[ci * G + g], acc[g]);
+        }
+        float *o = W1 + row * G;
+        if (G % 4 == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g += 4) *(float4 *)(o + g) = make_float4(acc[g], acc[g + 1], acc[g + 2], acc[g + 3]);
+        } else if (G % 2 == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g += 2) *(float2 *)(o + g) = make_float2(acc[g], acc[g + 1]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) o[g] = acc[g];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            t1[g] += acc[g];
+            t2[g] = __builtin_fmaf(acc[g], acc[g], t2[g]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float v1 = wave_sum(t1[g]), v2 = wave_sum(t2[g]);
+        if ((threadIdx.x & 63) == 0) {
+            s_w[threadIdx.x >> 6][g] = v1;
+            s_w[threadIdx.x >> 6][G + g] = v2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+        float v = 0.f;
+        for (int w = 0; w < WPB; ++w) v += s_w[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 2 * G + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------- aggregate forward --
+// LDS layout helpers shared with the backward kernel (gva_bwd.hip).
+struct AggLds {
+    // GP: padded (odd) row length of [row][g] images -> lanes that walk rows hit distinct banks
+    __host__ __device__ static constexpr int gp(int G) { return (G | 1) + ((G & 1) ? 2 : 0); }  // odd, >= G+1
+    __host__ __device__ static constexpr int G4(int G) { return (G + 3) & ~3; }
+    __host__ __device__ static constexpr size_t r4(size_t v) { return (v + 3) & ~(size_t)3; }
+    __host__ __device__ static constexpr size_t ab_off(int G) { return r4((size_t)G * gp(G) * 2 + 3 * (size_t)G); }
+    __host__ __device__ static constexpr size_t block_floats(int G, int C) { return ab_off(G) + 4 * (size_t)C; }
+    __host__ __device__ static constexpr size_t wave_floats(int G, int K) {
+        return r4((size_t)K * 4 + K + (size_t)K * gp(G) * 2 + (size_t)K * G4(G));
+    }
+};
+
+template <int G>
+__global__ __launch_bounds__(TPB) void aggregate_fwd_kernel(int n, int k, int c, const float *__restrict__ W1,
+                                                            const float *__restrict__ sc, const float *__restrict__ sh,
+                                                            const float *__restrict__ Ww2, const float *__restrict__ bw2,
+                                                            const float *__restrict__ v, const float *__restrict__ a,
+                                                            const float *__restrict__ b, const float *__restrict__ coord,
+                                                            const int *__restrict__ idx, float *__restrict__ out_v,
+                                                            float *__restrict__ A, float *__restrict__ sw) {
+    extern __shared__ float4 lds4[];
+    float *lds = (float *)lds4;
+    constexpr int GP = AggLds::gp(G);
+    constexpr int G4 = AggLds::G4(G);
+    // block-shared images
+    float *sWw2 = lds;                     // [G][GP]   Ww2[g][g']
+    float *sBw2 = sWw2 + G * GP * 2;       // (second G*GP slab is used by the backward kernel only)
+    float *sSc = sBw2 + G;
+    float *sSh = sSc + G;
+    float4 *sAB = (float4 *)(lds + AggLds::ab_off(G));  // [C] (a.x, a.y, a.z, b)
+    // per-wave images
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float *wbase = (float *)(sAB + c) + (size_t)wid * AggLds::wave_floats(G, k);
+    float4 *sPos = (float4 *)wbase;                 // [K] (x,y,z,valid)
+    int *sSrc = (int *)(wbase + 4 * k);             // [K]
+    float *sY = wbase + 5 * k;                      // [K][GP]
+    float *sW = sY + (size_t)k * GP * 2;            // [K][G4]  (second K*GP slab: backward only)
+
+    for (int i = threadIdx.x; i < G * G; i += TPB) sWw2[(i / G) * GP + (i % G)] = Ww2[i];
+    for (int i = threadIdx.x; i < G; i += TPB) { sBw2[i] = bw2[i]; sSc[i] = sc[i]; sSh[i] = sh[i]; }
+    for (int i = threadIdx.x; i < c; i += TPB) sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
+    __syncthreads();
+
+    const int I = c / G;
+    const int items = G * k;
+    const int npts_per_iter = gridDim.x * WPB;
+    const int iters = (n + npts_per_iter - 1) / npts_per_iter;
+    for (int it = 0; it < iters; ++it) {
+        const int pt = (it * gridDim.x + blockIdx.x) * WPB + wid;
+        const bool live = pt < n;
+        // P0: neighbour slots
+        if (live && lane < k) {
+            Rel r = rel_pos(coord, idx, (long long)pt * k + lane, pt);
+            sPos[lane] = make_float4(r.x, r.y, r.z, r.src >= 0 ? 1.f : 0.f);
+            sSrc[lane] = r.src;
+        }
+        // P1: y = ReLU(sc * W1 + sh)
+        if (live)
+            for (int item = lane; item < items; item += WAVE) {
+                int s = item / G, g = item - s * G;  // W1 is [s][g] contiguous: coalesced read
+                float u = W1[(long long)pt * items + item];
+                sY[s * GP + g] = fmaxf(__builtin_fmaf(sc[g], u, sh[g]), 0.f);
+            }
+        __syncthreads();
+        // P2: z = y Ww2^T + bw2 ; softmax over s (k-lane groups) ; mask ; sw
+        if (live)
+            for (int base = 0; base < items; base += WAVE) {
+                const int item = base + lane;
+                const bool act = item < items;
+                const int g = act ? item / k : 0, s = act ? item - g * k : 0;
+                float z = sBw2[g];
+                const float *yr = sY + s * GP, *wr = sWw2 + g * GP;
+                for (int j = 0; j < G; ++j) z = __builtin_fmaf(yr[j], wr[j], z);
+                float mx = z;
+                for (int o = k >> 1; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
+                float e = expf(z - mx);
+                float den = e;
+                for (int o = k >> 1; o >= 1; o >>= 1) den += __shfl_xor(den, o, WAVE);
+                float w = (e / den) * sPos[s].w;
+                float tot = w;
+                for (int o = k >> 1; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, WAVE);
+                if (act) {
+                    sW[s * G4 + g] = w;
+                    if (s == 0) sw[(long long)pt * G + g] = tot;
+                }
+            }
+        __syncthreads();
+        // P3: channel phase
+        if (live)
+            for (int ch = lane; ch < c; ch += WAVE) {
+                const int gl = ch / I;
+                const float4 ab = sAB[ch];
+                float accA[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) accA[g] = 0.f;
+                float ov = 0.f;
+                for (int s = 0; s < k; ++s) {
+                    const float4 ps = sPos[s];
+                    const int src = sSrc[s];
+                    const float p = pe_act(ab.x, ab.y, ab.z, ab.w, ps.x, ps.y, ps.z);
+                    const float *wrow = sW + s * G4;
+                    if (src >= 0) ov = __builtin_fmaf(wrow[gl], v[(long long)src * c + ch], ov);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) accA[g] = __builtin_fmaf(wrow[g], p, accA[g]);
+                }
+                out_v[(long long)pt * c + ch] = ov;
+#pragma unroll
+                for (int g = 0; g < G; ++g) A[((long long)g * n + pt) * c + ch] = accA[g];
+            }
+        __syncthreads();
+    }
+}
+
+inline int stage_grid(long long work_items, int per_block) {
+    long long b = (work_items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 256 * 8 ? 256 * 8 : b));
+}
+
+inline bool pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
+
+}  // namespace gva
+
+using namespace gva;
+
+extern "C" size_t gva_workspace_bytes(int n, int k, int c, int g) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
+    // [per-block partial sums of the widest stage][one (n,k,g) fp32 row buffer: gWt / w]
+    return rows_offset_bytes(c, g) + align_up(sizeof(float) * (size_t)n * k * g) + 1024;
+}
+
+extern "C" int gva_pos_stats_hip_launcher(int n, int k, const float *coord, const int *idx, double *s1, double *s2,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 0 || k < 1) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < sizeof(float) * 9 * 2048) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    int nblk = stage_grid((long long)n * k, TPB * 4);
+    hipLaunchKernelGGL(pos_stats_kernel, dim3(nblk), dim3(TPB), 0, st, n, k, coord, idx, part);
+    hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)part, nblk, s1, s2);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+#define GVA_DISPATCH_G(g, CALL)            \
+    switch (g) {                           \
+        case 6: { CALL(6); break; }        \
+        case 12: { CALL(12); break; }      \
+        case 24: { CALL(24); break; }      \
+        case 48: { CALL(48); break; }      \
+        case 64: { CALL(64); break; }      \
+        default: return PTV2_ERR_ARG;      \
+    }
+
+extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
+                                               const float *a, const float *b, const float *M, const float *cW,
+                                               const float *coord, const int *idx, float *W1, double *T1, double *T2,
+                                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < gva_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    const int nblk = stage_grid((long long)n * k, TPB * 2);
+#define CALL(GG)                                                                                                  \
+    hipLaunchKernelGGL(logits_fwd_kernel<GG>, dim3(nblk), dim3(TPB), 0, st, n, k, c, kW, qW, a, b, M, cW, coord, idx, \
+                       W1, part)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    // part is [nblk][2g]: columns 0..g-1 -> T1, g..2g-1 -> T2 (contiguous in the reduced vector)
+    hipLaunchKernelGGL(reduce_partials2_kernel<double>, dim3(divup(2 * g, 64)), dim3(64), 0, st, (const float *)part,
+                       nblk, g, g, T1, T2);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                                  const float *sh, const float *Ww2, const float *bw2, const float *v,
+                                                  const float *a, const float *b, const float *coord, const int *idx,
+                                                  float *out_v, float *A, float *sw, void *stream) {
+    if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds_bytes = sizeof(float) * (AggLds::block_floats(g, c) + WPB * AggLds::wave_floats(g, k));
+    if (lds_bytes > 160 * 1024) return PTV2_ERR_ARG;
+    const int nblk = stage_grid(n, WPB);
+#define CALL(GG)                                                                                                   \
+    if (lds_bytes > 48 * 1024)                                                                                     \
+        (void)hipFuncSetAttribute((const void *)aggregate_fwd_kernel<GG>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            (int)lds_bytes);                                                                       \
+    hipLaunchKernelGGL(aggregate_fwd_kernel<GG>, dim3(nblk), dim3(TPB), lds_bytes, st, n, k, c, W1, sc, sh, Ww2, bw2, v, \
+                       a, b, coord, idx, out_v, A, sw)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -1,0 +1,294 @@
+"""Fused grouped vector attention (GVA) for PT-v2m2 on MI355X.
+
+The reference evaluates GroupedVectorAttention.forward (point_transformer_v2m2_base.py:103-129)
+as ~25 eager ops that each stream an (N,K,C) fp32 tensor, including a dense (N*K,C)x(C,C) GEMM for
+the positional-encoding bias.  Here the same function is re-associated so that nothing of size
+N*K*C is ever materialised and the only per-neighbour tensors are of size N*K*G (G = C/8):
+
+  pos[n,s]   = mask * (coord[idx[n,s]] - coord[n])
+  P[n,s,:]   = ReLU(BN_p(pos Wp1^T + bp1))        = ReLU(pos a^T + b)      (BN_p folded, see below)
+  peb[n,s,:] = P Wp2^T + bp2                                               (never formed)
+  W1[n,s,:]  = (k[idx]*mask - q[n] + peb) Ww1^T + bw1
+             = kW[idx]*mask - qW[n] + P M + cW,   kW = k Ww1^T, qW = q Ww1^T (N,G),
+                                                  M = (Ww1 Wp2)^T (C,G), cW = Ww1 bp2 + bw1
+  w          = mask * softmax_s( ReLU(BN_w(W1)) Ww2^T + bw2 )
+  out[n,c]   = sum_s w[n,s,g(c)] (v[idx[n,s],c]*mask + peb[n,s,c])
+             = out_v[n,c] + sum_c' A[g(c),n,c'] Wp2[c,c'] + bp2[c] sw[n,g(c)],
+               A[g,n,:] = sum_s w[n,s,g] P[n,s,:],  sw[n,g] = sum_s w[n,s,g]
+
+BN_p (training) needs the batch statistics of pos Wp1^T + bp1 over all N*K rows; they follow in closed
+form from the mean (3) and covariance (3x3) of pos, which depend on the neighbour table only and are
+computed once per table by a HIP reduction.  BN_w statistics come out of the logits kernel as per-
+channel sums.  All dense products (kW, qW, M, the grouped A x Wp2 product) stay in torch on rocBLAS;
+autograd composes the two HIP stages (`logits`, `aggregate`) with them, which also yields the exact
+BatchNorm backward through the batch statistics.
+"""
+import torch
+
+from .. import _lib
+from ..profiling import clock
+
+_SIG = {
+    "gva_pos_stats_hip_launcher": (_lib._c_int, [_lib._c_int] * 2 + [_lib._vp] * 5 + [_lib._c_size, _lib._vp]),
+    "gva_logits_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 12 + [_lib._c_size, _lib._vp]),
+    "gva_logits_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 18 + [_lib._c_size, _lib._vp]),
+    "gva_aggregate_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 13 + [_lib._vp]),
+    "gva_aggregate_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 24 + [_lib._c_size, _lib._vp]),
+    "gva_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
+}
+_lib.register(_SIG)
+
+
+# ------------------------------------------------------------------ HIP stages --
+class _HipImpl:
+    """The product implementation: three launcher families of ao_amd/csrc/gva.hip."""
+
+    @staticmethod
+    def pos_stats(coord, idx):
+        _lib.require_cuda(coord, idx)
+        n, k = idx.shape
+        s1 = torch.empty(3, dtype=torch.float64, device=coord.device)
+        s2 = torch.empty(9, dtype=torch.float64, device=coord.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_workspace_bytes(n, k, 8, 1), coord.device)
+        rc = L.gva_pos_stats_hip_launcher(n, k, coord.data_ptr(), idx.data_ptr(), s1.data_ptr(), s2.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "gva_pos_stats_hip_launcher")
+        return s1, s2.view(3, 3)
+
+    @staticmethod
+    def logits(kW, qW, a, b, M, cW, coord, idx):
+        return _Logits.apply(kW, qW, a, b, M, cW, coord, idx)
+
+    @staticmethod
+    def aggregate(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx):
+        return _Aggregate.apply(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx)
+
+
+def _f32c(t):
+    return t.detach().float().contiguous()
+
+
+def inverse_table(idx):
+    """CSR inverse of the neighbour table: for every point j the slots r = n*K + s with idx[r] == j, in
+    ascending r (inv_ptr (N+1,) int32, inv_rows int32).  Depends on the table only -> cached on it; the
+    backward kernels use it to turn scatter-adds into fixed-order gathers (no float atomics)."""
+    cached = getattr(idx, "_ao_inverse", None)
+    if cached is not None and cached[0] == idx._version:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        flat = idx.reshape(-1)
+        inv_rows = torch.sort(flat, stable=True)[1].int().contiguous()  # slots ordered by target, -1 first
+        counts = torch.bincount((flat + 1).long(), minlength=idx.shape[0] + 1)  # bin 0 = the -1 placeholders
+        inv_ptr = torch.cumsum(counts, 0).int().contiguous()  # (N+1,): list of j is [inv_ptr[j], inv_ptr[j+1])
+    try:
+        idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
+    except AttributeError:
+        pass
+    return inv_ptr, inv_rows
+
+
+class _Logits(torch.autograd.Function):
+    """W1 (N,K,G) and its per-channel sums; see module docstring."""
+
+    @staticmethod
+    def forward(ctx, kW, qW, a, b, M, cW, coord, idx):
+        _lib.require_cuda(kW, qW, a, b, M, cW, coord, idx)
+        kW, qW, a, b, M, cW = (_f32c(t) for t in (kW, qW, a, b, M, cW))
+        n, k = idx.shape
+        c, g = M.shape
+        dev = kW.device
+        W1 = torch.empty((n, k, g), dtype=torch.float32, device=dev)
+        T1 = torch.empty(g, dtype=torch.float64, device=dev)
+        T2 = torch.empty(g, dtype=torch.float64, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
+        with clock.region("gva_logits_fwd", 4 * (n * (2 * g + 3 + k) + n * k * g)):
+            rc = L.gva_logits_forward_hip_launcher(
+                n, k, c, g, kW.data_ptr(), qW.data_ptr(), a.data_ptr(), b.data_ptr(), M.data_ptr(), cW.data_ptr(),
+                coord.data_ptr(), idx.data_ptr(), W1.data_ptr(), T1.data_ptr(), T2.data_ptr(), ws.data_ptr(),
+                ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "gva_logits_forward_hip_launcher")
+        inv_ptr, inv_rows = inverse_table(idx) if any(ctx.needs_input_grad) else (None, None)
+        ctx.save_for_backward(a, b, M, coord, idx, W1, inv_ptr, inv_rows)
+        return W1, T1, T2
+
+    @staticmethod
+    def backward(ctx, gW1, gT1, gT2):
+        a, b, M, coord, idx, W1, inv_ptr, inv_rows = ctx.saved_tensors
+        n, k = idx.shape
+        c, g = M.shape
+        dev = W1.device
+        gW1 = torch.zeros_like(W1) if gW1 is None else gW1.contiguous()
+        gT1 = torch.zeros(g, dtype=torch.float64, device=dev) if gT1 is None else gT1.contiguous()
+        gT2 = torch.zeros(g, dtype=torch.float64, device=dev) if gT2 is None else gT2.contiguous()
+        gkW = torch.zeros((n, g), dtype=torch.float32, device=dev)
+        gqW = torch.empty((n, g), dtype=torch.float32, device=dev)
+        ga = torch.empty((c, 3), dtype=torch.float32, device=dev)
+        gb = torch.empty(c, dtype=torch.float32, device=dev)
+        gM = torch.empty((c, g), dtype=torch.float32, device=dev)
+        gcW = torch.empty(g, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
+        with clock.region("gva_logits_bwd", 4 * (n * (2 * g + 3 + k) + 2 * n * k * g)):
+            rc = L.gva_logits_backward_hip_launcher(
+                n, k, c, g, a.data_ptr(), b.data_ptr(), M.data_ptr(), coord.data_ptr(), idx.data_ptr(),
+                W1.data_ptr(), gW1.data_ptr(), gT1.data_ptr(), gT2.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(),
+                gkW.data_ptr(), gqW.data_ptr(),
+                ga.data_ptr(), gb.data_ptr(), gM.data_ptr(), gcW.data_ptr(), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr())
+        _lib.check(rc, "gva_logits_backward_hip_launcher")
+        return gkW, gqW, ga, gb, gM, gcW, None, None
+
+
+class _Aggregate(torch.autograd.Function):
+    """(out_v (N,C), A (G,N,C), sw (N,G)); see module docstring."""
+
+    @staticmethod
+    def forward(ctx, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx):
+        _lib.require_cuda(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx)
+        W1, sc, sh, Ww2, bw2, v, a, b = (_f32c(t) for t in (W1, sc, sh, Ww2, bw2, v, a, b))
+        n, k = idx.shape
+        c = v.shape[1]
+        g = sc.shape[0]
+        dev = v.device
+        out_v = torch.empty((n, c), dtype=torch.float32, device=dev)
+        A = torch.empty((g, n, c), dtype=torch.float32, device=dev)
+        sw = torch.empty((n, g), dtype=torch.float32, device=dev)
+        with clock.region("gva_aggregate_fwd", 4 * (n * k * g + n * (2 * c + k + 3 + g) + g * n * c)):
+            rc = _lib.lib().gva_aggregate_forward_hip_launcher(
+                n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
+                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), out_v.data_ptr(), A.data_ptr(),
+                sw.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "gva_aggregate_forward_hip_launcher")
+        inv_ptr, inv_rows = inverse_table(idx) if any(ctx.needs_input_grad) else (None, None)
+        ctx.save_for_backward(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows)
+        return out_v, A, sw
+
+    @staticmethod
+    def backward(ctx, g_out, g_A, g_sw):
+        W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows = ctx.saved_tensors
+        n, k = idx.shape
+        c = v.shape[1]
+        g = sc.shape[0]
+        dev = v.device
+        g_out = torch.zeros((n, c), dtype=torch.float32, device=dev) if g_out is None else g_out.contiguous()
+        g_A = torch.zeros((g, n, c), dtype=torch.float32, device=dev) if g_A is None else g_A.contiguous()
+        g_sw = torch.zeros((n, g), dtype=torch.float32, device=dev) if g_sw is None else g_sw.contiguous()
+        gW1 = torch.empty_like(W1)
+        gv = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        gsc = torch.empty(g, dtype=torch.float32, device=dev)
+        gsh = torch.empty(g, dtype=torch.float32, device=dev)
+        gWw2 = torch.empty((g, g), dtype=torch.float32, device=dev)
+        gbw2 = torch.empty(g, dtype=torch.float32, device=dev)
+        ga = torch.empty((c, 3), dtype=torch.float32, device=dev)
+        gb = torch.empty(c, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
+        with clock.region("gva_aggregate_bwd", 4 * (2 * n * k * g + n * (3 * c + k + 3 + 2 * g) + g * n * c)):
+            rc = L.gva_aggregate_backward_hip_launcher(
+                n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
+                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), g_out.data_ptr(), g_A.data_ptr(),
+                g_sw.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(), gW1.data_ptr(), gsc.data_ptr(), gsh.data_ptr(),
+                gWw2.data_ptr(), gbw2.data_ptr(),
+                gv.data_ptr(), ga.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "gva_aggregate_backward_hip_launcher")
+        return gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, None, None
+
+
+def supported(channels, groups, k):
+    """Shapes the fused kernels are instantiated for (gva_fwd.hip / gva_bwd.hip); anything else runs the
+    unfused composition of gather ops."""
+    i = channels // groups
+    return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i & (i - 1) == 0 and i <= 64
+            and k & (k - 1) == 0 and 2 <= k <= 64)
+
+
+# -------------------------------------------------------------------- host logic --
+def _pos_moments(impl, coord, idx):
+    """(mu (3,), cov (3,3)) of the masked relative positions, float64; cached on the idx tensor because
+    every block of a BlockSequence (and the decoder stage at the same resolution) shares the table."""
+    cached = getattr(idx, "_ao_pos_moments", None)
+    if cached is not None and cached[0] == (coord.data_ptr(), idx._version):
+        return cached[1], cached[2]
+    with torch.no_grad():
+        s1, s2 = impl.pos_stats(coord, idx)
+        rows = idx.shape[0] * idx.shape[1]
+        mu = s1 / rows
+        cov = s2 / rows - torch.outer(mu, mu)
+    try:
+        idx._ao_pos_moments = ((coord.data_ptr(), idx._version), mu, cov)
+    except AttributeError:
+        pass
+    return mu, cov
+
+
+def _bn_update(bn, mean, var_biased, rows):
+    """Running-statistics update of nn.BatchNorm1d in training mode (momentum form)."""
+    if not bn.track_running_stats or bn.running_mean is None:
+        return
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        unbiased = var_biased * (rows / max(rows - 1, 1))
+        bn.running_mean.mul_(1 - m).add_(mean.detach().to(bn.running_mean.dtype), alpha=m)
+        bn.running_var.mul_(1 - m).add_(unbiased.detach().to(bn.running_var.dtype), alpha=m)
+
+
+def grouped_vector_attention(mod, query, key, value, coord, reference_index, impl=None):
+    """mod: GroupedVectorAttention (pe_bias=True, pe_multiplier=False); query/key/value (N,C) are the outputs
+    of mod.linear_q / linear_k / linear_v.  Returns (N,C).  `impl` swaps the three device stages
+    (tests pass a torch restatement to check this host logic on CPU)."""
+    impl = impl or _HipImpl
+    C, G = mod.embed_channels, mod.groups
+    I = C // G
+    idx = reference_index.contiguous()
+    N, K = idx.shape
+    rows = N * K
+    coord = coord.contiguous()
+    query, key, value = query.float(), key.float(), value.float()
+    lin_p1, bn_p, lin_p2 = mod.linear_p_bias[0], mod.linear_p_bias[1].norm, mod.linear_p_bias[3]
+    lin_w1, bn_w, lin_w2 = mod.weight_encoding[0], mod.weight_encoding[1].norm, mod.weight_encoding[3]
+    training_stats = mod.training or not bn_p.track_running_stats
+
+    # -- BN_p folded into an affine map of pos: P = ReLU(pos a^T + b) -----------------------------
+    Wp1, bp1 = lin_p1.weight.float(), lin_p1.bias.float()
+    if training_stats:
+        mu, cov = _pos_moments(impl, coord, idx)
+        mu32, cov32 = mu.float(), cov.float()
+        mean_p = Wp1 @ mu32 + bp1
+        var_p = ((Wp1 @ cov32) * Wp1).sum(1).clamp_min(0)
+        if mod.training:
+            _bn_update(bn_p, mean_p, var_p, rows)
+    else:
+        mean_p, var_p = bn_p.running_mean.float(), bn_p.running_var.float()
+    scale_p = bn_p.weight.float() * torch.rsqrt(var_p + bn_p.eps)
+    a = Wp1 * scale_p.unsqueeze(1)
+    b = (bp1 - mean_p) * scale_p + bn_p.bias.float()
+
+    # -- logits: W1 = kW[idx] - qW + P M + cW ------------------------------------------------------
+    Wp2, bp2 = lin_p2.weight.float(), lin_p2.bias.float()
+    Ww1, bw1 = lin_w1.weight.float(), lin_w1.bias.float()
+    M = (Ww1 @ Wp2).t()
+    cW = Ww1 @ bp2 + bw1
+    kW = key @ Ww1.t()
+    qW = query @ Ww1.t()
+    W1, T1, T2 = impl.logits(kW, qW, a, b, M, cW, coord, idx)
+
+    # -- BN_w from the per-channel sums of W1 --------------------------------------------------------
+    if mod.training or not bn_w.track_running_stats:
+        mean_w = T1 / rows
+        var_w = (T2 / rows - mean_w * mean_w).clamp_min(0)
+        if mod.training:
+            _bn_update(bn_w, mean_w, var_w, rows)
+    else:
+        mean_w, var_w = bn_w.running_mean.double(), bn_w.running_var.double()
+    sc64 = bn_w.weight.double() * torch.rsqrt(var_w + bn_w.eps)
+    sh64 = bn_w.bias.double() - mean_w * sc64
+    sc, sh = sc64.float(), sh64.float()
+
+    # -- softmax over neighbours, aggregation of v and of the folded positional bias ---------------
+    out_v, A, sw = impl.aggregate(W1, sc, sh, lin_w2.weight.float(), lin_w2.bias.float(), value, a, b, coord, idx)
+    peb = torch.bmm(A, Wp2.view(G, I, C).transpose(1, 2))            # (G,N,I)
+    out = out_v + peb.permute(1, 0, 2).reshape(N, C) + (sw.unsqueeze(-1) * bp2.view(1, G, I)).reshape(N, C)
+    return out

@@ -90,12 +90,13 @@ class GroupedVectorAttention(nn.Module):
 
     def forward(self, feat, coord, reference_index):
         query, key, value = self.linear_q(feat), self.linear_k(feat), self.linear_v(feat)
-        mode = os.environ.get("AO_AMD_GVA", "unfused")
+        mode = os.environ.get("AO_AMD_GVA", "fused")
         fusable = self.pe_bias and not self.pe_multiplier and (self.attn_drop_rate == 0.0 or not self.training)
         if mode == "fused" and fusable:
             from . import gva
 
-            return gva.grouped_vector_attention(self, query, key, value, coord, reference_index)
+            if gva.supported(self.embed_channels, self.groups, reference_index.shape[1]):
+                return gva.grouped_vector_attention(self, query, key, value, coord, reference_index)
         return self.gva_unfused(query, key, value, coord, reference_index)
 
 

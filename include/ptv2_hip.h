@@ -151,6 +151,55 @@ int attention_fusion_step_backward_hip_launcher(int m, int g, int c, const float
                                                 const int *index_refer, const float *grad_output,
                                                 void *stream);
 
+/* ------------------------------------------- fused grouped vector attention --
+ * Replaces the eager op sequence of GroupedVectorAttention.forward
+ *   (pointcept/models/point_transformer_v2/point_transformer_v2m2_base.py:109-128: two
+ *   pointops.grouping calls, linear_p_bias, weight_encoding, softmax, mask, einsum) -- the
+ *   "grouped-vector-attention kernel" of BASELINE.json -- with two device stages around
+ *   which the host keeps the dense products on rocBLAS (ao_amd/ptv2/gva.py has the algebra).
+ * n points, k neighbour slots (power of two <= 64 for the aggregate stage), c channels,
+ * g groups (6, 12, 24, 48 or 64), i = c / g.  idx (n,k) int32 with -1 placeholders, coord (n,3).
+ *   a (c,3), b (c):   folded Linear(3,c)+BatchNorm of linear_p_bias:  P = ReLU(pos a^T + b)
+ *   M (c,g), cW (g):  (Ww1 Wp2)^T and Ww1 bp2 + bw1
+ *   kW, qW (n,g):     key / query projected by weight_encoding[0]
+ * All reductions are per-block partial sums followed by a fixed-order final sum (bitwise
+ * reproducible; no float atomics).  workspace: gva_workspace_bytes(n,k,c,g) bytes.
+ */
+size_t gva_workspace_bytes(int n, int k, int c, int g);
+/* s1[3] = sum pos, s2[9] = sum pos pos^T over all n*k slots (float64, device) */
+int gva_pos_stats_hip_launcher(int n, int k, const float *coord, const int *idx, double *s1,
+                               double *s2, void *workspace, size_t workspace_bytes, void *stream);
+/* W1 (n,k,g) = kW[idx]*mask - qW + P M + cW ; T1[g] = sum W1, T2[g] = sum W1^2 (float64) */
+int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
+                                    const float *a, const float *b, const float *M, const float *cW,
+                                    const float *coord, const int *idx, float *W1, double *T1,
+                                    double *T2, void *workspace, size_t workspace_bytes, void *stream);
+/* inverse neighbour table (optional, may be NULL): inv_ptr (n+1), inv_rows: for point j the slots
+ * r = n'*k + s with idx[r] == j are inv_rows[inv_ptr[j] .. inv_ptr[j+1]) in ascending r.  With it the
+ * scatter-adds (grad kW, grad v) are fixed-order gathers; without it they fall back to float atomics. */
+/* given gW1 (n,k,g), gT1, gT2 (g, float64): gkW (n,g) [zeroed], gqW (n,g), ga (c,3), gb (c), gM (c,g), gcW (g) */
+int gva_logits_backward_hip_launcher(int n, int k, int c, int g, const float *a, const float *b,
+                                     const float *M, const float *coord, const int *idx,
+                                     const float *W1, const float *gW1, const double *gT1,
+                                     const double *gT2, const int *inv_ptr, const int *inv_rows,
+                                     float *gkW, float *gqW, float *ga, float *gb, float *gM, float *gcW,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+/* w = mask * softmax_s(ReLU(sc*W1+sh) Ww2^T + bw2); out_v (n,c) = sum_s w v[idx]; A (g,n,c) = sum_s w P; sw (n,g) = sum_s w */
+int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                       const float *sh, const float *Ww2, const float *bw2,
+                                       const float *v, const float *a, const float *b,
+                                       const float *coord, const int *idx, float *out_v, float *A,
+                                       float *sw, void *stream);
+/* given g_out (n,c), g_A (g,n,c), g_sw (n,g): gW1 (n,k,g), gsc, gsh (g), gWw2 (g,g), gbw2 (g), gv (n,c) [zeroed], ga (c,3), gb (c) */
+int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                        const float *sh, const float *Ww2, const float *bw2,
+                                        const float *v, const float *a, const float *b,
+                                        const float *coord, const int *idx, const float *g_out,
+                                        const float *g_A, const float *g_sw, const int *inv_ptr,
+                                        const int *inv_rows, float *gW1, float *gsc, float *gsh,
+                                        float *gWw2, float *gbw2, float *gv, float *ga, float *gb,
+                                        void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

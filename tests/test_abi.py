@@ -20,6 +20,7 @@ def declared_symbols():
 @pytest.fixture(scope="module")
 def lib():
     from ao_amd import _lib
+    import ao_amd.ptv2.gva  # noqa: F401  (registers the fused-attention entry points)
 
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()

@@ -1,0 +1,109 @@
+"""GPU: each device stage of the fused GVA (ao_amd/csrc/gva_*.hip, through ao_amd/ptv2/gva.py's autograd
+Functions) against the plain-torch statement of the same stage (tests/gva_torch_ref.py) on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from tests import synth
+from tests.gva_torch_ref import TorchImpl
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(48, 6, 16, 3000), (96, 12, 16, 1500), (192, 24, 16, 700), (384, 48, 16, 300), (48, 6, 8, 1000),
+          (512, 64, 16, 130)]
+
+
+def make(c, g, k, n, seed=0):
+    from ao_amd import pointops
+
+    torch.manual_seed(seed)
+    xyz = torch.from_numpy(synth.room_cloud(n, seed=seed)).cuda()
+    off = torch.tensor([n // 3, n], dtype=torch.int32).cuda()
+    idx, _ = pointops.knn_query(k, xyz, off)
+    idx = idx.clone()
+    idx[2::7, k - 2:] = -1
+    return xyz, idx
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, name=""):
+    a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    err = np.abs(a - b).max()
+    assert err <= atol * max(1.0, scale) + rtol * scale, (name, err, scale)
+
+
+@pytest.mark.parametrize("c,g,k,n", SHAPES)
+def test_pos_stats_and_logits(c, g, k, n):
+    from ao_amd.ptv2.gva import _HipImpl
+
+    xyz, idx = make(c, g, k, n)
+    s1, s2 = _HipImpl.pos_stats(xyz, idx)
+    r1, r2 = TorchImpl.pos_stats(xyz, idx)
+    close(s1, r1, 1e-5, 1e-6, "s1")
+    close(s2, r2, 1e-5, 1e-6, "s2")
+    args = [torch.randn(n, g), torch.randn(n, g), torch.randn(c, 3) * 3, torch.randn(c) * 0.3,
+            torch.randn(c, g) * 0.2, torch.randn(g)]
+    args = [t.cuda().requires_grad_(True) for t in args]
+    W1, T1, T2 = _HipImpl.logits(*args, xyz, idx)
+    rW1, rT1, rT2 = TorchImpl.logits(*args, xyz, idx)
+    close(W1, rW1, name="W1")
+    close(T1, rT1, 1e-5, 1e-6, "T1")
+    close(T2, rT2, 1e-5, 1e-6, "T2")
+
+
+@pytest.mark.parametrize("c,g,k,n", SHAPES)
+def test_aggregate_forward(c, g, k, n):
+    from ao_amd.ptv2.gva import _HipImpl
+
+    xyz, idx = make(c, g, k, n, seed=1)
+    args = [torch.randn(n, k, g), torch.rand(g) + 0.5, torch.randn(g) * 0.3, torch.randn(g, g) * 0.5, torch.randn(g),
+            torch.randn(n, c), torch.randn(c, 3) * 3, torch.randn(c) * 0.3]
+    args = [t.cuda() for t in args]
+    out_v, A, sw = _HipImpl.aggregate(*args, xyz, idx)
+    r_out, r_A, r_sw = TorchImpl.aggregate(*args, xyz, idx)
+    close(out_v, r_out, name="out_v")
+    close(A, r_A, name="A")
+    close(sw, r_sw, name="sw")
+
+
+def grads_close(out, ref, ins, gouts, names, rel=2e-3):
+    g1 = torch.autograd.grad(out, ins, gouts, allow_unused=True)
+    g2 = torch.autograd.grad(ref, ins, gouts, allow_unused=True)
+    for n_, a, b in zip(names, g1, g2):
+        a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+        err = np.linalg.norm(a - b)
+        if n_ == "bw2":  # softmax is shift invariant: the true gradient is exactly zero, both sides hold rounding noise
+            assert np.abs(a).max() < 1e-3 and np.abs(b).max() < 1e-3
+            continue
+        assert err <= rel * np.linalg.norm(b) + 1e-5, (n_, err, np.linalg.norm(b))
+        assert np.abs(a - b).max() <= 2e-2 * max(np.abs(b).max(), 1e-6) + 1e-5, (n_, np.abs(a - b).max(), np.abs(b).max())
+
+
+@pytest.mark.parametrize("c,g,k,n", SHAPES)
+def test_logits_backward(c, g, k, n):
+    from ao_amd.ptv2.gva import _HipImpl
+
+    xyz, idx = make(c, g, k, n, seed=2)
+    names = ["kW", "qW", "a", "b", "M", "cW"]
+    ins = [torch.randn(n, g), torch.randn(n, g), torch.randn(c, 3) * 3, torch.randn(c) * 0.3, torch.randn(c, g) * 0.2,
+           torch.randn(g)]
+    ins = [t.cuda().requires_grad_(True) for t in ins]
+    out = _HipImpl.logits(*ins, xyz, idx)
+    ref = TorchImpl.logits(*ins, xyz, idx)
+    gouts = [torch.randn(n, k, g).cuda(), torch.randn(g).double().cuda() * 0.1, torch.randn(g).double().cuda() * 0.01]
+    grads_close(out, ref, ins, gouts, names)
+
+
+@pytest.mark.parametrize("c,g,k,n", SHAPES)
+def test_aggregate_backward(c, g, k, n):
+    from ao_amd.ptv2.gva import _HipImpl
+
+    xyz, idx = make(c, g, k, n, seed=3)
+    names = ["W1", "sc", "sh", "Ww2", "bw2", "v", "a", "b"]
+    ins = [torch.randn(n, k, g), torch.rand(g) + 0.5, torch.randn(g) * 0.3, torch.randn(g, g) * 0.5, torch.randn(g),
+           torch.randn(n, c), torch.randn(c, 3) * 3, torch.randn(c) * 0.3]
+    ins = [t.cuda().requires_grad_(True) for t in ins]
+    out = _HipImpl.aggregate(*ins, xyz, idx)
+    ref = TorchImpl.aggregate(*ins, xyz, idx)
+    gouts = [torch.randn(n, c).cuda(), torch.randn(g, n, c).cuda(), torch.randn(n, g).cuda()]
+    grads_close(out, ref, ins, gouts, names)
