@@ -182,19 +182,16 @@ __global__ __launch_bounds__(TPB) void logits_bwd_params_kernel(int n, int k, in
 }
 
 // final: partials [nblk][c][G+4] -> gM (c,G), ga (c,3), gb (c)
-__global__ void logits_bwd_params_finalize_kernel(const float *__restrict__ part, int nblk, int c, int g,
-                                                  float *__restrict__ gM, float *__restrict__ ga,
-                                                  float *__restrict__ gb) {
-    const int per = g + 4;
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= c * per) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)part[(size_t)b * c * per + e];
-    const int ch = e / per, j = e - ch * per;
-    if (j < g) gM[ch * g + j] = (float)acc;
-    else if (j < g + 3) ga[ch * 3 + (j - g)] = (float)acc;
-    else gb[ch] = (float)acc;
-}
+struct MapLogitsParams {
+    float *gM, *ga, *gb;
+    int g;
+    __device__ void operator()(int e, double v) const {
+        const int per = g + 4, ch = e / per, j = e - ch * per;
+        if (j < g) gM[ch * g + j] = (float)v;
+        else if (j < g + 3) ga[ch * 3 + (j - g)] = (float)v;
+        else gb[ch] = (float)v;
+    }
+};
 
 // ========================================================= aggregate backward ==
 // one wavefront (= one 64-thread workgroup) per point; all LDS images are private to the wave.
@@ -426,25 +423,21 @@ __global__ __launch_bounds__(WAVE) void aggregate_bwd_kernel(
     for (int i = lane; i < 4 * c; i += WAVE) mypart[3 * G + G * G + i] = accAB[i];
 }
 
-__global__ void aggregate_bwd_finalize_kernel(const float *__restrict__ part, int nblk, int c, int g,
-                                              float *__restrict__ gsc, float *__restrict__ gsh,
-                                              float *__restrict__ gWw2, float *__restrict__ gbw2,
-                                              float *__restrict__ ga, float *__restrict__ gb) {
-    const int len = 3 * g + g * g + 4 * c;
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= len) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)part[(size_t)b * len + e];
-    const float v = (float)acc;
-    if (e < g) gsc[e] = v;
-    else if (e < 2 * g) gsh[e - g] = v;
-    else if (e < 3 * g) gbw2[e - 2 * g] = v;
-    else if (e < 3 * g + g * g) gWw2[e - 3 * g] = v;
-    else {
-        const int r = e - 3 * g - g * g, ch = r >> 2, j = r & 3;
-        if (j < 3) ga[ch * 3 + j] = v; else gb[ch] = v;
+struct MapAggParams {  // columns: [gsc G][gsh G][gbw2 G][gWw2 G*G][(ga,gb) C*4]
+    float *gsc, *gsh, *gWw2, *gbw2, *ga, *gb;
+    int g;
+    __device__ void operator()(int e, double acc) const {
+        const float v = (float)acc;
+        if (e < g) gsc[e] = v;
+        else if (e < 2 * g) gsh[e - g] = v;
+        else if (e < 3 * g) gbw2[e - 2 * g] = v;
+        else if (e < 3 * g + g * g) gWw2[e - 3 * g] = v;
+        else {
+            const int r = e - 3 * g - g * g, ch = r >> 2, j = r & 3;
+            if (j < 3) ga[ch * 3 + j] = v; else gb[ch] = v;
+        }
     }
-}
+};
 
 // grad v[j,c] = sum over slots r that point at j of w[r, g(c)] * g_out[r / k, c]
 __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int c, int g,
@@ -501,8 +494,7 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part)
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
-    hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(divup(g, 64)), dim3(64), 0, st, (const float *)part, nb_rows, g,
-                       gcW);
+    launch_finalize(st, (const float *)part, nb_rows, g, MapVec<float>{gcW});
     hipLaunchKernelGGL(logits_bwd_gather_kernel, dim3(stage_grid((long long)n * g, TPB)), dim3(TPB), 0, st, n, k, g,
                        (const float *)gWt, idx, inv_ptr, inv_rows, gkW, gqW);
     // params kernel: its partials go after the rows-kernel partials (still inside the partial region)
@@ -518,8 +510,7 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
                        (const float *)gWt, ppart)
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
-    hipLaunchKernelGGL(logits_bwd_params_finalize_kernel, dim3(divup((long long)c * (g + 4), 128)), dim3(128), 0, st,
-                       (const float *)ppart, nb_par, c, g, gM, ga, gb);
+    launch_finalize(st, (const float *)ppart, nb_par, c * (g + 4), MapLogitsParams{gM, ga, gb, g});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -551,8 +542,7 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
     const int len = 3 * g + g * g + 4 * c;
-    hipLaunchKernelGGL(aggregate_bwd_finalize_kernel, dim3(divup(len, 128)), dim3(128), 0, st, (const float *)part, nblk, c,
-                       g, gsc, gsh, gWw2, gbw2, ga, gb);
+    launch_finalize(st, (const float *)part, nblk, len, MapAggParams{gsc, gsh, gWw2, gbw2, ga, gb, g});
     if (inv_ptr)
         hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3(stage_grid((long long)n * c, TPB)), dim3(TPB), 0, st, n, k, c, g,
                            (const float *)wbuf, g_out, inv_ptr, inv_rows, gv);

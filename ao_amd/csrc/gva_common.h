@@ -53,26 +53,49 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Sum `len` per-block partial vectors (float) into double or float outputs: out[j] = sum_b part[b*len + j].
-template <typename OutT>
-__global__ void reduce_partials_kernel(const float *__restrict__ part, int nblk, int len, OutT *__restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
+// Fixed-order column sums of a [nblk][len] partial matrix: out(j) = sum_b part[b][j].
+// 64 columns x 16 row slices per 1024-thread block; each thread adds its slice sequentially (coalesced
+// across columns), the 16 slice sums are combined in slice order -> bitwise reproducible.
+// `Map` receives (column, sum) and writes the value wherever the stage wants it.
+constexpr int FIN_COLS = 64, FIN_SLICES = 16;
+
+template <class Map>
+__global__ __launch_bounds__(FIN_COLS *FIN_SLICES) void finalize_kernel(const float *__restrict__ part, int nblk,
+                                                                        int len, Map map) {
+    __shared__ double s_acc[FIN_SLICES][FIN_COLS];
+    const int col = threadIdx.x & (FIN_COLS - 1), sl = threadIdx.x / FIN_COLS;
+    const int j = blockIdx.x * FIN_COLS + col;
     double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)part[(size_t)b * len + j];
-    out[j] = (OutT)acc;
+    if (j < len)
+        for (int b = sl; b < nblk; b += FIN_SLICES) acc += (double)part[(size_t)b * len + j];
+    s_acc[sl][col] = acc;
+    __syncthreads();
+    if (sl == 0 && j < len) {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < FIN_SLICES; ++t) v += s_acc[t][col];
+        map(j, v);
+    }
 }
 
-// Same, split into two outputs: columns [0,len1) -> out1, [len1, len1+len2) -> out2.
-template <typename OutT>
-__global__ void reduce_partials2_kernel(const float *__restrict__ part, int nblk, int len1, int len2,
-                                        OutT *__restrict__ out1, OutT *__restrict__ out2) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int len = len1 + len2;
-    if (j >= len) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)part[(size_t)b * len + j];
-    if (j < len1) out1[j] = (OutT)acc; else out2[j - len1] = (OutT)acc;
+template <class Map>
+inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len, Map map) {
+    hipLaunchKernelGGL(finalize_kernel<Map>, dim3((len + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS * FIN_SLICES), 0, st,
+                       part, nblk, len, map);
 }
+
+template <typename T>
+struct MapVec {  // out[j] = v
+    T *out;
+    __device__ void operator()(int j, double v) const { out[j] = (T)v; }
+};
+template <typename T>
+struct MapSplit2 {  // columns [0,len1) -> out1, rest -> out2
+    T *out1, *out2;
+    int len1;
+    __device__ void operator()(int j, double v) const {
+        if (j < len1) out1[j] = (T)v; else out2[j - len1] = (T)v;
+    }
+};
 
 }  // namespace gva

@@ -40,21 +40,16 @@ __global__ __launch_bounds__(TPB) void pos_stats_kernel(int n, int k, const floa
     }
 }
 
-__global__ void pos_stats_finalize_kernel(const float *__restrict__ part, int nblk, double *s1, double *s2) {
-    __shared__ double s[9];
-    if (threadIdx.x < 9) {
-        double acc = 0.0;
-        for (int b = 0; b < nblk; ++b) acc += (double)part[b * 9 + threadIdx.x];
-        s[threadIdx.x] = acc;
+struct MapPosStats {  // columns: x y z xx xy xz yy yz zz -> s1[3], symmetric s2[9]
+    double *s1, *s2;
+    __device__ void operator()(int j, double v) const {
+        if (j < 3) { s1[j] = v; return; }
+        const int r[6] = {0, 0, 0, 1, 1, 2}, c[6] = {0, 1, 2, 1, 2, 2};
+        const int a = r[j - 3], b = c[j - 3];
+        s2[a * 3 + b] = v;
+        s2[b * 3 + a] = v;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s1[0] = s[0]; s1[1] = s[1]; s1[2] = s[2];
-        s2[0] = s[3]; s2[1] = s[4]; s2[2] = s[5];
-        s2[3] = s[4]; s2[4] = s[6]; s2[5] = s[7];
-        s2[6] = s[5]; s2[7] = s[7]; s2[8] = s[8];
-    }
-}
+};
 
 // ------------------------------------------------------------- logits forward --
 template <int G>
@@ -256,7 +251,7 @@ extern "C" int gva_pos_stats_hip_launcher(int n, int k, const float *coord, cons
     float *part = (float *)workspace;
     int nblk = stage_grid((long long)n * k, TPB * 4);
     hipLaunchKernelGGL(pos_stats_kernel, dim3(nblk), dim3(TPB), 0, st, n, k, coord, idx, part);
-    hipLaunchKernelGGL(pos_stats_finalize_kernel, dim3(1), dim3(64), 0, st, (const float *)part, nblk, s1, s2);
+    launch_finalize(st, (const float *)part, nblk, 9, MapPosStats{s1, s2});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -286,8 +281,7 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
     // part is [nblk][2g]: columns 0..g-1 -> T1, g..2g-1 -> T2 (contiguous in the reduced vector)
-    hipLaunchKernelGGL(reduce_partials2_kernel<double>, dim3(divup(2 * g, 64)), dim3(64), 0, st, (const float *)part,
-                       nblk, g, g, T1, T2);
+    launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

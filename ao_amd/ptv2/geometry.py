@@ -12,7 +12,7 @@ from typing import List, Optional
 
 import torch
 
-from .. import pointops
+from .. import _lib, pointops
 from ..pointops.interpolation import interpolation_index_weight
 
 
@@ -25,6 +25,8 @@ class Level:
     cluster: Optional[torch.Tensor] = None   # (N,) int64: fine point -> coarse point
     order: Optional[torch.Tensor] = None     # (N,) int64: fine points sorted by cluster (stable)
     idx_ptr: Optional[torch.Tensor] = None   # (N'+1,) int64 CSR over `order`
+    order32: Optional[torch.Tensor] = None   # int32 copies for the HIP pooling kernels
+    idx_ptr32: Optional[torch.Tensor] = None
     # link from the next coarser level back to this one ("interp" unpooling)
     up_idx: Optional[torch.Tensor] = None    # (N,3) int32 into the coarser level
     up_weight: Optional[torch.Tensor] = None  # (N,3) fp32
@@ -50,13 +52,25 @@ def offset2batch(offset):
     return torch.repeat_interleave(torch.arange(off.numel(), device=off.device), counts)
 
 
+def segment_minmax(coord, offset):
+    """Per-cloud coordinate (min, max), each (B,3) (ao_amd/csrc/pool.hip)."""
+    _lib.require_cuda(coord, offset)
+    b = offset.numel()
+    lo = torch.empty((b, 3), dtype=torch.float32, device=coord.device)
+    hi = torch.empty((b, 3), dtype=torch.float32, device=coord.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.segment_minmax_hip_workspace_bytes(b), coord.device)
+    rc = L.segment_minmax_hip_launcher(b, coord.data_ptr(), offset.int().contiguous().data_ptr(), lo.data_ptr(),
+                                       hi.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "segment_minmax_hip_launcher")
+    return lo, hi
+
+
 def voxel_cluster_ids(coord, offset, grid_size):
     """Cluster id of GridPool (:246-259): per-cloud min-shifted coords, torch_cluster.grid_cluster
     formula with the batch index as the most significant digit (oracle/ptv2_ref.py:voxel_grid)."""
     batch = offset2batch(offset)
-    nb = offset.numel()
-    start = torch.full((nb, 3), float("inf"), device=coord.device, dtype=coord.dtype)
-    start = start.scatter_reduce(0, batch.view(-1, 1).expand(-1, 3), coord, "amin", include_self=True)
+    start, _ = segment_minmax(coord, offset)
     pos = coord - start[batch]
     size = coord.new_tensor([grid_size, grid_size, grid_size])
     num = (pos.max(0)[0] / size).long() + 1          # voxels per axis over the whole batch
@@ -94,6 +108,7 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
             break
         nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, grid_sizes[i])
         cur.cluster, cur.order, cur.idx_ptr = cluster, order, idx_ptr
+        cur.order32, cur.idx_ptr32 = order.int().contiguous(), idx_ptr.int().contiguous()
         if interp:
             cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
         cur = Level(coord=nc, offset=noff)

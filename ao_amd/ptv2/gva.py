@@ -35,6 +35,8 @@ _SIG = {
     "gva_aggregate_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 13 + [_lib._vp]),
     "gva_aggregate_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 24 + [_lib._c_size, _lib._vp]),
     "gva_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
+    "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
+    "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
 }
 _lib.register(_SIG)
 
@@ -63,6 +65,10 @@ class _HipImpl:
     @staticmethod
     def aggregate(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx):
         return _Aggregate.apply(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx)
+
+    @staticmethod
+    def project(A, Wp2, bp2, sw, out_v):
+        return _PebProject.apply(A, Wp2, bp2, sw, out_v)
 
 
 def _f32c(t):
@@ -200,8 +206,43 @@ def supported(channels, groups, k):
     """Shapes the fused kernels are instantiated for (gva_fwd.hip / gva_bwd.hip); anything else runs the
     unfused composition of gather ops."""
     i = channels // groups
-    return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i & (i - 1) == 0 and i <= 64
+    return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i in (2, 4, 8, 16) and channels % 4 == 0
             and k & (k - 1) == 0 and 2 <= k <= 64)
+
+
+class _PebProject(torch.autograd.Function):
+    """out = out_v + (A x Wp2 per group) + bp2 * sw  (gva_peb.hip); grad Wp2 / bp2 are dense rocBLAS products."""
+
+    @staticmethod
+    def forward(ctx, A, Wp2, bp2, sw, out_v):
+        _lib.require_cuda(A, Wp2, bp2, sw, out_v)
+        A, Wp2, bp2, sw, out_v = (_f32c(t) for t in (A, Wp2, bp2, sw, out_v))
+        g, n, c = A.shape
+        out = torch.empty((n, c), dtype=torch.float32, device=A.device)
+        with clock.region("gva_peb_fwd", 4 * (g * n * c + 2 * n * c + n * g + c * c)):
+            rc = _lib.lib().gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
+                                                         sw.data_ptr(), out_v.data_ptr(), out.data_ptr(),
+                                                         _lib.stream_ptr())
+        _lib.check(rc, "gva_peb_forward_hip_launcher")
+        ctx.save_for_backward(A, Wp2, bp2, sw)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        A, Wp2, bp2, sw = ctx.saved_tensors
+        g, n, c = A.shape
+        i = c // g
+        g_out = g_out.contiguous()
+        g_A = torch.empty_like(A)
+        g_sw = torch.empty_like(sw)
+        with clock.region("gva_peb_bwd", 4 * (g * n * c + n * c + n * g + c * c)):
+            rc = _lib.lib().gva_peb_backward_hip_launcher(n, c, g, g_out.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
+                                                          g_A.data_ptr(), g_sw.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "gva_peb_backward_hip_launcher")
+        go3 = g_out.view(n, g, i)
+        g_Wp2 = torch.bmm(go3.permute(1, 2, 0), A).reshape(c, c)   # (G,I,N) x (G,N,C') : K-dim = N, MFMA-friendly
+        g_bp2 = (go3 * sw.unsqueeze(-1)).sum(0).reshape(c)
+        return g_A, g_Wp2, g_bp2, g_sw, g_out
 
 
 # -------------------------------------------------------------------- host logic --
@@ -289,6 +330,7 @@ def grouped_vector_attention(mod, query, key, value, coord, reference_index, imp
 
     # -- softmax over neighbours, aggregation of v and of the folded positional bias ---------------
     out_v, A, sw = impl.aggregate(W1, sc, sh, lin_w2.weight.float(), lin_w2.bias.float(), value, a, b, coord, idx)
+    if hasattr(impl, "project"):
+        return impl.project(A, Wp2, bp2, sw, out_v)
     peb = torch.bmm(A, Wp2.view(G, I, C).transpose(1, 2))            # (G,N,I)
-    out = out_v + peb.permute(1, 0, 2).reshape(N, C) + (sw.unsqueeze(-1) * bp2.view(1, G, I)).reshape(N, C)
-    return out
+    return out_v + peb.permute(1, 0, 2).reshape(N, C) + (sw.unsqueeze(-1) * bp2.view(1, G, I)).reshape(N, C)

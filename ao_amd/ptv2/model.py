@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import pointops
+from .. import _lib, pointops
 from ..pointops.interpolation import _InterpolateRows
 from .geometry import build_geometry
 
@@ -170,29 +170,33 @@ class BlockSequence(nn.Module):
 
 
 class _SegmentMax(torch.autograd.Function):
-    """Per-cluster channel max over CSR segments of `order` (torch_scatter.segment_csr(reduce="max"),
-    reference :266); the gradient goes to the arg-max row."""
+    """Per-cluster channel max over the CSR segments of `order` (torch_scatter.segment_csr(reduce="max"),
+    reference :266) on ao_amd/csrc/pool.hip; the gradient goes to the arg-max row."""
 
     @staticmethod
-    def forward(ctx, feat, cluster, n_out):
-        idx = cluster.view(-1, 1).expand(-1, feat.shape[1])
-        out = feat.new_full((n_out, feat.shape[1]), float("-inf")).scatter_reduce(0, idx, feat, "amax", include_self=True)
-        ctx.save_for_backward(feat, cluster, out)
+    def forward(ctx, feat, order, idx_ptr):
+        _lib.require_cuda(feat, order, idx_ptr)
+        feat = feat.contiguous()
+        n_out, c = idx_ptr.shape[0] - 1, feat.shape[1]
+        out = torch.empty((n_out, c), dtype=torch.float32, device=feat.device)
+        arg = torch.empty((n_out, c), dtype=torch.int32, device=feat.device)
+        rc = _lib.lib().pool_max_forward_hip_launcher(n_out, c, feat.data_ptr(), order.data_ptr(), idx_ptr.data_ptr(),
+                                                      out.data_ptr(), arg.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "pool_max_forward_hip_launcher")
+        ctx.n_in = feat.shape[0]
+        ctx.save_for_backward(arg)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        feat, cluster, out = ctx.saved_tensors
-        hit = feat == out[cluster]
-        # exactly one winner per (cluster, channel): the first row in point order among equal maxima
-        n = feat.shape[0]
-        rank = torch.arange(n, device=feat.device).view(-1, 1).expand_as(feat)
-        big = torch.full_like(rank, n)
-        first = torch.full((out.shape[0], feat.shape[1]), n, device=feat.device, dtype=rank.dtype)
-        first = first.scatter_reduce(0, cluster.view(-1, 1).expand_as(feat), torch.where(hit, rank, big), "amin",
-                                     include_self=True)
-        win = hit & (rank == first[cluster])
-        return torch.where(win, grad[cluster], torch.zeros_like(feat)), None, None
+        (arg,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        n_out, c = grad.shape
+        gfeat = torch.zeros((ctx.n_in, c), dtype=torch.float32, device=grad.device)
+        rc = _lib.lib().pool_max_backward_hip_launcher(n_out, c, grad.data_ptr(), arg.data_ptr(), gfeat.data_ptr(),
+                                                       _lib.stream_ptr())
+        _lib.check(rc, "pool_max_backward_hip_launcher")
+        return gfeat, None, None
 
 
 class GridPool(nn.Module):
@@ -207,7 +211,7 @@ class GridPool(nn.Module):
 
     def forward(self, feat, fine_level, coarse_level):
         feat = self.act(self.norm(self.fc(feat)))
-        return _SegmentMax.apply(feat, fine_level.cluster, coarse_level.coord.shape[0])
+        return _SegmentMax.apply(feat, fine_level.order32, fine_level.idx_ptr32)
 
 
 class UnpoolWithSkip(nn.Module):

@@ -200,6 +200,30 @@ int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float 
                                         float *gWw2, float *gbw2, float *gv, float *ga, float *gb,
                                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* grouped positional-bias projection applied after the neighbour sum (linear_p_bias[3], :92,117-119):
+ *   out[n,g*I+i] = out_v[n,g*I+i] + sum_c' A[g,n,c'] Wp2[g*I+i,c'] + bp2[g*I+i] sw[n,g],  I = c/g in {2,4,8,16}
+ * backward w.r.t. A and sw: g_A (g,n,c), g_sw (n,g) from g_out (n,c) (grad Wp2 / bp2 are dense products the
+ * host takes with rocBLAS). */
+int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const float *Wp2, const float *bp2,
+                                 const float *sw, const float *out_v, float *out, void *stream);
+int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g_out, const float *Wp2,
+                                  const float *bp2, float *g_A, float *g_sw, void *stream);
+
+/* ---------------------------------------------------------- grid pooling --
+ * Device pieces of GridPool.forward (point_transformer_v2m2_base.py:244-269), which the reference
+ * builds from torch_scatter.segment_csr calls (third party, not vendored):
+ *   segment_minmax: per-cloud coordinate min/max, lo/hi (b,3)                         (:249-253)
+ *   pool_max:       out[j,:] = max over rows order[idx_ptr[j]..idx_ptr[j+1]) of feat; arg = winning row
+ *                   (first wins ties); backward scatters grad_out to grad_feat[arg] [zeroed]   (:266)
+ */
+size_t segment_minmax_hip_workspace_bytes(int b);
+int segment_minmax_hip_launcher(int b, const float *xyz, const int *offset, float *lo, float *hi,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int pool_max_forward_hip_launcher(int n_out, int c, const float *feat, const int *order,
+                                  const int *idx_ptr, float *out, int *arg, void *stream);
+int pool_max_backward_hip_launcher(int n_out, int c, const float *grad_out, const int *arg,
+                                   float *grad_feat, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
