@@ -40,6 +40,14 @@ _SIGNATURES = {
     "segment_minmax_hip_launcher": (_c_int, [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "pool_max_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6),
     "pool_max_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 4),
+    "dense_workspace_bytes": (_c_size, [_c_int] * 3),
+    "bn_stats_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [ctypes.c_float] * 2 + [_vp, _c_size, _vp]),
+    "bn_apply_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 5 + [_c_int, _vp, _vp]),
+    "bn_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
+    "linear_wgrad_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5 + [_c_size, _vp]),
+    "linear_wgrad_strided_hip_launcher": (_c_int, [_c_int] * 4 + [_vp, ctypes.c_longlong, ctypes.c_longlong, _vp,
+                                                                 ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp,
+                                                                 _c_size, _vp]),
 }
 
 _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace too small)",

@@ -1,0 +1,375 @@
+// ao_amd/csrc/dense.hip -- the per-point (N,C) layers around the attention on gfx950:
+//   * BatchNorm1d over N rows (training / eval) with optional fused ReLU, forward and backward,
+//   * the weight gradient of nn.Linear as a split-K reduction.
+//
+// Why these exist.  PT-v2m2 wraps every Linear in PointBatchNorm (+ReLU)
+// (point_transformer_v2m2_base.py:26-45,67-76,153-177): 86 BatchNorms per training step at S3DIS sizes.
+// The stock channels-last BN kernels stream (N,48..384) fp32 at ~0.65 TB/s (profiles/r01_fused_v1_*),
+// and the weight gradients dW = dY^T X have a 48x48 .. 384x384 output with K = N up to 1.2e5, for which
+// the BLAS picks a 9-workgroup kernel (353 us per call).  Both are pure HBM streaming problems:
+//   bn_stats / bn_backward_reduce  column sums over row chunks, float4 per lane, per-block partials +
+//                                  fixed-order final (bitwise reproducible); the finalizer also writes
+//                                  mean / rstd and updates the running statistics in place
+//   bn_apply / bn_backward_apply   one read-modify-write pass each
+//   linear_wgrad                   each workgroup owns a 48x48 output tile for a chunk of rows (operands
+//                                  staged through LDS, 3x3 register patch per lane), partial tiles
+//                                  summed in fixed order; the bias gradient falls out of the same pass
+#include <algorithm>
+
+#include "gva_common.h"
+
+namespace dense {
+
+using gva::finalize_kernel;
+using gva::launch_finalize;
+constexpr int TPB = 256;
+constexpr int MAX_BLK = 1024;
+
+// ------------------------------------------------------------------ BN: stats --
+// lanes: (row lane, float4 column quad); requires c % 4 == 0
+__global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float *__restrict__ x,
+                                                       float *__restrict__ part) {
+    extern __shared__ float4 lds4[];
+    const int cq = c >> 2;
+    const int rl = TPB / cq;                 // row lanes per block (>= 1 for c <= 1024)
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (r < rl)
+        for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
+            const float4 v = ((const float4 *)x)[row * cq + q];
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x = __builtin_fmaf(v.x, v.x, s2.x); s2.y = __builtin_fmaf(v.y, v.y, s2.y);
+            s2.z = __builtin_fmaf(v.z, v.z, s2.z); s2.w = __builtin_fmaf(v.w, v.w, s2.w);
+        }
+    float4 *sa = lds4, *sb = lds4 + TPB;
+    sa[threadIdx.x] = s1;
+    sb[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        for (int k = 0; k < rl; ++k) {
+            const float4 u = sa[k * cq + threadIdx.x], w = sb[k * cq + threadIdx.x];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+        }
+        float *p = part + (size_t)blockIdx.x * 2 * c;
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b;
+    }
+}
+
+struct MapBnStats {  // columns [0,c): sum x, [c,2c): sum x^2  ->  mean, rstd, running stats
+    float *mean, *rstd, *run_mean, *run_var;
+    long long *batches;
+    int c, n;
+    float eps, momentum;
+    // needs both sums of a channel: the finalize kernel calls us per column, so pair them through memory:
+    // column j < c stores the mean; column j >= c (same block row of the launch or a later one) needs it,
+    // therefore the launcher runs TWO finalize passes (means first).
+    int pass;
+    __device__ void operator()(int j, double v) const {
+        if (pass == 0) {
+            if (j < c) mean[j] = (float)(v / n);
+            return;
+        }
+        if (j < c) return;
+        const int ch = j - c;
+        const double m = (double)mean[ch];
+        double var = v / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+        if (run_mean) {
+            const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+            run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
+            run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
+            if (ch == 0 && batches) *batches += 1;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ BN: apply --
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(long long total4, int cq, const float *__restrict__ x,
+                                                       const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       int relu, float *__restrict__ y) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
+        const int q = (int)(e % cq);
+        const float4 v = ((const float4 *)x)[e];
+        const float4 m = ((const float4 *)mean)[q], r = ((const float4 *)rstd)[q];
+        const float4 g = ((const float4 *)gamma)[q], b = ((const float4 *)beta)[q];
+        float4 o;
+        o.x = __builtin_fmaf((v.x - m.x) * r.x, g.x, b.x);
+        o.y = __builtin_fmaf((v.y - m.y) * r.y, g.y, b.y);
+        o.z = __builtin_fmaf((v.z - m.z) * r.z, g.z, b.z);
+        o.w = __builtin_fmaf((v.w - m.w) * r.w, g.w, b.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        ((float4 *)y)[e] = o;
+    }
+}
+
+// -------------------------------------------------------- BN: backward reduce --
+// partial columns [0,c): sum gy' ; [c,2c): sum gy' * xhat, with gy' = gy masked by the fused ReLU
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const float *__restrict__ x,
+                                                            const float *__restrict__ gy,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int relu,
+                                                            float *__restrict__ part) {
+    extern __shared__ float4 lds4[];
+    const int cq = c >> 2;
+    const int rl = TPB / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (r < rl) {
+        const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q];
+        const float4 g = ((const float4 *)gamma)[q], b = ((const float4 *)beta)[q];
+        for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
+            const float4 v = ((const float4 *)x)[row * cq + q];
+            float4 d = ((const float4 *)gy)[row * cq + q];
+            float4 h;
+            h.x = (v.x - m.x) * rs.x; h.y = (v.y - m.y) * rs.y; h.z = (v.z - m.z) * rs.z; h.w = (v.w - m.w) * rs.w;
+            if (relu) {
+                if (__builtin_fmaf(h.x, g.x, b.x) <= 0.f) d.x = 0.f;
+                if (__builtin_fmaf(h.y, g.y, b.y) <= 0.f) d.y = 0.f;
+                if (__builtin_fmaf(h.z, g.z, b.z) <= 0.f) d.z = 0.f;
+                if (__builtin_fmaf(h.w, g.w, b.w) <= 0.f) d.w = 0.f;
+            }
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = __builtin_fmaf(d.x, h.x, s2.x); s2.y = __builtin_fmaf(d.y, h.y, s2.y);
+            s2.z = __builtin_fmaf(d.z, h.z, s2.z); s2.w = __builtin_fmaf(d.w, h.w, s2.w);
+        }
+    }
+    float4 *sa = lds4, *sb = lds4 + TPB;
+    sa[threadIdx.x] = s1;
+    sb[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a;
+        for (int k = 0; k < rl; ++k) {
+            const float4 u = sa[k * cq + threadIdx.x], w = sb[k * cq + threadIdx.x];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
+        }
+        float *p = part + (size_t)blockIdx.x * 2 * c;
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b2;
+    }
+}
+
+// gx = gamma * rstd * (gy' - dbeta/n - xhat * dgamma/n)   (training);   gamma * rstd * gy' (eval)
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int cq, float inv_n,
+                                                           const float *__restrict__ x, const float *__restrict__ gy,
+                                                           const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int relu,
+                                                           const float *__restrict__ dbeta,
+                                                           const float *__restrict__ dgamma, int training,
+                                                           float *__restrict__ gx) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
+        const int q = (int)(e % cq);
+        const float4 v = ((const float4 *)x)[e];
+        float4 d = ((const float4 *)gy)[e];
+        const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q];
+        const float4 g = ((const float4 *)gamma)[q], b = ((const float4 *)beta)[q];
+        float4 h;
+        h.x = (v.x - m.x) * rs.x; h.y = (v.y - m.y) * rs.y; h.z = (v.z - m.z) * rs.z; h.w = (v.w - m.w) * rs.w;
+        if (relu) {
+            if (__builtin_fmaf(h.x, g.x, b.x) <= 0.f) d.x = 0.f;
+            if (__builtin_fmaf(h.y, g.y, b.y) <= 0.f) d.y = 0.f;
+            if (__builtin_fmaf(h.z, g.z, b.z) <= 0.f) d.z = 0.f;
+            if (__builtin_fmaf(h.w, g.w, b.w) <= 0.f) d.w = 0.f;
+        }
+        float4 o;
+        if (training) {
+            const float4 db = ((const float4 *)dbeta)[q], dg = ((const float4 *)dgamma)[q];
+            o.x = g.x * rs.x * (d.x - db.x * inv_n - h.x * dg.x * inv_n);
+            o.y = g.y * rs.y * (d.y - db.y * inv_n - h.y * dg.y * inv_n);
+            o.z = g.z * rs.z * (d.z - db.z * inv_n - h.z * dg.z * inv_n);
+            o.w = g.w * rs.w * (d.w - db.w * inv_n - h.w * dg.w * inv_n);
+        } else {
+            o.x = g.x * rs.x * d.x; o.y = g.y * rs.y * d.y; o.z = g.z * rs.z * d.z; o.w = g.w * rs.w * d.w;
+        }
+        ((float4 *)gx)[e] = o;
+    }
+}
+
+// --------------------------------------------------------------- Linear wgrad --
+// dW[b][o][i] = sum_n gY[n*ldy + b*sy + o] * X[n*ldx + b*sx + i];  db[b][o] = sum_n gY[...]   (b < batch)
+// fp32 MFMA 16x16x4 (exact f32 FMA chain): the reduction index n is the MFMA k; both operand fragments are
+// read straight from global memory -- lane l of a fragment holds element [row0 + (l>>4)][col0 + (l&15)],
+// i.e. four 64-byte row segments per load, no LDS staging.  A workgroup = 4 waves = one (up to) 48x48
+// output tile for one chunk of rows; the waves interleave k-steps and are summed through LDS.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int WG_MT = 3, WG_TILE = 16 * WG_MT, WG_CHUNK = 256;
+
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
+                                                           const float *__restrict__ gY, long long ldy, long long sy,
+                                                           const float *__restrict__ X, long long ldx, long long sx,
+                                                           float *__restrict__ part, float *__restrict__ part_b,
+                                                           int batch) {
+    __shared__ float sRed[TPB / WAVE][WG_MT * WG_MT * 4 + WG_MT][WAVE + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int bz = blockIdx.z;
+    const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
+    const float *A = gY + (long long)bz * sy, *B = X + (long long)bz * sx;
+    const long long r0 = (long long)blockIdx.x * WG_CHUNK;
+    const long long r1 = (r0 + WG_CHUNK) < (long long)n ? (r0 + WG_CHUNK) : (long long)n;
+    const int lr = lane >> 4, lc = lane & 15;
+    f32x4 acc[WG_MT][WG_MT];
+    float bsum[WG_MT];
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) {
+        bsum[m] = 0.f;
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    bool mo[WG_MT], mi[WG_MT];
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) { mo[m] = to + m * 16 + lc < cout; mi[m] = ti + m * 16 + lc < cin; }
+    for (long long rb = r0 + 4 * wid; rb < r1; rb += 4 * (TPB / WAVE)) {
+        const long long row = rb + lr;
+        const bool rok = row < r1;
+        float a[WG_MT], b[WG_MT];
+#pragma unroll
+        for (int m = 0; m < WG_MT; ++m) {
+            a[m] = (rok && mo[m]) ? A[row * ldy + to + m * 16 + lc] : 0.f;
+            b[m] = (rok && mi[m]) ? B[row * ldx + ti + m * 16 + lc] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < WG_MT; ++m) {
+            bsum[m] += a[m];
+#pragma unroll
+            for (int t = 0; t < WG_MT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
+        }
+    }
+    // combine the 4 waves (fixed order) and write the partial tile
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) {
+        float bs = bsum[m];
+        bs += __shfl_xor(bs, 16, WAVE);
+        bs += __shfl_xor(bs, 32, WAVE);
+        sRed[wid][WG_MT * WG_MT * 4 + m][lane] = bs;
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sRed[wid][(m * WG_MT + t) * 4 + r][lane] = acc[m][t][r];
+    }
+    __syncthreads();
+    float *p = part + ((size_t)blockIdx.x * batch + bz) * cout * cin;
+    for (int e = threadIdx.x; e < WG_MT * WG_MT * 4 * WAVE; e += TPB) {
+        const int q = e / WAVE, l = e - q * WAVE;
+        const int mt = q / 4, r = q - mt * 4, m = mt / WG_MT, t = mt - m * WG_MT;
+        const int o = to + m * 16 + (l >> 4) * 4 + r, i = ti + t * 16 + (l & 15);  // D: row=(lane>>4)*4+reg, col=lane&15
+        if (o < cout && i < cin) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][q][l];
+            p[(size_t)o * cin + i] = v;
+        }
+    }
+    if (part_b && ti == 0 && threadIdx.x < WG_TILE) {
+        const int m = threadIdx.x >> 4, l = threadIdx.x & 15, o = to + threadIdx.x;
+        if (o < cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][WG_MT * WG_MT * 4 + m][l];
+            part_b[((size_t)blockIdx.x * batch + bz) * cout + o] = v;
+        }
+    }
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace dense
+
+using namespace dense;
+
+extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin = total outputs over all batches
+    const size_t chunks = (size_t)(n + WG_CHUNK - 1) / WG_CHUNK + 1;
+    const size_t wg = sizeof(float) * chunks * ((size_t)cout * cin + cout);
+    const size_t bn = sizeof(float) * (size_t)MAX_BLK * 2 * (size_t)std::max(cout, cin);
+    return align_up(std::max(wg, bn)) + 1024;
+}
+
+static int bn_grid(int n, int c) {
+    const int rl = std::max(1, TPB / (c >> 2));
+    long long b = ((long long)n + rl * 4 - 1) / (rl * 4);
+    return (int)std::max<long long>(1, std::min<long long>(b, MAX_BLK));
+}
+
+extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
+                                     float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < dense_workspace_bytes(n, c, c)) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_grid(n, c);
+    float *part = (float *)workspace;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
+    MapBnStats m{mean, rstd, running_mean, running_var, num_batches_tracked, c, n, eps, momentum, 0};
+    launch_finalize(st, (const float *)part, nblk, 2 * c, m);
+    m.pass = 1;
+    launch_finalize(st, (const float *)part, nblk, 2 * c, m);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
+                                     const float *gamma, const float *beta, int relu, float *y, void *stream) {
+    if (n < 0 || c < 4 || c % 4 != 0) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const long long total4 = (long long)n * (c >> 2);
+    const int nblk = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total4, c >> 2, x, mean, rstd, gamma,
+                       beta, relu, y);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, const float *mean,
+                                        const float *rstd, const float *gamma, const float *beta, int relu,
+                                        int training, float *gx, float *dgamma, float *dbeta, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < dense_workspace_bytes(n, c, c)) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_grid(n, c);
+    float *part = (float *)workspace;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean, rstd,
+                       gamma, beta, relu, part);
+    launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
+    const long long total4 = (long long)n * (c >> 2);
+    const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean, rstd,
+                       gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const float *gY, long long ldy,
+                                                 long long sy, const float *X, long long ldx, long long sx, float *dW,
+                                                 float *db, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 1 || cout < 1 || cin < 1 || batch < 1) return PTV2_ERR_ARG;
+    const int chunks = (n + WG_CHUNK - 1) / WG_CHUNK;
+    const size_t need = sizeof(float) * (size_t)chunks * batch * ((size_t)cout * cin + cout);
+    if (!workspace || workspace_bytes < need) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    float *part_b = part + (size_t)chunks * batch * cout * cin;
+    const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
+    dim3 grid(chunks, tiles_o * tiles_i, batch);
+    hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
+                       db ? part_b : (float *)nullptr, batch);
+    launch_finalize(st, (const float *)part, chunks, batch * cout * cin, gva::MapVec<float>{dW});
+    if (db) launch_finalize(st, (const float *)part_b, chunks, batch * cout, gva::MapVec<float>{db});
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
+                                         float *db, void *workspace, size_t workspace_bytes, void *stream) {
+    return linear_wgrad_strided_hip_launcher(n, cout, cin, 1, gY, cout, 0, X, cin, 0, dW, db, workspace, workspace_bytes,
+                                             stream);
+}

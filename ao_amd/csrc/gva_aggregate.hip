@@ -1,0 +1,499 @@
+// ao_amd/csrc/gva_aggregate.hip -- softmax + aggregation stages of the fused grouped vector attention.
+// Math: ao_amd/ptv2/gva.py.  Each stage is a flat, fully parallel kernel with ONE load phase, so that
+// the chip hides gather latency with occupancy instead of serialising it per point:
+//
+//  forward
+//   softmax_rows   one lane per neighbour slot (n,s): y = ReLU(sc*W1+sh) (G regs), z = y Ww2^T + bw2 with
+//                  Ww2 as wave-uniform scalar operands, softmax over the K slots of a point through
+//                  K-lane shuffles, mask.  W1 in, w (N,K,G) and sw (N,G) out -- one streaming pass.
+//   aggregate_tile a workgroup takes a tile of points, stages their neighbour ids, relative positions and
+//                  softmax rows in LDS once, then one lane per (point, channel):
+//                  out_v = sum_s w v[idx] (row gathers, coalesced over channels),
+//                  A[n,g,:] = sum_s w[s,g] ReLU(a.pos_s + b).
+//  backward
+//   bwd_tile       one wavefront per point: grad w = g_sw + <g_out, v[idx]> per group (8-lane shuffle
+//                  reduce) + <P, g_A> (lanes = slot x channel-slice, g_A streamed through LDS in 64-channel
+//                  chunks), and the folded-BN_p parameter gradients (ga, gb) as per-wave partials.
+//   bwd_rows       one lane per slot: softmax backward, Linear(G,G) backward, ReLU, BN_w affine backward;
+//                  writes gW1 and the two (N*K,G) operands (gz, y) of the Ww2 weight gradient, which is
+//                  then the same split-K MFMA reduction as any Linear (dense.hip); gsc / gsh partials.
+//   bwd_gv         grad v through the inverse neighbour table (fixed-order gather, no atomics).
+#include <algorithm>
+
+#include "gva_common.h"
+
+namespace gva {
+
+inline bool pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
+__host__ __device__ constexpr int G4of(int G) { return (G + 3) & ~3; }
+__host__ __device__ constexpr int GPof(int G) { return (G | 1) + ((G & 1) ? 2 : 0); }  // odd, >= G+1
+
+template <int G>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, float (&v)[G]) {
+    if (G % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g += 4) {
+            const float4 t = *(const float4 *)(p + g);
+            v[g] = t.x; v[g + 1] = t.y; v[g + 2] = t.z; v[g + 3] = t.w;
+        }
+    } else if (G % 2 == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const float2 t = *(const float2 *)(p + g);
+            v[g] = t.x; v[g + 1] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[g] = p[g];
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void store_row(float *__restrict__ p, const float (&v)[G]) {
+    if (G % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g += 4) *(float4 *)(p + g) = make_float4(v[g], v[g + 1], v[g + 2], v[g + 3]);
+    } else if (G % 2 == 0) {
+#pragma unroll
+        for (int g = 0; g < G; g += 2) *(float2 *)(p + g) = make_float2(v[g], v[g + 1]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) p[g] = v[g];
+    }
+}
+
+// z[g] = bw2[g] + sum_j y[j] Ww2[g][j]  (Ww2, bw2 wave-uniform), then softmax over the k lanes of a point
+template <int G>
+__device__ __forceinline__ void logits_softmax(const float (&y)[G], const float *__restrict__ Ww2,
+                                               const float *__restrict__ bw2, int k, float (&wt)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float z = bw2[g];
+#pragma unroll
+        for (int j = 0; j < G; ++j) z = __builtin_fmaf(y[j], Ww2[g * G + j], z);
+        wt[g] = z;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float mx = wt[g];
+        for (int o = k >> 1; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
+        const float e = expf(wt[g] - mx);
+        float den = e;
+        for (int o = k >> 1; o >= 1; o >>= 1) den += __shfl_xor(den, o, WAVE);
+        wt[g] = e / den;
+    }
+}
+
+// =================================================================== forward ==
+template <int G>
+__global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k, const float *__restrict__ W1,
+                                                           const float *__restrict__ sc, const float *__restrict__ sh,
+                                                           const float *__restrict__ Ww2,
+                                                           const float *__restrict__ bw2, const int *__restrict__ idx,
+                                                           float *__restrict__ w, float *__restrict__ sw) {
+    const long long rows_pad = (rows + WAVE - 1) / WAVE * WAVE;  // whole waves: shuffles need every lane
+    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows_pad; row += (long long)gridDim.x * TPB) {
+        const bool act = row < rows;
+        const long long r = act ? row : rows - 1;
+        float y[G], wt[G];
+        load_row<G>(W1 + r * G, y);
+#pragma unroll
+        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sc[g], y[g], sh[g]), 0.f);
+        logits_softmax<G>(y, Ww2, bw2, k, wt);
+        const float valid = (act && idx[r] >= 0) ? 1.f : 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) wt[g] *= valid;
+        if (act) store_row<G>(w + r * G, wt);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            for (int o = k >> 1; o >= 1; o >>= 1) wt[g] += __shfl_xor(wt[g], o, WAVE);
+        if (act && (r & (k - 1)) == 0) store_row<G>(sw + (r / k) * G, wt);
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c, int tp, const float *__restrict__ w,
+                                                             const float *__restrict__ v, const float *__restrict__ a,
+                                                             const float *__restrict__ b,
+                                                             const float *__restrict__ coord,
+                                                             const int *__restrict__ idx, float *__restrict__ out_v,
+                                                             float *__restrict__ A) {
+    extern __shared__ float4 lds4[];
+    constexpr int G4 = G4of(G);
+    float4 *sPos = lds4;                           // [tp*k]  (x,y,z,-)
+    float *sW = (float *)(sPos + (size_t)tp * k);   // [tp*k][G4]
+    int *sSrc = (int *)(sW + (size_t)tp * k * G4);  // [tp*k]
+    const int n0 = blockIdx.x * tp;
+    const int cnt = (n - n0) < tp ? (n - n0) : tp;
+    for (int e = threadIdx.x; e < cnt * k; e += TPB) {
+        const int p = e / k;
+        const Rel r = rel_pos(coord, idx, (long long)n0 * k + e, n0 + p);
+        sPos[e] = make_float4(r.x, r.y, r.z, 0.f);
+        sSrc[e] = r.src;
+    }
+    for (int e = threadIdx.x; e < cnt * k * G; e += TPB) {
+        const int r = e / G, g = e - r * G;
+        sW[r * G4 + g] = w[(long long)n0 * k * G + e];
+    }
+    __syncthreads();
+    const int I = c / G;
+    for (int item = threadIdx.x; item < cnt * c; item += TPB) {
+        const int p = item / c, ch = item - p * c;
+        const int gl = ch / I;
+        const float ax = a[3 * ch], ay = a[3 * ch + 1], az = a[3 * ch + 2], bb = b[ch];
+        float accA[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) accA[g] = 0.f;
+        float ov = 0.f;
+        for (int s = 0; s < k; ++s) {
+            const float4 ps = sPos[p * k + s];
+            const int src = sSrc[p * k + s];
+            const float P = pe_act(ax, ay, az, bb, ps.x, ps.y, ps.z);
+            const float *wrow = sW + (size_t)(p * k + s) * G4;
+            if (src >= 0) ov = __builtin_fmaf(wrow[gl], v[(long long)src * c + ch], ov);
+            if (G % 4 == 0) {
+#pragma unroll
+                for (int g = 0; g < G; g += 4) {
+                    const float4 t = *(const float4 *)(wrow + g);
+                    accA[g] = __builtin_fmaf(t.x, P, accA[g]);
+                    accA[g + 1] = __builtin_fmaf(t.y, P, accA[g + 1]);
+                    accA[g + 2] = __builtin_fmaf(t.z, P, accA[g + 2]);
+                    accA[g + 3] = __builtin_fmaf(t.w, P, accA[g + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) accA[g] = __builtin_fmaf(wrow[g], P, accA[g]);
+            }
+        }
+        const long long pt = n0 + p;
+        out_v[pt * c + ch] = ov;
+#pragma unroll
+        for (int g = 0; g < G; ++g) A[(pt * G + g) * c + ch] = accA[g];
+    }
+}
+
+// ================================================================== backward ==
+// grad w (pre-mask) and the (ga, gb) partials; one wavefront (64-thread workgroup) per point
+template <int G>
+__global__ __launch_bounds__(WAVE) void aggregate_bwd_tile_kernel(
+    int n, int k, int c, const float *__restrict__ w, const float *__restrict__ v, const float *__restrict__ a,
+    const float *__restrict__ b, const float *__restrict__ coord, const int *__restrict__ idx,
+    const float *__restrict__ g_out, const float *__restrict__ g_A, const float *__restrict__ g_sw,
+    float *__restrict__ gw, float *gv_atomic, float *__restrict__ part) {
+    extern __shared__ float4 lds4[];
+    constexpr int GP = GPof(G), G4 = G4of(G);
+    const int lane = threadIdx.x;
+    float4 *sAB = lds4;                                   // [c]   (a, b)
+    float4 *accAB = sAB + c;                              // [c]   per-wave (ga, gb) sums
+    float4 *sPos = accAB + c;                             // [k]
+    float *sW = (float *)(sPos + k);                      // [k][G4]
+    float *sGW = sW + (size_t)k * G4;                     // [k][GP]
+    float *sT = sGW + (((size_t)k * GP + 3) & ~(size_t)3);  // [64][GP]  g_A chunk
+    int *sSrc = (int *)(sT + (((size_t)64 * GP + 3) & ~(size_t)3));  // [k]
+    for (int i = lane; i < c; i += WAVE) {
+        sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
+        accAB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int I = c / G;
+    const int items = G * k;
+    const int J = WAVE / k;
+    const int ms = lane & (k - 1), mj = lane / k;
+    for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
+        __syncthreads();
+        if (lane < k) {
+            const Rel r = rel_pos(coord, idx, (long long)pt * k + lane, pt);
+            sPos[lane] = make_float4(r.x, r.y, r.z, 0.f);
+            sSrc[lane] = r.src;
+        }
+        for (int item = lane; item < items; item += WAVE) {
+            const int s = item / G, g = item - s * G;
+            sW[s * G4 + g] = w[(long long)pt * items + item];
+            sGW[s * GP + g] = g_sw[(long long)pt * G + g];
+        }
+        __syncthreads();
+        // v path: grad w[s,g] += sum_{ch in g} g_out[ch] v[idx[s],ch]
+        for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
+            const int ch = cb0 + lane;
+            const bool act = ch < c;
+            const float go = act ? g_out[(long long)pt * c + ch] : 0.f;
+            const int gl = act ? ch / I : 0;
+            for (int s = 0; s < k; ++s) {
+                const int src = sSrc[s];
+                float val = 0.f;
+                if (act && src >= 0) {
+                    val = go * v[(long long)src * c + ch];
+                    if (gv_atomic) atomicAdd(gv_atomic + (long long)src * c + ch, go * sW[s * G4 + gl]);
+                }
+                for (int o = I >> 1; o >= 1; o >>= 1) val += __shfl_xor(val, o, WAVE);
+                if (act && (ch & (I - 1)) == 0) sGW[s * GP + gl] += val;
+            }
+        }
+        // positional path: lanes = (slot ms, channel slice mj)
+        {
+            float wrow[G], acc[G];
+            const float4 ps = sPos[ms];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { wrow[g] = sW[ms * G4 + g]; acc[g] = 0.f; }
+            for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
+                __syncthreads();
+                const int chl = cb0 + lane;
+                if (chl < c) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sT[lane * GP + g] = g_A[((long long)pt * G + g) * c + chl];
+                }
+                __syncthreads();
+                const int cend = (c - cb0) < WAVE ? (c - cb0) : WAVE;
+                for (int cl = mj; cl < WAVE; cl += J) {  // uniform trip count: the shuffles need every lane
+                    const bool act = cl < cend;
+                    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, gb0 = 0.f;
+                    if (act) {
+                        const float4 ab = sAB[cb0 + cl];
+                        const float P = pe_act(ab.x, ab.y, ab.z, ab.w, ps.x, ps.y, ps.z);
+                        const float *tr = sT + cl * GP;
+                        float gP = 0.f;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const float t = tr[g];
+                            gP = __builtin_fmaf(wrow[g], t, gP);
+                            acc[g] = __builtin_fmaf(P, t, acc[g]);
+                        }
+                        const float gpre = P > 0.f ? gP : 0.f;
+                        ga0 = gpre * ps.x; ga1 = gpre * ps.y; ga2 = gpre * ps.z; gb0 = gpre;
+                    }
+                    for (int o = k >> 1; o >= 1; o >>= 1) {
+                        ga0 += __shfl_xor(ga0, o, WAVE); ga1 += __shfl_xor(ga1, o, WAVE);
+                        ga2 += __shfl_xor(ga2, o, WAVE); gb0 += __shfl_xor(gb0, o, WAVE);
+                    }
+                    if (act && ms == 0) {
+                        const float4 cur = accAB[cb0 + cl];
+                        accAB[cb0 + cl] = make_float4(cur.x + ga0, cur.y + ga1, cur.z + ga2, cur.w + gb0);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float t = acc[g];
+                for (int o = WAVE >> 1; o >= k; o >>= 1) t += __shfl_xor(t, o, WAVE);
+                if (mj == 0) sGW[ms * GP + g] += t;
+            }
+        }
+        __syncthreads();
+        for (int item = lane; item < items; item += WAVE) {
+            const int s = item / G, g = item - s * G;
+            gw[(long long)pt * items + item] = sGW[s * GP + g];
+        }
+    }
+    __syncthreads();
+    float4 *mypart = (float4 *)part + (size_t)blockIdx.x * c;
+    for (int i = lane; i < c; i += WAVE) mypart[i] = accAB[i];
+}
+
+// softmax / Linear(G,G) / ReLU / affine backward per slot; outputs gW1, gz, y; partial [gsc G][gsh G]
+template <int G>
+__global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows, int k, const float *__restrict__ W1,
+                                                                 const float *__restrict__ sc,
+                                                                 const float *__restrict__ sh,
+                                                                 const float *__restrict__ Ww2,
+                                                                 const float *__restrict__ bw2,
+                                                                 const int *__restrict__ idx,
+                                                                 const float *__restrict__ gw, float *__restrict__ gW1,
+                                                                 float *__restrict__ gz_out, float *__restrict__ y_out,
+                                                                 float *__restrict__ part) {
+    __shared__ float s_w[WPB][2 * G];
+    float t_sc[G], t_sh[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t_sc[g] = t_sh[g] = 0.f;
+    const long long rows_pad = (rows + WAVE - 1) / WAVE * WAVE;
+    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows_pad; row += (long long)gridDim.x * TPB) {
+        const bool act = row < rows;
+        const long long r = act ? row : rows - 1;
+        float y[G], gz[G];
+        load_row<G>(W1 + r * G, y);
+#pragma unroll
+        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sc[g], y[g], sh[g]), 0.f);
+        logits_softmax<G>(y, Ww2, bw2, k, gz);  // gz holds the unmasked softmax for now
+        if (act) store_row<G>(y_out + r * G, y);
+        const float valid = (act && idx[r] >= 0) ? 1.f : 0.f;
+        {
+            float gwr[G];
+            load_row<G>(gw + r * G, gwr);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float gm = gwr[g] * valid;
+                float dot = gz[g] * gm;
+                for (int o = k >> 1; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
+                gz[g] = act ? gz[g] * (gm - dot) : 0.f;
+            }
+        }
+        if (act) store_row<G>(gz_out + r * G, gz);
+        // Linear(G,G)^T, ReLU mask, BN_w-affine backward, four output channels at a time (keeps only y, gz live)
+        constexpr int STEP = (G % 4 == 0) ? 4 : ((G % 2 == 0) ? 2 : 1);
+#pragma unroll
+        for (int j0 = 0; j0 < G; j0 += STEP) {
+            float gu[STEP], u[STEP];
+#pragma unroll
+            for (int t = 0; t < STEP; ++t) {
+                float gy = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; ++g) gy = __builtin_fmaf(gz[g], Ww2[g * G + j0 + t], gy);
+                gu[t] = y[j0 + t] > 0.f ? gy : 0.f;
+            }
+            load_row<STEP>(W1 + r * G + j0, u);
+#pragma unroll
+            for (int t = 0; t < STEP; ++t) {
+                t_sc[j0 + t] = __builtin_fmaf(gu[t], u[t], t_sc[j0 + t]);
+                t_sh[j0 + t] += gu[t];
+                gu[t] *= sc[j0 + t];
+            }
+            if (act) store_row<STEP>(gW1 + r * G + j0, gu);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float v1 = wave_sum(t_sc[g]), v2 = wave_sum(t_sh[g]);
+        if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6][g] = v1; s_w[threadIdx.x >> 6][G + g] = v2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * G) {
+        float t = 0.f;
+        for (int wv = 0; wv < WPB; ++wv) t += s_w[wv][threadIdx.x];
+        part[(size_t)blockIdx.x * 2 * G + threadIdx.x] = t;
+    }
+}
+
+// grad v[j,ch] = sum over slots r that point at j of w[r, g(ch)] * g_out[r / k, ch]
+__global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int c, int g,
+                                                               const float *__restrict__ w,
+                                                               const float *__restrict__ g_out,
+                                                               const int *__restrict__ inv_ptr,
+                                                               const int *__restrict__ inv_rows,
+                                                               float *__restrict__ gv) {
+    const int I = c / g;
+    const long long total = (long long)n * c;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const int j = (int)(e / c), ch = (int)(e - (long long)j * c);
+        const int gl = ch / I;
+        float acc = 0.f;
+        for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) {
+            const int r = inv_rows[p];
+            acc = __builtin_fmaf(w[(long long)r * g + gl], g_out[(long long)(r / k) * c + ch], acc);
+        }
+        gv[e] = acc;
+    }
+}
+
+struct MapAB {  // columns (ch, j): ga (c,3), gb (c)
+    float *ga, *gb;
+    __device__ void operator()(int e, double v) const {
+        const int ch = e >> 2, j = e & 3;
+        if (j < 3) ga[ch * 3 + j] = (float)v; else gb[ch] = (float)v;
+    }
+};
+
+constexpr int BWD_TILE_BLOCKS = 256 * 16;
+
+}  // namespace gva
+
+using namespace gva;
+
+#define GVA_DISPATCH_G(g, CALL)            \
+    switch (g) {                           \
+        case 6: { CALL(6); break; }        \
+        case 12: { CALL(12); break; }      \
+        case 24: { CALL(24); break; }      \
+        case 48: { CALL(48); break; }      \
+        case 64: { CALL(64); break; }      \
+        default: return PTV2_ERR_ARG;      \
+    }
+
+extern "C" size_t gva_workspace_bytes(int n, int k, int c, int g);
+extern "C" size_t dense_workspace_bytes(int n, int cout, int cin);
+extern "C" int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
+                                         float *db, void *workspace, size_t workspace_bytes, void *stream);
+
+extern "C" size_t gva_aggregate_workspace_bytes(int n, int k, int c, int g) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
+    const size_t rows = (size_t)n * k;
+    const size_t part = align_up(sizeof(float) * std::max((size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g));
+    return part + 3 * align_up(sizeof(float) * rows * g) + dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g) + 1024;
+}
+
+extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                                  const float *sh, const float *Ww2, const float *bw2, const float *v,
+                                                  const float *a, const float *b, const float *coord, const int *idx,
+                                                  float *out_v, float *A, float *sw, float *w, void *stream) {
+    if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)n * k;
+    const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS * 4);
+#define CALL(GG) \
+    hipLaunchKernelGGL(softmax_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, w, sw)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    const int tp = std::max(1, TPB / c);
+    const size_t lds = (size_t)tp * k * (sizeof(float4) + sizeof(float) * G4of(g) + sizeof(int));
+#define CALL(GG)                                                                                                       \
+    hipLaunchKernelGGL(aggregate_tile_kernel<GG>, dim3((n + tp - 1) / tp), dim3(TPB), lds, st, n, k, c, tp, (const float *)w, \
+                       v, a, b, coord, idx, out_v, A)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                                   const float *sh, const float *Ww2, const float *bw2,
+                                                   const float *v, const float *a, const float *b,
+                                                   const float *coord, const int *idx, const float *w,
+                                                   const float *g_out, const float *g_A, const float *g_sw,
+                                                   const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
+                                                   float *gsh, float *gWw2, float *gbw2, float *gv, float *ga,
+                                                   float *gb, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0 || !pow2(c / g) || c / g > 64) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < gva_aggregate_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
+    if (n == 0) return PTV2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)n * k;
+    const size_t part_bytes = align_up(sizeof(float) * std::max((size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g));
+    const size_t rows_bytes = align_up(sizeof(float) * (size_t)rows * g);
+    char *base = (char *)workspace;
+    float *part = (float *)base;
+    float *gw = (float *)(base + part_bytes);
+    float *gz = (float *)(base + part_bytes + rows_bytes);
+    float *yb = (float *)(base + part_bytes + 2 * rows_bytes);
+    void *dense_ws = base + part_bytes + 3 * rows_bytes;
+    const size_t dense_bytes = workspace_bytes - (part_bytes + 3 * rows_bytes);
+
+    constexpr int dummy = 0;
+    (void)dummy;
+    const size_t lds_tile = sizeof(float4) * (2 * (size_t)c + k) +
+                            sizeof(float) * ((size_t)k * G4of(g) + (((size_t)k * GPof(g) + 3) & ~(size_t)3) +
+                                             (((size_t)64 * GPof(g) + 3) & ~(size_t)3)) + sizeof(int) * k;
+    if (lds_tile > 160 * 1024) return PTV2_ERR_ARG;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_tile));
+    const int nb_tile = std::min(n, std::min(256 * per_cu, (int)BWD_TILE_BLOCKS));
+#define CALL(GG)                                                                                                        \
+    if (lds_tile > 32 * 1024)                                                                                           \
+        (void)hipFuncSetAttribute((const void *)aggregate_bwd_tile_kernel<GG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds_tile);                                                                       \
+    hipLaunchKernelGGL(aggregate_bwd_tile_kernel<GG>, dim3(nb_tile), dim3(WAVE), lds_tile, st, n, k, c, w, v, a, b, coord, idx, \
+                       g_out, g_A, g_sw, gw, inv_ptr ? (float *)nullptr : gv, part)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    launch_finalize(st, (const float *)part, nb_tile, 4 * c, MapAB{ga, gb});
+    if (inv_ptr)
+        hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3((int)std::min<long long>(((long long)n * c + TPB - 1) / TPB, MAX_BLOCKS * 4)),
+                           dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+    const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS);
+#define CALL(GG)                                                                                                      \
+    hipLaunchKernelGGL(aggregate_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, \
+                       (const float *)gw, gW1, gz, yb, part)
+    GVA_DISPATCH_G(g, CALL)
+#undef CALL
+    launch_finalize(st, (const float *)part, nb_rows, 2 * g, MapSplit2<float>{gsc, gsh, g});
+    PTV2_CHECK_LAUNCH();
+    // grad Ww2[g][g'] = sum_rows gz[r,g] y[r,g'],  grad bw2 = column sums of gz: the Linear weight-gradient reduction
+    return linear_wgrad_hip_launcher((int)rows, g, g, gz, yb, gWw2, gbw2, dense_ws, dense_bytes, stream);
+}

@@ -11,10 +11,7 @@
 //                     gather kernel grad kW (via inverse table), grad qW
 //                     params kernel grad M, grad a, grad b   (lanes over channels, rows streamed
 //                                   through LDS as broadcast operands: no cross-lane reductions)
-//   aggregate backward one wavefront per point: recompute y, softmax; grad w from the v path, the
-//                     positional path (g_A) and g_sw; softmax / Linear(G,G) / ReLU / BN_w-affine
-//                     backward; writes gW1 and w; accumulates grad sc, sh, Ww2, bw2, a, b
-//                     gather kernel grad v (via inverse table)
+//   (aggregate backward: gva_aggregate.hip)
 #include <algorithm>
 
 #include "gva_common.h"
@@ -193,273 +190,6 @@ struct MapLogitsParams {
     }
 };
 
-// ========================================================= aggregate backward ==
-// one wavefront (= one 64-thread workgroup) per point; all LDS images are private to the wave.
-struct BwdLds {
-    __host__ __device__ static constexpr size_t floats(int G, int K, int C) {
-        const size_t GP = AggLds::gp(G), G4 = AggLds::G4(G);
-        return AggLds::r4(2 * (size_t)G * GP + 3 * (size_t)G)      // Ww2, Ww2^T, bw2, sc, sh
-               + 4 * (size_t)C                                       // (a, b)
-               + AggLds::r4(5 * (size_t)K + 3 * (size_t)K * GP)      // pos, src, Y, Wt, GW
-               + (size_t)K * G4                                      // W rows
-               + AggLds::r4(64 * GP)                                 // g_A chunk tile
-               + AggLds::r4(3 * (size_t)G + (size_t)G * G) + 4 * (size_t)C;  // accumulators
-    }
-};
-
-template <int G>
-__global__ __launch_bounds__(WAVE) void aggregate_bwd_kernel(
-    int n, int k, int c, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
-    const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
-    const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
-    const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ g_A,
-    const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ wbuf, float *gv_atomic,
-    float *__restrict__ part) {
-    extern __shared__ float4 lds4[];
-    float *lds = (float *)lds4;
-    constexpr int GP = AggLds::gp(G);
-    constexpr int G4 = AggLds::G4(G);
-    const int lane = threadIdx.x;
-    float *sWw2 = lds;                    // [G][GP]  Ww2[g][g']
-    float *sWw2T = sWw2 + G * GP;         // [G][GP]  Ww2[g][g'] stored at [g'][g]
-    float *sBw2 = sWw2T + G * GP;
-    float *sSc = sBw2 + G;
-    float *sSh = sSc + G;
-    float4 *sAB = (float4 *)(lds + AggLds::r4(2 * (size_t)G * GP + 3 * (size_t)G));
-    float *pbase = (float *)(sAB + c);
-    float4 *sPos = (float4 *)pbase;       // [K]
-    int *sSrc = (int *)(pbase + 4 * k);   // [K]
-    float *sY = pbase + 5 * k;            // [K][GP]
-    float *sWt = sY + (size_t)k * GP;     // [K][GP] unmasked softmax; later: gW1 staging
-    float *sGW = sWt + (size_t)k * GP;    // [K][GP] grad w, then grad z
-    float *sW = pbase + AggLds::r4(5 * (size_t)k + 3 * (size_t)k * GP);  // [K][G4] masked softmax
-    float *sT = sW + (size_t)k * G4;      // [64][GP] g_A chunk tile
-    float *accS = sT + AggLds::r4(64 * GP);  // [3G]: gsc, gsh, gbw2 ; then [G*G] gWw2
-    float *accW = accS + 3 * G;
-    float *accAB = accS + AggLds::r4(3 * (size_t)G + (size_t)G * G);  // [C][4]
-
-    for (int i = lane; i < G * G; i += WAVE) {
-        const int g = i / G, gq = i - g * G;
-        sWw2[g * GP + gq] = Ww2[i];
-        sWw2T[gq * GP + g] = Ww2[i];
-        accW[i] = 0.f;
-    }
-    for (int i = lane; i < G; i += WAVE) {
-        sBw2[i] = bw2[i]; sSc[i] = sc[i]; sSh[i] = sh[i];
-        accS[i] = accS[G + i] = accS[2 * G + i] = 0.f;
-    }
-    for (int i = lane; i < c; i += WAVE) {
-        sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
-        ((float4 *)accAB)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-
-    const int I = c / G;
-    const int items = G * k;
-    const int J = WAVE / k;              // channel slices of the (s, j) mapping
-    const int ms = lane & (k - 1), mj = lane / k;
-
-    for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
-        // 0: neighbour slots
-        if (lane < k) {
-            Rel r = rel_pos(coord, idx, (long long)pt * k + lane, pt);
-            sPos[lane] = make_float4(r.x, r.y, r.z, r.src >= 0 ? 1.f : 0.f);
-            sSrc[lane] = r.src;
-        }
-        // 1: y = ReLU(sc W1 + sh); grad-w accumulator starts at g_sw
-        for (int item = lane; item < items; item += WAVE) {
-            const int s = item / G, g = item - s * G;
-            sY[s * GP + g] = fmaxf(__builtin_fmaf(sSc[g], W1[(long long)pt * items + item], sSh[g]), 0.f);
-            sGW[s * GP + g] = g_sw[(long long)pt * G + g];
-        }
-        __syncthreads();
-        // 2: softmax over s
-        for (int base = 0; base < items; base += WAVE) {
-            const int item = base + lane;
-            const bool act = item < items;
-            const int g = act ? item / k : 0, s = act ? item - g * k : 0;
-            float z = sBw2[g];
-            const float *yr = sY + s * GP, *wr = sWw2 + g * GP;
-            for (int j = 0; j < G; ++j) z = __builtin_fmaf(yr[j], wr[j], z);
-            float mx = z;
-            for (int o = k >> 1; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-            const float e = expf(z - mx);
-            float den = e;
-            for (int o = k >> 1; o >= 1; o >>= 1) den += __shfl_xor(den, o, WAVE);
-            const float wt = e / den;
-            if (act) {
-                sWt[s * GP + g] = wt;
-                sW[s * G4 + g] = wt * sPos[s].w;
-            }
-        }
-        __syncthreads();
-        for (int item = lane; item < items; item += WAVE) {  // w (N,K,G) for the grad-v gather, coalesced
-            const int s = item / G, g = item - s * G;
-            wbuf[(long long)pt * items + item] = sW[s * G4 + g];
-        }
-        // 3: v path: grad w[s,g] += sum_{c in g} g_out[c] v[idx[s],c]
-        for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
-            const int ch = cb0 + lane;
-            const bool act = ch < c;
-            const float go = act ? g_out[(long long)pt * c + ch] : 0.f;
-            const int gl = act ? ch / I : 0;
-            for (int s = 0; s < k; ++s) {
-                const int src = sSrc[s];
-                float val = 0.f;
-                if (act && src >= 0) {
-                    val = go * v[(long long)src * c + ch];
-                    if (gv_atomic) atomicAdd(gv_atomic + (long long)src * c + ch, go * sW[s * G4 + gl]);
-                }
-                for (int o = I >> 1; o >= 1; o >>= 1) val += __shfl_xor(val, o, WAVE);
-                if (act && (ch & (I - 1)) == 0) sGW[s * GP + gl] += val;
-            }
-        }
-        __syncthreads();
-        // 4: positional path through g_A, lanes = (slot s, channel slice j)
-        {
-            float wrow[G], acc[G];
-            const float4 ps = sPos[ms];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { wrow[g] = sW[ms * G4 + g]; acc[g] = 0.f; }
-            for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
-                const int chl = cb0 + lane;
-                if (chl < c) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sT[lane * GP + g] = g_A[((long long)g * n + pt) * c + chl];
-                }
-                __syncthreads();
-                const int cend = (c - cb0) < WAVE ? (c - cb0) : WAVE;
-                for (int cl = mj; cl < WAVE; cl += J) {  // uniform trip count: shuffles below need every lane
-                    const bool act = cl < cend;
-                    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, gb0 = 0.f;
-                    if (act) {
-                        const float4 ab = sAB[cb0 + cl];
-                        const float P = pe_act(ab.x, ab.y, ab.z, ab.w, ps.x, ps.y, ps.z);
-                        const float *tr = sT + cl * GP;
-                        float gP = 0.f;
-#pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            const float t = tr[g];
-                            gP = __builtin_fmaf(wrow[g], t, gP);
-                            acc[g] = __builtin_fmaf(P, t, acc[g]);
-                        }
-                        const float gpre = P > 0.f ? gP : 0.f;
-                        ga0 = gpre * ps.x; ga1 = gpre * ps.y; ga2 = gpre * ps.z; gb0 = gpre;
-                    }
-                    for (int o = k >> 1; o >= 1; o >>= 1) {  // sum over the k slots of this point
-                        ga0 += __shfl_xor(ga0, o, WAVE); ga1 += __shfl_xor(ga1, o, WAVE);
-                        ga2 += __shfl_xor(ga2, o, WAVE); gb0 += __shfl_xor(gb0, o, WAVE);
-                    }
-                    if (act && ms == 0) {
-                        float4 *d = (float4 *)accAB + (cb0 + cl);
-                        float4 cur = *d;
-                        *d = make_float4(cur.x + ga0, cur.y + ga1, cur.z + ga2, cur.w + gb0);
-                    }
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float t = acc[g];
-                for (int o = WAVE >> 1; o >= k; o >>= 1) t += __shfl_xor(t, o, WAVE);
-                if (mj == 0) sGW[ms * GP + g] += t;
-            }
-        }
-        __syncthreads();
-        // 5: softmax backward -> grad z (in sGW); grad bw2
-        for (int base = 0; base < items; base += WAVE) {
-            const int item = base + lane;
-            const bool act = item < items;
-            const int g = act ? item / k : 0, s = act ? item - g * k : 0;
-            const float gw = act ? sGW[s * GP + g] * sPos[s].w : 0.f;
-            const float wt = act ? sWt[s * GP + g] : 0.f;
-            float dot = wt * gw;
-            for (int o = k >> 1; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, WAVE);
-            const float gz = wt * (gw - dot);
-            float tot = gz;
-            for (int o = k >> 1; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, WAVE);
-            if (act) {
-                sGW[s * GP + g] = gz;
-                if (s == 0) accS[2 * G + g] += tot;
-            }
-        }
-        __syncthreads();
-        // 6: Linear(G,G) / ReLU / BN_w-affine backward -> gW1 (staged in sWt), grad sc / sh
-        for (int base = 0; base < items; base += WAVE) {
-            const int item = base + lane;
-            const bool act = item < items;
-            const int gq = act ? item / k : 0, s = act ? item - gq * k : 0;
-            float gy = 0.f;
-            const float *zr = sGW + s * GP, *wt = sWw2T + gq * GP;
-            for (int g = 0; g < G; ++g) gy = __builtin_fmaf(zr[g], wt[g], gy);
-            const float y = sY[s * GP + gq];
-            const float gu = (act && y > 0.f) ? gy : 0.f;
-            const float u = act ? W1[((long long)pt * k + s) * G + gq] : 0.f;
-            float t1 = gu, t2 = gu * u;
-            for (int o = k >> 1; o >= 1; o >>= 1) { t1 += __shfl_xor(t1, o, WAVE); t2 += __shfl_xor(t2, o, WAVE); }
-            if (act) {
-                sWt[s * GP + gq] = sSc[gq] * gu;
-                if (s == 0) { accS[gq] += t2; accS[G + gq] += t1; }
-            }
-        }
-        // 7: grad Ww2[g][g'] += sum_s gz[s][g] y[s][g']
-        for (int p = lane; p < G * G; p += WAVE) {
-            const int g = p / G, gq = p - g * G;
-            float t = 0.f;
-            for (int s = 0; s < k; ++s) t = __builtin_fmaf(sGW[s * GP + g], sY[s * GP + gq], t);
-            accW[p] += t;
-        }
-        __syncthreads();
-        for (int item = lane; item < items; item += WAVE) {
-            const int s = item / G, g = item - s * G;
-            gW1[(long long)pt * items + item] = sWt[s * GP + g];
-        }
-        __syncthreads();
-    }
-    // per-wave partials: [gsc G][gsh G][gbw2 G][gWw2 G*G][ga,gb C*4]
-    float *mypart = part + (size_t)blockIdx.x * (3 * G + G * G + 4 * (size_t)c);
-    for (int i = lane; i < 3 * G; i += WAVE) mypart[i] = accS[i];
-    for (int i = lane; i < G * G; i += WAVE) mypart[3 * G + i] = accW[i];
-    for (int i = lane; i < 4 * c; i += WAVE) mypart[3 * G + G * G + i] = accAB[i];
-}
-
-struct MapAggParams {  // columns: [gsc G][gsh G][gbw2 G][gWw2 G*G][(ga,gb) C*4]
-    float *gsc, *gsh, *gWw2, *gbw2, *ga, *gb;
-    int g;
-    __device__ void operator()(int e, double acc) const {
-        const float v = (float)acc;
-        if (e < g) gsc[e] = v;
-        else if (e < 2 * g) gsh[e - g] = v;
-        else if (e < 3 * g) gbw2[e - 2 * g] = v;
-        else if (e < 3 * g + g * g) gWw2[e - 3 * g] = v;
-        else {
-            const int r = e - 3 * g - g * g, ch = r >> 2, j = r & 3;
-            if (j < 3) ga[ch * 3 + j] = v; else gb[ch] = v;
-        }
-    }
-};
-
-// grad v[j,c] = sum over slots r that point at j of w[r, g(c)] * g_out[r / k, c]
-__global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int c, int g,
-                                                               const float *__restrict__ wbuf,
-                                                               const float *__restrict__ g_out,
-                                                               const int *__restrict__ inv_ptr,
-                                                               const int *__restrict__ inv_rows,
-                                                               float *__restrict__ gv) {
-    const int I = c / g;
-    const long long total = (long long)n * c;
-    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
-        const int j = (int)(e / c), ch = (int)(e - (long long)j * c);
-        const int gl = ch / I;
-        float acc = 0.f;
-        for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) {
-            const int r = inv_rows[p];
-            acc = __builtin_fmaf(wbuf[(long long)r * g + gl], g_out[(long long)(r / k) * c + ch], acc);
-        }
-        gv[e] = acc;
-    }
-}
-
 }  // namespace gva
 
 using namespace gva;
@@ -511,41 +241,6 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
     launch_finalize(st, (const float *)ppart, nb_par, c * (g + 4), MapLogitsParams{gM, ga, gb, g});
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-
-extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
-                                                   const float *sh, const float *Ww2, const float *bw2,
-                                                   const float *v, const float *a, const float *b,
-                                                   const float *coord, const int *idx, const float *g_out,
-                                                   const float *g_A, const float *g_sw, const int *inv_ptr,
-                                                   const int *inv_rows, float *gW1, float *gsc, float *gsh,
-                                                   float *gWw2, float *gbw2, float *gv, float *ga, float *gb,
-                                                   void *workspace, size_t workspace_bytes, void *stream) {
-    if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0 || !pow2(c / g) || c / g > 64) return PTV2_ERR_ARG;
-    if (!workspace || workspace_bytes < gva_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
-    if (n == 0) return PTV2_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = sizeof(float) * BwdLds::floats(g, k, c);
-    if (lds_bytes > 160 * 1024) return PTV2_ERR_ARG;
-    float *part = (float *)workspace;
-    float *wbuf = (float *)((char *)workspace + rows_offset_bytes(c, g));
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes));
-    const int nblk = std::min(n, std::min(256 * per_cu, (int)MAX_BLOCKS));
-#define CALL(GG)                                                                                                    \
-    if (lds_bytes > 32 * 1024)                                                                                      \
-        (void)hipFuncSetAttribute((const void *)aggregate_bwd_kernel<GG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds_bytes);                                                                  \
-    hipLaunchKernelGGL(aggregate_bwd_kernel<GG>, dim3(nblk), dim3(WAVE), lds_bytes, st, n, k, c, W1, sc, sh, Ww2, bw2, v, a, \
-                       b, coord, idx, g_out, g_A, g_sw, gW1, wbuf, inv_ptr ? (float *)nullptr : gv, part)
-    GVA_DISPATCH_G(g, CALL)
-#undef CALL
-    const int len = 3 * g + g * g + 4 * c;
-    launch_finalize(st, (const float *)part, nblk, len, MapAggParams{gsc, gsh, gWw2, gbw2, ga, gb, g});
-    if (inv_ptr)
-        hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3(stage_grid((long long)n * c, TPB)), dim3(TPB), 0, st, n, k, c, g,
-                           (const float *)wbuf, g_out, inv_ptr, inv_rows, gv);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -8,9 +8,7 @@
 //                       registers; a, b, M are wave-uniform operands (scalar loads, SGPR FMA sources).
 //                       HBM traffic per launch: idx + coord + kW/qW gathers in, W1 out -- the
 //                       (N,K,C) intermediate of the reference never exists.
-//   gva_aggregate_forward  per point (one wavefront): BN_w affine + ReLU + Linear(G,G) + softmax over
-//                       the K neighbours (K-lane shuffle groups) + mask, then with lanes over channels
-//                       out_v = sum_s w v[idx], A[g] = sum_s w[s,g] P[s,:], sw = sum_s w.
+// (softmax / aggregation stages: gva_aggregate.hip)
 #include "gva_common.h"
 
 namespace gva {
@@ -111,121 +109,6 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
     }
 }
 
-// ---------------------------------------------------------- aggregate forward --
-// LDS layout helpers shared with the backward kernel (gva_bwd.hip).
-struct AggLds {
-    // GP: padded (odd) row length of [row][g] images -> lanes that walk rows hit distinct banks
-    __host__ __device__ static constexpr int gp(int G) { return (G | 1) + ((G & 1) ? 2 : 0); }  // odd, >= G+1
-    __host__ __device__ static constexpr int G4(int G) { return (G + 3) & ~3; }
-    __host__ __device__ static constexpr size_t r4(size_t v) { return (v + 3) & ~(size_t)3; }
-    __host__ __device__ static constexpr size_t ab_off(int G) { return r4((size_t)G * gp(G) * 2 + 3 * (size_t)G); }
-    __host__ __device__ static constexpr size_t block_floats(int G, int C) { return ab_off(G) + 4 * (size_t)C; }
-    __host__ __device__ static constexpr size_t wave_floats(int G, int K) {
-        return r4((size_t)K * 4 + K + (size_t)K * gp(G) * 2 + (size_t)K * G4(G));
-    }
-};
-
-template <int G>
-__global__ __launch_bounds__(TPB) void aggregate_fwd_kernel(int n, int k, int c, const float *__restrict__ W1,
-                                                            const float *__restrict__ sc, const float *__restrict__ sh,
-                                                            const float *__restrict__ Ww2, const float *__restrict__ bw2,
-                                                            const float *__restrict__ v, const float *__restrict__ a,
-                                                            const float *__restrict__ b, const float *__restrict__ coord,
-                                                            const int *__restrict__ idx, float *__restrict__ out_v,
-                                                            float *__restrict__ A, float *__restrict__ sw) {
-    extern __shared__ float4 lds4[];
-    float *lds = (float *)lds4;
-    constexpr int GP = AggLds::gp(G);
-    constexpr int G4 = AggLds::G4(G);
-    // block-shared images
-    float *sWw2 = lds;                     // [G][GP]   Ww2[g][g']
-    float *sBw2 = sWw2 + G * GP * 2;       // (second G*GP slab is used by the backward kernel only)
-    float *sSc = sBw2 + G;
-    float *sSh = sSc + G;
-    float4 *sAB = (float4 *)(lds + AggLds::ab_off(G));  // [C] (a.x, a.y, a.z, b)
-    // per-wave images
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float *wbase = (float *)(sAB + c) + (size_t)wid * AggLds::wave_floats(G, k);
-    float4 *sPos = (float4 *)wbase;                 // [K] (x,y,z,valid)
-    int *sSrc = (int *)(wbase + 4 * k);             // [K]
-    float *sY = wbase + 5 * k;                      // [K][GP]
-    float *sW = sY + (size_t)k * GP * 2;            // [K][G4]  (second K*GP slab: backward only)
-
-    for (int i = threadIdx.x; i < G * G; i += TPB) sWw2[(i / G) * GP + (i % G)] = Ww2[i];
-    for (int i = threadIdx.x; i < G; i += TPB) { sBw2[i] = bw2[i]; sSc[i] = sc[i]; sSh[i] = sh[i]; }
-    for (int i = threadIdx.x; i < c; i += TPB) sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
-    __syncthreads();
-
-    const int I = c / G;
-    const int items = G * k;
-    const int npts_per_iter = gridDim.x * WPB;
-    const int iters = (n + npts_per_iter - 1) / npts_per_iter;
-    for (int it = 0; it < iters; ++it) {
-        const int pt = (it * gridDim.x + blockIdx.x) * WPB + wid;
-        const bool live = pt < n;
-        // P0: neighbour slots
-        if (live && lane < k) {
-            Rel r = rel_pos(coord, idx, (long long)pt * k + lane, pt);
-            sPos[lane] = make_float4(r.x, r.y, r.z, r.src >= 0 ? 1.f : 0.f);
-            sSrc[lane] = r.src;
-        }
-        // P1: y = ReLU(sc * W1 + sh)
-        if (live)
-            for (int item = lane; item < items; item += WAVE) {
-                int s = item / G, g = item - s * G;  // W1 is [s][g] contiguous: coalesced read
-                float u = W1[(long long)pt * items + item];
-                sY[s * GP + g] = fmaxf(__builtin_fmaf(sc[g], u, sh[g]), 0.f);
-            }
-        __syncthreads();
-        // P2: z = y Ww2^T + bw2 ; softmax over s (k-lane groups) ; mask ; sw
-        if (live)
-            for (int base = 0; base < items; base += WAVE) {
-                const int item = base + lane;
-                const bool act = item < items;
-                const int g = act ? item / k : 0, s = act ? item - g * k : 0;
-                float z = sBw2[g];
-                const float *yr = sY + s * GP, *wr = sWw2 + g * GP;
-                for (int j = 0; j < G; ++j) z = __builtin_fmaf(yr[j], wr[j], z);
-                float mx = z;
-                for (int o = k >> 1; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-                float e = expf(z - mx);
-                float den = e;
-                for (int o = k >> 1; o >= 1; o >>= 1) den += __shfl_xor(den, o, WAVE);
-                float w = (e / den) * sPos[s].w;
-                float tot = w;
-                for (int o = k >> 1; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, WAVE);
-                if (act) {
-                    sW[s * G4 + g] = w;
-                    if (s == 0) sw[(long long)pt * G + g] = tot;
-                }
-            }
-        __syncthreads();
-        // P3: channel phase
-        if (live)
-            for (int ch = lane; ch < c; ch += WAVE) {
-                const int gl = ch / I;
-                const float4 ab = sAB[ch];
-                float accA[G];
-#pragma unroll
-                for (int g = 0; g < G; ++g) accA[g] = 0.f;
-                float ov = 0.f;
-                for (int s = 0; s < k; ++s) {
-                    const float4 ps = sPos[s];
-                    const int src = sSrc[s];
-                    const float p = pe_act(ab.x, ab.y, ab.z, ab.w, ps.x, ps.y, ps.z);
-                    const float *wrow = sW + s * G4;
-                    if (src >= 0) ov = __builtin_fmaf(wrow[gl], v[(long long)src * c + ch], ov);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) accA[g] = __builtin_fmaf(wrow[g], p, accA[g]);
-                }
-                out_v[(long long)pt * c + ch] = ov;
-#pragma unroll
-                for (int g = 0; g < G; ++g) A[((long long)g * n + pt) * c + ch] = accA[g];
-            }
-        __syncthreads();
-    }
-}
-
 inline int stage_grid(long long work_items, int per_block) {
     long long b = (work_items + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 256 * 8 ? 256 * 8 : b));
@@ -282,28 +165,6 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
 #undef CALL
     // part is [nblk][2g]: columns 0..g-1 -> T1, g..2g-1 -> T2 (contiguous in the reduced vector)
     launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-
-extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
-                                                  const float *sh, const float *Ww2, const float *bw2, const float *v,
-                                                  const float *a, const float *b, const float *coord, const int *idx,
-                                                  float *out_v, float *A, float *sw, void *stream) {
-    if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
-    if (n == 0) return PTV2_OK;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds_bytes = sizeof(float) * (AggLds::block_floats(g, c) + WPB * AggLds::wave_floats(g, k));
-    if (lds_bytes > 160 * 1024) return PTV2_ERR_ARG;
-    const int nblk = stage_grid(n, WPB);
-#define CALL(GG)                                                                                                   \
-    if (lds_bytes > 48 * 1024)                                                                                     \
-        (void)hipFuncSetAttribute((const void *)aggregate_fwd_kernel<GG>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            (int)lds_bytes);                                                                       \
-    hipLaunchKernelGGL(aggregate_fwd_kernel<GG>, dim3(nblk), dim3(TPB), lds_bytes, st, n, k, c, W1, sc, sh, Ww2, bw2, v, \
-                       a, b, coord, idx, out_v, A, sw)
-    GVA_DISPATCH_G(g, CALL)
-#undef CALL
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -1,6 +1,6 @@
 // ao_amd/csrc/gva_peb.hip -- the grouped positional-bias projection of the fused GVA (gfx950).
 //
-//   out[n, g*I+i] = out_v[n, g*I+i] + sum_c' A[g,n,c'] * Wp2[g*I+i, c'] + bp2[g*I+i] * sw[n,g]
+//   out[n, g*I+i] = out_v[n, g*I+i] + sum_c' A[n,g,c'] * Wp2[g*I+i, c'] + bp2[g*I+i] * sw[n,g]
 //
 // i.e. linear_p_bias[3] applied AFTER the softmax-weighted sum over neighbours (see ao_amd/ptv2/gva.py).
 // It is a batch of G thin GEMMs (N x C') x (C' x I) with I = C/G = 8 output columns each -- a shape
@@ -30,10 +30,9 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, const
         const int cnt = (n - n0) < T ? (n - n0) : T;
         for (int gi = 0; gi < g; ++gi) {
             __syncthreads();
-            const float4 *src = (const float4 *)(A + ((size_t)gi * n + n0) * c);
             for (int e = threadIdx.x; e < cnt * (c / 4); e += TPB) {
                 const int r = e / (c / 4), q = e - r * (c / 4);
-                *(float4 *)(sA + (size_t)r * ldA + 4 * q) = src[e];
+                *(float4 *)(sA + (size_t)r * ldA + 4 * q) = *(const float4 *)(A + ((size_t)(n0 + r) * g + gi) * c + 4 * q);
             }
             const float4 *wsrc = (const float4 *)(Wp2 + (size_t)gi * I * c);
             for (int e = threadIdx.x; e < I * (c / 4); e += TPB) ((float4 *)sW)[e] = wsrc[e];
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, const
     }
 }
 
-// gA[g,n,c'] = sum_i gO[n, g*I+i] * Wp2[g*I+i, c'] ;  g_sw[n,g] = sum_i gO[n, g*I+i] * bp2[g*I+i]
+// gA[n,g,c'] = sum_i gO[n, g*I+i] * Wp2[g*I+i, c'] ;  g_sw[n,g] = sum_i gO[n, g*I+i] * bp2[g*I+i]
 template <int I>
 __global__ __launch_bounds__(TPB) void peb_bwd_kernel(int n, int c, int g, const float *__restrict__ gO,
                                                       const float *__restrict__ Wp2, const float *__restrict__ bp2,
@@ -63,8 +62,8 @@ __global__ __launch_bounds__(TPB) void peb_bwd_kernel(int n, int c, int g, const
     const long long total = (long long)g * n * (c / 4);
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
         const int q = (int)(e % (c / 4));
-        const long long gn = e / (c / 4);
-        const int nn = (int)(gn % n), gi = (int)(gn / n);
+        const long long ng = e / (c / 4);
+        const int gi = (int)(ng % g), nn = (int)(ng / g);
         const float *go = gO + (size_t)nn * c + gi * I;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

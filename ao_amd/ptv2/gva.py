@@ -13,8 +13,8 @@ N*K*C is ever materialised and the only per-neighbour tensors are of size N*K*G 
                                                   M = (Ww1 Wp2)^T (C,G), cW = Ww1 bp2 + bw1
   w          = mask * softmax_s( ReLU(BN_w(W1)) Ww2^T + bw2 )
   out[n,c]   = sum_s w[n,s,g(c)] (v[idx[n,s],c]*mask + peb[n,s,c])
-             = out_v[n,c] + sum_c' A[g(c),n,c'] Wp2[c,c'] + bp2[c] sw[n,g(c)],
-               A[g,n,:] = sum_s w[n,s,g] P[n,s,:],  sw[n,g] = sum_s w[n,s,g]
+             = out_v[n,c] + sum_c' A[n,g(c),c'] Wp2[c,c'] + bp2[c] sw[n,g(c)],
+               A[n,g,:] = sum_s w[n,s,g] P[n,s,:],  sw[n,g] = sum_s w[n,s,g]
 
 BN_p (training) needs the batch statistics of pos Wp1^T + bp1 over all N*K rows; they follow in closed
 form from the mean (3) and covariance (3x3) of pos, which depend on the neighbour table only and are
@@ -32,8 +32,9 @@ _SIG = {
     "gva_pos_stats_hip_launcher": (_lib._c_int, [_lib._c_int] * 2 + [_lib._vp] * 5 + [_lib._c_size, _lib._vp]),
     "gva_logits_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 12 + [_lib._c_size, _lib._vp]),
     "gva_logits_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 18 + [_lib._c_size, _lib._vp]),
-    "gva_aggregate_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 13 + [_lib._vp]),
-    "gva_aggregate_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 24 + [_lib._c_size, _lib._vp]),
+    "gva_aggregate_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
+    "gva_aggregate_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 14 + [_lib._vp]),
+    "gva_aggregate_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 25 + [_lib._c_size, _lib._vp]),
     "gva_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
     "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
     "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
@@ -148,7 +149,7 @@ class _Logits(torch.autograd.Function):
 
 
 class _Aggregate(torch.autograd.Function):
-    """(out_v (N,C), A (G,N,C), sw (N,G)); see module docstring."""
+    """(out_v (N,C), A (N,G,C), sw (N,G)); see module docstring."""
 
     @staticmethod
     def forward(ctx, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx):
@@ -159,27 +160,28 @@ class _Aggregate(torch.autograd.Function):
         g = sc.shape[0]
         dev = v.device
         out_v = torch.empty((n, c), dtype=torch.float32, device=dev)
-        A = torch.empty((g, n, c), dtype=torch.float32, device=dev)
+        A = torch.empty((n, g, c), dtype=torch.float32, device=dev)
         sw = torch.empty((n, g), dtype=torch.float32, device=dev)
-        with clock.region("gva_aggregate_fwd", 4 * (n * k * g + n * (2 * c + k + 3 + g) + g * n * c)):
+        w = torch.empty((n, k, g), dtype=torch.float32, device=dev)
+        with clock.region("gva_aggregate_fwd", 4 * (2 * n * k * g + n * (2 * c + k + 3 + g) + g * n * c)):
             rc = _lib.lib().gva_aggregate_forward_hip_launcher(
                 n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
                 a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), out_v.data_ptr(), A.data_ptr(),
-                sw.data_ptr(), _lib.stream_ptr())
+                sw.data_ptr(), w.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "gva_aggregate_forward_hip_launcher")
         inv_ptr, inv_rows = inverse_table(idx) if any(ctx.needs_input_grad) else (None, None)
-        ctx.save_for_backward(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows)
+        ctx.save_for_backward(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows, w)
         return out_v, A, sw
 
     @staticmethod
     def backward(ctx, g_out, g_A, g_sw):
-        W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows = ctx.saved_tensors
+        W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows, w = ctx.saved_tensors
         n, k = idx.shape
         c = v.shape[1]
         g = sc.shape[0]
         dev = v.device
         g_out = torch.zeros((n, c), dtype=torch.float32, device=dev) if g_out is None else g_out.contiguous()
-        g_A = torch.zeros((g, n, c), dtype=torch.float32, device=dev) if g_A is None else g_A.contiguous()
+        g_A = torch.zeros((n, g, c), dtype=torch.float32, device=dev) if g_A is None else g_A.contiguous()
         g_sw = torch.zeros((n, g), dtype=torch.float32, device=dev) if g_sw is None else g_sw.contiguous()
         gW1 = torch.empty_like(W1)
         gv = torch.zeros((n, c), dtype=torch.float32, device=dev)
@@ -190,11 +192,11 @@ class _Aggregate(torch.autograd.Function):
         ga = torch.empty((c, 3), dtype=torch.float32, device=dev)
         gb = torch.empty(c, dtype=torch.float32, device=dev)
         L = _lib.lib()
-        ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
-        with clock.region("gva_aggregate_bwd", 4 * (2 * n * k * g + n * (3 * c + k + 3 + 2 * g) + g * n * c)):
+        ws = _lib.workspace(L.gva_aggregate_workspace_bytes(n, k, c, g), dev)
+        with clock.region("gva_aggregate_bwd", 4 * (3 * n * k * g + n * (3 * c + k + 3 + 2 * g) + g * n * c)):
             rc = L.gva_aggregate_backward_hip_launcher(
                 n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
-                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), g_out.data_ptr(), g_A.data_ptr(),
+                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), w.data_ptr(), g_out.data_ptr(), g_A.data_ptr(),
                 g_sw.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(), gW1.data_ptr(), gsc.data_ptr(), gsh.data_ptr(),
                 gWw2.data_ptr(), gbw2.data_ptr(),
                 gv.data_ptr(), ga.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
@@ -217,7 +219,7 @@ class _PebProject(torch.autograd.Function):
     def forward(ctx, A, Wp2, bp2, sw, out_v):
         _lib.require_cuda(A, Wp2, bp2, sw, out_v)
         A, Wp2, bp2, sw, out_v = (_f32c(t) for t in (A, Wp2, bp2, sw, out_v))
-        g, n, c = A.shape
+        n, g, c = A.shape
         out = torch.empty((n, c), dtype=torch.float32, device=A.device)
         with clock.region("gva_peb_fwd", 4 * (g * n * c + 2 * n * c + n * g + c * c)):
             rc = _lib.lib().gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
@@ -230,7 +232,7 @@ class _PebProject(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         A, Wp2, bp2, sw = ctx.saved_tensors
-        g, n, c = A.shape
+        n, g, c = A.shape
         i = c // g
         g_out = g_out.contiguous()
         g_A = torch.empty_like(A)
@@ -239,9 +241,14 @@ class _PebProject(torch.autograd.Function):
             rc = _lib.lib().gva_peb_backward_hip_launcher(n, c, g, g_out.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
                                                           g_A.data_ptr(), g_sw.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "gva_peb_backward_hip_launcher")
-        go3 = g_out.view(n, g, i)
-        g_Wp2 = torch.bmm(go3.permute(1, 2, 0), A).reshape(c, c)   # (G,I,N) x (G,N,C') : K-dim = N, MFMA-friendly
-        g_bp2 = (go3 * sw.unsqueeze(-1)).sum(0).reshape(c)
+        # grad Wp2[g*I+i, c'] = sum_n g_out[n, g*I+i] A[n,g,c']: G batched (I x C') weight-gradient reductions
+        g_Wp2 = torch.empty((c, c), dtype=torch.float32, device=A.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.dense_workspace_bytes(n, c, c), A.device)
+        rc = L.linear_wgrad_strided_hip_launcher(n, i, c, g, g_out.data_ptr(), c, i, A.data_ptr(), g * c, c,
+                                                 g_Wp2.data_ptr(), 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "linear_wgrad_strided_hip_launcher")
+        g_bp2 = (g_out.view(n, g, i) * sw.unsqueeze(-1)).sum(0).reshape(c)
         return g_A, g_Wp2, g_bp2, g_sw, g_out
 
 
@@ -332,5 +339,5 @@ def grouped_vector_attention(mod, query, key, value, coord, reference_index, imp
     out_v, A, sw = impl.aggregate(W1, sc, sh, lin_w2.weight.float(), lin_w2.bias.float(), value, a, b, coord, idx)
     if hasattr(impl, "project"):
         return impl.project(A, Wp2, bp2, sw, out_v)
-    peb = torch.bmm(A, Wp2.view(G, I, C).transpose(1, 2))            # (G,N,I)
-    return out_v + peb.permute(1, 0, 2).reshape(N, C) + (sw.unsqueeze(-1) * bp2.view(1, G, I)).reshape(N, C)
+    peb = torch.einsum("ngc,gic->ngi", A, Wp2.view(G, I, C))
+    return out_v + peb.reshape(N, C) + (sw.unsqueeze(-1) * bp2.view(1, G, I)).reshape(N, C)

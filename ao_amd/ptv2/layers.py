@@ -1,0 +1,119 @@
+"""Per-point dense layers of PT-v2m2 on the HIP kernels of ao_amd/csrc/dense.hip.
+
+`RowLinear` / `RowBatchNorm1d` subclass nn.Linear / nn.BatchNorm1d, so parameter names, buffers and
+state_dict layout are exactly the reference's; only the execution differs:
+  * BatchNorm (+ fused ReLU) forward/backward run as HBM-streaming HIP passes,
+  * the Linear forward and input gradient stay on rocBLAS (MFMA), the weight/bias gradient is a
+    split-K HIP reduction (dW = dY^T X has a tiny output and K = N up to 1e5+).
+Anything the kernels do not cover (CPU tensors, c % 4 != 0, non-fp32, cumulative-average momentum)
+takes the stock torch path of the parent class.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..profiling import clock
+
+WGRAD_MIN_ROWS = 2048
+
+
+def _ws(n, cout, cin, device):
+    return _lib.workspace(_lib.lib().dense_workspace_bytes(n, cout, cin), device)
+
+
+class _BNRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        n, c = x.shape
+        L = _lib.lib()
+        training = bn.training or bn.running_mean is None
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            track = bn.track_running_stats and bn.training and bn.running_mean is not None
+            ws = _ws(n, c, c, x.device)
+            with clock.region("bn_stats", 4 * n * c):
+                rc = L.bn_stats_hip_launcher(
+                    n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                    bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                    bn.num_batches_tracked.data_ptr() if track else 0, float(bn.eps), float(bn.momentum),
+                    ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "bn_stats_hip_launcher")
+        else:
+            mean = bn.running_mean
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+        y = torch.empty_like(x)
+        with clock.region("bn_apply", 8 * n * c):
+            rc = L.bn_apply_hip_launcher(n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), int(relu), y.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "bn_apply_hip_launcher")
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.relu, ctx.training = bool(relu), bool(training)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        n, c = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _ws(n, c, c, x.device)
+        with clock.region("bn_backward", 16 * n * c):
+            rc = _lib.lib().bn_backward_hip_launcher(
+                n, c, x.data_ptr(), gy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                int(ctx.relu), int(ctx.training), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "bn_backward_hip_launcher")
+        return gx, dgamma, dbeta, None, None
+
+
+class RowBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d on (N,C) rows; `forward(x, relu=True)` fuses the activation."""
+
+    def _fast(self, x):
+        return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0
+                and 4 <= x.shape[1] <= 1024 and x.shape[0] > 1 and self.affine and self.momentum is not None)
+
+    def forward(self, x, relu=False):
+        if not self._fast(x):
+            y = super().forward(x)
+            return F.relu(y) if relu else y
+        return _BNRows.apply(x.contiguous(), self.weight, self.bias, self, relu)
+
+
+class _LinearRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, cin = x.shape
+        cout = weight.shape[0]
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        ws = _ws(n, cout, cin, x.device)
+        with clock.region("linear_wgrad", 4 * n * (cin + cout)):
+            rc = _lib.lib().linear_wgrad_hip_launcher(n, cout, cin, gy.data_ptr(), x.data_ptr(), dW.data_ptr(),
+                                                      db.data_ptr() if db is not None else 0, ws.data_ptr(), ws.numel(),
+                                                      _lib.stream_ptr())
+        _lib.check(rc, "linear_wgrad_hip_launcher")
+        return gx, dW, db
+
+
+class RowLinear(nn.Linear):
+    """nn.Linear on (N,Cin) rows with the split-K weight gradient."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+                and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_grad_enabled() and self.weight.requires_grad):
+            return _LinearRows.apply(x.contiguous(), self.weight, self.bias)
+        return super().forward(x)

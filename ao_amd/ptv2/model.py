@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .. import _lib, pointops
 from ..pointops.interpolation import _InterpolateRows
 from .geometry import build_geometry
+from .layers import RowBatchNorm1d, RowLinear
 
 
 class PointBatchNorm(nn.Module):
@@ -30,19 +31,30 @@ class PointBatchNorm(nn.Module):
 
     def __init__(self, embed_channels):
         super().__init__()
-        self.norm = nn.BatchNorm1d(embed_channels)
+        self.norm = RowBatchNorm1d(embed_channels)
 
-    def forward(self, input):
+    def forward(self, input, relu=False):
         if input.dim() == 2:
-            return self.norm(input)
+            return self.norm(input, relu)
         if input.dim() == 3:
             n, l, c = input.shape
-            return self.norm(input.reshape(n * l, c)).view(n, l, c)
+            return self.norm(input.reshape(n * l, c), relu).view(n, l, c)
         raise NotImplementedError
 
 
+class LinBnRelu(nn.Sequential):
+    """Sequential(Linear, PointBatchNorm, ReLU) -- the reference's layout and key names ("0.weight",
+    "1.norm.*") -- executed as Linear + one fused BatchNorm/ReLU pass."""
+
+    def __init__(self, cin, cout, bias):
+        super().__init__(RowLinear(cin, cout, bias=bias), PointBatchNorm(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self[1](self[0](x), relu=True)
+
+
 def _lin_bn_relu(cin, cout, bias):
-    return nn.Sequential(nn.Linear(cin, cout, bias=bias), PointBatchNorm(cout), nn.ReLU(inplace=True))
+    return LinBnRelu(cin, cout, bias)
 
 
 class GroupedVectorAttention(nn.Module):
@@ -56,7 +68,7 @@ class GroupedVectorAttention(nn.Module):
         c, g = embed_channels, groups
         self.linear_q = _lin_bn_relu(c, c, qkv_bias)
         self.linear_k = _lin_bn_relu(c, c, qkv_bias)
-        self.linear_v = nn.Linear(c, c, bias=qkv_bias)
+        self.linear_v = RowLinear(c, c, bias=qkv_bias)
         if pe_multiplier:
             self.linear_p_multiplier = nn.Sequential(nn.Linear(3, c), PointBatchNorm(c), nn.ReLU(inplace=True),
                                                      nn.Linear(c, c))
@@ -121,8 +133,8 @@ class Block(nn.Module):
                  attn_drop_rate=0.0, drop_path_rate=0.0, enable_checkpoint=False):
         super().__init__()
         self.attn = GroupedVectorAttention(embed_channels, groups, attn_drop_rate, qkv_bias, pe_multiplier, pe_bias)
-        self.fc1 = nn.Linear(embed_channels, embed_channels, bias=False)
-        self.fc3 = nn.Linear(embed_channels, embed_channels, bias=False)
+        self.fc1 = RowLinear(embed_channels, embed_channels, bias=False)
+        self.fc3 = RowLinear(embed_channels, embed_channels, bias=False)
         self.norm1 = PointBatchNorm(embed_channels)
         self.norm2 = PointBatchNorm(embed_channels)
         self.norm3 = PointBatchNorm(embed_channels)
@@ -133,12 +145,12 @@ class Block(nn.Module):
     def forward(self, points, reference_index):
         coord, feat, offset = points
         identity = feat
-        feat = self.act(self.norm1(self.fc1(feat)))
+        feat = self.norm1(self.fc1(feat), relu=True)
         if self.enable_checkpoint and self.training:
             feat = torch.utils.checkpoint.checkpoint(self.attn, feat, coord, reference_index, use_reentrant=False)
         else:
             feat = self.attn(feat, coord, reference_index)
-        feat = self.act(self.norm2(feat))
+        feat = self.norm2(feat, relu=True)
         feat = self.norm3(self.fc3(feat))
         feat = self.act(identity + self.drop_path(feat))
         return [coord, feat, offset]
@@ -205,12 +217,12 @@ class GridPool(nn.Module):
     def __init__(self, in_channels, out_channels, grid_size, bias=False):
         super().__init__()
         self.in_channels, self.out_channels, self.grid_size = in_channels, out_channels, grid_size
-        self.fc = nn.Linear(in_channels, out_channels, bias=bias)
+        self.fc = RowLinear(in_channels, out_channels, bias=bias)
         self.norm = PointBatchNorm(out_channels)
         self.act = nn.ReLU(inplace=True)
 
     def forward(self, feat, fine_level, coarse_level):
-        feat = self.act(self.norm(self.fc(feat)))
+        feat = self.norm(self.fc(feat), relu=True)
         return _SegmentMax.apply(feat, fine_level.order32, fine_level.idx_ptr32)
 
 
@@ -300,8 +312,8 @@ class PointTransformerV2(nn.Module):
                 dec_channels[i + 1], enc_channels[i], dec_channels[i], dec_groups[i], dec_depths[i], dec_neighbours[i],
                 attn_qkv_bias, pe_multiplier, pe_bias, attn_drop_rate,
                 dec_dp[sum(dec_depths[:i]):sum(dec_depths[:i + 1])], enable_checkpoint, unpool_backend))
-        self.seg_head = (nn.Sequential(nn.Linear(dec_channels[0], dec_channels[0]), PointBatchNorm(dec_channels[0]),
-                                       nn.ReLU(inplace=True), nn.Linear(dec_channels[0], num_classes))
+        self.seg_head = (nn.Sequential(RowLinear(dec_channels[0], dec_channels[0]), PointBatchNorm(dec_channels[0]),
+                                       nn.ReLU(inplace=True), RowLinear(dec_channels[0], num_classes))
                          if num_classes > 0 else nn.Identity())
 
     def geometry(self, coord, offset):

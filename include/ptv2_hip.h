@@ -184,25 +184,28 @@ int gva_logits_backward_hip_launcher(int n, int k, int c, int g, const float *a,
                                      const double *gT2, const int *inv_ptr, const int *inv_rows,
                                      float *gkW, float *gqW, float *ga, float *gb, float *gM, float *gcW,
                                      void *workspace, size_t workspace_bytes, void *stream);
-/* w = mask * softmax_s(ReLU(sc*W1+sh) Ww2^T + bw2); out_v (n,c) = sum_s w v[idx]; A (g,n,c) = sum_s w P; sw (n,g) = sum_s w */
+/* w (n,k,g) = mask * softmax_s(ReLU(sc*W1+sh) Ww2^T + bw2)   [kept by the caller for the backward]
+ * out_v (n,c) = sum_s w v[idx];  A (n,g,c) = sum_s w[s,g] P[s,:];  sw (n,g) = sum_s w */
+size_t gva_aggregate_workspace_bytes(int n, int k, int c, int g);
 int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
                                        const float *sh, const float *Ww2, const float *bw2,
                                        const float *v, const float *a, const float *b,
                                        const float *coord, const int *idx, float *out_v, float *A,
-                                       float *sw, void *stream);
-/* given g_out (n,c), g_A (g,n,c), g_sw (n,g): gW1 (n,k,g), gsc, gsh (g), gWw2 (g,g), gbw2 (g), gv (n,c) [zeroed], ga (c,3), gb (c) */
+                                       float *sw, float *w, void *stream);
+/* given w and g_out (n,c), g_A (n,g,c), g_sw (n,g): gW1 (n,k,g), gsc, gsh (g), gWw2 (g,g), gbw2 (g), gv (n,c)
+ * [zeroed], ga (c,3), gb (c).  workspace: gva_aggregate_workspace_bytes(n,k,c,g) */
 int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
                                         const float *sh, const float *Ww2, const float *bw2,
                                         const float *v, const float *a, const float *b,
-                                        const float *coord, const int *idx, const float *g_out,
-                                        const float *g_A, const float *g_sw, const int *inv_ptr,
-                                        const int *inv_rows, float *gW1, float *gsc, float *gsh,
-                                        float *gWw2, float *gbw2, float *gv, float *ga, float *gb,
-                                        void *workspace, size_t workspace_bytes, void *stream);
+                                        const float *coord, const int *idx, const float *w,
+                                        const float *g_out, const float *g_A, const float *g_sw,
+                                        const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
+                                        float *gsh, float *gWw2, float *gbw2, float *gv, float *ga,
+                                        float *gb, void *workspace, size_t workspace_bytes, void *stream);
 
 /* grouped positional-bias projection applied after the neighbour sum (linear_p_bias[3], :92,117-119):
- *   out[n,g*I+i] = out_v[n,g*I+i] + sum_c' A[g,n,c'] Wp2[g*I+i,c'] + bp2[g*I+i] sw[n,g],  I = c/g in {2,4,8,16}
- * backward w.r.t. A and sw: g_A (g,n,c), g_sw (n,g) from g_out (n,c) (grad Wp2 / bp2 are dense products the
+ *   out[n,g*I+i] = out_v[n,g*I+i] + sum_c' A[n,g,c'] Wp2[g*I+i,c'] + bp2[g*I+i] sw[n,g],  I = c/g in {2,4,8,16}
+ * backward w.r.t. A and sw: g_A (n,g,c), g_sw (n,g) from g_out (n,c) (grad Wp2 / bp2 are dense products the
  * host takes with rocBLAS). */
 int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const float *Wp2, const float *bp2,
                                  const float *sw, const float *out_v, float *out, void *stream);
@@ -223,6 +226,35 @@ int pool_max_forward_hip_launcher(int n_out, int c, const float *feat, const int
                                   const int *idx_ptr, float *out, int *arg, void *stream);
 int pool_max_backward_hip_launcher(int n_out, int c, const float *grad_out, const int *arg,
                                    float *grad_feat, void *stream);
+
+/* ------------------------------------------------ per-point dense layers --
+ * PointBatchNorm on (N,C) rows (point_transformer_v2m2_base.py:26-45: nn.BatchNorm1d) with an optional
+ * fused ReLU, and the weight/bias gradient of nn.Linear as a split-K reduction.  c % 4 == 0, c <= 1024.
+ *   bn_stats:    batch mean / rstd (biased variance) of x (n,c); when running_mean != NULL also the
+ *                momentum update of running_mean / running_var (unbiased) and ++*num_batches_tracked
+ *   bn_apply:    y = (x - mean) * rstd * gamma + beta, then max(.,0) if relu
+ *   bn_backward: gx, dgamma, dbeta from gy (n,c); relu != 0 masks gy where the forward output was <= 0;
+ *                training == 0 treats mean / rstd as constants (eval mode)
+ *   linear_wgrad: dW (cout,cin) = gY^T X, db (cout) = column sums of gY (db may be NULL)
+ */
+size_t dense_workspace_bytes(int n, int cout, int cin);
+int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
+                          float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
+                          const float *gamma, const float *beta, int relu, float *y, void *stream);
+int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, const float *mean,
+                             const float *rstd, const float *gamma, const float *beta, int relu,
+                             int training, float *gx, float *dgamma, float *dbeta, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
+                              float *db, void *workspace, size_t workspace_bytes, void *stream);
+/* batched / strided form: dW[b][o][i] = sum_n gY[n*ldy + b*sy + o] * X[n*ldx + b*sx + i], b < batch
+ * (workspace: dense_workspace_bytes(n, batch*cout, cin)) */
+int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const float *gY,
+                                      long long ldy, long long sy, const float *X, long long ldx,
+                                      long long sx, float *dW, float *db, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

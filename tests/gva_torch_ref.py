@@ -38,5 +38,5 @@ class TorchImpl:
         vm = v[safe] * mask.unsqueeze(-1)
         out_v = (vm.view(n, k, g, c // g) * w.unsqueeze(-1)).sum(1).reshape(n, c)
         P = torch.relu(pos @ a.t() + b)
-        A = torch.einsum("nsg,nsc->gnc", w, P)
+        A = torch.einsum("nsg,nsc->ngc", w, P)
         return out_v, A, w.sum(1)

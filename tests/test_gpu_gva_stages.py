@@ -105,5 +105,5 @@ def test_aggregate_backward(c, g, k, n):
     ins = [t.cuda().requires_grad_(True) for t in ins]
     out = _HipImpl.aggregate(*ins, xyz, idx)
     ref = TorchImpl.aggregate(*ins, xyz, idx)
-    gouts = [torch.randn(n, c).cuda(), torch.randn(g, n, c).cuda(), torch.randn(n, g).cuda()]
+    gouts = [torch.randn(n, c).cuda(), torch.randn(n, g, c).cuda(), torch.randn(n, g).cuda()]
     grads_close(out, ref, ins, gouts, names)
