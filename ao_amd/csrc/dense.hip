@@ -34,9 +34,13 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
     const int rl = TPB / cq;                 // row lanes per block (>= 1 for c <= 1024)
     const int q = threadIdx.x % cq, r = threadIdx.x / cq;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    // sums of (x - x[0,:]): shifting by one sample of the column removes the catastrophic cancellation of
+    // E[x^2] - E[x]^2 when |mean| >> std, at no extra pass
+    const float4 sft = ((const float4 *)x)[q];
     if (r < rl)
         for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
-            const float4 v = ((const float4 *)x)[row * cq + q];
+            float4 v = ((const float4 *)x)[row * cq + q];
+            v.x -= sft.x; v.y -= sft.y; v.z -= sft.z; v.w -= sft.w;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
             s2.x = __builtin_fmaf(v.x, v.x, s2.x); s2.y = __builtin_fmaf(v.y, v.y, s2.y);
             s2.z = __builtin_fmaf(v.z, v.z, s2.z); s2.w = __builtin_fmaf(v.w, v.w, s2.w);
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
     }
 }
 
-struct MapBnStats {  // columns [0,c): sum x, [c,2c): sum x^2  ->  mean, rstd, running stats
+struct MapBnStats {  // columns [0,c): sum (x-x0), [c,2c): sum (x-x0)^2  ->  mean, rstd, running stats
+    const float *x0;  // row 0 of x: the shift used by bn_stats_kernel
     float *mean, *rstd, *run_mean, *run_var;
     long long *batches;
     int c, n;
@@ -69,13 +74,14 @@ struct MapBnStats {  // columns [0,c): sum x, [c,2c): sum x^2  ->  mean, rstd, r
     int pass;
     __device__ void operator()(int j, double v) const {
         if (pass == 0) {
-            if (j < c) mean[j] = (float)(v / n);
+            if (j < c) mean[j] = (float)((double)x0[j] + v / n);
             return;
         }
         if (j < c) return;
         const int ch = j - c;
         const double m = (double)mean[ch];
-        double var = v / n - m * m;
+        const double d = m - (double)x0[ch];  // mean of the shifted samples
+        double var = v / n - d * d;
         var = var > 0.0 ? var : 0.0;
         rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
         if (run_mean) {
@@ -308,7 +314,7 @@ extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, 
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
-    MapBnStats m{mean, rstd, running_mean, running_var, num_batches_tracked, c, n, eps, momentum, 0};
+    MapBnStats m{x, mean, rstd, running_mean, running_var, num_batches_tracked, c, n, eps, momentum, 0};
     launch_finalize(st, (const float *)part, nblk, 2 * c, m);
     m.pass = 1;
     launch_finalize(st, (const float *)part, nblk, 2 * c, m);
