@@ -173,7 +173,14 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
 }
 
 // ================================================================== backward ==
-// grad w (pre-mask) and the (ga, gb) partials; one wavefront (64-thread workgroup) per point
+// grad w (pre-mask) and the (ga, gb) partials; one wavefront (64-thread workgroup) per point.
+// Three lane mappings, none of which needs a cross-lane reduction inside its inner loop:
+//   A  lane = (slot s, group g):      grad w += <g_out[g-th group], v[idx[s], g-th group]>   (I contiguous floats)
+//   C  lane = channel:                g_A column in registers; gP[s] = <w[s,:], g_A[:,ch]>; (ga, gb) accumulate in
+//                                     registers across slots AND points; the column is also parked in LDS for
+//   B  lane = (slot s, channel slice): grad w[s,:] += P[s,ch] g_A[:,ch] over the 64-channel chunk
+constexpr int bwd_rounds(int G) { return (8 * G + WAVE - 1) / WAVE; }  // channel rounds for I = C/G <= 8
+
 template <int G>
 __global__ __launch_bounds__(WAVE) void aggregate_bwd_tile_kernel(
     int n, int k, int c, const float *__restrict__ w, const float *__restrict__ v, const float *__restrict__ a,
@@ -181,23 +188,24 @@ __global__ __launch_bounds__(WAVE) void aggregate_bwd_tile_kernel(
     const float *__restrict__ g_out, const float *__restrict__ g_A, const float *__restrict__ g_sw,
     float *__restrict__ gw, float *gv_atomic, float *__restrict__ part) {
     extern __shared__ float4 lds4[];
-    constexpr int GP = GPof(G), G4 = G4of(G);
+    constexpr int GP = GPof(G), G4 = G4of(G), ROUNDS = bwd_rounds(G);
     const int lane = threadIdx.x;
-    float4 *sAB = lds4;                                   // [c]   (a, b)
-    float4 *accAB = sAB + c;                              // [c]   per-wave (ga, gb) sums
-    float4 *sPos = accAB + c;                             // [k]
+    float4 *sPos = lds4;                                  // [k]
     float *sW = (float *)(sPos + k);                      // [k][G4]
     float *sGW = sW + (size_t)k * G4;                     // [k][GP]
     float *sT = sGW + (((size_t)k * GP + 3) & ~(size_t)3);  // [64][GP]  g_A chunk
     int *sSrc = (int *)(sT + (((size_t)64 * GP + 3) & ~(size_t)3));  // [k]
-    for (int i = lane; i < c; i += WAVE) {
-        sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
-        accAB[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     const int I = c / G;
     const int items = G * k;
     const int J = WAVE / k;
     const int ms = lane & (k - 1), mj = lane / k;
+    float4 ab[ROUNDS], acc4[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int ch = r * WAVE + lane;
+        ab[r] = ch < c ? make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int pt = blockIdx.x; pt < n; pt += gridDim.x) {
         __syncthreads();
         if (lane < k) {
@@ -208,75 +216,73 @@ __global__ __launch_bounds__(WAVE) void aggregate_bwd_tile_kernel(
         for (int item = lane; item < items; item += WAVE) {
             const int s = item / G, g = item - s * G;
             sW[s * G4 + g] = w[(long long)pt * items + item];
-            sGW[s * GP + g] = g_sw[(long long)pt * G + g];
         }
         __syncthreads();
-        // v path: grad w[s,g] += sum_{ch in g} g_out[ch] v[idx[s],ch]
-        for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
-            const int ch = cb0 + lane;
-            const bool act = ch < c;
-            const float go = act ? g_out[(long long)pt * c + ch] : 0.f;
-            const int gl = act ? ch / I : 0;
-            for (int s = 0; s < k; ++s) {
-                const int src = sSrc[s];
-                float val = 0.f;
-                if (act && src >= 0) {
-                    val = go * v[(long long)src * c + ch];
-                    if (gv_atomic) atomicAdd(gv_atomic + (long long)src * c + ch, go * sW[s * G4 + gl]);
+        // A: v path
+        for (int item = lane; item < items; item += WAVE) {
+            const int s = item / G, g = item - s * G;
+            const int src = sSrc[s];
+            float val = g_sw[(long long)pt * G + g];
+            if (src >= 0) {
+                const float *go = g_out + (long long)pt * c + g * I, *vr = v + (long long)src * c + g * I;
+                for (int i = 0; i < I; ++i) val = __builtin_fmaf(go[i], vr[i], val);
+                if (gv_atomic) {
+                    const float wv = sW[s * G4 + g];
+                    for (int i = 0; i < I; ++i) atomicAdd(gv_atomic + (long long)src * c + g * I + i, go[i] * wv);
                 }
-                for (int o = I >> 1; o >= 1; o >>= 1) val += __shfl_xor(val, o, WAVE);
-                if (act && (ch & (I - 1)) == 0) sGW[s * GP + gl] += val;
+            }
+            sGW[s * GP + g] = val;
+        }
+        // C + B per 64-channel chunk
+        float accB[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) accB[g] = 0.f;
+        const float4 psB = sPos[ms];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int cb0 = r * WAVE;
+            if (cb0 < c) {  // wave-uniform
+                const int ch = cb0 + lane;
+                const bool act = ch < c;
+                float col[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) col[g] = act ? g_A[((long long)pt * G + g) * c + ch] : 0.f;
+                // C: lane = channel
+                float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, gb0 = 0.f;
+                for (int s = 0; s < k; ++s) {
+                    const float4 ps = sPos[s];
+                    const float P = pe_act(ab[r].x, ab[r].y, ab[r].z, ab[r].w, ps.x, ps.y, ps.z);
+                    const float *wr = sW + s * G4;
+                    float gP = 0.f;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) gP = __builtin_fmaf(wr[g], col[g], gP);
+                    const float gpre = P > 0.f ? gP : 0.f;
+                    ga0 = __builtin_fmaf(gpre, ps.x, ga0);
+                    ga1 = __builtin_fmaf(gpre, ps.y, ga1);
+                    ga2 = __builtin_fmaf(gpre, ps.z, ga2);
+                    gb0 += gpre;
+                }
+                acc4[r].x += ga0; acc4[r].y += ga1; acc4[r].z += ga2; acc4[r].w += gb0;
+                __syncthreads();  // previous chunk's B readers are done with sT
+#pragma unroll
+                for (int g = 0; g < G; ++g) sT[lane * GP + g] = col[g];
+                __syncthreads();
+                // B: lane = (slot ms, slice mj)
+                const int cend = (c - cb0) < WAVE ? (c - cb0) : WAVE;
+                for (int cl = mj; cl < cend; cl += J) {
+                    const int chb = cb0 + cl;
+                    const float P = pe_act(a[3 * chb], a[3 * chb + 1], a[3 * chb + 2], b[chb], psB.x, psB.y, psB.z);
+                    const float *tr = sT + cl * GP;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) accB[g] = __builtin_fmaf(P, tr[g], accB[g]);
+                }
             }
         }
-        // positional path: lanes = (slot ms, channel slice mj)
-        {
-            float wrow[G], acc[G];
-            const float4 ps = sPos[ms];
 #pragma unroll
-            for (int g = 0; g < G; ++g) { wrow[g] = sW[ms * G4 + g]; acc[g] = 0.f; }
-            for (int cb0 = 0; cb0 < c; cb0 += WAVE) {
-                __syncthreads();
-                const int chl = cb0 + lane;
-                if (chl < c) {
-#pragma unroll
-                    for (int g = 0; g < G; ++g) sT[lane * GP + g] = g_A[((long long)pt * G + g) * c + chl];
-                }
-                __syncthreads();
-                const int cend = (c - cb0) < WAVE ? (c - cb0) : WAVE;
-                for (int cl = mj; cl < WAVE; cl += J) {  // uniform trip count: the shuffles need every lane
-                    const bool act = cl < cend;
-                    float ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, gb0 = 0.f;
-                    if (act) {
-                        const float4 ab = sAB[cb0 + cl];
-                        const float P = pe_act(ab.x, ab.y, ab.z, ab.w, ps.x, ps.y, ps.z);
-                        const float *tr = sT + cl * GP;
-                        float gP = 0.f;
-#pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            const float t = tr[g];
-                            gP = __builtin_fmaf(wrow[g], t, gP);
-                            acc[g] = __builtin_fmaf(P, t, acc[g]);
-                        }
-                        const float gpre = P > 0.f ? gP : 0.f;
-                        ga0 = gpre * ps.x; ga1 = gpre * ps.y; ga2 = gpre * ps.z; gb0 = gpre;
-                    }
-                    for (int o = k >> 1; o >= 1; o >>= 1) {
-                        ga0 += __shfl_xor(ga0, o, WAVE); ga1 += __shfl_xor(ga1, o, WAVE);
-                        ga2 += __shfl_xor(ga2, o, WAVE); gb0 += __shfl_xor(gb0, o, WAVE);
-                    }
-                    if (act && ms == 0) {
-                        const float4 cur = accAB[cb0 + cl];
-                        accAB[cb0 + cl] = make_float4(cur.x + ga0, cur.y + ga1, cur.z + ga2, cur.w + gb0);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float t = acc[g];
-                for (int o = WAVE >> 1; o >= k; o >>= 1) t += __shfl_xor(t, o, WAVE);
-                if (mj == 0) sGW[ms * GP + g] += t;
-            }
+        for (int g = 0; g < G; ++g) {
+            float t = accB[g];
+            for (int o = WAVE >> 1; o >= k; o >>= 1) t += __shfl_xor(t, o, WAVE);
+            if (mj == 0) sGW[ms * GP + g] += t;
         }
         __syncthreads();
         for (int item = lane; item < items; item += WAVE) {
@@ -284,9 +290,10 @@ __global__ __launch_bounds__(WAVE) void aggregate_bwd_tile_kernel(
             gw[(long long)pt * items + item] = sGW[s * GP + g];
         }
     }
-    __syncthreads();
     float4 *mypart = (float4 *)part + (size_t)blockIdx.x * c;
-    for (int i = lane; i < c; i += WAVE) mypart[i] = accAB[i];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+        if (r * WAVE + lane < c) mypart[r * WAVE + lane] = acc4[r];
 }
 
 // softmax / Linear(G,G) / ReLU / affine backward per slot; outputs gW1, gz, y; partial [gsc G][gsh G]
@@ -468,10 +475,10 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
 
     constexpr int dummy = 0;
     (void)dummy;
-    const size_t lds_tile = sizeof(float4) * (2 * (size_t)c + k) +
+    const size_t lds_tile = sizeof(float4) * (size_t)k +
                             sizeof(float) * ((size_t)k * G4of(g) + (((size_t)k * GPof(g) + 3) & ~(size_t)3) +
                                              (((size_t)64 * GPof(g) + 3) & ~(size_t)3)) + sizeof(int) * k;
-    if (lds_tile > 160 * 1024) return PTV2_ERR_ARG;
+    if (lds_tile > 160 * 1024 || c > WAVE * bwd_rounds(g)) return PTV2_ERR_ARG;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / lds_tile));
     const int nb_tile = std::min(n, std::min(256 * per_cu, (int)BWD_TILE_BLOCKS));
 #define CALL(GG)                                                                                                        \

@@ -1,0 +1,186 @@
+// ao_amd/csrc/gva_fold.hip -- the parameter-sized algebra around the fused GVA stages, as single launches.
+//
+// Folding the two BatchNorms of GroupedVectorAttention into affine maps (ao_amd/ptv2/gva.py) is a few
+// dozen elementwise ops on (C,3) / (C,) / (G,) tensors; as eager torch ops (with their autograd) they were
+// ~130 launches per attention block and made the step host-bound (profiles/r01_fused_v4_*).  Each fold and
+// its hand-derived backward is one tiny kernel here:
+//
+//  fold_p  (linear_p_bias[0..1]: Linear(3,C) -> BatchNorm over all N*K neighbour slots)
+//     mean_c = Wp1[c].mu + bp1[c],  var_c = Wp1[c]^T Cov Wp1[c]      (closed form from pos moments; training)
+//     s_c = gamma_c / sqrt(var_c + eps);  a[c,:] = Wp1[c,:] s_c;  b[c] = (bp1[c] - mean_c) s_c + beta_c
+//     eval: mean / var are the running statistics.  Training also updates the running statistics.
+//  fold_w  (weight_encoding[1]: BatchNorm over the (N*K, G) logits, from their column sums T1, T2)
+//     mean = T1/R, var = T2/R - mean^2, sc = gamma / sqrt(var + eps), sh = beta - mean sc
+#include "gva_common.h"
+
+namespace gva {
+
+__global__ void fold_p_fwd_kernel(int c, const float *__restrict__ Wp1, const float *__restrict__ bp1,
+                                  const float *__restrict__ gamma, const float *__restrict__ beta,
+                                  const double *__restrict__ mu, const double *__restrict__ cov, float *run_mean,
+                                  float *run_var, long long *batches, int training, double rows, float eps,
+                                  float momentum, float *__restrict__ a, float *__restrict__ b,
+                                  float *__restrict__ rstd_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double w0 = Wp1[3 * ch], w1 = Wp1[3 * ch + 1], w2 = Wp1[3 * ch + 2];
+    double mean, rstd;
+    if (training) {
+        mean = w0 * mu[0] + w1 * mu[1] + w2 * mu[2] + (double)bp1[ch];
+        const double t0 = cov[0] * w0 + cov[1] * w1 + cov[2] * w2;
+        const double t1 = cov[3] * w0 + cov[4] * w1 + cov[5] * w2;
+        const double t2 = cov[6] * w0 + cov[7] * w1 + cov[8] * w2;
+        double var = w0 * t0 + w1 * t1 + w2 * t2;
+        var = var > 0.0 ? var : 0.0;
+        rstd = 1.0 / sqrt(var + (double)eps);
+        if (run_mean) {
+            const double unb = rows > 1.0 ? var * (rows / (rows - 1.0)) : var;
+            run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * mean);
+            run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
+            if (ch == 0 && batches) *batches += 1;
+        }
+    } else {
+        mean = (double)run_mean[ch];
+        rstd = 1.0 / sqrt((double)run_var[ch] + (double)eps);
+    }
+    const double s = (double)gamma[ch] * rstd;
+    a[3 * ch] = (float)(w0 * s);
+    a[3 * ch + 1] = (float)(w1 * s);
+    a[3 * ch + 2] = (float)(w2 * s);
+    b[ch] = (float)(((double)bp1[ch] - mean) * s + (double)beta[ch]);
+    rstd_out[ch] = (float)rstd;
+}
+
+__global__ void fold_p_bwd_kernel(int c, const float *__restrict__ Wp1, const float *__restrict__ bp1,
+                                  const float *__restrict__ gamma, const double *__restrict__ mu,
+                                  const double *__restrict__ cov, const float *__restrict__ run_mean,
+                                  const float *__restrict__ rstd_in, int training, const float *__restrict__ ga,
+                                  const float *__restrict__ gb, float *__restrict__ gWp1, float *__restrict__ gbp1,
+                                  float *__restrict__ ggamma, float *__restrict__ gbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double w[3] = {Wp1[3 * ch], Wp1[3 * ch + 1], Wp1[3 * ch + 2]};
+    const double g[3] = {ga[3 * ch], ga[3 * ch + 1], ga[3 * ch + 2]};
+    const double gbv = gb[ch], rstd = rstd_in[ch], gam = gamma[ch];
+    const double s = gam * rstd;
+    gbeta[ch] = (float)gbv;
+    if (training) {
+        const double wmu = w[0] * mu[0] + w[1] * mu[1] + w[2] * mu[2];  // b = -wmu * s + beta
+        const double gs = g[0] * w[0] + g[1] * w[1] + g[2] * w[2] - gbv * wmu;
+        ggamma[ch] = (float)(gs * rstd);
+        const double gvar = gs * gam * (-0.5) * rstd * rstd * rstd;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double cw = cov[3 * d] * w[0] + cov[3 * d + 1] * w[1] + cov[3 * d + 2] * w[2];
+            gWp1[3 * ch + d] = (float)(g[d] * s - gbv * mu[d] * s + gvar * 2.0 * cw);
+        }
+        gbp1[ch] = 0.f;  // the batch mean removes the bias
+    } else {
+        const double dm = (double)bp1[ch] - (double)run_mean[ch];
+        ggamma[ch] = (float)((g[0] * w[0] + g[1] * w[1] + g[2] * w[2] + gbv * dm) * rstd);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gWp1[3 * ch + d] = (float)(g[d] * s);
+        gbp1[ch] = (float)(gbv * s);
+    }
+}
+
+__global__ void fold_w_fwd_kernel(int g, const double *__restrict__ T1, const double *__restrict__ T2,
+                                  const float *__restrict__ gamma, const float *__restrict__ beta, float *run_mean,
+                                  float *run_var, long long *batches, int training, double rows, float eps,
+                                  float momentum, float *__restrict__ sc, float *__restrict__ sh,
+                                  double *__restrict__ mean_out, double *__restrict__ rstd_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g) return;
+    double mean, rstd;
+    if (training) {
+        mean = T1[j] / rows;
+        double var = T2[j] / rows - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        rstd = 1.0 / sqrt(var + (double)eps);
+        if (run_mean) {
+            const double unb = rows > 1.0 ? var * (rows / (rows - 1.0)) : var;
+            run_mean[j] = (float)((1.0 - momentum) * (double)run_mean[j] + momentum * mean);
+            run_var[j] = (float)((1.0 - momentum) * (double)run_var[j] + momentum * unb);
+            if (j == 0 && batches) *batches += 1;
+        }
+    } else {
+        mean = (double)run_mean[j];
+        rstd = 1.0 / sqrt((double)run_var[j] + (double)eps);
+    }
+    const double s = (double)gamma[j] * rstd;
+    sc[j] = (float)s;
+    sh[j] = (float)((double)beta[j] - mean * s);
+    mean_out[j] = mean;
+    rstd_out[j] = rstd;
+}
+
+__global__ void fold_w_bwd_kernel(int g, const float *__restrict__ gamma, const double *__restrict__ mean_in,
+                                  const double *__restrict__ rstd_in, int training, double rows,
+                                  const float *__restrict__ gsc, const float *__restrict__ gsh,
+                                  double *__restrict__ gT1, double *__restrict__ gT2, float *__restrict__ ggamma,
+                                  float *__restrict__ gbeta) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= g) return;
+    const double mean = mean_in[j], rstd = rstd_in[j], gam = gamma[j];
+    const double gs = (double)gsc[j] - (double)gsh[j] * mean;  // d/ds of (sc = s, sh = beta - mean s)
+    gbeta[j] = gsh[j];
+    ggamma[j] = (float)(gs * rstd);
+    if (training) {
+        const double gvar = gs * gam * (-0.5) * rstd * rstd * rstd;
+        const double gmean = -(double)gsh[j] * gam * rstd + gvar * (-2.0 * mean);
+        gT1[j] = gmean / rows;
+        gT2[j] = gvar / rows;
+    } else {
+        gT1[j] = 0.0;
+        gT2[j] = 0.0;
+    }
+}
+
+}  // namespace gva
+
+using namespace gva;
+
+extern "C" int gva_fold_p_forward_hip_launcher(int c, const float *Wp1, const float *bp1, const float *gamma,
+                                               const float *beta, const double *mu, const double *cov,
+                                               float *running_mean, float *running_var,
+                                               long long *num_batches_tracked, int training, double rows, float eps,
+                                               float momentum, float *a, float *b, float *rstd, void *stream) {
+    if (c < 1) return PTV2_ERR_ARG;
+    hipLaunchKernelGGL(fold_p_fwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, beta,
+                       mu, cov, running_mean, running_var, num_batches_tracked, training, rows, eps, momentum, a, b, rstd);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_fold_p_backward_hip_launcher(int c, const float *Wp1, const float *bp1, const float *gamma,
+                                                const double *mu, const double *cov, const float *running_mean,
+                                                const float *rstd, int training, const float *ga, const float *gb,
+                                                float *gWp1, float *gbp1, float *ggamma, float *gbeta, void *stream) {
+    if (c < 1) return PTV2_ERR_ARG;
+    hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, mu,
+                       cov, running_mean, rstd, training, ga, gb, gWp1, gbp1, ggamma, gbeta);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_fold_w_forward_hip_launcher(int g, const double *T1, const double *T2, const float *gamma,
+                                               const float *beta, float *running_mean, float *running_var,
+                                               long long *num_batches_tracked, int training, double rows, float eps,
+                                               float momentum, float *sc, float *sh, double *mean, double *rstd,
+                                               void *stream) {
+    if (g < 1) return PTV2_ERR_ARG;
+    hipLaunchKernelGGL(fold_w_fwd_kernel, dim3(divup(g, 64)), dim3(64), 0, (hipStream_t)stream, g, T1, T2, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, training, rows, eps, momentum, sc, sh, mean, rstd);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_fold_w_backward_hip_launcher(int g, const float *gamma, const double *mean, const double *rstd,
+                                                int training, double rows, const float *gsc, const float *gsh,
+                                                double *gT1, double *gT2, float *ggamma, float *gbeta, void *stream) {
+    if (g < 1) return PTV2_ERR_ARG;
+    hipLaunchKernelGGL(fold_w_bwd_kernel, dim3(divup(g, 64)), dim3(64), 0, (hipStream_t)stream, g, gamma, mean, rstd,
+                       training, rows, gsc, gsh, gT1, gT2, ggamma, gbeta);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -23,6 +23,8 @@ channel sums.  All dense products (kW, qW, M, the grouped A x Wp2 product) stay 
 autograd composes the two HIP stages (`logits`, `aggregate`) with them, which also yields the exact
 BatchNorm backward through the batch statistics.
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -36,6 +38,15 @@ _SIG = {
     "gva_aggregate_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 14 + [_lib._vp]),
     "gva_aggregate_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 25 + [_lib._c_size, _lib._vp]),
     "gva_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
+    "gva_fold_p_forward_hip_launcher": (_lib._c_int, [_lib._c_int] + [_lib._vp] * 9 + [_lib._c_int, ctypes.c_double,
+                                                                               ctypes.c_float, ctypes.c_float]
+                                        + [_lib._vp] * 4),
+    "gva_fold_p_backward_hip_launcher": (_lib._c_int, [_lib._c_int] + [_lib._vp] * 7 + [_lib._c_int] + [_lib._vp] * 7),
+    "gva_fold_w_forward_hip_launcher": (_lib._c_int, [_lib._c_int] + [_lib._vp] * 7 + [_lib._c_int, ctypes.c_double,
+                                                                               ctypes.c_float, ctypes.c_float]
+                                        + [_lib._vp] * 5),
+    "gva_fold_w_backward_hip_launcher": (_lib._c_int, [_lib._c_int] + [_lib._vp] * 3 + [_lib._c_int, ctypes.c_double]
+                                         + [_lib._vp] * 7),
     "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
     "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
 }
@@ -70,6 +81,14 @@ class _HipImpl:
     @staticmethod
     def project(A, Wp2, bp2, sw, out_v):
         return _PebProject.apply(A, Wp2, bp2, sw, out_v)
+
+    @staticmethod
+    def fold_p(lin, bn, mu, cov, rows, training):
+        return _FoldP.apply(lin.weight, lin.bias, bn.weight, bn.bias, mu, cov, bn, float(rows), bool(training))
+
+    @staticmethod
+    def fold_w(T1, T2, bn, rows, training):
+        return _FoldW.apply(T1, T2, bn.weight, bn.bias, bn, float(rows), bool(training))
 
 
 def _f32c(t):
@@ -208,8 +227,92 @@ def supported(channels, groups, k):
     """Shapes the fused kernels are instantiated for (gva_fwd.hip / gva_bwd.hip); anything else runs the
     unfused composition of gather ops."""
     i = channels // groups
-    return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i in (2, 4, 8, 16) and channels % 4 == 0
+    return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i in (2, 4, 8) and channels % 4 == 0
             and k & (k - 1) == 0 and 2 <= k <= 64)
+
+
+def _track(bn, training):
+    return training and bn.track_running_stats and bn.running_mean is not None
+
+
+class _FoldP(torch.autograd.Function):
+    """(a (C,3), b (C)) of P = ReLU(pos a^T + b) from linear_p_bias[0] and its BatchNorm (gva_fold.hip)."""
+
+    @staticmethod
+    def forward(ctx, Wp1, bp1, gamma, beta, mu, cov, bn, rows, training):
+        c = Wp1.shape[0]
+        dev = Wp1.device
+        a = torch.empty((c, 3), dtype=torch.float32, device=dev)
+        b = torch.empty(c, dtype=torch.float32, device=dev)
+        rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        trk = _track(bn, training)
+        if not training and bn.running_mean is None:
+            raise RuntimeError("eval-mode fold needs running statistics")
+        need_run = trk or not training
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+        rc = _lib.lib().gva_fold_p_forward_hip_launcher(
+            c, Wp1.data_ptr(), bp1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _lib.ptr(mu), _lib.ptr(cov),
+            bn.running_mean.data_ptr() if need_run else 0, bn.running_var.data_ptr() if need_run else 0,
+            bn.num_batches_tracked.data_ptr() if trk else 0, int(training), rows, float(bn.eps), float(mom),
+            a.data_ptr(), b.data_ptr(), rstd.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "gva_fold_p_forward_hip_launcher")
+        ctx.save_for_backward(Wp1, bp1, gamma, mu, cov, rstd)
+        ctx.bn, ctx.training = bn, training
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        Wp1, bp1, gamma, mu, cov, rstd = ctx.saved_tensors
+        c = Wp1.shape[0]
+        gWp1, gbp1 = torch.empty_like(Wp1), torch.empty_like(bp1)
+        ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        rm = ctx.bn.running_mean
+        rc = _lib.lib().gva_fold_p_backward_hip_launcher(
+            c, Wp1.data_ptr(), bp1.data_ptr(), gamma.data_ptr(), _lib.ptr(mu), _lib.ptr(cov),
+            rm.data_ptr() if rm is not None else 0, rstd.data_ptr(), int(ctx.training), ga.contiguous().data_ptr(),
+            gb.contiguous().data_ptr(), gWp1.data_ptr(), gbp1.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(),
+            _lib.stream_ptr())
+        _lib.check(rc, "gva_fold_p_backward_hip_launcher")
+        return gWp1, gbp1, ggamma, gbeta, None, None, None, None, None
+
+
+class _FoldW(torch.autograd.Function):
+    """(sc, sh) of the BatchNorm over the logits from their column sums (gva_fold.hip)."""
+
+    @staticmethod
+    def forward(ctx, T1, T2, gamma, beta, bn, rows, training):
+        g = gamma.shape[0]
+        dev = gamma.device
+        sc = torch.empty(g, dtype=torch.float32, device=dev)
+        sh = torch.empty(g, dtype=torch.float32, device=dev)
+        mean = torch.empty(g, dtype=torch.float64, device=dev)
+        rstd = torch.empty(g, dtype=torch.float64, device=dev)
+        trk = _track(bn, training)
+        need_run = trk or not training
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+        rc = _lib.lib().gva_fold_w_forward_hip_launcher(
+            g, T1.data_ptr(), T2.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            bn.running_mean.data_ptr() if need_run else 0, bn.running_var.data_ptr() if need_run else 0,
+            bn.num_batches_tracked.data_ptr() if trk else 0, int(training), rows, float(bn.eps), float(mom),
+            sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "gva_fold_w_forward_hip_launcher")
+        ctx.save_for_backward(gamma, mean, rstd)
+        ctx.training, ctx.rows = training, rows
+        return sc, sh
+
+    @staticmethod
+    def backward(ctx, gsc, gsh):
+        gamma, mean, rstd = ctx.saved_tensors
+        g = gamma.shape[0]
+        gT1 = torch.empty(g, dtype=torch.float64, device=gamma.device)
+        gT2 = torch.empty(g, dtype=torch.float64, device=gamma.device)
+        ggamma, gbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        rc = _lib.lib().gva_fold_w_backward_hip_launcher(
+            g, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), int(ctx.training), ctx.rows,
+            gsc.contiguous().data_ptr(), gsh.contiguous().data_ptr(), gT1.data_ptr(), gT2.data_ptr(), ggamma.data_ptr(),
+            gbeta.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "gva_fold_w_backward_hip_launcher")
+        return gT1, gT2, ggamma, gbeta, None, None, None
 
 
 class _PebProject(torch.autograd.Function):
@@ -297,43 +400,52 @@ def grouped_vector_attention(mod, query, key, value, coord, reference_index, imp
     query, key, value = query.float(), key.float(), value.float()
     lin_p1, bn_p, lin_p2 = mod.linear_p_bias[0], mod.linear_p_bias[1].norm, mod.linear_p_bias[3]
     lin_w1, bn_w, lin_w2 = mod.weight_encoding[0], mod.weight_encoding[1].norm, mod.weight_encoding[3]
-    training_stats = mod.training or not bn_p.track_running_stats
+    training_stats = mod.training or not bn_p.track_running_stats or bn_p.running_mean is None
 
     # -- BN_p folded into an affine map of pos: P = ReLU(pos a^T + b) -----------------------------
     Wp1, bp1 = lin_p1.weight.float(), lin_p1.bias.float()
+    mu = cov = None
     if training_stats:
         mu, cov = _pos_moments(impl, coord, idx)
-        mu32, cov32 = mu.float(), cov.float()
-        mean_p = Wp1 @ mu32 + bp1
-        var_p = ((Wp1 @ cov32) * Wp1).sum(1).clamp_min(0)
-        if mod.training:
-            _bn_update(bn_p, mean_p, var_p, rows)
+    if hasattr(impl, "fold_p"):
+        a, b = impl.fold_p(lin_p1, bn_p, mu, cov, rows, training_stats)
     else:
-        mean_p, var_p = bn_p.running_mean.float(), bn_p.running_var.float()
-    scale_p = bn_p.weight.float() * torch.rsqrt(var_p + bn_p.eps)
-    a = Wp1 * scale_p.unsqueeze(1)
-    b = (bp1 - mean_p) * scale_p + bn_p.bias.float()
+        if training_stats:
+            mu32, cov32 = mu.float(), cov.float()
+            mean_p = Wp1 @ mu32 + bp1
+            var_p = ((Wp1 @ cov32) * Wp1).sum(1).clamp_min(0)
+            if mod.training:
+                _bn_update(bn_p, mean_p, var_p, rows)
+        else:
+            mean_p, var_p = bn_p.running_mean.float(), bn_p.running_var.float()
+        scale_p = bn_p.weight.float() * torch.rsqrt(var_p + bn_p.eps)
+        a = Wp1 * scale_p.unsqueeze(1)
+        b = (bp1 - mean_p) * scale_p + bn_p.bias.float()
 
     # -- logits: W1 = kW[idx] - qW + P M + cW ------------------------------------------------------
     Wp2, bp2 = lin_p2.weight.float(), lin_p2.bias.float()
     Ww1, bw1 = lin_w1.weight.float(), lin_w1.bias.float()
-    M = (Ww1 @ Wp2).t()
-    cW = Ww1 @ bp2 + bw1
+    M = Wp2.t() @ Ww1.t()                      # (C,G): M[c',g] = sum_c Wp2[c,c'] Ww1[g,c]
+    cW = torch.addmv(bw1, Ww1, bp2)
     kW = key @ Ww1.t()
     qW = query @ Ww1.t()
     W1, T1, T2 = impl.logits(kW, qW, a, b, M, cW, coord, idx)
 
     # -- BN_w from the per-channel sums of W1 --------------------------------------------------------
-    if mod.training or not bn_w.track_running_stats:
-        mean_w = T1 / rows
-        var_w = (T2 / rows - mean_w * mean_w).clamp_min(0)
-        if mod.training:
-            _bn_update(bn_w, mean_w, var_w, rows)
+    train_w = mod.training or not bn_w.track_running_stats
+    if hasattr(impl, "fold_w"):
+        sc, sh = impl.fold_w(T1, T2, bn_w, rows, train_w)
     else:
-        mean_w, var_w = bn_w.running_mean.double(), bn_w.running_var.double()
-    sc64 = bn_w.weight.double() * torch.rsqrt(var_w + bn_w.eps)
-    sh64 = bn_w.bias.double() - mean_w * sc64
-    sc, sh = sc64.float(), sh64.float()
+        if train_w:
+            mean_w = T1 / rows
+            var_w = (T2 / rows - mean_w * mean_w).clamp_min(0)
+            if mod.training:
+                _bn_update(bn_w, mean_w, var_w, rows)
+        else:
+            mean_w, var_w = bn_w.running_mean.double(), bn_w.running_var.double()
+        sc64 = bn_w.weight.double() * torch.rsqrt(var_w + bn_w.eps)
+        sh64 = bn_w.bias.double() - mean_w * sc64
+        sc, sh = sc64.float(), sh64.float()
 
     # -- softmax over neighbours, aggregation of v and of the folded positional bias ---------------
     out_v, A, sw = impl.aggregate(W1, sc, sh, lin_w2.weight.float(), lin_w2.bias.float(), value, a, b, coord, idx)

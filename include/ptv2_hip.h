@@ -203,6 +203,29 @@ int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float 
                                         float *gsh, float *gWw2, float *gbw2, float *gv, float *ga,
                                         float *gb, void *workspace, size_t workspace_bytes, void *stream);
 
+/* BatchNorm folds of GroupedVectorAttention as single launches (ao_amd/csrc/gva_fold.hip): fold_p maps
+ * linear_p_bias[0..1] (Linear(3,c) + BatchNorm over all n*k slots, statistics in closed form from the position
+ * moments mu[3], cov[9], float64) to P = ReLU(pos a^T + b); fold_w maps weight_encoding[1] (BatchNorm over the
+ * (n*k, g) logits, from their column sums T1, T2) to the affine sc, sh.  training != 0 uses batch statistics and
+ * updates running_mean / running_var / num_batches_tracked (pass NULL to skip); rows = n*k. */
+int gva_fold_p_forward_hip_launcher(int c, const float *Wp1, const float *bp1, const float *gamma,
+                                    const float *beta, const double *mu, const double *cov,
+                                    float *running_mean, float *running_var,
+                                    long long *num_batches_tracked, int training, double rows, float eps,
+                                    float momentum, float *a, float *b, float *rstd, void *stream);
+int gva_fold_p_backward_hip_launcher(int c, const float *Wp1, const float *bp1, const float *gamma,
+                                     const double *mu, const double *cov, const float *running_mean,
+                                     const float *rstd, int training, const float *ga, const float *gb,
+                                     float *gWp1, float *gbp1, float *ggamma, float *gbeta, void *stream);
+int gva_fold_w_forward_hip_launcher(int g, const double *T1, const double *T2, const float *gamma,
+                                    const float *beta, float *running_mean, float *running_var,
+                                    long long *num_batches_tracked, int training, double rows, float eps,
+                                    float momentum, float *sc, float *sh, double *mean, double *rstd,
+                                    void *stream);
+int gva_fold_w_backward_hip_launcher(int g, const float *gamma, const double *mean, const double *rstd,
+                                     int training, double rows, const float *gsc, const float *gsh,
+                                     double *gT1, double *gT2, float *ggamma, float *gbeta, void *stream);
+
 /* grouped positional-bias projection applied after the neighbour sum (linear_p_bias[3], :92,117-119):
  *   out[n,g*I+i] = out_v[n,g*I+i] + sum_c' A[n,g,c'] Wp2[g*I+i,c'] + bp2[g*I+i] sw[n,g],  I = c/g in {2,4,8,16}
  * backward w.r.t. A and sw: g_A (n,g,c), g_sw (n,g) from g_out (n,c) (grad Wp2 / bp2 are dense products the
