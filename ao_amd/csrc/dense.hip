@@ -23,7 +23,7 @@ namespace dense {
 using gva::finalize_kernel;
 using gva::launch_finalize;
 constexpr int TPB = 256;
-constexpr int MAX_BLK = 1024;
+constexpr int MAX_BLK = 512;
 
 // ------------------------------------------------------------------ BN: stats --
 // lanes: (row lane, float4 column quad); requires c % 4 == 0
@@ -62,27 +62,39 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
     }
 }
 
-struct MapBnStats {  // columns [0,c): sum (x-x0), [c,2c): sum (x-x0)^2  ->  mean, rstd, running stats
-    const float *x0;  // row 0 of x: the shift used by bn_stats_kernel
-    float *mean, *rstd, *run_mean, *run_var;
-    long long *batches;
-    int c, n;
-    float eps, momentum;
-    // needs both sums of a channel: the finalize kernel calls us per column, so pair them through memory:
-    // column j < c stores the mean; column j >= c (same block row of the launch or a later one) needs it,
-    // therefore the launcher runs TWO finalize passes (means first).
-    int pass;
-    __device__ void operator()(int j, double v) const {
-        if (pass == 0) {
-            if (j < c) mean[j] = (float)((double)x0[j] + v / n);
-            return;
+// finalize: column sums of (x-x0) and (x-x0)^2 over the per-block partials -> mean, rstd, running statistics
+__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_kernel(
+    const float *__restrict__ part, int nblk, int c, int n, const float *__restrict__ x0, float eps, float momentum,
+    float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches) {
+    __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+    const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
+    const int ch = blockIdx.x * gva::FIN_COLS + col;
+    double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
+    if (ch < c) {
+        int k = sl;
+        for (; k + gva::FIN_SLICES < nblk; k += 2 * gva::FIN_SLICES) {
+            a += (double)part[(size_t)k * 2 * c + ch];
+            b += (double)part[(size_t)k * 2 * c + c + ch];
+            a2 += (double)part[(size_t)(k + gva::FIN_SLICES) * 2 * c + ch];
+            b2 += (double)part[(size_t)(k + gva::FIN_SLICES) * 2 * c + c + ch];
         }
-        if (j < c) return;
-        const int ch = j - c;
-        const double m = (double)mean[ch];
-        const double d = m - (double)x0[ch];  // mean of the shifted samples
-        double var = v / n - d * d;
+        for (; k < nblk; k += gva::FIN_SLICES) {
+            a += (double)part[(size_t)k * 2 * c + ch];
+            b += (double)part[(size_t)k * 2 * c + c + ch];
+        }
+    }
+    s1[sl][col] = a + a2;
+    s2[sl][col] = b + b2;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        const double d = t1 / n;                       // mean of the shifted samples
+        const double m = (double)x0[ch] + d;
+        double var = t2 / n - d * d;
         var = var > 0.0 ? var : 0.0;
+        mean[ch] = (float)m;
         rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
         if (run_mean) {
             const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
@@ -91,7 +103,7 @@ struct MapBnStats {  // columns [0,c): sum (x-x0), [c,2c): sum (x-x0)^2  ->  mea
             if (ch == 0 && batches) *batches += 1;
         }
     }
-};
+}
 
 // ------------------------------------------------------------------ BN: apply --
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(long long total4, int cq, const float *__restrict__ x,
@@ -263,7 +275,8 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
             for (int r = 0; r < 4; ++r) sRed[wid][(m * WG_MT + t) * 4 + r][lane] = acc[m][t][r];
     }
     __syncthreads();
-    float *p = part + ((size_t)blockIdx.x * batch + bz) * cout * cin;
+    const size_t rec = (size_t)batch * cout * cin + (part_b ? (size_t)batch * cout : 0);
+    float *p = part + (size_t)blockIdx.x * rec + (size_t)bz * cout * cin;
     for (int e = threadIdx.x; e < WG_MT * WG_MT * 4 * WAVE; e += TPB) {
         const int q = e / WAVE, l = e - q * WAVE;
         const int mt = q / 4, r = q - mt * 4, m = mt / WG_MT, t = mt - m * WG_MT;
@@ -281,8 +294,56 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][WG_MT * WG_MT * 4 + m][l];
-            part_b[((size_t)blockIdx.x * batch + bz) * cout + o] = v;
+            part[(size_t)blockIdx.x * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
         }
+    }
+}
+
+// ----------------------------------------------------------- skinny projection --
+// y[n,o] = sum_i x[n,i] W[o,i] for cout <= 64 (the G-wide projections kW, qW of the attention logits); the
+// BLAS kernel chosen for an N x 48 x 6 product runs 190 us (profiles/r01_fused_v5_*).  One lane per output,
+// W in LDS, the x row is shared by the cout lanes of a point.
+__global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, int cout, const float *__restrict__ x,
+                                                         const float *__restrict__ W, float *__restrict__ y) {
+    extern __shared__ float4 lds4[];
+    float *sW = (float *)lds4;  // [cout][cin + 4]
+    const int ldw = cin + 4, cq = cin >> 2;
+    for (int e = threadIdx.x; e < cout * cq; e += TPB) {
+        const int r = e / cq, q = e - r * cq;
+        *(float4 *)(sW + (size_t)r * ldw + 4 * q) = *(const float4 *)(W + (size_t)r * cin + 4 * q);
+    }
+    __syncthreads();
+    const long long total = n * cout;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long row = e / cout;
+        const int o = (int)(e - row * cout);
+        const float4 *xr = (const float4 *)(x + row * cin), *wr = (const float4 *)(sW + (size_t)o * ldw);
+        float acc = 0.f;
+        for (int q = 0; q < cq; ++q) {
+            const float4 a = xr[q], w = wr[q];
+            acc = __builtin_fmaf(a.x, w.x, acc); acc = __builtin_fmaf(a.y, w.y, acc);
+            acc = __builtin_fmaf(a.z, w.z, acc); acc = __builtin_fmaf(a.w, w.w, acc);
+        }
+        y[e] = acc;
+    }
+}
+
+// gx[n,i] = sum_o gy[n,o] W[o,i]; one lane per float4 of gx
+__global__ __launch_bounds__(TPB) void skinny_bwd_kernel(long long n, int cin, int cout, const float *__restrict__ gy,
+                                                         const float *__restrict__ W, float *__restrict__ gx) {
+    const int cq = cin >> 2;
+    const long long total = n * cq;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long row = e / cq;
+        const int q = (int)(e - row * cq);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 0; o < cout; ++o) {
+            const float s = gy[row * cout + o];
+            const float4 w = *(const float4 *)(W + (size_t)o * cin + 4 * q);
+            acc.x = __builtin_fmaf(s, w.x, acc.x); acc.y = __builtin_fmaf(s, w.y, acc.y);
+            acc.z = __builtin_fmaf(s, w.z, acc.z); acc.w = __builtin_fmaf(s, w.w, acc.w);
+        }
+        ((float4 *)gx)[e] = acc;
     }
 }
 
@@ -314,10 +375,9 @@ extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, 
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
-    MapBnStats m{x, mean, rstd, running_mean, running_var, num_batches_tracked, c, n, eps, momentum, 0};
-    launch_finalize(st, (const float *)part, nblk, 2 * c, m);
-    m.pass = 1;
-    launch_finalize(st, (const float *)part, nblk, 2 * c, m);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
+                       dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, st, (const float *)part, nblk, c, n, x, eps, momentum, mean,
+                       rstd, running_mean, running_var, num_batches_tracked);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -354,6 +414,32 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     return PTV2_OK;
 }
 
+extern "C" int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
+                                                 void *stream) {
+    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1 || cout > 64) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const size_t lds = sizeof(float) * (size_t)cout * (cin + 4);
+    if (lds > 160 * 1024) return PTV2_ERR_ARG;
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void *)skinny_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long long total = (long long)n * cout;
+    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 8);
+    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, y);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int skinny_linear_backward_hip_launcher(int n, int cin, int cout, const float *gy, const float *W, float *gx,
+                                                  void *stream) {
+    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const long long total = (long long)n * (cin >> 2);
+    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
+    hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const float *gY, long long ldy,
                                                  long long sy, const float *X, long long ldx, long long sx, float *dW,
                                                  float *db, void *workspace, size_t workspace_bytes, void *stream) {
@@ -363,13 +449,14 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     if (!workspace || workspace_bytes < need) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
-    float *part_b = part + (size_t)chunks * batch * cout * cin;
+    float *part_b = part;  // non-null flag: bias partials live behind the weight partials of each chunk record
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     dim3 grid(chunks, tiles_o * tiles_i, batch);
     hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                        db ? part_b : (float *)nullptr, batch);
-    launch_finalize(st, (const float *)part, chunks, batch * cout * cin, gva::MapVec<float>{dW});
-    if (db) launch_finalize(st, (const float *)part_b, chunks, batch * cout, gva::MapVec<float>{db});
+    if (db) launch_finalize(st, (const float *)part, chunks, batch * cout * cin + batch * cout,
+                            gva::MapSplit2<float>{dW, db, batch * cout * cin});
+    else launch_finalize(st, (const float *)part, chunks, batch * cout * cin, gva::MapVec<float>{dW});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -65,9 +65,19 @@ __global__ __launch_bounds__(FIN_COLS *FIN_SLICES) void finalize_kernel(const fl
     __shared__ double s_acc[FIN_SLICES][FIN_COLS];
     const int col = threadIdx.x & (FIN_COLS - 1), sl = threadIdx.x / FIN_COLS;
     const int j = blockIdx.x * FIN_COLS + col;
-    double acc = 0.0;
-    if (j < len)
-        for (int b = sl; b < nblk; b += FIN_SLICES) acc += (double)part[(size_t)b * len + j];
+    // four independent chains per thread (fixed association: ((a0+a1)+(a2+a3))) keep the loads in flight
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (j < len) {
+        int b = sl;
+        for (; b + 3 * FIN_SLICES < nblk; b += 4 * FIN_SLICES) {
+            a0 += (double)part[(size_t)b * len + j];
+            a1 += (double)part[(size_t)(b + FIN_SLICES) * len + j];
+            a2 += (double)part[(size_t)(b + 2 * FIN_SLICES) * len + j];
+            a3 += (double)part[(size_t)(b + 3 * FIN_SLICES) * len + j];
+        }
+        for (; b < nblk; b += FIN_SLICES) a0 += (double)part[(size_t)b * len + j];
+    }
+    const double acc = (a0 + a1) + (a2 + a3);
     s_acc[sl][col] = acc;
     __syncthreads();
     if (sl == 0 && j < len) {

@@ -13,44 +13,50 @@
 
 namespace gva {
 
-template <int I>
-__global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, const float *__restrict__ A,
+// One lane per output element (n, c).  A workgroup keeps the Wp2 rows of its CT output channels in LDS
+// (rows padded by 4 floats) and walks tiles of TP = 256/CT points; the A row of (n, group) is read straight
+// from global memory as float4 -- the I lanes of a group read identical addresses, which the memory pipeline
+// serves as one request, so A is streamed exactly once.
+__global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, int ct, const float *__restrict__ A,
                                                       const float *__restrict__ Wp2, const float *__restrict__ bp2,
                                                       const float *__restrict__ sw, const float *__restrict__ out_v,
                                                       float *__restrict__ out) {
-    constexpr int T = TPB / I;  // points per tile
     extern __shared__ float4 lds4[];
-    float *sA = (float *)lds4;            // [T][c + 4]  (padded rows: threads of different points hit different banks)
-    const int ldA = c + 4;
-    float *sW = sA + (size_t)T * ldA;      // [I][c]
-    const int t = threadIdx.x / I, i = threadIdx.x - t * I;
-    const int ntiles = (n + T - 1) / T;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n0 = tile * T;
-        const int cnt = (n - n0) < T ? (n - n0) : T;
-        for (int gi = 0; gi < g; ++gi) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < cnt * (c / 4); e += TPB) {
-                const int r = e / (c / 4), q = e - r * (c / 4);
-                *(float4 *)(sA + (size_t)r * ldA + 4 * q) = *(const float4 *)(A + ((size_t)(n0 + r) * g + gi) * c + 4 * q);
-            }
-            const float4 *wsrc = (const float4 *)(Wp2 + (size_t)gi * I * c);
-            for (int e = threadIdx.x; e < I * (c / 4); e += TPB) ((float4 *)sW)[e] = wsrc[e];
-            __syncthreads();
-            if (t < cnt) {
-                const float4 *ar = (const float4 *)(sA + (size_t)t * ldA), *wr = (const float4 *)(sW + (size_t)i * c);
-                float acc = 0.f;
-                for (int q = 0; q < c / 4; ++q) {
-                    const float4 x = ar[q], w = wr[q];
-                    acc = __builtin_fmaf(x.x, w.x, acc);
-                    acc = __builtin_fmaf(x.y, w.y, acc);
-                    acc = __builtin_fmaf(x.z, w.z, acc);
-                    acc = __builtin_fmaf(x.w, w.w, acc);
-                }
-                const size_t o = (size_t)(n0 + t) * c + gi * I + i;
-                out[o] = out_v[o] + acc + bp2[gi * I + i] * sw[(size_t)(n0 + t) * g + gi];
-            }
+    float *sW = (float *)lds4;  // [ct][c + 4]
+    const int ldw = c + 4;
+    const int c0 = blockIdx.y * ct;
+    const int cq = c >> 2;
+    for (int e = threadIdx.x; e < ct * cq; e += TPB) {
+        const int r = e / cq, q = e - r * cq;
+        if (c0 + r < c) *(float4 *)(sW + (size_t)r * ldw + 4 * q) = *(const float4 *)(Wp2 + (size_t)(c0 + r) * c + 4 * q);
+    }
+    __syncthreads();
+    const int I = c / g;
+    const int tp = TPB / ct;
+    const int p = threadIdx.x / ct, cl = threadIdx.x - p * ct;
+    const int ch = c0 + cl;
+    if (p >= tp || ch >= c) return;
+    const int gi = ch / I;
+    const float bias = bp2[ch];
+    const float4 *wr = (const float4 *)(sW + (size_t)cl * ldw);
+    for (long long pt = (long long)blockIdx.x * tp + p; pt < n; pt += (long long)gridDim.x * tp) {
+        const float4 *ar = (const float4 *)(A + ((size_t)pt * g + gi) * c);
+        float acc0 = 0.f, acc1 = 0.f;
+        int q = 0;
+        for (; q + 1 < cq; q += 2) {
+            const float4 x0 = ar[q], w0 = wr[q], x1 = ar[q + 1], w1 = wr[q + 1];
+            acc0 = __builtin_fmaf(x0.x, w0.x, acc0); acc0 = __builtin_fmaf(x0.y, w0.y, acc0);
+            acc0 = __builtin_fmaf(x0.z, w0.z, acc0); acc0 = __builtin_fmaf(x0.w, w0.w, acc0);
+            acc1 = __builtin_fmaf(x1.x, w1.x, acc1); acc1 = __builtin_fmaf(x1.y, w1.y, acc1);
+            acc1 = __builtin_fmaf(x1.z, w1.z, acc1); acc1 = __builtin_fmaf(x1.w, w1.w, acc1);
         }
+        for (; q < cq; ++q) {
+            const float4 x0 = ar[q], w0 = wr[q];
+            acc0 = __builtin_fmaf(x0.x, w0.x, acc0); acc0 = __builtin_fmaf(x0.y, w0.y, acc0);
+            acc0 = __builtin_fmaf(x0.z, w0.z, acc0); acc0 = __builtin_fmaf(x0.w, w0.w, acc0);
+        }
+        const size_t o = (size_t)pt * c + ch;
+        out[o] = out_v[o] + (acc0 + acc1) + bias * sw[(size_t)pt * g + gi];
     }
 }
 
@@ -102,19 +108,16 @@ extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A,
                                             const float *sw, const float *out_v, float *out, void *stream) {
     if (n < 0 || c < 4 || g < 1 || c % g != 0 || c % 4 != 0) return PTV2_ERR_ARG;
     if (n == 0) return PTV2_OK;
-    const int I = c / g;
-    if (TPB % I != 0) return PTV2_ERR_ARG;
-    const int T = TPB / I;
-    const size_t lds = sizeof(float) * ((size_t)T * (c + 4) + (size_t)I * c);
+    const int ct = c <= 128 ? c : 64;  // output channels per workgroup
+    if (ct > TPB) return PTV2_ERR_ARG;
+    const size_t lds = sizeof(float) * (size_t)ct * (c + 4);
     if (lds > 160 * 1024) return PTV2_ERR_ARG;
-    const int ntiles = (n + T - 1) / T;
-    const int nblk = ntiles < 256 * 4 ? ntiles : 256 * 4;
-#define CALL(II)                                                                                                      \
-    if (lds > 32 * 1024)                                                                                              \
-        (void)hipFuncSetAttribute((const void *)peb_fwd_kernel<II>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(peb_fwd_kernel<II>, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, n, c, g, A, Wp2, bp2, sw, out_v, out)
-    PEB_DISPATCH_I(I, CALL)
-#undef CALL
+    const int tp = TPB / ct;
+    const int gx = (int)std::min<long long>(((long long)n + tp - 1) / tp, lds > 40 * 1024 ? 256 : 1024);
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void *)peb_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(peb_fwd_kernel, dim3(gx, (c + ct - 1) / ct), dim3(TPB), lds, (hipStream_t)stream, n, c, g, ct, A, Wp2,
+                       bp2, sw, out_v, out);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

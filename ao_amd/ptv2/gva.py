@@ -29,6 +29,7 @@ import torch
 
 from .. import _lib
 from ..profiling import clock
+from .layers import skinny_linear
 
 _SIG = {
     "gva_pos_stats_hip_launcher": (_lib._c_int, [_lib._c_int] * 2 + [_lib._vp] * 5 + [_lib._c_size, _lib._vp]),
@@ -148,7 +149,7 @@ class _Logits(torch.autograd.Function):
         gW1 = torch.zeros_like(W1) if gW1 is None else gW1.contiguous()
         gT1 = torch.zeros(g, dtype=torch.float64, device=dev) if gT1 is None else gT1.contiguous()
         gT2 = torch.zeros(g, dtype=torch.float64, device=dev) if gT2 is None else gT2.contiguous()
-        gkW = torch.zeros((n, g), dtype=torch.float32, device=dev)
+        gkW = torch.empty((n, g), dtype=torch.float32, device=dev) if inv_ptr is not None else torch.zeros((n, g), dtype=torch.float32, device=dev)
         gqW = torch.empty((n, g), dtype=torch.float32, device=dev)
         ga = torch.empty((c, 3), dtype=torch.float32, device=dev)
         gb = torch.empty(c, dtype=torch.float32, device=dev)
@@ -203,7 +204,7 @@ class _Aggregate(torch.autograd.Function):
         g_A = torch.zeros((n, g, c), dtype=torch.float32, device=dev) if g_A is None else g_A.contiguous()
         g_sw = torch.zeros((n, g), dtype=torch.float32, device=dev) if g_sw is None else g_sw.contiguous()
         gW1 = torch.empty_like(W1)
-        gv = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        gv = torch.empty((n, c), dtype=torch.float32, device=dev) if inv_ptr is not None else torch.zeros((n, c), dtype=torch.float32, device=dev)
         gsc = torch.empty(g, dtype=torch.float32, device=dev)
         gsh = torch.empty(g, dtype=torch.float32, device=dev)
         gWw2 = torch.empty((g, g), dtype=torch.float32, device=dev)
@@ -427,8 +428,8 @@ def grouped_vector_attention(mod, query, key, value, coord, reference_index, imp
     Ww1, bw1 = lin_w1.weight.float(), lin_w1.bias.float()
     M = Wp2.t() @ Ww1.t()                      # (C,G): M[c',g] = sum_c Wp2[c,c'] Ww1[g,c]
     cW = torch.addmv(bw1, Ww1, bp2)
-    kW = key @ Ww1.t()
-    qW = query @ Ww1.t()
+    kW = skinny_linear(key, Ww1)
+    qW = skinny_linear(query, Ww1)
     W1, T1, T2 = impl.logits(kW, qW, a, b, M, cW, coord, idx)
 
     # -- BN_w from the per-channel sums of W1 --------------------------------------------------------

@@ -117,3 +117,48 @@ class RowLinear(nn.Linear):
                 and x.shape[0] >= WGRAD_MIN_ROWS and torch.is_grad_enabled() and self.weight.requires_grad):
             return _LinearRows.apply(x.contiguous(), self.weight, self.bias)
         return super().forward(x)
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    """y = x W^T for a narrow output (cout <= 64): HIP forward / input-gradient kernels, MFMA split-K wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x, weight = x.contiguous(), weight.contiguous()
+        n, cin = x.shape
+        cout = weight.shape[0]
+        y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
+        with clock.region("skinny_fwd", 4 * n * (cin + cout)):
+            rc = _lib.lib().skinny_linear_forward_hip_launcher(n, cin, cout, x.data_ptr(), weight.data_ptr(), y.data_ptr(),
+                                                               _lib.stream_ptr())
+        _lib.check(rc, "skinny_linear_forward_hip_launcher")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        n, cin = x.shape
+        cout = weight.shape[0]
+        L = _lib.lib()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = L.skinny_linear_backward_hip_launcher(n, cin, cout, gy.data_ptr(), weight.data_ptr(), gx.data_ptr(),
+                                                       _lib.stream_ptr())
+            _lib.check(rc, "skinny_linear_backward_hip_launcher")
+        dW = torch.empty_like(weight)
+        ws = _ws(n, cout, cin, x.device)
+        rc = L.linear_wgrad_hip_launcher(n, cout, cin, gy.data_ptr(), x.data_ptr(), dW.data_ptr(), 0, ws.data_ptr(),
+                                         ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "linear_wgrad_hip_launcher")
+        return gx, dW
+
+
+def skinny_linear(x, weight):
+    """x (N,Cin) @ weight (Cout,Cin)^T with Cout <= 64; falls back to torch off-GPU / odd shapes."""
+    if (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] % 4 == 0 and weight.shape[0] <= 64 and x.shape[0] >= 256):
+        return _SkinnyLinear.apply(x, weight)
+    return x @ weight.t()

@@ -272,6 +272,12 @@ int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, cons
                              size_t workspace_bytes, void *stream);
 int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
                               float *db, void *workspace, size_t workspace_bytes, void *stream);
+/* skinny projection y (n,cout) = x (n,cin) W^T (cout,cin), cout <= 64, cin % 4 == 0, and its input gradient
+ * gx = gy W (the weight gradient is linear_wgrad) */
+int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
+                                       void *stream);
+int skinny_linear_backward_hip_launcher(int n, int cin, int cout, const float *gy, const float *W,
+                                        float *gx, void *stream);
 /* batched / strided form: dW[b][o][i] = sum_n gY[n*ldy + b*sy + o] * X[n*ldx + b*sx + i], b < batch
  * (workspace: dense_workspace_bytes(n, batch*cout, cin)) */
 int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const float *gY,

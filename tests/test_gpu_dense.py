@@ -66,3 +66,20 @@ def test_row_linear(n, cin, cout, bias):
     g_ref = torch.autograd.grad(y_ref, params, go)
     for a, b in zip(g, g_ref):
         assert rel(a, b) < 1e-4, rel(a, b)
+
+
+@pytest.mark.parametrize("n,cin,cout", [(120000, 48, 6), (18905, 96, 12), (4501, 192, 24), (1074, 384, 48), (300, 512, 64)])
+def test_skinny_linear(n, cin, cout):
+    from ao_amd.ptv2.layers import skinny_linear
+
+    torch.manual_seed(2)
+    x = torch.randn(n, cin, device="cuda", requires_grad=True)
+    w = (torch.randn(cout, cin, device="cuda") * 0.2).requires_grad_(True)
+    y = skinny_linear(x, w)
+    y_ref = x @ w.t()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    go = torch.randn_like(y)
+    g = torch.autograd.grad(y, [x, w], go)
+    g_ref = torch.autograd.grad(y_ref, [x, w], go)
+    for a, b in zip(g, g_ref):
+        assert rel(a, b) < 1e-4, rel(a, b)
