@@ -20,6 +20,11 @@ _c_int, _c_size, _vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 _SIGNATURES = {
     "ptv2_abi_version": (_c_int, []),
     "ptv2_build_info": (ctypes.c_char_p, []),
+    "ptv2_profile_enable": (_c_int, [_c_int]),
+    "ptv2_profile_is_on": (_c_int, []),
+    "ptv2_profile_kernel_count": (_c_int, []),
+    "ptv2_profile_read": (_c_int, [_c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),
     "knn_query_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _vp]),
     "farthest_point_sampling_hip_workspace_bytes": (_c_size, [_c_int] * 2),
@@ -112,3 +117,21 @@ def ptr(t):
 
 def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def kernel_timer(enable):
+    """Switch the in-library per-kernel HIP-event timer (include/ptv2_hip.h: ptv2_profile_*)."""
+    lib().ptv2_profile_enable(1 if enable else 0)
+
+
+def kernel_timer_read():
+    """{kernel name: dict(launches, total_us, avg_us, bytes_per_launch)} for kernels launched while enabled."""
+    L = lib()
+    out = {}
+    name = ctypes.create_string_buffer(64)
+    us, cnt, byt = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+    for kid in range(L.ptv2_profile_kernel_count()):
+        if L.ptv2_profile_read(kid, name, ctypes.byref(us), ctypes.byref(cnt), ctypes.byref(byt)) == 0 and cnt.value > 0:
+            out[name.value.decode()] = dict(launches=cnt.value, total_us=us.value, avg_us=us.value / cnt.value,
+                                            bytes_per_launch=byt.value)
+    return out

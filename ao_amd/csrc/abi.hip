@@ -1,8 +1,88 @@
-// ao_amd/csrc/abi.hip -- library identification (host only).
+// ao_amd/csrc/abi.hip -- library identification and the optional per-kernel timer (host only).
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 extern "C" int ptv2_abi_version(void) { return 1; }
 
 extern "C" const char *ptv2_build_info(void) {
     return "libptv2_hip gfx950 (MI355X) hipcc " __VERSION__ " built " __DATE__;
+}
+
+// ---------------------------------------------------------------- kernel timer --
+// A debugging / measurement facility, off by default: no events are created and launchers take no extra
+// branch beyond one flag read.  Enabled by bench.py for its roofline object (HIP events on the launch
+// stream around ONE named kernel per launcher, so the averages are comparable with rocprofv3 --stats).
+namespace {
+const char *kNames[KID_COUNT] = {
+    "knn_grid_query_kernel", "logits_fwd_kernel", "softmax_rows_kernel", "aggregate_tile_kernel", "peb_fwd_kernel",
+    "peb_bwd_kernel", "aggregate_bwd_tile_kernel", "aggregate_bwd_rows_kernel", "aggregate_bwd_gv_kernel",
+    "logits_bwd_rows_kernel", "logits_bwd_gather_kernel", "logits_bwd_params_kernel", "linear_wgrad_kernel",
+    "bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "skinny_fwd_kernel",
+    "skinny_bwd_kernel"};
+struct Rec { hipEvent_t a, b; double bytes; };
+std::mutex g_mu;
+int g_on = 0;
+std::vector<Rec> g_recs[KID_COUNT];
+std::vector<hipEvent_t> g_pending[KID_COUNT];
+}  // namespace
+
+extern "C" int ptv2_profile_is_on(void) { return g_on; }
+
+void ptv2_profile_begin(int kid, hipStream_t st) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending[kid].push_back(e);
+}
+
+void ptv2_profile_end(int kid, hipStream_t st, double bytes) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_pending[kid].empty()) { (void)hipEventDestroy(e); return; }
+    hipEvent_t a = g_pending[kid].back();
+    g_pending[kid].pop_back();
+    g_recs[kid].push_back(Rec{a, e, bytes});
+}
+
+// on != 0: clear the table and start recording; on == 0: stop recording (records stay readable)
+extern "C" int ptv2_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (on) {
+        for (int k = 0; k < KID_COUNT; ++k) {
+            for (auto &r : g_recs[k]) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+            g_recs[k].clear();
+            for (auto e : g_pending[k]) (void)hipEventDestroy(e);
+            g_pending[k].clear();
+        }
+    }
+    g_on = on ? 1 : 0;
+    return PTV2_OK;
+}
+
+extern "C" int ptv2_profile_kernel_count(void) { return KID_COUNT; }
+
+// Synchronises on the recorded events.  Returns PTV2_OK and fills name (>= 64 bytes), total microseconds,
+// number of launches and mean algorithmic bytes per launch of kernel id `kid`.
+extern "C" int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch) {
+    if (kid < 0 || kid >= KID_COUNT) return PTV2_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    double us = 0.0, bytes = 0.0;
+    for (auto &r : g_recs[kid]) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) us += 1e3 * (double)ms;
+        bytes += r.bytes;
+    }
+    int i = 0;
+    for (; kNames[kid][i] && i < 63; ++i) name[i] = kNames[kid][i];
+    name[i] = 0;
+    *total_us = us;
+    *launches = (long long)g_recs[kid].size();
+    *bytes_per_launch = g_recs[kid].empty() ? 0.0 : bytes / (double)g_recs[kid].size();
+    return PTV2_OK;
 }

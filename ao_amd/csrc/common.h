@@ -14,6 +14,24 @@
 
 static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Optional per-kernel timing for bench.py's roofline leg (abi.hip): when enabled through
+// ptv2_profile_enable(1), launchers bracket their main kernel with HIP events on the launch stream.
+enum PtvKernelId {
+    KID_KNN_QUERY = 0, KID_LOGITS_FWD, KID_SOFTMAX_ROWS, KID_AGG_TILE, KID_PEB_FWD, KID_PEB_BWD, KID_BWD_TILE,
+    KID_BWD_ROWS, KID_BWD_GV, KID_LOGITS_BWD_ROWS, KID_LOGITS_BWD_GATHER, KID_LOGITS_BWD_PARAMS, KID_WGRAD,
+    KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_COUNT
+};
+extern "C" int ptv2_profile_is_on(void);
+void ptv2_profile_begin(int kid, hipStream_t st);
+void ptv2_profile_end(int kid, hipStream_t st, double algorithmic_bytes);
+struct PtvScopedTimer {
+    int kid; hipStream_t st; double bytes; bool on;
+    PtvScopedTimer(int k, hipStream_t s, double b) : kid(k), st(s), bytes(b), on(ptv2_profile_is_on() != 0) {
+        if (on) ptv2_profile_begin(kid, st);
+    }
+    ~PtvScopedTimer() { if (on) ptv2_profile_end(kid, st, bytes); }
+};
+
 // Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):
 // fma(dz,dz, fma(dx,dx, dy*dy)), q - p per component.  The only add that could be
 // contracted is already inside an explicit fma, so -ffp-contract cannot change it.

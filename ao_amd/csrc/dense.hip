@@ -374,7 +374,10 @@ extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, 
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
+    {
+        PtvScopedTimer t(KID_BN_STATS, st, 4.0 * n * c);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
                        dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, st, (const float *)part, nblk, c, n, x, eps, momentum, mean,
                        rstd, running_mean, running_var, num_batches_tracked);
@@ -388,8 +391,11 @@ extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *
     if (n == 0) return PTV2_OK;
     const long long total4 = (long long)n * (c >> 2);
     const int nblk = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total4, c >> 2, x, mean, rstd, gamma,
-                       beta, relu, y);
+    {
+        PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 8.0 * n * c);
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total4, c >> 2, x, mean, rstd,
+                           gamma, beta, relu, y);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -403,13 +409,19 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean, rstd,
-                       gamma, beta, relu, part);
+    {
+        PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 8.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean,
+                           rstd, gamma, beta, relu, part);
+    }
     launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean, rstd,
-                       gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx);
+    {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean,
+                           rstd, gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -424,7 +436,10 @@ extern "C" int skinny_linear_forward_hip_launcher(int n, int cin, int cout, cons
         (void)hipFuncSetAttribute((const void *)skinny_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long long total = (long long)n * cout;
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 8);
-    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, y);
+    {
+        PtvScopedTimer t(KID_SKINNY_FWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, y);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -435,7 +450,10 @@ extern "C" int skinny_linear_backward_hip_launcher(int n, int cin, int cout, con
     if (n == 0) return PTV2_OK;
     const long long total = (long long)n * (cin >> 2);
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
-    hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx);
+    {
+        PtvScopedTimer t(KID_SKINNY_BWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
+        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -452,8 +470,11 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     float *part_b = part;  // non-null flag: bias partials live behind the weight partials of each chunk record
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     dim3 grid(chunks, tiles_o * tiles_i, batch);
-    hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
-                       db ? part_b : (float *)nullptr, batch);
+    {
+        PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)chunks * cout * cin));
+        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
+                           db ? part_b : (float *)nullptr, batch);
+    }
     if (db) launch_finalize(st, (const float *)part, chunks, batch * cout * cin + batch * cout,
                             gva::MapSplit2<float>{dW, db, batch * cout * cin});
     else launch_finalize(st, (const float *)part, chunks, batch * cout * cin, gva::MapVec<float>{dW});

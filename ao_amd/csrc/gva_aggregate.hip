@@ -435,17 +435,24 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)n * k;
     const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS * 4);
+    {
+        PtvScopedTimer t(KID_SOFTMAX_ROWS, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * g));
 #define CALL(GG) \
     hipLaunchKernelGGL(softmax_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, w, sw)
-    GVA_DISPATCH_G(g, CALL)
+        GVA_DISPATCH_G(g, CALL)
 #undef CALL
+    }
     const int tp = std::max(1, TPB / c);
     const size_t lds = (size_t)tp * k * (sizeof(float4) + sizeof(float) * G4of(g) + sizeof(int));
+    {
+        // w + idx + coord in; v rows (each unique row once); out_v and A out
+        PtvScopedTimer t(KID_AGG_TILE, st, 4.0 * ((double)rows * (g + 1) + (double)n * (3 + 2 * c) + (double)n * g * c));
 #define CALL(GG)                                                                                                       \
     hipLaunchKernelGGL(aggregate_tile_kernel<GG>, dim3((n + tp - 1) / tp), dim3(TPB), lds, st, n, k, c, tp, (const float *)w, \
                        v, a, b, coord, idx, out_v, A)
-    GVA_DISPATCH_G(g, CALL)
+        GVA_DISPATCH_G(g, CALL)
 #undef CALL
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -487,17 +494,27 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
                                   (int)lds_tile);                                                                       \
     hipLaunchKernelGGL(aggregate_bwd_tile_kernel<GG>, dim3(nb_tile), dim3(WAVE), lds_tile, st, n, k, c, w, v, a, b, coord, idx, \
                        g_out, g_A, g_sw, gw, inv_ptr ? (float *)nullptr : gv, part)
-    GVA_DISPATCH_G(g, CALL)
+    {
+        // w, idx, coord, g_out, g_sw, v rows (unique once), g_A in; grad w out
+        PtvScopedTimer t(KID_BWD_TILE, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
+        GVA_DISPATCH_G(g, CALL)
+    }
 #undef CALL
     launch_finalize(st, (const float *)part, nb_tile, 4 * c, MapAB{ga, gb});
     if (inv_ptr)
+    {
+        PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
         hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3((int)std::min<long long>(((long long)n * c + TPB - 1) / TPB, MAX_BLOCKS * 4)),
                            dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+    }
     const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS);
 #define CALL(GG)                                                                                                      \
     hipLaunchKernelGGL(aggregate_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, \
                        (const float *)gw, gW1, gz, yb, part)
-    GVA_DISPATCH_G(g, CALL)
+    {
+        PtvScopedTimer t(KID_BWD_ROWS, st, 4.0 * (double)rows * (5 * g + 1));
+        GVA_DISPATCH_G(g, CALL)
+    }
 #undef CALL
     launch_finalize(st, (const float *)part, nb_rows, 2 * g, MapSplit2<float>{gsc, gsh, g});
     PTV2_CHECK_LAUNCH();

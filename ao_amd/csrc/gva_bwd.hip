@@ -238,7 +238,11 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)comb_bytes);                    \
     hipLaunchKernelGGL(logits_bwd_params_kernel<GG>, dim3(nb_par), dim3(TPB), comb_bytes, st, n, k, c, a, b, M, coord, idx, \
                        (const float *)gWt, ppart)
-    GVA_DISPATCH_G(g, CALL)
+    {
+        const int passes = (c + TPB - 1) / TPB;  // the row stream is re-read once per 256-channel pass
+        PtvScopedTimer t(KID_LOGITS_BWD_PARAMS, st, 4.0 * passes * ((double)rows * (g + 1) + 3.0 * n));
+        GVA_DISPATCH_G(g, CALL)
+    }
 #undef CALL
     launch_finalize(st, (const float *)ppart, nb_par, c * (g + 4), MapLogitsParams{gM, ga, gb, g});
     PTV2_CHECK_LAUNCH();

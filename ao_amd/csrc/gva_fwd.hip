@@ -161,7 +161,11 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
 #define CALL(GG)                                                                                                  \
     hipLaunchKernelGGL(logits_fwd_kernel<GG>, dim3(nblk), dim3(TPB), 0, st, n, k, c, kW, qW, a, b, M, cW, coord, idx, \
                        W1, part)
-    GVA_DISPATCH_G(g, CALL)
+    {
+        // idx, coord, kW (unique rows once), qW in; W1 out
+        PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
+        GVA_DISPATCH_G(g, CALL)
+    }
 #undef CALL
     // part is [nblk][2g]: columns 0..g-1 -> T1, g..2g-1 -> T2 (contiguous in the reduced vector)
     launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});

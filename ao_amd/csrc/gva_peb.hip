@@ -116,8 +116,11 @@ extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A,
     const int gx = (int)std::min<long long>(((long long)n + tp - 1) / tp, lds > 40 * 1024 ? 256 : 1024);
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void *)peb_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(peb_fwd_kernel, dim3(gx, (c + ct - 1) / ct), dim3(TPB), lds, (hipStream_t)stream, n, c, g, ct, A, Wp2,
-                       bp2, sw, out_v, out);
+    {
+        PtvScopedTimer t(KID_PEB_FWD, (hipStream_t)stream, 4.0 * ((double)n * g * c + 2.0 * n * c + (double)n * g + (double)c * c));
+        hipLaunchKernelGGL(peb_fwd_kernel, dim3(gx, (c + ct - 1) / ct), dim3(TPB), lds, (hipStream_t)stream, n, c, g, ct, A, Wp2,
+                           bp2, sw, out_v, out);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -131,7 +134,10 @@ extern "C" int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
 #define CALL(II) \
     hipLaunchKernelGGL(peb_bwd_kernel<II>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, n, c, g, g_out, Wp2, bp2, g_A, g_sw)
-    PEB_DISPATCH_I(I, CALL)
+    {
+        PtvScopedTimer t(KID_PEB_BWD, (hipStream_t)stream, 4.0 * ((double)n * g * c + (double)n * c + (double)n * g + (double)c * c));
+        PEB_DISPATCH_I(I, CALL)
+    }
 #undef CALL
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

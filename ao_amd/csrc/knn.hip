@@ -507,11 +507,14 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        w.cell_start, ntiles);
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, w.cell_start, w.point_cell,
                        w.point_rank, w.sorted);
+    {
+    PtvScopedTimer qt(KID_KNN_QUERY, st, 12.0 * n + 12.0 * m + 8.0 * (double)m * k);
     if (k <= 1) launch_query<2>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 3) launch_query<4>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 8) launch_query<9>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 16) launch_query<17>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else launch_query<33>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    }
     hipLaunchKernelGGL(knn_exact_kernel, dim3(512), dim3(EX_WAVES * WAVE), 0, st, m, k, xyz, new_xyz, offset,
                        new_offset, b, idx, dist2, pad_with_start, (const int *)w.tie_count, (const int *)w.tie_list, 0);
     PTV2_CHECK_LAUNCH();

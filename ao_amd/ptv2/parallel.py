@@ -1,0 +1,53 @@
+"""Data-parallel step plumbing shared by bench.py and the CPU (gloo) tests.
+
+The hot path shards by scene: one process per GPU, whole scenes per rank, no data-path
+collective; the only exchange is the gradient all-reduce, which torch's DistributedDataParallel buckets and
+overlaps with backward over RCCL (backend "nccl" on ROCm) -- the reference does exactly this
+(pointcept/engines/defaults.py:22-43, train_sam_pp2s.py:209-213).
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def rank_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def scene_seeds(rank, scenes_per_rank):
+    """Scenes owned by `rank` (disjoint across ranks; weak scaling: fixed work per rank)."""
+    return [rank * scenes_per_rank + i for i in range(scenes_per_rank)]
+
+
+def wrap_ddp(module, device):
+    """DDP with the reference's settings (broadcast_buffers=False: BatchNorm statistics stay per process)."""
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, broadcast_buffers=False,
+                                                     gradient_as_bucket_view=True)
+
+
+def fence(device):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_steps(step_fn, steps, device, points_this_rank):
+    """Run exactly `steps` steps bracketed by barrier+synchronize; returns (max elapsed over ranks,
+    total points per step over all ranks, last loss)."""
+    fence(device)
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(steps):
+        loss = step_fn()
+    fence(device)
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    pts = torch.tensor([float(points_this_rank)], device=device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(pts.item()), loss

@@ -46,8 +46,9 @@ def parse():
 def make_batch(rank, scenes, points, device):
     from ao_amd import synth
 
-    seeds = [rank * scenes + i for i in range(scenes)]
-    b = synth.scene_batch(seeds, point_max=points, room=1)
+    from ao_amd.ptv2.parallel import scene_seeds
+
+    b = synth.scene_batch(scene_seeds(rank, scenes), point_max=points, room=1)
     return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
 
 
@@ -91,9 +92,9 @@ def cpu_baseline(cfg, sample_points):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from ao_amd.ptv2 import parallel
+
+    rank, local_rank, world = parallel.rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
@@ -105,15 +106,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import ao_amd.ptv2 as ptv2
-    from ao_amd.profiling import clock
+    from ao_amd import _lib
 
     torch.manual_seed(4242)
     cfg = dict(ptv2.S3DIS_BACKBONE)
     seg = ptv2.DefaultSegmentor(cfg).to(device).train()
     net = seg
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(seg, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+        net = parallel.wrap_ddp(seg, device)
     opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     data = make_batch(rank, args.scenes, args.points, device)
     n_points = int(data["coord"].shape[0])
@@ -130,29 +130,13 @@ def main():
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    clock.enabled = not args.no_roofline
-    clock.reset()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    clock.enabled = False
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    total_points = torch.tensor([n_points], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(total_points, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    points_per_step = float(total_points.item())
+    if not args.no_roofline:
+        _lib.kernel_timer(True)
+    elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points)
+    if not args.no_roofline:
+        _lib.lib().ptv2_profile_enable(0)
 
     if rank == 0:
         with torch.no_grad():
@@ -173,17 +157,20 @@ def main():
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
         out["config"]["step_frac_of_hbm_roofline"] = (step_bytes / (ms * 1e-3)) / (HBM_PEAK_GBS * 1e9)
         if not args.no_roofline:
-            summ = clock.summary()
+            summ = _lib.kernel_timer_read()
             if summ:
-                name, rec = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+                # dominant hand-written kernel of the step = largest total time inside the timed region
+                name, rec = max(summ.items(), key=lambda kv: kv[1]["total_us"])
                 achieved = rec["bytes_per_launch"] / (rec["avg_us"] * 1e-6) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                    "avg_us": rec["avg_us"], "launches": rec["launches"],
+                                   "ms_per_step": rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                                    "all_kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
+                                                       "ms_per_step": round(v["total_us"] / 1e3 / args.steps, 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
-                                                   for k, v in summ.items()}}
+                                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_us"])}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_points)
         print(json.dumps(out))

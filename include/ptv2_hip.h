@@ -39,6 +39,15 @@ extern "C" {
 int ptv2_abi_version(void);
 const char *ptv2_build_info(void);
 
+/* Optional per-kernel timer (measurement aid, off by default; bench.py's roofline object uses it).
+ * enable(1) clears the table and makes every launcher bracket its main kernel with HIP events on the launch
+ * stream; read() synchronises on them and returns, for kernel id kid in [0, kernel_count), its name (>= 64
+ * bytes), the summed duration in microseconds, the number of launches and the mean algorithmic bytes. */
+int ptv2_profile_enable(int on);
+int ptv2_profile_is_on(void);
+int ptv2_profile_kernel_count(void);
+int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch);
+
 /* ------------------------------------------------------------------ kNN --
  * Replaces knn_query_cuda_launcher
  *   (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13, kernel .cu:60-112)
