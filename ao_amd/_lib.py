@@ -115,8 +115,21 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_WS = {}
+
+
 def workspace(nbytes, device):
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch for one launcher call.  One grow-only buffer per (device, stream): launches on a stream are
+    ordered, and no launcher needs its scratch after it returns, so consecutive calls can share it (saves an
+    allocator round trip per op; at 288 GB per GPU the retained high-water mark is irrelevant)."""
+    nbytes = max(int(nbytes), 256)
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
 
 
 def kernel_timer(enable):

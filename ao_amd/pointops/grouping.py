@@ -23,9 +23,8 @@ class Grouping(Function):
         assert input.dtype == torch.float32 and idx.dtype == torch.int32
         m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
         output = torch.empty((m, nsample, c), dtype=torch.float32, device=input.device)
-        with clock.region("grouping_forward", 4 * (n * c + m * nsample + m * nsample * c)):
-            rc = _lib.lib().grouping_forward_hip_launcher(m, nsample, c, input.data_ptr(), idx.data_ptr(),
-                                                          output.data_ptr(), _lib.stream_ptr())
+        rc = _lib.lib().grouping_forward_hip_launcher(m, nsample, c, input.data_ptr(), idx.data_ptr(),
+                                                      output.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "grouping_forward_hip_launcher")
         ctx.n = n
         ctx.save_for_backward(idx)

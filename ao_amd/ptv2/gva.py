@@ -130,11 +130,10 @@ class _Logits(torch.autograd.Function):
         T2 = torch.empty(g, dtype=torch.float64, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
-        with clock.region("gva_logits_fwd", 4 * (n * (2 * g + 3 + k) + n * k * g)):
-            rc = L.gva_logits_forward_hip_launcher(
-                n, k, c, g, kW.data_ptr(), qW.data_ptr(), a.data_ptr(), b.data_ptr(), M.data_ptr(), cW.data_ptr(),
-                coord.data_ptr(), idx.data_ptr(), W1.data_ptr(), T1.data_ptr(), T2.data_ptr(), ws.data_ptr(),
-                ws.numel(), _lib.stream_ptr())
+        rc = L.gva_logits_forward_hip_launcher(
+            n, k, c, g, kW.data_ptr(), qW.data_ptr(), a.data_ptr(), b.data_ptr(), M.data_ptr(), cW.data_ptr(),
+            coord.data_ptr(), idx.data_ptr(), W1.data_ptr(), T1.data_ptr(), T2.data_ptr(), ws.data_ptr(),
+            ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "gva_logits_forward_hip_launcher")
         inv_ptr, inv_rows = inverse_table(idx) if any(ctx.needs_input_grad) else (None, None)
         ctx.save_for_backward(a, b, M, coord, idx, W1, inv_ptr, inv_rows)
@@ -157,13 +156,12 @@ class _Logits(torch.autograd.Function):
         gcW = torch.empty(g, dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gva_workspace_bytes(n, k, c, g), dev)
-        with clock.region("gva_logits_bwd", 4 * (n * (2 * g + 3 + k) + 2 * n * k * g)):
-            rc = L.gva_logits_backward_hip_launcher(
-                n, k, c, g, a.data_ptr(), b.data_ptr(), M.data_ptr(), coord.data_ptr(), idx.data_ptr(),
-                W1.data_ptr(), gW1.data_ptr(), gT1.data_ptr(), gT2.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(),
-                gkW.data_ptr(), gqW.data_ptr(),
-                ga.data_ptr(), gb.data_ptr(), gM.data_ptr(), gcW.data_ptr(), ws.data_ptr(), ws.numel(),
-                _lib.stream_ptr())
+        rc = L.gva_logits_backward_hip_launcher(
+            n, k, c, g, a.data_ptr(), b.data_ptr(), M.data_ptr(), coord.data_ptr(), idx.data_ptr(),
+            W1.data_ptr(), gW1.data_ptr(), gT1.data_ptr(), gT2.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(),
+            gkW.data_ptr(), gqW.data_ptr(),
+            ga.data_ptr(), gb.data_ptr(), gM.data_ptr(), gcW.data_ptr(), ws.data_ptr(), ws.numel(),
+            _lib.stream_ptr())
         _lib.check(rc, "gva_logits_backward_hip_launcher")
         return gkW, gqW, ga, gb, gM, gcW, None, None
 
@@ -183,11 +181,10 @@ class _Aggregate(torch.autograd.Function):
         A = torch.empty((n, g, c), dtype=torch.float32, device=dev)
         sw = torch.empty((n, g), dtype=torch.float32, device=dev)
         w = torch.empty((n, k, g), dtype=torch.float32, device=dev)
-        with clock.region("gva_aggregate_fwd", 4 * (2 * n * k * g + n * (2 * c + k + 3 + g) + g * n * c)):
-            rc = _lib.lib().gva_aggregate_forward_hip_launcher(
-                n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
-                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), out_v.data_ptr(), A.data_ptr(),
-                sw.data_ptr(), w.data_ptr(), _lib.stream_ptr())
+        rc = _lib.lib().gva_aggregate_forward_hip_launcher(
+            n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
+            a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), out_v.data_ptr(), A.data_ptr(),
+            sw.data_ptr(), w.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "gva_aggregate_forward_hip_launcher")
         inv_ptr, inv_rows = inverse_table(idx) if any(ctx.needs_input_grad) else (None, None)
         ctx.save_for_backward(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows, w)
@@ -213,13 +210,12 @@ class _Aggregate(torch.autograd.Function):
         gb = torch.empty(c, dtype=torch.float32, device=dev)
         L = _lib.lib()
         ws = _lib.workspace(L.gva_aggregate_workspace_bytes(n, k, c, g), dev)
-        with clock.region("gva_aggregate_bwd", 4 * (3 * n * k * g + n * (3 * c + k + 3 + 2 * g) + g * n * c)):
-            rc = L.gva_aggregate_backward_hip_launcher(
-                n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
-                a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), w.data_ptr(), g_out.data_ptr(), g_A.data_ptr(),
-                g_sw.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(), gW1.data_ptr(), gsc.data_ptr(), gsh.data_ptr(),
-                gWw2.data_ptr(), gbw2.data_ptr(),
-                gv.data_ptr(), ga.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        rc = L.gva_aggregate_backward_hip_launcher(
+            n, k, c, g, W1.data_ptr(), sc.data_ptr(), sh.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(), v.data_ptr(),
+            a.data_ptr(), b.data_ptr(), coord.data_ptr(), idx.data_ptr(), w.data_ptr(), g_out.data_ptr(), g_A.data_ptr(),
+            g_sw.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(), gW1.data_ptr(), gsc.data_ptr(), gsh.data_ptr(),
+            gWw2.data_ptr(), gbw2.data_ptr(),
+            gv.data_ptr(), ga.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "gva_aggregate_backward_hip_launcher")
         return gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, None, None
 
@@ -325,10 +321,9 @@ class _PebProject(torch.autograd.Function):
         A, Wp2, bp2, sw, out_v = (_f32c(t) for t in (A, Wp2, bp2, sw, out_v))
         n, g, c = A.shape
         out = torch.empty((n, c), dtype=torch.float32, device=A.device)
-        with clock.region("gva_peb_fwd", 4 * (g * n * c + 2 * n * c + n * g + c * c)):
-            rc = _lib.lib().gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
-                                                         sw.data_ptr(), out_v.data_ptr(), out.data_ptr(),
-                                                         _lib.stream_ptr())
+        rc = _lib.lib().gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
+                                                     sw.data_ptr(), out_v.data_ptr(), out.data_ptr(),
+                                                     _lib.stream_ptr())
         _lib.check(rc, "gva_peb_forward_hip_launcher")
         ctx.save_for_backward(A, Wp2, bp2, sw)
         return out
@@ -341,9 +336,8 @@ class _PebProject(torch.autograd.Function):
         g_out = g_out.contiguous()
         g_A = torch.empty_like(A)
         g_sw = torch.empty_like(sw)
-        with clock.region("gva_peb_bwd", 4 * (g * n * c + n * c + n * g + c * c)):
-            rc = _lib.lib().gva_peb_backward_hip_launcher(n, c, g, g_out.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
-                                                          g_A.data_ptr(), g_sw.data_ptr(), _lib.stream_ptr())
+        rc = _lib.lib().gva_peb_backward_hip_launcher(n, c, g, g_out.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(),
+                                                      g_A.data_ptr(), g_sw.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "gva_peb_backward_hip_launcher")
         # grad Wp2[g*I+i, c'] = sum_n g_out[n, g*I+i] A[n,g,c']: G batched (I x C') weight-gradient reductions
         g_Wp2 = torch.empty((c, c), dtype=torch.float32, device=A.device)

@@ -33,20 +33,18 @@ class _BNRows(torch.autograd.Function):
             rstd = torch.empty(c, dtype=torch.float32, device=x.device)
             track = bn.track_running_stats and bn.training and bn.running_mean is not None
             ws = _ws(n, c, c, x.device)
-            with clock.region("bn_stats", 4 * n * c):
-                rc = L.bn_stats_hip_launcher(
-                    n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                    bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
-                    bn.num_batches_tracked.data_ptr() if track else 0, float(bn.eps), float(bn.momentum),
-                    ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            rc = L.bn_stats_hip_launcher(
+                n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                bn.num_batches_tracked.data_ptr() if track else 0, float(bn.eps), float(bn.momentum),
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "bn_stats_hip_launcher")
         else:
             mean = bn.running_mean
             rstd = torch.rsqrt(bn.running_var + bn.eps)
         y = torch.empty_like(x)
-        with clock.region("bn_apply", 8 * n * c):
-            rc = L.bn_apply_hip_launcher(n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                                         beta.data_ptr(), int(relu), y.data_ptr(), _lib.stream_ptr())
+        rc = L.bn_apply_hip_launcher(n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), int(relu), y.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "bn_apply_hip_launcher")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.relu, ctx.training = bool(relu), bool(training)
@@ -61,11 +59,10 @@ class _BNRows(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         ws = _ws(n, c, c, x.device)
-        with clock.region("bn_backward", 16 * n * c):
-            rc = _lib.lib().bn_backward_hip_launcher(
-                n, c, x.data_ptr(), gy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                int(ctx.relu), int(ctx.training), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
-                ws.numel(), _lib.stream_ptr())
+        rc = _lib.lib().bn_backward_hip_launcher(
+            n, c, x.data_ptr(), gy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            int(ctx.relu), int(ctx.training), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+            ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "bn_backward_hip_launcher")
         return gx, dgamma, dbeta, None, None
 
@@ -101,10 +98,9 @@ class _LinearRows(torch.autograd.Function):
         dW = torch.empty_like(weight)
         db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
         ws = _ws(n, cout, cin, x.device)
-        with clock.region("linear_wgrad", 4 * n * (cin + cout)):
-            rc = _lib.lib().linear_wgrad_hip_launcher(n, cout, cin, gy.data_ptr(), x.data_ptr(), dW.data_ptr(),
-                                                      db.data_ptr() if db is not None else 0, ws.data_ptr(), ws.numel(),
-                                                      _lib.stream_ptr())
+        rc = _lib.lib().linear_wgrad_hip_launcher(n, cout, cin, gy.data_ptr(), x.data_ptr(), dW.data_ptr(),
+                                                  db.data_ptr() if db is not None else 0, ws.data_ptr(), ws.numel(),
+                                                  _lib.stream_ptr())
         _lib.check(rc, "linear_wgrad_hip_launcher")
         return gx, dW, db
 
@@ -128,9 +124,8 @@ class _SkinnyLinear(torch.autograd.Function):
         n, cin = x.shape
         cout = weight.shape[0]
         y = torch.empty((n, cout), dtype=torch.float32, device=x.device)
-        with clock.region("skinny_fwd", 4 * n * (cin + cout)):
-            rc = _lib.lib().skinny_linear_forward_hip_launcher(n, cin, cout, x.data_ptr(), weight.data_ptr(), y.data_ptr(),
-                                                               _lib.stream_ptr())
+        rc = _lib.lib().skinny_linear_forward_hip_launcher(n, cin, cout, x.data_ptr(), weight.data_ptr(), y.data_ptr(),
+                                                           _lib.stream_ptr())
         _lib.check(rc, "skinny_linear_forward_hip_launcher")
         ctx.save_for_backward(x, weight)
         return y

@@ -112,7 +112,11 @@ def main():
     cfg = dict(ptv2.S3DIS_BACKBONE)
     seg = ptv2.DefaultSegmentor(cfg).to(device).train()
     net = seg
-    if world > 1:
+    if world > 1 or os.environ.get("AO_AMD_FORCE_DDP") == "1":  # the env switch lets a 1-GPU box exercise the DDP path
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         net = parallel.wrap_ddp(seg, device)
     opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     data = make_batch(rank, args.scenes, args.points, device)
@@ -151,7 +155,7 @@ def main():
             "config": {"workload": "s3dis semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
-                       "parallelism": "dp%d" % world, "loss": float(loss)},
+                       "parallelism": "dp%d" % world, "loss": float(loss.detach())},
         }
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
@@ -174,7 +178,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_points)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
