@@ -1,0 +1,274 @@
+// ao_amd/csrc/gva_block.hip -- GroupedVectorAttention forward / backward as ONE native call each.
+//
+// The stage launchers (gva_fwd / gva_aggregate / gva_bwd / gva_peb / gva_fold / dense) are enqueued back to
+// back on the caller's stream from here; the only additional device code is the parameter-sized glue
+// (M = (Ww1 Wp2)^T, cW = Ww1 bp2 + bw1 and their gradients, a couple of vector adds, the bp2 gradient).
+// With ~35 python-level ops per block the step was host-bound (profiles/r01_*: 2 350 launches, 32 ms of host
+// time vs 30 ms of kernel time); behind this entry point a block costs two host calls.
+#include <algorithm>
+
+#include "gva_common.h"
+
+namespace gva {
+
+// M[c',g] = sum_c Wp2[c,c'] Ww1[g,c];  cW[g] = sum_c Ww1[g,c] bp2[c] + bw1[g]
+__global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
+                                                         const float *__restrict__ bp2, const float *__restrict__ Ww1,
+                                                         const float *__restrict__ bw1, float *__restrict__ M,
+                                                         float *__restrict__ cW) {
+    const int e = blockIdx.x * TPB + threadIdx.x;
+    if (e < c * g) {
+        const int cp = e / g, gi = e - cp * g;
+        float acc = 0.f;
+        for (int ci = 0; ci < c; ++ci) acc = __builtin_fmaf(Wp2[(size_t)ci * c + cp], Ww1[(size_t)gi * c + ci], acc);
+        M[e] = acc;
+    } else if (e < c * g + g) {
+        const int gi = e - c * g;
+        float acc = bw1[gi];
+        for (int ci = 0; ci < c; ++ci) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
+        cW[gi] = acc;
+    }
+}
+
+// gWw1[g,c] (+)= sum_c' gM[c',g] Wp2[c,c'] + gcW[g] bp2[c];  gWp2[c,c'] += sum_g Ww1[g,c] gM[c',g];
+// gbp2[c] += sum_g gcW[g] Ww1[g,c];  gbw1 = gcW.   gWw1 accumulates onto the two projection gradients.
+__global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const float *__restrict__ Wp2,
+                                                         const float *__restrict__ bp2, const float *__restrict__ Ww1,
+                                                         const float *__restrict__ gM, const float *__restrict__ gcW,
+                                                         const float *__restrict__ gWw1_k,
+                                                         const float *__restrict__ gWw1_q, float *__restrict__ gWw1,
+                                                         float *gWp2, float *gbp2, float *__restrict__ gbw1) {
+    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+    const long long n1 = (long long)g * c, n2 = (long long)c * c;
+    if (e < n1) {
+        const int gi = (int)(e / c), ci = (int)(e - (long long)gi * c);
+        float acc = gcW[gi] * bp2[ci] + gWw1_k[e] + gWw1_q[e];
+        for (int cp = 0; cp < c; ++cp) acc = __builtin_fmaf(gM[(size_t)cp * g + gi], Wp2[(size_t)ci * c + cp], acc);
+        gWw1[e] = acc;
+    } else if (e < n1 + n2) {
+        const long long r = e - n1;
+        const int ci = (int)(r / c), cp = (int)(r - (long long)ci * c);
+        float acc = gWp2[r];
+        for (int gi = 0; gi < g; ++gi) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], gM[(size_t)cp * g + gi], acc);
+        gWp2[r] = acc;
+    } else if (e < n1 + n2 + c) {
+        const int ci = (int)(e - n1 - n2);
+        float acc = gbp2[ci];
+        for (int gi = 0; gi < g; ++gi) acc = __builtin_fmaf(gcW[gi], Ww1[(size_t)gi * c + ci], acc);
+        gbp2[ci] = acc;
+    } else if (e < n1 + n2 + c + g) {
+        const int gi = (int)(e - n1 - n2 - c);
+        gbw1[gi] = gcW[gi];
+    }
+}
+
+__global__ void add_vec_kernel(int len, float *__restrict__ dst, const float *__restrict__ src) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < len) dst[e] += src[e];
+}
+
+// partial[blk][c] = sum over the block's rows of g_out[n,c] * sw[n, c / I]
+__global__ __launch_bounds__(TPB) void bp2_grad_kernel(int n, int c, int g, const float *__restrict__ g_out,
+                                                       const float *__restrict__ sw, float *__restrict__ part) {
+    extern __shared__ float lds[];
+    const int I = c / g;
+    const int rl = TPB / c > 0 ? TPB / c : 1;
+    const int ch0 = threadIdx.x % c, r = threadIdx.x / c;
+    for (int cb = 0; cb < c; cb += TPB) {  // channels beyond 256 in further passes
+        const int ch = cb + (c >= TPB ? threadIdx.x : ch0);
+        float acc = 0.f;
+        if (ch < c && (c >= TPB || r < rl))
+            for (long long row = (long long)blockIdx.x * rl + (c >= TPB ? 0 : r); row < n; row += (long long)gridDim.x * rl)
+                acc = __builtin_fmaf(g_out[row * c + ch], sw[row * g + ch / I], acc);
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        if (c >= TPB) {
+            if (ch < c) part[(size_t)blockIdx.x * c + ch] = acc;
+        } else if (threadIdx.x < c) {
+            float t = 0.f;
+            for (int kk = 0; kk < rl; ++kk) t += lds[kk * c + threadIdx.x];
+            part[(size_t)blockIdx.x * c + threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (c < TPB) break;
+    }
+}
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace gva
+
+using namespace gva;
+
+extern "C" {
+size_t gva_workspace_bytes(int n, int k, int c, int g);
+size_t gva_aggregate_workspace_bytes(int n, int k, int c, int g);
+size_t dense_workspace_bytes(int n, int cout, int cin);
+int gva_fold_p_forward_hip_launcher(int, const float *, const float *, const float *, const float *, const double *,
+                                    const double *, float *, float *, long long *, int, double, float, float, float *,
+                                    float *, float *, void *);
+int gva_fold_p_backward_hip_launcher(int, const float *, const float *, const float *, const double *, const double *,
+                                     const float *, const float *, int, const float *, const float *, float *, float *,
+                                     float *, float *, void *);
+int gva_fold_w_forward_hip_launcher(int, const double *, const double *, const float *, const float *, float *, float *,
+                                    long long *, int, double, float, float, float *, float *, double *, double *, void *);
+int gva_fold_w_backward_hip_launcher(int, const float *, const double *, const double *, int, double, const float *,
+                                     const float *, double *, double *, float *, float *, void *);
+int skinny_linear_forward_hip_launcher(int, int, int, const float *, const float *, float *, void *);
+int skinny_linear_backward_hip_launcher(int, int, int, const float *, const float *, float *, void *);
+int linear_wgrad_hip_launcher(int, int, int, const float *, const float *, float *, float *, void *, size_t, void *);
+int linear_wgrad_strided_hip_launcher(int, int, int, int, const float *, long long, long long, const float *, long long,
+                                      long long, float *, float *, void *, size_t, void *);
+int gva_logits_forward_hip_launcher(int, int, int, int, const float *, const float *, const float *, const float *,
+                                    const float *, const float *, const float *, const int *, float *, double *, double *,
+                                    void *, size_t, void *);
+int gva_logits_backward_hip_launcher(int, int, int, int, const float *, const float *, const float *, const float *,
+                                     const int *, const float *, const float *, const double *, const double *,
+                                     const int *, const int *, float *, float *, float *, float *, float *, float *, void *,
+                                     size_t, void *);
+int gva_aggregate_forward_hip_launcher(int, int, int, int, const float *, const float *, const float *, const float *,
+                                       const float *, const float *, const float *, const float *, const float *,
+                                       const int *, float *, float *, float *, float *, void *);
+int gva_aggregate_backward_hip_launcher(int, int, int, int, const float *, const float *, const float *, const float *,
+                                        const float *, const float *, const float *, const float *, const float *,
+                                        const int *, const float *, const float *, const float *, const float *,
+                                        const int *, const int *, float *, float *, float *, float *, float *, float *,
+                                        float *, float *, void *, size_t, void *);
+int gva_peb_forward_hip_launcher(int, int, int, const float *, const float *, const float *, const float *, const float *,
+                                 float *, void *);
+int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, const float *, float *, float *, void *);
+}
+
+namespace {
+struct BlockWs {  // carve the block workspace
+    char *stage; size_t stage_bytes;       // scratch handed to the stage launchers
+    float *out_v, *gA, *g_sw, *gW1, *gkW, *gqW, *ga2, *gb2, *ga1, *gb1, *gM, *gcW, *gsc, *gsh, *gWw1_k, *gWw1_q, *part;
+    double *T1, *T2, *gT1, *gT2;
+    size_t bytes;
+};
+
+BlockWs carve(void *base, int n, int k, int c, int g) {
+    BlockWs w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    const size_t rows = (size_t)n * k;
+    w.stage_bytes = std::max({gva_workspace_bytes(n, k, c, g), gva_aggregate_workspace_bytes(n, k, c, g),
+                              dense_workspace_bytes(n, c, c), dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g)});
+    w.stage = take(w.stage_bytes);
+    w.out_v = (float *)take(sizeof(float) * (size_t)n * c);
+    w.gA = (float *)take(sizeof(float) * (size_t)n * g * c);
+    w.g_sw = (float *)take(sizeof(float) * (size_t)n * g);
+    w.gW1 = (float *)take(sizeof(float) * rows * g);
+    w.gkW = (float *)take(sizeof(float) * (size_t)n * g);
+    w.gqW = (float *)take(sizeof(float) * (size_t)n * g);
+    w.ga1 = (float *)take(sizeof(float) * 3 * c);
+    w.gb1 = (float *)take(sizeof(float) * c);
+    w.ga2 = (float *)take(sizeof(float) * 3 * c);
+    w.gb2 = (float *)take(sizeof(float) * c);
+    w.gM = (float *)take(sizeof(float) * (size_t)c * g);
+    w.gcW = (float *)take(sizeof(float) * g);
+    w.gsc = (float *)take(sizeof(float) * g);
+    w.gsh = (float *)take(sizeof(float) * g);
+    w.gWw1_k = (float *)take(sizeof(float) * (size_t)g * c);
+    w.gWw1_q = (float *)take(sizeof(float) * (size_t)g * c);
+    w.part = (float *)take(sizeof(float) * (size_t)MAX_BLOCKS * c);
+    w.T1 = (double *)take(sizeof(double) * g);
+    w.T2 = (double *)take(sizeof(double) * g);
+    w.gT1 = (double *)take(sizeof(double) * g);
+    w.gT2 = (double *)take(sizeof(double) * g);
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+#define RUN(call)                  \
+    do {                           \
+        int rc_ = (call);          \
+        if (rc_ != PTV2_OK) return rc_; \
+    } while (0)
+
+extern "C" size_t gva_block_workspace_bytes(int n, int k, int c, int g) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
+    return carve(nullptr, n, k, c, g).bytes + 1024;
+}
+
+extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *workspace, size_t workspace_bytes,
+                                              void *stream) {
+    if (!B) return PTV2_ERR_ARG;
+    const int n = B->n, k = B->k, c = B->c, g = B->g;
+    if (n < 0 || k < 1 || c < 4 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    BlockWs W = carve(workspace, n, k, c, g);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const double rows = (double)n * k;
+    RUN(gva_fold_p_forward_hip_launcher(c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p,
+                                        B->run_var_p, B->batches_p, B->training, rows, B->eps_p, B->momentum_p, B->a, B->b,
+                                        B->rstd_p, stream));
+    hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup((long long)c * g + g, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
+                       B->Ww1, B->bw1, B->M, B->cW);
+    RUN(skinny_linear_forward_hip_launcher(n, c, g, B->key, B->Ww1, B->kW, stream));
+    RUN(skinny_linear_forward_hip_launcher(n, c, g, B->q, B->Ww1, B->qW, stream));
+    RUN(gva_logits_forward_hip_launcher(n, k, c, g, B->kW, B->qW, B->a, B->b, B->M, B->cW, B->coord, B->idx, B->W1, W.T1,
+                                        W.T2, W.stage, W.stage_bytes, stream));
+    RUN(gva_fold_w_forward_hip_launcher(g, W.T1, W.T2, B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w,
+                                        B->training, rows, B->eps_w, B->momentum_w, B->sc, B->sh, B->mean_w, B->rstd_w,
+                                        stream));
+    RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
+                                           B->idx, W.out_v, B->A, B->sw, B->w, stream));
+    RUN(gva_peb_forward_hip_launcher(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, stream));
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const ptv2_gva_block_grads *G, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
+    if (!B || !G) return PTV2_ERR_ARG;
+    const int n = B->n, k = B->k, c = B->c, g = B->g;
+    if (n < 0 || k < 1 || c < 4 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    BlockWs W = carve(workspace, n, k, c, g);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const double rows = (double)n * k;
+    const int I = c / g;
+    // 1. projection after the neighbour sum: g_A, g_sw, grad Wp2 (direct part), grad bp2 (direct part)
+    RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
+    RUN(linear_wgrad_strided_hip_launcher(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, nullptr, W.stage,
+                                          W.stage_bytes, stream));
+    {
+        const int rl = std::max(1, TPB / c);
+        const int nblk = (int)std::min<long long>(((long long)n + rl * 8 - 1) / (rl * 8), MAX_BLOCKS);
+        hipLaunchKernelGGL(bp2_grad_kernel, dim3(nblk), dim3(TPB), sizeof(float) * TPB, st, n, c, g, G->g_out, B->sw, W.part);
+        launch_finalize(st, (const float *)W.part, nblk, c, MapVec<float>{G->gbp2});
+    }
+    // 2. softmax / aggregation stage
+    RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
+                                            B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
+                                            W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
+    // 3. BatchNorm over the logits
+    RUN(gva_fold_w_backward_hip_launcher(g, B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, W.gT1, W.gT2,
+                                         G->ggamma_w, G->gbeta_w, stream));
+    // 4. logits stage
+    if (!G->inv_ptr) (void)hipMemsetAsync(W.gkW, 0, sizeof(float) * (size_t)n * g, st);
+    RUN(gva_logits_backward_hip_launcher(n, k, c, g, B->a, B->b, B->M, B->coord, B->idx, B->W1, W.gW1, W.gT1, W.gT2,
+                                         G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage,
+                                         W.stage_bytes, stream));
+    // 5. folded BN_p: both stages contribute to (a, b)
+    hipLaunchKernelGGL(add_vec_kernel, dim3(divup(3 * c, 256)), dim3(256), 0, st, 3 * c, W.ga1, (const float *)W.ga2);
+    hipLaunchKernelGGL(add_vec_kernel, dim3(divup(c, 256)), dim3(256), 0, st, c, W.gb1, (const float *)W.gb2);
+    RUN(gva_fold_p_backward_hip_launcher(c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p,
+                                         B->training, W.ga1, W.gb1, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p, stream));
+    // 6. projections kW = k Ww1^T, qW = q Ww1^T
+    RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gkW, B->Ww1, G->gk, stream));
+    RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gqW, B->Ww1, G->gq, stream));
+    RUN(linear_wgrad_hip_launcher(n, g, c, W.gkW, B->key, W.gWw1_k, nullptr, W.stage, W.stage_bytes, stream));
+    RUN(linear_wgrad_hip_launcher(n, g, c, W.gqW, B->q, W.gWw1_q, nullptr, W.stage, W.stage_bytes, stream));
+    // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1
+    hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c + (long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,
+                       g, B->Wp2, B->bp2, B->Ww1, (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k,
+                       (const float *)W.gWw1_q, G->gWw1, G->gWp2, G->gbp2, G->gbw1);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -24,6 +24,7 @@ autograd composes the two HIP stages (`logits`, `aggregate`) with them, which al
 BatchNorm backward through the batch statistics.
 """
 import ctypes
+import os
 
 import torch
 
@@ -48,6 +49,9 @@ _SIG = {
                                         + [_lib._vp] * 5),
     "gva_fold_w_backward_hip_launcher": (_lib._c_int, [_lib._c_int] + [_lib._vp] * 3 + [_lib._c_int, ctypes.c_double]
                                          + [_lib._vp] * 7),
+    "gva_block_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
+    "gva_block_forward_hip_launcher": (_lib._c_int, [_lib._vp, _lib._vp, _lib._c_size, _lib._vp]),
+    "gva_block_backward_hip_launcher": (_lib._c_int, [_lib._vp, _lib._vp, _lib._vp, _lib._c_size, _lib._vp]),
     "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
     "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
 }
@@ -350,6 +354,130 @@ class _PebProject(torch.autograd.Function):
         return g_A, g_Wp2, g_bp2, g_sw, g_out
 
 
+# ------------------------------------------------------- whole block, one call --
+_P = ctypes.c_void_p
+
+
+class _BlockArgs(ctypes.Structure):  # mirrors ptv2_gva_block (include/ptv2_hip.h)
+    _fields_ = ([(n_, ctypes.c_int) for n_ in ("n", "k", "c", "g", "training")]
+                + [(n_, ctypes.c_float) for n_ in ("eps_p", "momentum_p", "eps_w", "momentum_w")]
+                + [(n_, _P) for n_ in (
+                    "q", "key", "v", "coord", "idx", "mu", "cov",
+                    "Wp1", "bp1", "gamma_p", "beta_p", "Wp2", "bp2", "Ww1", "bw1", "gamma_w", "beta_w", "Ww2", "bw2",
+                    "run_mean_p", "run_var_p", "run_mean_w", "run_var_w", "batches_p", "batches_w",
+                    "out", "a", "b", "rstd_p", "M", "cW", "kW", "qW", "W1", "w", "A", "sw", "sc", "sh",
+                    "mean_w", "rstd_w")])
+
+
+class _BlockGrads(ctypes.Structure):  # mirrors ptv2_gva_block_grads
+    _fields_ = [(n_, _P) for n_ in (
+        "g_out", "inv_ptr", "inv_rows", "gq", "gk", "gv", "gWp1", "gbp1", "ggamma_p", "gbeta_p", "gWp2", "gbp2",
+        "gWw1", "gbw1", "ggamma_w", "gbeta_w", "gWw2", "gbw2")]
+
+
+def _momentum(bn):
+    return bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+
+
+class _GvaBlock(torch.autograd.Function):
+    """GroupedVectorAttention core (everything after linear_q/k/v) as one native call per direction
+    (ao_amd/csrc/gva_block.hip)."""
+
+    PARAMS = ("Wp1", "bp1", "gamma_p", "beta_p", "Wp2", "bp2", "Ww1", "bw1", "gamma_w", "beta_w", "Ww2", "bw2")
+
+    @staticmethod
+    def forward(ctx, q, key, v, coord, idx, mu, cov, bn_p, bn_w, training, *params):
+        q, key, v = (_f32c(t) for t in (q, key, v))
+        params = [p.contiguous() for p in params]
+        n, k = idx.shape
+        c, g = q.shape[1], params[6].shape[0]
+        dev = q.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        sv = dict(a=torch.empty((c, 3), **f32), b=torch.empty(c, **f32), rstd_p=torch.empty(c, **f32),
+                  M=torch.empty((c, g), **f32), cW=torch.empty(g, **f32), kW=torch.empty((n, g), **f32),
+                  qW=torch.empty((n, g), **f32), W1=torch.empty((n, k, g), **f32), w=torch.empty((n, k, g), **f32),
+                  A=torch.empty((n, g, c), **f32), sw=torch.empty((n, g), **f32), sc=torch.empty(g, **f32),
+                  sh=torch.empty(g, **f32), mean_w=torch.empty(g, **f64), rstd_w=torch.empty(g, **f64))
+        out = torch.empty((n, c), **f32)
+        args = _BlockArgs()
+        args.n, args.k, args.c, args.g, args.training = n, k, c, g, int(training)
+        args.eps_p, args.momentum_p = float(bn_p.eps), float(_momentum(bn_p))
+        args.eps_w, args.momentum_w = float(bn_w.eps), float(_momentum(bn_w))
+        for name, t in (("q", q), ("key", key), ("v", v), ("coord", coord), ("idx", idx), ("mu", mu), ("cov", cov),
+                        ("out", out)):
+            setattr(args, name, _lib.ptr(t))
+        for name, t in zip(_GvaBlock.PARAMS, params):
+            setattr(args, name, t.data_ptr())
+        for tag, bn in (("p", bn_p), ("w", bn_w)):
+            trk = _track(bn, training)
+            need = trk or not training
+            setattr(args, "run_mean_" + tag, bn.running_mean.data_ptr() if need else 0)
+            setattr(args, "run_var_" + tag, bn.running_var.data_ptr() if need else 0)
+            setattr(args, "batches_" + tag, bn.num_batches_tracked.data_ptr() if trk else 0)
+        for name, t in sv.items():
+            setattr(args, name, t.data_ptr())
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_block_workspace_bytes(n, k, c, g), dev)
+        rc = L.gva_block_forward_hip_launcher(ctypes.addressof(args), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "gva_block_forward_hip_launcher")
+        need_grad = any(ctx.needs_input_grad)
+        inv_ptr, inv_rows = inverse_table(idx) if need_grad else (None, None)
+        ctx.save_for_backward(q, key, v, coord, idx, mu, cov, inv_ptr, inv_rows, *params, *sv.values())
+        ctx.sv_names = list(sv.keys())
+        ctx.bns, ctx.training, ctx.dims = (bn_p, bn_w), training, (n, k, c, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved = ctx.saved_tensors
+        q, key, v, coord, idx, mu, cov, inv_ptr, inv_rows = saved[:9]
+        params = saved[9:9 + len(_GvaBlock.PARAMS)]
+        sv = dict(zip(ctx.sv_names, saved[9 + len(_GvaBlock.PARAMS):]))
+        n, k, c, g = ctx.dims
+        bn_p, bn_w = ctx.bns
+        dev = q.device
+        g_out = g_out.contiguous()
+        args = _BlockArgs()
+        args.n, args.k, args.c, args.g, args.training = n, k, c, g, int(ctx.training)
+        args.eps_p, args.momentum_p, args.eps_w, args.momentum_w = float(bn_p.eps), 0.0, float(bn_w.eps), 0.0
+        for name, t in (("q", q), ("key", key), ("v", v), ("coord", coord), ("idx", idx), ("mu", mu), ("cov", cov)):
+            setattr(args, name, _lib.ptr(t))
+        for name, t in zip(_GvaBlock.PARAMS, params):
+            setattr(args, name, t.data_ptr())
+        args.run_mean_p = bn_p.running_mean.data_ptr() if bn_p.running_mean is not None else 0
+        args.run_mean_w = bn_w.running_mean.data_ptr() if bn_w.running_mean is not None else 0
+        for name, t in sv.items():
+            setattr(args, name, t.data_ptr())
+        grads = _BlockGrads()
+        gq, gk = torch.empty_like(q), torch.empty_like(key)
+        gv = torch.empty_like(v) if inv_ptr is not None else torch.zeros_like(v)
+        gp = [torch.empty_like(p) for p in params]
+        grads.g_out, grads.inv_ptr, grads.inv_rows = g_out.data_ptr(), _lib.ptr(inv_ptr), _lib.ptr(inv_rows)
+        grads.gq, grads.gk, grads.gv = gq.data_ptr(), gk.data_ptr(), gv.data_ptr()
+        for name, t in zip(("gWp1", "gbp1", "ggamma_p", "gbeta_p", "gWp2", "gbp2", "gWw1", "gbw1", "ggamma_w", "gbeta_w",
+                            "gWw2", "gbw2"), gp):
+            setattr(grads, name, t.data_ptr())
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_block_workspace_bytes(n, k, c, g), dev)
+        rc = L.gva_block_backward_hip_launcher(ctypes.addressof(args), ctypes.addressof(grads), ws.data_ptr(), ws.numel(),
+                                               _lib.stream_ptr())
+        _lib.check(rc, "gva_block_backward_hip_launcher")
+        return (gq, gk, gv, None, None, None, None, None, None, None, *gp)
+
+
+def _block_call(mod, query, key, value, coord, idx):
+    lin_p1, bn_p, lin_p2 = mod.linear_p_bias[0], mod.linear_p_bias[1].norm, mod.linear_p_bias[3]
+    lin_w1, bn_w, lin_w2 = mod.weight_encoding[0], mod.weight_encoding[1].norm, mod.weight_encoding[3]
+    training = mod.training or not bn_p.track_running_stats or bn_p.running_mean is None
+    mu = cov = None
+    if training:
+        mu, cov = _pos_moments(_HipImpl, coord, idx)
+    return _GvaBlock.apply(query, key, value, coord, idx, mu, cov, bn_p, bn_w, training,
+                           lin_p1.weight, lin_p1.bias, bn_p.weight, bn_p.bias, lin_p2.weight, lin_p2.bias,
+                           lin_w1.weight, lin_w1.bias, bn_w.weight, bn_w.bias, lin_w2.weight, lin_w2.bias)
+
+
 # -------------------------------------------------------------------- host logic --
 def _pos_moments(impl, coord, idx):
     """(mu (3,), cov (3,3)) of the masked relative positions, float64; cached on the idx tensor because
@@ -385,6 +513,9 @@ def grouped_vector_attention(mod, query, key, value, coord, reference_index, imp
     """mod: GroupedVectorAttention (pe_bias=True, pe_multiplier=False); query/key/value (N,C) are the outputs
     of mod.linear_q / linear_k / linear_v.  Returns (N,C).  `impl` swaps the three device stages
     (tests pass a torch restatement to check this host logic on CPU)."""
+    if impl is None and os.environ.get("AO_AMD_GVA", "fused") != "staged":
+        return _block_call(mod, query.float(), key.float(), value.float(), coord.contiguous(),
+                           reference_index.contiguous())
     impl = impl or _HipImpl
     C, G = mod.embed_channels, mod.groups
     I = C // G

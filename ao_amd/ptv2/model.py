@@ -104,7 +104,7 @@ class GroupedVectorAttention(nn.Module):
         query, key, value = self.linear_q(feat), self.linear_k(feat), self.linear_v(feat)
         mode = os.environ.get("AO_AMD_GVA", "fused")
         fusable = self.pe_bias and not self.pe_multiplier and (self.attn_drop_rate == 0.0 or not self.training)
-        if mode == "fused" and fusable:
+        if mode in ("fused", "staged") and fusable:
             from . import gva
 
             if gva.supported(self.embed_channels, self.groups, reference_index.shape[1]):

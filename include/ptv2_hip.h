@@ -244,6 +244,45 @@ int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const floa
 int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g_out, const float *Wp2,
                                   const float *bp2, float *g_A, float *g_sw, void *stream);
 
+/* ------------------------------------------ whole attention block, one call --
+ * GroupedVectorAttention.forward / backward (point_transformer_v2m2_base.py:103-129) behind ONE launcher each:
+ * the stage launchers above are enqueued back to back from native code, so the host pays one call instead of
+ * ~35 python-level ops per block.  All tensors are caller-owned; the forward fills the
+ * "saved" fields, which the backward reads.  q, k are the outputs of linear_q / linear_k (after BN+ReLU), v of
+ * linear_v; mu[3], cov[9] are the float64 position moments of the neighbour table (gva_pos_stats); bn_*
+ * running statistics may be NULL (no tracking); training selects batch statistics. */
+typedef struct ptv2_gva_block {
+    int n, k, c, g, training;
+    float eps_p, momentum_p, eps_w, momentum_w;
+    /* inputs */
+    const float *q, *key, *v, *coord;
+    const int *idx;
+    const double *mu, *cov;
+    /* parameters: linear_p_bias[0], its BatchNorm, linear_p_bias[3], weight_encoding[0], its BatchNorm, [3] */
+    const float *Wp1, *bp1, *gamma_p, *beta_p, *Wp2, *bp2, *Ww1, *bw1, *gamma_w, *beta_w, *Ww2, *bw2;
+    float *run_mean_p, *run_var_p, *run_mean_w, *run_var_w;
+    long long *batches_p, *batches_w;
+    /* output */
+    float *out;                                   /* (n,c) */
+    /* saved by forward for backward */
+    float *a, *b, *rstd_p, *M, *cW;               /* (c,3) (c) (c) (c,g) (g) */
+    float *kW, *qW, *W1, *w, *A, *sw, *sc, *sh;   /* (n,g) (n,g) (n,k,g) (n,k,g) (n,g,c) (n,g) (g) (g) */
+    double *mean_w, *rstd_w;                      /* (g) (g) */
+} ptv2_gva_block;
+
+typedef struct ptv2_gva_block_grads {
+    const float *g_out;                           /* (n,c) */
+    const int *inv_ptr, *inv_rows;                /* inverse neighbour table (may be NULL) */
+    float *gq, *gk, *gv;                          /* (n,c) each; gv [zeroed] when inv_ptr == NULL */
+    float *gWp1, *gbp1, *ggamma_p, *gbeta_p, *gWp2, *gbp2, *gWw1, *gbw1, *ggamma_w, *gbeta_w, *gWw2, *gbw2;
+} ptv2_gva_block_grads;
+
+size_t gva_block_workspace_bytes(int n, int k, int c, int g);
+int gva_block_forward_hip_launcher(const ptv2_gva_block *blk, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+int gva_block_backward_hip_launcher(const ptv2_gva_block *blk, const ptv2_gva_block_grads *grads,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------- grid pooling --
  * Device pieces of GridPool.forward (point_transformer_v2m2_base.py:244-269), which the reference
  * builds from torch_scatter.segment_csr calls (third party, not vendored):

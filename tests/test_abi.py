@@ -67,6 +67,7 @@ def test_ops_fail_loudly_without_gpu(lib):
 def test_binding_arity_matches_header(lib):
     """ctypes argtypes must have exactly one entry per parameter declared in the header."""
     txt = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    txt = re.sub(r"typedef struct.*?\}\s*\w+\s*;", "", txt, flags=re.S)
     for name, params in re.findall(r"\b([a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", txt):
         if name not in lib._SIGNATURES:
             continue

@@ -24,10 +24,10 @@ def ptv2():
     return ptv2
 
 
-@pytest.fixture(params=["unfused", "fused"])
+@pytest.fixture(params=["unfused", "staged", "fused"])
 def gva_mode(request, monkeypatch):
     monkeypatch.setenv("AO_AMD_GVA", request.param)
-    if request.param == "fused":
+    if request.param != "unfused":
         pytest.importorskip("ao_amd.ptv2.gva")
     return request.param
 
