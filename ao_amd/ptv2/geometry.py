@@ -37,7 +37,13 @@ class Level:
         that works at this resolution (encoder and decoder)."""
         if k not in self.knn:
             with torch.no_grad():
-                self.knn[k] = pointops.knn_query(k, self.coord, self.offset)[0]
+                idx = pointops.knn_query(k, self.coord, self.offset)[0]
+                # table-only quantities the fused attention needs (their host syncs belong to the geometry phase)
+                from . import gva
+                if gva.supported(8 * 6, 6, k):
+                    gva.inverse_table(idx)
+                    gva._pos_moments(gva._HipImpl, self.coord, idx)
+                self.knn[k] = idx
         return self.knn[k]
 
 

@@ -233,3 +233,21 @@ def test_dropin_import_path():
     xyz = dev(synth.random_cloud(100, seed=0))
     idx, dist = pointops.knn_query(4, xyz, dev(np.array([100], np.int32)))
     assert idx.dtype == torch.int32 and idx.shape == (100, 4) and dist.dtype == torch.float32
+
+
+def test_fps_cooperative_multi_workgroup(hp):
+    """Clouds above 8 K points take the multi-workgroup path (granule hand-off per sample); bit-exact vs oracle,
+    including exact ties (lattice) and clouds of very different sizes in one call."""
+    xyz = np.concatenate([synth.random_cloud(30000, seed=11), synth.lattice_cloud(24, 24, 16, 0.05),
+                          synth.random_cloud(700, seed=12)])
+    off = np.array([30000, 30000 + 9216, 30000 + 9216 + 700], np.int32)
+    noff = np.array([400, 700, 760], np.int32)
+    idx = hp.farthest_point_sampling(dev(xyz), dev(off), dev(noff))
+    ref = P.farthest_point_sampling(cpu(xyz), cpu(off), cpu(noff))
+    assert torch.equal(idx.cpu(), ref)
+    # > 2048 samples: the granule's sample tag wraps
+    b = synth.scene_batch([2], point_max=20000)
+    n = b["coord"].shape[0]
+    idx = hp.farthest_point_sampling(dev(b["coord"]), dev(b["offset"]), dev(np.array([2300], np.int32)))
+    ref = P.farthest_point_sampling(cpu(b["coord"]), cpu(b["offset"]), torch.tensor([2300], dtype=torch.int32))
+    assert torch.equal(idx.cpu(), ref) and len(set(idx.cpu().tolist())) == 2300
