@@ -231,7 +231,9 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     float *ppart = part + (size_t)nb_rows * g;
     const int cbk = c < TPB ? c : TPB, nsl = c < TPB ? TPB / c : 1;
     const size_t comb_bytes = sizeof(float) * (size_t)nsl * cbk * (g + 4);
-    const int nb_par = stage_grid(rows, PR_TILE * 2, MAX_PARAM_BLOCKS);
+    // enough workgroups to hide the tile-load latency (8 per CU), bounded by the partial-sum budget
+    const int par_cap = (int)std::max<long long>(64, std::min<long long>(MAX_BLOCKS, ((long long)MAX_PARAM_BLOCKS * 24576) / ((long long)c * (g + 4))));
+    const int nb_par = stage_grid(rows, PR_TILE, par_cap);
 #define CALL(GG)                                                                                                   \
     if (comb_bytes > 32 * 1024)                                                                                    \
         (void)hipFuncSetAttribute((const void *)logits_bwd_params_kernel<GG>,                                      \

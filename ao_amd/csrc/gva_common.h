@@ -1,5 +1,7 @@
 // ao_amd/csrc/gva_common.h -- shared pieces of the fused grouped-vector-attention kernels.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace gva {
@@ -15,7 +17,7 @@ constexpr int MAX_PARAM_BLOCKS = 256; // grid cap of the channel-parallel parame
 // floats of per-block partial sums any stage may write (the workspace's first region)
 inline size_t part_floats(int c, int g) {
     size_t logits_fwd = (size_t)MAX_BLOCKS * 2 * g;
-    size_t logits_bwd = (size_t)MAX_BLOCKS * g + (size_t)MAX_PARAM_BLOCKS * c * (g + 4);
+    size_t logits_bwd = (size_t)MAX_BLOCKS * g + std::max((size_t)MAX_PARAM_BLOCKS * 24576, (size_t)64 * c * (g + 4));
     size_t agg_bwd = (size_t)MAX_BLOCKS * (3 * (size_t)g + (size_t)g * g + 4 * (size_t)c);
     size_t m = logits_fwd > logits_bwd ? logits_fwd : logits_bwd;
     m = m > agg_bwd ? m : agg_bwd;

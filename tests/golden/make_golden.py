@@ -349,9 +349,19 @@ def gen_model(ref):
             out["loss_" + mode] = loss
             if mode == "train":
                 params = dict(model.named_parameters())
-                grads = torch.autograd.grad(loss, [params[w] for w in watch])
+                grads = torch.autograd.grad(loss, [params[w] for w in watch], retain_graph=True)
                 for w, gr in zip(watch, grads):
                     out["grad_" + w] = gr
+                # one optimizer step with the reference recipe (configs/s3dis/semseg-pt-v2m2-0-base.py:41-42:
+                # AdamW lr 0.006, weight_decay 0.05) and the loss of the next forward: SURVEY 8f-1
+                opt = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                for w in watch:
+                    out["step1_" + w] = params[w].detach().clone()
+                logits2 = model(dict(coord=coord, feat=feat, offset=offset))
+                out["loss_step2"] = torch.nn.functional.cross_entropy(logits2, label, ignore_index=-1)
         save("ptv2_%s.npz" % tag, **out)
     with open(os.path.join(HERE, "state_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)

@@ -130,3 +130,33 @@ def test_train_step_runs_and_reduces_loss(ptv2):
         opt.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_optimizer_step_matches_reference(ptv2, golden):
+    """same init + batch + AdamW(lr 0.006, wd 0.05) -> same post-step weights and next loss as the
+    reference module with torch.optim.AdamW (captured in tests/golden/ptv2_s3dis.npz)."""
+    g = golden("ptv2_s3dis.npz")
+    if "loss_step2" not in g.files:
+        pytest.skip("fixture without optimizer step")
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    st0 = M.init_state(cfg, seed=int(g["state_seed"]))
+    seg = ptv2.DefaultSegmentor(ptv2.PointTransformerV2(**cfg)).cuda().train()
+    seg.backbone.load_state_dict(st0, strict=True)
+    data = dict(coord=dev(g["coord"]), feat=dev(g["feat"]), offset=dev(g["offset"]), segment=dev(g["label"]))
+    opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+    loss = seg(data)["loss"]
+    assert abs(float(loss.detach()) - float(g["loss_train"])) < 2e-5
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    params = dict(seg.backbone.named_parameters())
+    for k in g.files:
+        if k.startswith("step1_"):
+            w, ref = params[k[len("step1_"):]].detach().cpu().numpy(), g[k]
+            # the first Adam step moves every weight by ~lr * sign(grad): compare the update, not just the weight
+            upd, ref_upd = w - st0[k[len("step1_"):]].numpy(), ref - st0[k[len("step1_"):]].numpy()
+            agree = np.mean(np.sign(upd) == np.sign(ref_upd))
+            assert agree > 0.995, (k, agree)
+            np.testing.assert_allclose(w, ref, rtol=0, atol=2 * 0.006 + 1e-6)
+    loss2 = seg(data)["loss"]
+    assert abs(float(loss2.detach()) - float(g["loss_step2"])) < 5e-3 * max(1.0, abs(float(g["loss_step2"])))
