@@ -7,6 +7,7 @@ from .. import _lib
 
 class Aggregation(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, input, position, weight, idx):
         """
         input: input: (n, c), position: (n, nsample, c), weight : (n, nsample, c'), idx: (n, nsample)
@@ -26,6 +27,7 @@ class Aggregation(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         input, position, weight, idx = ctx.saved_tensors
         grad_output = grad_output.contiguous()

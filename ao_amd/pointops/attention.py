@@ -7,6 +7,7 @@ from .. import _lib
 
 class AttentionRelationStep(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, query, key, weight, index_target, index_refer):
         """
         input - query: (n, g, c), key: (n, g, c), weight: (c)  1_c for scatter attention,
@@ -29,6 +30,7 @@ class AttentionRelationStep(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         query, key, weight, tgt, ref = ctx.saved_tensors
         grad_output = grad_output.contiguous()
@@ -46,6 +48,7 @@ class AttentionRelationStep(Function):
 
 class AttentionFusionStep(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, weight, value, index_target, index_refer):
         """
         input - weight: (m, g), value: (n, g, c)
@@ -68,6 +71,7 @@ class AttentionFusionStep(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         weight, value, tgt, ref = ctx.saved_tensors
         grad_output = grad_output.contiguous()

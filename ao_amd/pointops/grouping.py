@@ -13,6 +13,7 @@ from ..profiling import clock
 
 class Grouping(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, input, idx):
         """
         input: input: (n, c), idx : (m, nsample)
@@ -31,6 +32,7 @@ class Grouping(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         (idx,) = ctx.saved_tensors
         grad_output = grad_output.contiguous()

@@ -21,6 +21,7 @@ class _InterpolateRows(Function):
     """output[n,:] = sum_i input[idx[n,i],:] * weight[n,i] with the scatter-add backward."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, input, idx, weight):
         _lib.require_cuda(input, idx, weight)
         input = input.contiguous()
@@ -35,6 +36,7 @@ class _InterpolateRows(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         idx, weight = ctx.saved_tensors
         grad_output = grad_output.contiguous()

@@ -7,6 +7,7 @@ from .. import _lib
 
 class Subtraction(Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, input1, input2, idx):
         """
         input: input1: (n, c), input2: (n, c), idx: (n, nsample)
@@ -25,6 +26,7 @@ class Subtraction(Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         (idx,) = ctx.saved_tensors
         grad_output = grad_output.contiguous()

@@ -123,6 +123,7 @@ class _Logits(torch.autograd.Function):
     """W1 (N,K,G) and its per-channel sums; see module docstring."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, kW, qW, a, b, M, cW, coord, idx):
         _lib.require_cuda(kW, qW, a, b, M, cW, coord, idx)
         kW, qW, a, b, M, cW = (_f32c(t) for t in (kW, qW, a, b, M, cW))
@@ -144,6 +145,7 @@ class _Logits(torch.autograd.Function):
         return W1, T1, T2
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gW1, gT1, gT2):
         a, b, M, coord, idx, W1, inv_ptr, inv_rows = ctx.saved_tensors
         n, k = idx.shape
@@ -174,6 +176,7 @@ class _Aggregate(torch.autograd.Function):
     """(out_v (N,C), A (N,G,C), sw (N,G)); see module docstring."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx):
         _lib.require_cuda(W1, sc, sh, Ww2, bw2, v, a, b, coord, idx)
         W1, sc, sh, Ww2, bw2, v, a, b = (_f32c(t) for t in (W1, sc, sh, Ww2, bw2, v, a, b))
@@ -195,6 +198,7 @@ class _Aggregate(torch.autograd.Function):
         return out_v, A, sw
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_out, g_A, g_sw):
         W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, inv_ptr, inv_rows, w = ctx.saved_tensors
         n, k = idx.shape
@@ -240,6 +244,7 @@ class _FoldP(torch.autograd.Function):
     """(a (C,3), b (C)) of P = ReLU(pos a^T + b) from linear_p_bias[0] and its BatchNorm (gva_fold.hip)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, Wp1, bp1, gamma, beta, mu, cov, bn, rows, training):
         c = Wp1.shape[0]
         dev = Wp1.device
@@ -262,6 +267,7 @@ class _FoldP(torch.autograd.Function):
         return a, b
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, ga, gb):
         Wp1, bp1, gamma, mu, cov, rstd = ctx.saved_tensors
         c = Wp1.shape[0]
@@ -281,6 +287,7 @@ class _FoldW(torch.autograd.Function):
     """(sc, sh) of the BatchNorm over the logits from their column sums (gva_fold.hip)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, T1, T2, gamma, beta, bn, rows, training):
         g = gamma.shape[0]
         dev = gamma.device
@@ -302,6 +309,7 @@ class _FoldW(torch.autograd.Function):
         return sc, sh
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gsc, gsh):
         gamma, mean, rstd = ctx.saved_tensors
         g = gamma.shape[0]
@@ -320,6 +328,7 @@ class _PebProject(torch.autograd.Function):
     """out = out_v + (A x Wp2 per group) + bp2 * sw  (gva_peb.hip); grad Wp2 / bp2 are dense rocBLAS products."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, A, Wp2, bp2, sw, out_v):
         _lib.require_cuda(A, Wp2, bp2, sw, out_v)
         A, Wp2, bp2, sw, out_v = (_f32c(t) for t in (A, Wp2, bp2, sw, out_v))
@@ -333,6 +342,7 @@ class _PebProject(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_out):
         A, Wp2, bp2, sw = ctx.saved_tensors
         n, g, c = A.shape
@@ -386,6 +396,7 @@ class _GvaBlock(torch.autograd.Function):
     PARAMS = ("Wp1", "bp1", "gamma_p", "beta_p", "Wp2", "bp2", "Ww1", "bw1", "gamma_w", "beta_w", "Ww2", "bw2")
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, q, key, v, coord, idx, mu, cov, bn_p, bn_w, training, *params):
         q, key, v = (_f32c(t) for t in (q, key, v))
         params = [p.contiguous() for p in params]
@@ -429,6 +440,7 @@ class _GvaBlock(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_out):
         saved = ctx.saved_tensors
         q, key, v, coord, idx, mu, cov, inv_ptr, inv_rows = saved[:9]

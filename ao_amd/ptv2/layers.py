@@ -24,6 +24,7 @@ def _ws(n, cout, cin, device):
 
 class _BNRows(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, gamma, beta, bn, relu):
         n, c = x.shape
         L = _lib.lib()
@@ -51,6 +52,7 @@ class _BNRows(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, mean, rstd, gamma, beta = ctx.saved_tensors
         n, c = x.shape
@@ -83,12 +85,14 @@ class RowBatchNorm1d(nn.BatchNorm1d):
 
 class _LinearRows(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return F.linear(x, weight, bias)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
@@ -119,6 +123,7 @@ class _SkinnyLinear(torch.autograd.Function):
     """y = x W^T for a narrow output (cout <= 64): HIP forward / input-gradient kernels, MFMA split-K wgrad."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, weight):
         x, weight = x.contiguous(), weight.contiguous()
         n, cin = x.shape
@@ -131,6 +136,7 @@ class _SkinnyLinear(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()

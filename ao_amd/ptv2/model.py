@@ -186,6 +186,7 @@ class _SegmentMax(torch.autograd.Function):
     reference :266) on ao_amd/csrc/pool.hip; the gradient goes to the arg-max row."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, feat, order, idx_ptr):
         _lib.require_cuda(feat, order, idx_ptr)
         feat = feat.contiguous()
@@ -200,6 +201,7 @@ class _SegmentMax(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         (arg,) = ctx.saved_tensors
         grad = grad.contiguous()
