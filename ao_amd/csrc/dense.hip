@@ -125,6 +125,102 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(long long total4, int cq,
     }
 }
 
+// Block tail fused into the last BatchNorm of a Block (point_transformer_v2m2_base.py:174-176):
+//   y = ReLU(residual + rowscale[n] * BN(x))      rowscale = per-point DropPath factor (0 or 1/keep), may be NULL
+__global__ __launch_bounds__(TPB) void bn_apply_residual_kernel(long long total4, int cq, const float *__restrict__ x,
+                                                                const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta,
+                                                                const float *__restrict__ residual,
+                                                                const float *__restrict__ rowscale,
+                                                                float *__restrict__ y) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
+        const int q = (int)(e % cq);
+        const float rsc = rowscale ? rowscale[e / cq] : 1.f;
+        const float4 v = ((const float4 *)x)[e], res = ((const float4 *)residual)[e];
+        const float4 m = ((const float4 *)mean)[q], r = ((const float4 *)rstd)[q];
+        const float4 g = ((const float4 *)gamma)[q], b = ((const float4 *)beta)[q];
+        float4 o;
+        o.x = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.x - m.x) * r.x, g.x, b.x), res.x), 0.f);
+        o.y = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.y - m.y) * r.y, g.y, b.y), res.y), 0.f);
+        o.z = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.z - m.z) * r.z, g.z, b.z), res.z), 0.f);
+        o.w = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.w - m.w) * r.w, g.w, b.w), res.w), 0.f);
+        ((float4 *)y)[e] = o;
+    }
+}
+
+// backward of the fused tail: d = gy * (y > 0) is the gradient of the residual; d * rowscale[n] enters the BN backward
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_residual_kernel(int n, int c, const float *__restrict__ x,
+                                                                     const float *__restrict__ gy,
+                                                                     const float *__restrict__ y,
+                                                                     const float *__restrict__ rowscale,
+                                                                     const float *__restrict__ mean,
+                                                                     const float *__restrict__ rstd,
+                                                                     float *__restrict__ part) {
+    extern __shared__ float4 lds4[];
+    const int cq = c >> 2;
+    const int rl = TPB / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (r < rl) {
+        const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q];
+        for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
+            const float4 v = ((const float4 *)x)[row * cq + q], o = ((const float4 *)y)[row * cq + q];
+            float4 d = ((const float4 *)gy)[row * cq + q];
+            const float rsc = rowscale ? rowscale[row] : 1.f;
+            d.x = o.x > 0.f ? d.x * rsc : 0.f; d.y = o.y > 0.f ? d.y * rsc : 0.f;
+            d.z = o.z > 0.f ? d.z * rsc : 0.f; d.w = o.w > 0.f ? d.w * rsc : 0.f;
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = __builtin_fmaf(d.x, (v.x - m.x) * rs.x, s2.x); s2.y = __builtin_fmaf(d.y, (v.y - m.y) * rs.y, s2.y);
+            s2.z = __builtin_fmaf(d.z, (v.z - m.z) * rs.z, s2.z); s2.w = __builtin_fmaf(d.w, (v.w - m.w) * rs.w, s2.w);
+        }
+    }
+    float4 *sa = lds4, *sb = lds4 + TPB;
+    sa[threadIdx.x] = s1;
+    sb[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a;
+        for (int k = 0; k < rl; ++k) {
+            const float4 u = sa[k * cq + threadIdx.x], w = sb[k * cq + threadIdx.x];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
+        }
+        float *p = part + (size_t)blockIdx.x * 2 * c;
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b2;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_residual_kernel(
+    long long total4, int cq, float inv_n, const float *__restrict__ x, const float *__restrict__ gy,
+    const float *__restrict__ y, const float *__restrict__ rowscale, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ dbeta,
+    const float *__restrict__ dgamma, int training, float *__restrict__ gx, float *__restrict__ g_residual) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
+        const int q = (int)(e % cq);
+        const float rsc = rowscale ? rowscale[e / cq] : 1.f;
+        const float4 v = ((const float4 *)x)[e], o = ((const float4 *)y)[e];
+        float4 d = ((const float4 *)gy)[e];
+        d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+        ((float4 *)g_residual)[e] = d;
+        d.x *= rsc; d.y *= rsc; d.z *= rsc; d.w *= rsc;
+        const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q], g = ((const float4 *)gamma)[q];
+        float4 out;
+        if (training) {
+            const float4 db = ((const float4 *)dbeta)[q], dg = ((const float4 *)dgamma)[q];
+            out.x = g.x * rs.x * (d.x - db.x * inv_n - (v.x - m.x) * rs.x * dg.x * inv_n);
+            out.y = g.y * rs.y * (d.y - db.y * inv_n - (v.y - m.y) * rs.y * dg.y * inv_n);
+            out.z = g.z * rs.z * (d.z - db.z * inv_n - (v.z - m.z) * rs.z * dg.z * inv_n);
+            out.w = g.w * rs.w * (d.w - db.w * inv_n - (v.w - m.w) * rs.w * dg.w * inv_n);
+        } else {
+            out.x = g.x * rs.x * d.x; out.y = g.y * rs.y * d.y; out.z = g.z * rs.z * d.z; out.w = g.w * rs.w * d.w;
+        }
+        ((float4 *)gx)[e] = out;
+    }
+}
+
 // -------------------------------------------------------- BN: backward reduce --
 // partial columns [0,c): sum gy' ; [c,2c): sum gy' * xhat, with gy' = gy masked by the fused ReLU
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const float *__restrict__ x,
@@ -395,6 +491,49 @@ extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *
         PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 8.0 * n * c);
         hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total4, c >> 2, x, mean, rstd,
                            gamma, beta, relu, y);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int bn_apply_residual_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
+                                              const float *gamma, const float *beta, const float *residual,
+                                              const float *rowscale, float *y, void *stream) {
+    if (n < 0 || c < 4 || c % 4 != 0 || !residual) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const long long total4 = (long long)n * (c >> 2);
+    const int nblk = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    {
+        PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 12.0 * n * c);
+        hipLaunchKernelGGL(bn_apply_residual_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total4, c >> 2, x, mean,
+                           rstd, gamma, beta, residual, rowscale, y);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int bn_backward_residual_hip_launcher(int n, int c, const float *x, const float *gy, const float *y,
+                                                 const float *rowscale, const float *mean, const float *rstd,
+                                                 const float *gamma, int training, float *gx, float *g_residual,
+                                                 float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                                 void *stream) {
+    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < dense_workspace_bytes(n, c, c)) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_grid(n, c);
+    float *part = (float *)workspace;
+    {
+        PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 12.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_reduce_residual_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, y,
+                           rowscale, mean, rstd, part);
+    }
+    launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
+    const long long total4 = (long long)n * (c >> 2);
+    const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 20.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_apply_residual_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, y,
+                           rowscale, mean, rstd, gamma, (const float *)dbeta, (const float *)dgamma, training, gx, g_residual);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

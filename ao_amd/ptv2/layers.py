@@ -69,6 +69,67 @@ class _BNRows(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None
 
 
+class _BNResidualRelu(torch.autograd.Function):
+    """y = ReLU(identity + rowscale * BN(x)): the tail of a Block in one apply pass (dense.hip)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, gamma, beta, identity, rowscale, bn):
+        n, c = x.shape
+        L = _lib.lib()
+        training = bn.training or bn.running_mean is None
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+            track = bn.track_running_stats and bn.training and bn.running_mean is not None
+            ws = _ws(n, c, c, x.device)
+            rc = L.bn_stats_hip_launcher(
+                n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                bn.num_batches_tracked.data_ptr() if track else 0, float(bn.eps), float(bn.momentum),
+                ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "bn_stats_hip_launcher")
+        else:
+            mean = bn.running_mean
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+        y = torch.empty_like(x)
+        rc = L.bn_apply_residual_hip_launcher(n, c, x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), identity.data_ptr(), _lib.ptr(rowscale), y.data_ptr(),
+                                              _lib.stream_ptr())
+        _lib.check(rc, "bn_apply_residual_hip_launcher")
+        ctx.save_for_backward(x, mean, rstd, gamma, y, rowscale)
+        ctx.training = bool(training)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, y, rowscale = ctx.saved_tensors
+        n, c = x.shape
+        gy = gy.contiguous()
+        gx, gres = torch.empty_like(x), torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        ws = _ws(n, c, c, x.device)
+        rc = _lib.lib().bn_backward_residual_hip_launcher(
+            n, c, x.data_ptr(), gy.data_ptr(), y.data_ptr(), _lib.ptr(rowscale), mean.data_ptr(), rstd.data_ptr(),
+            gamma.data_ptr(), int(ctx.training), gx.data_ptr(), gres.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+            ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "bn_backward_residual_hip_launcher")
+        return gx, dgamma, dbeta, gres, None, None
+
+
+def bn_residual_relu(bn, x, identity, rowscale=None):
+    """ReLU(identity + rowscale[:,None] * bn(x)) with the fused kernels when they apply."""
+    if isinstance(bn, RowBatchNorm1d) and bn._fast(x) and identity.dtype == torch.float32:
+        return _BNResidualRelu.apply(x.contiguous(), bn.weight, bn.bias, identity.contiguous(),
+                                     None if rowscale is None else rowscale.contiguous(), bn)
+    y = bn(x)
+    if rowscale is not None:
+        y = y * rowscale.unsqueeze(1)
+    return F.relu(identity + y)
+
+
 class RowBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d on (N,C) rows; `forward(x, relu=True)` fuses the activation."""
 

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import _lib, pointops
 from ..pointops.interpolation import _InterpolateRows
 from .geometry import build_geometry
-from .layers import RowBatchNorm1d, RowLinear
+from .layers import RowBatchNorm1d, RowLinear, bn_residual_relu
 
 
 class PointBatchNorm(nn.Module):
@@ -151,8 +151,11 @@ class Block(nn.Module):
         else:
             feat = self.attn(feat, coord, reference_index)
         feat = self.norm2(feat, relu=True)
-        feat = self.norm3(self.fc3(feat))
-        feat = self.act(identity + self.drop_path(feat))
+        rowscale = None
+        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.0:
+            keep = 1.0 - self.drop_path.drop_prob  # timm DropPath: per-point Bernoulli(keep) / keep
+            rowscale = torch.empty(feat.shape[0], device=feat.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        feat = bn_residual_relu(self.norm3.norm, self.fc3(feat), identity, rowscale)
         return [coord, feat, offset]
 
 

@@ -318,6 +318,17 @@ int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, cons
                              const float *rstd, const float *gamma, const float *beta, int relu,
                              int training, float *gx, float *dgamma, float *dbeta, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* Block tail fused into the Block's last BatchNorm (point_transformer_v2m2_base.py:174-176):
+ * y = ReLU(residual + rowscale[n] * BN(x)); rowscale (n) = per-point DropPath factor or NULL.  Backward returns
+ * the BN input gradient gx, the residual gradient g_residual = gy * (y > 0), dgamma, dbeta. */
+int bn_apply_residual_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
+                                   const float *gamma, const float *beta, const float *residual,
+                                   const float *rowscale, float *y, void *stream);
+int bn_backward_residual_hip_launcher(int n, int c, const float *x, const float *gy, const float *y,
+                                      const float *rowscale, const float *mean, const float *rstd,
+                                      const float *gamma, int training, float *gx, float *g_residual,
+                                      float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
                               float *db, void *workspace, size_t workspace_bytes, void *stream);
 /* skinny projection y (n,cout) = x (n,cin) W^T (cout,cin), cout <= 64, cin % 4 == 0, and its input gradient

@@ -66,7 +66,7 @@ def _worker(rank, world, port, out_dir):
 
     elapsed, pts, loss = parallel.timed_steps(step, 2, device, data["coord"].shape[0])
     torch.save(dict(seeds=seeds, grads=grads, params={k: p.detach().clone() for k, p in model.named_parameters()},
-                    elapsed=elapsed, pts=pts, n=data["coord"].shape[0], loss=float(loss)),
+                    elapsed=elapsed, pts=pts, n=data["coord"].shape[0], loss=float(loss.detach())),
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -97,4 +97,4 @@ def test_two_rank_data_parallel_step(tmp_path):
         for k, p in model.named_parameters():
             ref[k] = ref.get(k, 0) + p.grad / 2
     for k, g in ref.items():
-        np.testing.assert_allclose(r0["grads"][k].numpy(), g.numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(r0["grads"][k].numpy(), g.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)  # pre-BN biases: zero gradient + noise

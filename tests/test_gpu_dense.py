@@ -83,3 +83,32 @@ def test_skinny_linear(n, cin, cout):
     g_ref = torch.autograd.grad(y_ref, [x, w], go)
     for a, b in zip(g, g_ref):
         assert rel(a, b) < 1e-4, rel(a, b)
+
+
+@pytest.mark.parametrize("n,c", [(120000, 48), (4501, 192), (300, 384)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("drop", [False, True])
+def test_bn_residual_relu(n, c, training, drop):
+    from ao_amd.ptv2.layers import RowBatchNorm1d, bn_residual_relu
+
+    torch.manual_seed(3)
+    x = torch.randn(n, c, device="cuda", requires_grad=True)
+    ident = torch.randn(n, c, device="cuda", requires_grad=True)
+    rowscale = (torch.rand(n, device="cuda") < 0.7).float() / 0.7 if drop else None
+    ref = nn.BatchNorm1d(c).cuda()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.normal_(0, 0.3)
+    mine = RowBatchNorm1d(c).cuda()
+    mine.load_state_dict(copy.deepcopy(ref.state_dict()))
+    ref.train(training)
+    mine.train(training)
+    yr = ref(x)
+    yr = F.relu(ident + (yr * rowscale.unsqueeze(1) if drop else yr))
+    y = bn_residual_relu(mine, x, ident, rowscale)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    go = torch.randn_like(y)
+    g_ref = torch.autograd.grad(yr, [x, ident, ref.weight, ref.bias], go)
+    g = torch.autograd.grad(y, [x, ident, mine.weight, mine.bias], go)
+    for a, b, nm in zip(g, g_ref, ("gx", "gident", "dgamma", "dbeta")):
+        assert rel(a, b) < 1e-3, (nm, rel(a, b))
