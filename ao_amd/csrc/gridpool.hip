@@ -1,0 +1,183 @@
+// ao_amd/csrc/gridpool.hip -- the coordinates-only half of GridPool.forward on the device
+// (pointcept/models/point_transformer_v2/point_transformer_v2m2_base.py:246-268).
+//
+// The reference chains a python-loop offset2batch (host sync per cloud), torch_scatter.segment_csr(min),
+// torch_geometric.voxel_grid, torch.unique (sync), torch.sort and two more segment_csr calls.  Here:
+//   key[i]   = batch-major voxel id of point i      (torch_cluster.grid_cluster formula, same float ops)
+//   sort     stable LSD radix sort of (key, i) over exactly the key's significant bits (rocPRIM via hipCUB --
+//            a library sort, like the BLAS GEMMs; everything around it is hand-written)
+//   heads    key[i] != key[i-1]  -> inclusive scan -> cluster rank; N' = number of clusters
+//   outputs  cluster (N) fine->coarse map, order (N), idx_ptr (N'+1), pooled coordinates (N',3) as the mean of
+//            the members in ascending point order (bit-identical to a sequential segment mean), new_offset (B)
+// One 4-byte read-back (N') per pooling instead of ~8 host syncs.  Pooled features (segment max) are pool.hip.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct PoolDims {
+    long long nx, ny, nz;  // voxels per axis over the whole batch
+    long long total;       // nx * ny * nz * clouds: must stay below 2^KEY_BITS
+};
+constexpr int KEY_BITS = 48;  // radix-sorted key width (6 passes); 2^48 voxels = (65536 per axis)^3
+
+// per-axis max over clouds of (hi - lo), then trunc(/size) + 1   (grid_cluster: (end - start) / size + 1)
+__global__ void pool_dims_kernel(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size,
+                                 PoolDims *dims) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float e[3] = {0.f, 0.f, 0.f};
+    for (int s = 0; s < b; ++s)
+        for (int a = 0; a < 3; ++a) e[a] = fmaxf(e[a], hi[3 * s + a] - lo[3 * s + a]);
+    dims->nx = (long long)(e[0] / size) + 1;
+    dims->ny = (long long)(e[1] / size) + 1;
+    dims->nz = (long long)(e[2] / size) + 1;
+    dims->total = dims->nx * dims->ny * dims->nz * (long long)b;
+}
+
+__global__ __launch_bounds__(TPB) void pool_keys_kernel(int n, int b, const float *__restrict__ coord,
+                                                        const int *__restrict__ offset, const float *__restrict__ lo,
+                                                        float size, const PoolDims *__restrict__ dims,
+                                                        unsigned long long *__restrict__ keys, int *__restrict__ vals) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg_of(i, offset, b);
+    const long long cx = (long long)((coord[3 * (size_t)i] - lo[3 * s]) / size);
+    const long long cy = (long long)((coord[3 * (size_t)i + 1] - lo[3 * s + 1]) / size);
+    const long long cz = (long long)((coord[3 * (size_t)i + 2] - lo[3 * s + 2]) / size);
+    const long long nx = dims->nx, ny = dims->ny, nz = dims->nz;
+    keys[i] = (unsigned long long)(cx + cy * nx + cz * nx * ny + (long long)s * nx * ny * nz);
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(TPB) void pool_heads_kernel(int n, const unsigned long long *__restrict__ keys,
+                                                         int *__restrict__ flags) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// rank[i] = inclusive scan of flags (1-based cluster number of sorted position i)
+__global__ __launch_bounds__(TPB) void pool_scatter_kernel(int n, const int *__restrict__ rank,
+                                                           const int *__restrict__ flags, const int *__restrict__ order,
+                                                           long long *__restrict__ cluster, int *__restrict__ idx_ptr,
+                                                           int *__restrict__ n_out, const PoolDims *__restrict__ dims) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i] - 1;
+    cluster[order[i]] = r;
+    if (flags[i]) idx_ptr[r] = i;
+    if (i == n - 1) {
+        idx_ptr[r + 1] = n;
+        *n_out = (dims->total > 0 && dims->total < (1ll << KEY_BITS)) ? r + 1 : -1;  // -1: voxel ids exceed the sort key
+    }
+}
+
+// pooled coordinate = sequential fp32 sum over the members in sorted (= ascending point) order / count;
+// new_offset[s] = number of clusters whose cloud index is <= s
+__global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ n_out, int b,
+                                                        const float *__restrict__ coord, const int *__restrict__ offset,
+                                                        const int *__restrict__ order, const int *__restrict__ idx_ptr,
+                                                        float *__restrict__ new_coord, int *__restrict__ new_offset) {
+    const int m = *n_out;  // negative on key overflow: nothing to do
+    for (int j = blockIdx.x * TPB + threadIdx.x; j < m; j += gridDim.x * TPB) {
+        const int p0 = idx_ptr[j], p1 = idx_ptr[j + 1];
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const size_t r = (size_t)order[p];
+            sx += coord[3 * r]; sy += coord[3 * r + 1]; sz += coord[3 * r + 2];
+        }
+        const float cnt = (float)(p1 - p0);
+        new_coord[3 * (size_t)j] = sx / cnt;
+        new_coord[3 * (size_t)j + 1] = sy / cnt;
+        new_coord[3 * (size_t)j + 2] = sz / cnt;
+        const int s0 = seg_of(order[p0], offset, b);
+        const int s1 = (j + 1 < m) ? seg_of(order[idx_ptr[j + 1]], offset, b) : b;
+        for (int s = s0; s < s1; ++s) new_offset[s] = j + 1;  // clouds s0 .. s1-1 end after cluster j
+        if (j == 0)
+            for (int s = 0; s < s0; ++s) new_offset[s] = 0;    // empty leading clouds
+    }
+}
+
+struct Ws {
+    float *lo, *hi;
+    PoolDims *dims;
+    unsigned long long *keys_in, *keys_out;
+    int *vals_in, *flags, *rank;
+    void *mm, *cub;
+    size_t mm_bytes, cub_bytes, bytes;
+};
+
+}  // namespace
+
+extern "C" size_t segment_minmax_hip_workspace_bytes(int b);
+extern "C" int segment_minmax_hip_launcher(int b, const float *xyz, const int *offset, float *lo, float *hi,
+                                           void *workspace, size_t workspace_bytes, void *stream);
+
+static Ws carve(void *base, int n, int b) {
+    Ws w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    w.lo = (float *)take(sizeof(float) * 3 * b);
+    w.hi = (float *)take(sizeof(float) * 3 * b);
+    w.dims = (PoolDims *)take(sizeof(PoolDims));
+    w.keys_in = (unsigned long long *)take(sizeof(unsigned long long) * n);
+    w.keys_out = (unsigned long long *)take(sizeof(unsigned long long) * n);
+    w.vals_in = (int *)take(sizeof(int) * n);
+    w.flags = (int *)take(sizeof(int) * n);
+    w.rank = (int *)take(sizeof(int) * n);
+    w.mm_bytes = segment_minmax_hip_workspace_bytes(b);
+    w.mm = take(w.mm_bytes);
+    size_t s1 = 0, s2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s1, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const int *)nullptr, (int *)nullptr, n, 0, 64, (hipStream_t)0);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, s2, (const int *)nullptr, (int *)nullptr, n, (hipStream_t)0);
+    w.cub_bytes = std::max(s1, s2) + 256;
+    w.cub = take(w.cub_bytes);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t grid_pool_hip_workspace_bytes(int n, int b) {
+    if (n < 1 || b < 1) return 0;
+    return carve(nullptr, n, b).bytes + 1024;
+}
+
+// cluster (n) int64, order (n) int32, idx_ptr (n+1) int32 [first n_out+1 entries valid], new_coord (n,3) and
+// new_offset (b) [first n_out rows valid], n_out (1) int32 -- all device pointers; the caller reads n_out back.
+extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const int *offset, float grid_size,
+                                      long long *cluster, int *order, int *idx_ptr, float *new_coord,
+                                      int *new_offset, int *n_out, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    if (n < 1 || b < 1 || !(grid_size > 0.f)) return PTV2_ERR_ARG;
+    Ws w = carve(workspace, n, b);
+    if (!workspace || workspace_bytes < w.bytes) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = segment_minmax_hip_launcher(b, coord, offset, w.lo, w.hi, w.mm, w.mm_bytes, stream);
+    if (rc != PTV2_OK) return rc;
+    hipLaunchKernelGGL(pool_dims_kernel, dim3(1), dim3(64), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
+                       w.dims);
+    const int nb = divup(n, TPB);
+    hipLaunchKernelGGL(pool_keys_kernel, dim3(nb), dim3(TPB), 0, st, n, b, coord, offset, (const float *)w.lo, grid_size,
+                       (const PoolDims *)w.dims, w.keys_in, w.vals_in);
+    size_t cb = w.cub_bytes;
+    // KEY_BITS key bits: the voxel counts live on the device, so the range is fixed (and checked) instead of trimmed
+    if (hipcub::DeviceRadixSort::SortPairs(w.cub, cb, (const unsigned long long *)w.keys_in, w.keys_out,
+                                           (const int *)w.vals_in, order, n, 0, KEY_BITS, st) != hipSuccess)
+        return PTV2_ERR_LAUNCH;
+    hipLaunchKernelGGL(pool_heads_kernel, dim3(nb), dim3(TPB), 0, st, n, (const unsigned long long *)w.keys_out, w.flags);
+    cb = w.cub_bytes;
+    if (hipcub::DeviceScan::InclusiveSum(w.cub, cb, (const int *)w.flags, w.rank, n, st) != hipSuccess) return PTV2_ERR_LAUNCH;
+    hipLaunchKernelGGL(pool_scatter_kernel, dim3(nb), dim3(TPB), 0, st, n, (const int *)w.rank, (const int *)w.flags,
+                       (const int *)order, cluster, idx_ptr, n_out, (const PoolDims *)w.dims);
+    hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out, b, coord, offset,
+                       (const int *)order, (const int *)idx_ptr, new_coord, new_offset);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

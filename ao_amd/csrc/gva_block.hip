@@ -12,21 +12,25 @@
 namespace gva {
 
 // M[c',g] = sum_c Wp2[c,c'] Ww1[g,c];  cW[g] = sum_c Ww1[g,c] bp2[c] + bw1[g]
+// one wavefront per output, lanes over the reduction index (the outputs are few, the reduction is long)
 __global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
                                                          const float *__restrict__ bp2, const float *__restrict__ Ww1,
                                                          const float *__restrict__ bw1, float *__restrict__ M,
                                                          float *__restrict__ cW) {
-    const int e = blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int e = (blockIdx.x * TPB + threadIdx.x) >> 6;  // wave index = output index
     if (e < c * g) {
         const int cp = e / g, gi = e - cp * g;
         float acc = 0.f;
-        for (int ci = 0; ci < c; ++ci) acc = __builtin_fmaf(Wp2[(size_t)ci * c + cp], Ww1[(size_t)gi * c + ci], acc);
-        M[e] = acc;
+        for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Wp2[(size_t)ci * c + cp], Ww1[(size_t)gi * c + ci], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) M[e] = acc;
     } else if (e < c * g + g) {
         const int gi = e - c * g;
-        float acc = bw1[gi];
-        for (int ci = 0; ci < c; ++ci) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
-        cW[gi] = acc;
+        float acc = 0.f;
+        for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) cW[gi] = acc + bw1[gi];
     }
 }
 
@@ -206,7 +210,7 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
     RUN(gva_fold_p_forward_hip_launcher(c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p,
                                         B->run_var_p, B->batches_p, B->training, rows, B->eps_p, B->momentum_p, B->a, B->b,
                                         B->rstd_p, stream));
-    hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup((long long)c * g + g, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
+    hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup(((long long)c * g + g) * WAVE, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
                        B->Ww1, B->bw1, B->M, B->cW);
     RUN(skinny_linear_forward_hip_launcher(n, c, g, B->key, B->Ww1, B->kW, stream));
     RUN(skinny_linear_forward_hip_launcher(n, c, g, B->q, B->Ww1, B->qW, stream));

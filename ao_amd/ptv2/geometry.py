@@ -7,6 +7,7 @@ every GridPool voxelises + sorts (:244-269, with a host-sync python loop in offs
 computed ONCE per batch, up front, under no_grad: 1 + S self-kNNs, S grid poolings, S cross-kNNs
 for an S-stage model -- and handed to the layers as a `SceneGeometry`.
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -23,10 +24,8 @@ class Level:
     knn: dict = field(default_factory=dict)  # K -> (N,K) int32 neighbour table of this level
     # link to the next coarser level (filled for all but the last level)
     cluster: Optional[torch.Tensor] = None   # (N,) int64: fine point -> coarse point
-    order: Optional[torch.Tensor] = None     # (N,) int64: fine points sorted by cluster (stable)
-    idx_ptr: Optional[torch.Tensor] = None   # (N'+1,) int64 CSR over `order`
-    order32: Optional[torch.Tensor] = None   # int32 copies for the HIP pooling kernels
-    idx_ptr32: Optional[torch.Tensor] = None
+    order32: Optional[torch.Tensor] = None   # (N,) int32: fine points sorted by cluster (stable)
+    idx_ptr32: Optional[torch.Tensor] = None  # (N'+1,) int32 CSR over `order32`
     # link from the next coarser level back to this one ("interp" unpooling)
     up_idx: Optional[torch.Tensor] = None    # (N,3) int32 into the coarser level
     up_weight: Optional[torch.Tensor] = None  # (N,3) fp32
@@ -85,9 +84,9 @@ def voxel_cluster_ids(coord, offset, grid_size):
     return cell[:, 0] + cell[:, 1] * stride_y + cell[:, 2] * stride_z + batch * stride_b, batch
 
 
-def grid_pool_geometry(coord, offset, grid_size):
-    """Coordinates-only half of GridPool.forward (:257-268).  Cluster means are accumulated in
-    ascending point order (as a stable sort + sequential segment sum does in the oracle)."""
+def grid_pool_geometry_torch(coord, offset, grid_size):
+    """Coordinates-only half of GridPool.forward (:257-268) as torch ops (kept as the in-framework statement
+    of what the device kernel computes; AO_AMD_GRIDPOOL=torch selects it)."""
     key, batch = voxel_cluster_ids(coord, offset, grid_size)
     _, cluster, counts = torch.unique(key, sorted=True, return_inverse=True, return_counts=True)
     order = torch.sort(cluster, stable=True)[1]
@@ -95,7 +94,34 @@ def grid_pool_geometry(coord, offset, grid_size):
     new_coord = torch.segment_reduce(coord[order], "mean", offsets=idx_ptr, axis=0)
     new_batch = batch[order[idx_ptr[:-1]]]
     new_offset = torch.cumsum(new_batch.bincount(minlength=offset.numel()), dim=0).int()
-    return new_coord.contiguous(), new_offset, cluster, order, idx_ptr
+    return new_coord.contiguous(), new_offset, cluster, order.int().contiguous(), idx_ptr.int().contiguous()
+
+
+def grid_pool_geometry(coord, offset, grid_size):
+    """(new_coord (N',3), new_offset (B) int32, cluster (N) int64, order (N) int32, idx_ptr (N'+1) int32) on
+    ao_amd/csrc/gridpool.hip: one launcher call and ONE 4-byte read-back (the number of clusters)."""
+    if os.environ.get("AO_AMD_GRIDPOOL", "hip") == "torch":
+        return grid_pool_geometry_torch(coord, offset, grid_size)
+    _lib.require_cuda(coord, offset)
+    n, b = coord.shape[0], offset.numel()
+    dev = coord.device
+    off = offset.int().contiguous()
+    cluster = torch.empty(n, dtype=torch.int64, device=dev)
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    idx_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    new_coord = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    new_offset = torch.empty(b, dtype=torch.int32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = _lib.workspace(L.grid_pool_hip_workspace_bytes(n, b), dev)
+    rc = L.grid_pool_hip_launcher(n, b, coord.data_ptr(), off.data_ptr(), float(grid_size), cluster.data_ptr(),
+                                  order.data_ptr(), idx_ptr.data_ptr(), new_coord.data_ptr(), new_offset.data_ptr(),
+                                  n_out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "grid_pool_hip_launcher")
+    m = int(n_out.item())  # the one host sync of the pooling: the output size is data dependent
+    if m < 0:
+        raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
+    return new_coord[:m], new_offset, cluster, order, idx_ptr[: m + 1]
 
 
 @torch.no_grad()
@@ -113,8 +139,7 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
         if i == len(grid_sizes):
             break
         nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, grid_sizes[i])
-        cur.cluster, cur.order, cur.idx_ptr = cluster, order, idx_ptr
-        cur.order32, cur.idx_ptr32 = order.int().contiguous(), idx_ptr.int().contiguous()
+        cur.cluster, cur.order32, cur.idx_ptr32 = cluster, order, idx_ptr
         if interp:
             cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
         cur = Level(coord=nc, offset=noff)

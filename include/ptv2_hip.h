@@ -290,6 +290,14 @@ int gva_block_backward_hip_launcher(const ptv2_gva_block *blk, const ptv2_gva_bl
  *   pool_max:       out[j,:] = max over rows order[idx_ptr[j]..idx_ptr[j+1]) of feat; arg = winning row
  *                   (first wins ties); backward scatters grad_out to grad_feat[arg] [zeroed]   (:266)
  */
+/*   grid_pool:     the whole coordinate half of GridPool.forward (:246-268): voxel ids (grid_cluster formula,
+ *                  batch-major), stable sort, cluster ranks, pooled coordinates (mean in ascending point order),
+ *                  new offsets.  cluster (n) int64, order (n), idx_ptr (n+1), new_coord (n,3), new_offset (b) are
+ *                  sized for the worst case; *n_out (device int) = number of clusters (-1: voxel id overflow). */
+size_t grid_pool_hip_workspace_bytes(int n, int b);
+int grid_pool_hip_launcher(int n, int b, const float *coord, const int *offset, float grid_size,
+                           long long *cluster, int *order, int *idx_ptr, float *new_coord, int *new_offset,
+                           int *n_out, void *workspace, size_t workspace_bytes, void *stream);
 size_t segment_minmax_hip_workspace_bytes(int b);
 int segment_minmax_hip_launcher(int b, const float *xyz, const int *offset, float *lo, float *hi,
                                 void *workspace, size_t workspace_bytes, void *stream);
