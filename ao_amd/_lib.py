@@ -43,6 +43,8 @@ _SIGNATURES = {
     "attention_fusion_step_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 8),
     "grid_pool_hip_workspace_bytes": (_c_size, [_c_int] * 2),
     "grid_pool_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [ctypes.c_float] + [_vp] * 7 + [_c_size, _vp]),
+    "inverse_table_hip_workspace_bytes": (_c_size, [_c_int] * 2),
+    "inverse_table_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
     "segment_minmax_hip_workspace_bytes": (_c_size, [_c_int]),
     "segment_minmax_hip_launcher": (_c_int, [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "pool_max_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6),

@@ -107,11 +107,20 @@ def inverse_table(idx):
     cached = getattr(idx, "_ao_inverse", None)
     if cached is not None and cached[0] == idx._version:
         return cached[1], cached[2]
-    with torch.no_grad():
+    n, k = idx.shape
+    if idx.is_cuda:
+        inv_ptr = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
+        inv_rows = torch.empty(n * k, dtype=torch.int32, device=idx.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.inverse_table_hip_workspace_bytes(n, k), idx.device)
+        rc = L.inverse_table_hip_launcher(n, k, idx.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "inverse_table_hip_launcher")
+    else:  # host statement of the same table (CPU tests of the host logic)
         flat = idx.reshape(-1)
         inv_rows = torch.sort(flat, stable=True)[1].int().contiguous()  # slots ordered by target, -1 first
-        counts = torch.bincount((flat + 1).long(), minlength=idx.shape[0] + 1)  # bin 0 = the -1 placeholders
-        inv_ptr = torch.cumsum(counts, 0).int().contiguous()  # (N+1,): list of j is [inv_ptr[j], inv_ptr[j+1])
+        counts = torch.bincount((flat + 1).long(), minlength=n + 1)     # bin 0 = the -1 placeholders
+        inv_ptr = torch.cumsum(counts, 0).int().contiguous()            # list of j is [inv_ptr[j], inv_ptr[j+1])
     try:
         idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
     except AttributeError:

@@ -298,6 +298,11 @@ size_t grid_pool_hip_workspace_bytes(int n, int b);
 int grid_pool_hip_launcher(int n, int b, const float *coord, const int *offset, float grid_size,
                            long long *cluster, int *order, int *idx_ptr, float *new_coord, int *new_offset,
                            int *n_out, void *workspace, size_t workspace_bytes, void *stream);
+/*   inverse_table: CSR inverse of a neighbour table idx (n,k): for point j the slots r with idx[r] == j are
+ *                  inv_rows[inv_ptr[j] .. inv_ptr[j+1]) in ascending r; inv_ptr (n+1), inv_rows (n*k). */
+size_t inverse_table_hip_workspace_bytes(int n, int k);
+int inverse_table_hip_launcher(int n, int k, const int *idx, int *inv_ptr, int *inv_rows, void *workspace,
+                               size_t workspace_bytes, void *stream);
 size_t segment_minmax_hip_workspace_bytes(int b);
 int segment_minmax_hip_launcher(int b, const float *xyz, const int *offset, float *lo, float *hi,
                                 void *workspace, size_t workspace_bytes, void *stream);

@@ -107,3 +107,12 @@ def test_aggregate_backward(c, g, k, n):
     ref = TorchImpl.aggregate(*ins, xyz, idx)
     gouts = [torch.randn(n, c).cuda(), torch.randn(n, g, c).cuda(), torch.randn(n, g).cuda()]
     grads_close(out, ref, ins, gouts, names)
+
+
+def test_inverse_table_matches_host_statement():
+    from ao_amd.ptv2.gva import inverse_table
+
+    xyz, idx = make(48, 6, 16, 5000, seed=4)
+    ptr, rows = inverse_table(idx)
+    hptr, hrows = inverse_table(idx.cpu())
+    assert torch.equal(ptr.cpu(), hptr) and torch.equal(rows.cpu(), hrows)
