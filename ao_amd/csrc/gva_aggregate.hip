@@ -64,8 +64,8 @@ __device__ __forceinline__ void store_row(float *__restrict__ p, const float (&v
 
 // z[g] = bw2[g] + sum_j y[j] Ww2[g][j]  (Ww2, bw2 wave-uniform), then softmax over the k lanes of a point
 template <int G>
-__device__ __forceinline__ void logits_softmax(const float (&y)[G], const float *__restrict__ Ww2,
-                                               const float *__restrict__ bw2, int k, float (&wt)[G]) {
+__device__ __forceinline__ void logits_softmax(const float (&y)[G], const float *Ww2, const float *bw2, int k,
+                                               float (&wt)[G]) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float z = bw2[g];
@@ -91,6 +91,12 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k
                                                            const float *__restrict__ Ww2,
                                                            const float *__restrict__ bw2, const int *__restrict__ idx,
                                                            float *__restrict__ w, float *__restrict__ sw) {
+    // wave-uniform operands from LDS (broadcast reads) instead of scalar loads: the G x G matrix does not fit the
+    // scalar cache for G >= 24 and its miss latency dominated the deep-stage launches
+    __shared__ float sWw2[G * G], sBw2[G], sSc[G], sSh[G];
+    for (int i = threadIdx.x; i < G * G; i += TPB) sWw2[i] = Ww2[i];
+    for (int i = threadIdx.x; i < G; i += TPB) { sBw2[i] = bw2[i]; sSc[i] = sc[i]; sSh[i] = sh[i]; }
+    __syncthreads();
     const long long rows_pad = (rows + WAVE - 1) / WAVE * WAVE;  // whole waves: shuffles need every lane
     for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows_pad; row += (long long)gridDim.x * TPB) {
         const bool act = row < rows;
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k
         float y[G], wt[G];
         load_row<G>(W1 + r * G, y);
 #pragma unroll
-        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sc[g], y[g], sh[g]), 0.f);
-        logits_softmax<G>(y, Ww2, bw2, k, wt);
+        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sSc[g], y[g], sSh[g]), 0.f);
+        logits_softmax<G>(y, sWw2, sBw2, k, wt);
         const float valid = (act && idx[r] >= 0) ? 1.f : 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) wt[g] *= valid;
@@ -308,6 +314,10 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
                                                                  float *__restrict__ gz_out, float *__restrict__ y_out,
                                                                  float *__restrict__ part) {
     __shared__ float s_w[WPB][2 * G];
+    __shared__ float sWw2[G * G], sBw2[G], sSc[G], sSh[G];
+    for (int i = threadIdx.x; i < G * G; i += TPB) sWw2[i] = Ww2[i];
+    for (int i = threadIdx.x; i < G; i += TPB) { sBw2[i] = bw2[i]; sSc[i] = sc[i]; sSh[i] = sh[i]; }
+    __syncthreads();
     float t_sc[G], t_sh[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) t_sc[g] = t_sh[g] = 0.f;
@@ -318,8 +328,8 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
         float y[G], gz[G];
         load_row<G>(W1 + r * G, y);
 #pragma unroll
-        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sc[g], y[g], sh[g]), 0.f);
-        logits_softmax<G>(y, Ww2, bw2, k, gz);  // gz holds the unmasked softmax for now
+        for (int g = 0; g < G; ++g) y[g] = fmaxf(__builtin_fmaf(sSc[g], y[g], sSh[g]), 0.f);
+        logits_softmax<G>(y, sWw2, sBw2, k, gz);  // gz holds the unmasked softmax for now
         if (act) store_row<G>(y_out + r * G, y);
         const float valid = (act && idx[r] >= 0) ? 1.f : 0.f;
         {
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
             for (int t = 0; t < STEP; ++t) {
                 float gy = 0.f;
 #pragma unroll
-                for (int g = 0; g < G; ++g) gy = __builtin_fmaf(gz[g], Ww2[g * G + j0 + t], gy);
+                for (int g = 0; g < G; ++g) gy = __builtin_fmaf(gz[g], sWw2[g * G + j0 + t], gy);
                 gu[t] = y[j0 + t] > 0.f ? gy : 0.f;
             }
             load_row<STEP>(W1 + r * G + j0, u);
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
             for (int t = 0; t < STEP; ++t) {
                 t_sc[j0 + t] = __builtin_fmaf(gu[t], u[t], t_sc[j0 + t]);
                 t_sh[j0 + t] += gu[t];
-                gu[t] *= sc[j0 + t];
+                gu[t] *= sSc[j0 + t];
             }
             if (act) store_row<STEP>(gW1 + r * G + j0, gu);
         }

@@ -50,56 +50,104 @@ struct MapPosStats {  // columns: x y z xx xy xz yy yz zz -> s1[3], symmetric s2
 };
 
 // ------------------------------------------------------------- logits forward --
-template <int G>
+// a, b, M are staged in LDS once per workgroup and read back as wave-wide broadcasts (b128): with scalar loads
+// straight from memory the deep stages (C = 192 / 384: 18 - 73 KB of M per row) were bound by scalar-cache miss
+// latency (104 / 244 us at 72 k / 17 k rows, profiles/r01_*_v8).  SPLIT > 1 spreads the channel loop of one
+// 64-row group over the SPLIT waves of the workgroup (partial logits summed through LDS), which gives the small
+// deep-stage launches SPLIT x more waves to hide latency with.
+template <int G, int SPLIT>
 __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, const float *__restrict__ kW,
                                                          const float *__restrict__ qW, const float *__restrict__ a,
                                                          const float *__restrict__ b, const float *__restrict__ M,
                                                          const float *__restrict__ cW, const float *__restrict__ coord,
                                                          const int *__restrict__ idx, float *__restrict__ W1,
                                                          float *__restrict__ part) {
+    extern __shared__ float4 lds4[];
+    constexpr int G4 = (G + 3) & ~3;
+    constexpr int RPB = TPB / SPLIT;  // rows per workgroup iteration
+    float4 *sAB = lds4;                        // [c]  (a.x, a.y, a.z, b)
+    float *sM = (float *)(sAB + c);            // [c][G4]
+    float *sRed = sM + (size_t)c * G4;         // [SPLIT][64][G + 1]   (SPLIT > 1 only)
     __shared__ float s_w[WPB][2 * G];
+    for (int i = threadIdx.x; i < c; i += TPB) sAB[i] = make_float4(a[3 * i], a[3 * i + 1], a[3 * i + 2], b[i]);
+    for (int e = threadIdx.x; e < c * G; e += TPB) sM[(e / G) * G4 + (e % G)] = M[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const long long rows = (long long)n * k;
+    const long long iters = (rows + RPB - 1) / RPB;
+    const int cs = (c + SPLIT - 1) / SPLIT;
+    const int c0 = SPLIT == 1 ? 0 : wid * cs, c1 = SPLIT == 1 ? c : (c0 + cs < c ? c0 + cs : c);
+    const bool finisher = SPLIT == 1 || wid == 0;
     float t1[G], t2[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) t1[g] = t2[g] = 0.f;
-    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows; row += (long long)gridDim.x * TPB) {
-        const int nn = (int)(row / k);
-        const Rel r = rel_pos(coord, idx, row, nn);
+    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long long row = it * RPB + (SPLIT == 1 ? threadIdx.x : lane);
+        const bool act = row < rows;
+        const int nn = act ? (int)(row / k) : 0;
+        Rel r;
+        r.x = r.y = r.z = 0.f; r.src = -1;
+        if (act) r = rel_pos(coord, idx, row, nn);
         float acc[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float kv = r.src >= 0 ? kW[(long long)r.src * G + g] : 0.f;
-            acc[g] = (kv - qW[(long long)nn * G + g]) + cW[g];
+        for (int g = 0; g < G; ++g) acc[g] = 0.f;
+        for (int ci = c0; ci < c1; ++ci) {
+            const float4 ab = sAB[ci];
+            const float p = pe_act(ab.x, ab.y, ab.z, ab.w, r.x, r.y, r.z);
+            const float *mr = sM + (size_t)ci * G4;
+            if (G % 4 == 0) {
+#pragma unroll
+                for (int g = 0; g < G; g += 4) {
+                    const float4 m4 = *(const float4 *)(mr + g);
+                    acc[g] = __builtin_fmaf(p, m4.x, acc[g]); acc[g + 1] = __builtin_fmaf(p, m4.y, acc[g + 1]);
+                    acc[g + 2] = __builtin_fmaf(p, m4.z, acc[g + 2]); acc[g + 3] = __builtin_fmaf(p, m4.w, acc[g + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; g += 2) {
+                    const float2 m2 = *(const float2 *)(mr + g);
+                    acc[g] = __builtin_fmaf(p, m2.x, acc[g]); acc[g + 1] = __builtin_fmaf(p, m2.y, acc[g + 1]);
+                }
+            }
         }
-        for (int ci = 0; ci < c; ++ci) {  // wave-uniform operands: a, b, M
-            const float p = pe_act(a[3 * ci], a[3 * ci + 1], a[3 * ci + 2], b[ci], r.x, r.y, r.z);
+        if (SPLIT > 1) {
+            float *mine = sRed + ((size_t)wid * WAVE + lane) * (G + 1);
 #pragma unroll
-            for (int g = 0; g < G; ++g) acc[g] = __builtin_fmaf(p, M[ci * G + g], acc[g]);
+            for (int g = 0; g < G; ++g) mine[g] = acc[g];
+            __syncthreads();
+            if (wid == 0) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < SPLIT; ++w) t += sRed[((size_t)w * WAVE + lane) * (G + 1) + g];
+                    acc[g] = t;
+                }
+            }
         }
-        float *o = W1 + row * G;
-        if (G % 4 == 0) {
+        if (finisher && act) {
 #pragma unroll
-            for (int g = 0; g < G; g += 4) *(float4 *)(o + g) = make_float4(acc[g], acc[g + 1], acc[g + 2], acc[g + 3]);
-        } else if (G % 2 == 0) {
+            for (int g = 0; g < G; ++g) {
+                const float kv = r.src >= 0 ? kW[(long long)r.src * G + g] : 0.f;
+                acc[g] += (kv - qW[(long long)nn * G + g]) + cW[g];
+                t1[g] += acc[g];
+                t2[g] = __builtin_fmaf(acc[g], acc[g], t2[g]);
+            }
+            float *o = W1 + row * G;
+            if (G % 4 == 0) {
 #pragma unroll
-            for (int g = 0; g < G; g += 2) *(float2 *)(o + g) = make_float2(acc[g], acc[g + 1]);
-        } else {
+                for (int g = 0; g < G; g += 4) *(float4 *)(o + g) = make_float4(acc[g], acc[g + 1], acc[g + 2], acc[g + 3]);
+            } else {
 #pragma unroll
-            for (int g = 0; g < G; ++g) o[g] = acc[g];
+                for (int g = 0; g < G; g += 2) *(float2 *)(o + g) = make_float2(acc[g], acc[g + 1]);
+            }
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            t1[g] += acc[g];
-            t2[g] = __builtin_fmaf(acc[g], acc[g], t2[g]);
-        }
+        if (SPLIT > 1) __syncthreads();  // sRed is rewritten by the next iteration
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float v1 = wave_sum(t1[g]), v2 = wave_sum(t2[g]);
-        if ((threadIdx.x & 63) == 0) {
-            s_w[threadIdx.x >> 6][g] = v1;
-            s_w[threadIdx.x >> 6][G + g] = v2;
-        }
+        const float v1 = wave_sum(t1[g]), v2 = wave_sum(t2[g]);
+        if (lane == 0) { s_w[wid][g] = v1; s_w[wid][G + g] = v2; }
     }
     __syncthreads();
     if (threadIdx.x < 2 * G) {
@@ -157,17 +205,32 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     if (!workspace || workspace_bytes < gva_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
-    const int nblk = stage_grid((long long)n * k, TPB * 2);
-#define CALL(GG)                                                                                                  \
-    hipLaunchKernelGGL(logits_fwd_kernel<GG>, dim3(nblk), dim3(TPB), 0, st, n, k, c, kW, qW, a, b, M, cW, coord, idx, \
-                       W1, part)
+    const long long rows = (long long)n * k;
+    const bool split = rows < 400000;  // small launches: 4 waves per 64 rows instead of 1
+    const int g4 = (g + 3) & ~3;
+    const size_t lds = sizeof(float4) * (size_t)c + sizeof(float) * ((size_t)c * g4 + (split ? (size_t)4 * WAVE * (g + 1) : 0));
+    if (lds > 150 * 1024 || g % 2 != 0) return PTV2_ERR_ARG;
+    const int nblk = stage_grid(rows, split ? WAVE : TPB);
+#define CALL(GG)                                                                                                   \
+    if (split) {                                                                                                   \
+        if (lds > 32 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                   \
+        hipLaunchKernelGGL((logits_fwd_kernel<GG, 4>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
+                           idx, W1, part);                                                                         \
+    } else {                                                                                                       \
+        if (lds > 32 * 1024)                                                                                       \
+            (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                   \
+        hipLaunchKernelGGL((logits_fwd_kernel<GG, 1>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
+                           idx, W1, part);                                                                         \
+    }
     {
         // idx, coord, kW (unique rows once), qW in; W1 out
         PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
         GVA_DISPATCH_G(g, CALL)
     }
 #undef CALL
-    // part is [nblk][2g]: columns 0..g-1 -> T1, g..2g-1 -> T2 (contiguous in the reduced vector)
     launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
