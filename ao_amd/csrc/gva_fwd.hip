@@ -206,9 +206,12 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     const long long rows = (long long)n * k;
-    const bool split = rows < 400000;  // small launches: 4 waves per 64 rows instead of 1
     const int g4 = (g + 3) & ~3;
-    const size_t lds = sizeof(float4) * (size_t)c + sizeof(float) * ((size_t)c * g4 + (split ? (size_t)4 * WAVE * (g + 1) : 0));
+    const size_t lds_base = sizeof(float4) * (size_t)c + sizeof(float) * (size_t)c * g4;
+    const size_t lds_red = sizeof(float) * 4 * WAVE * (g + 1);
+    // small launches: 4 waves per 64 rows instead of 1 (when the cross-wave reduction buffer still fits in LDS)
+    const bool split = rows < 400000 && lds_base + lds_red <= 96 * 1024;
+    const size_t lds = lds_base + (split ? lds_red : 0);
     if (lds > 150 * 1024 || g % 2 != 0) return PTV2_ERR_ARG;
     const int nblk = stage_grid(rows, split ? WAVE : TPB);
 #define CALL(GG)                                                                                                   \
