@@ -1,0 +1,265 @@
+// ao_amd/csrc/block.hip -- a whole PT-v2m2 Block (point_transformer_v2m2_base.py:131-177) per native call.
+//
+//   forward:   h1 = x fc1^T            f1 = ReLU(BN1(h1))
+//              q = ReLU(BNq(f1 Wq^T+bq))  k = ReLU(BNk(f1 Wk^T+bk))  v = f1 Wv^T+bv
+//              attn = GVA(q,k,v,coord,idx)                       (gva_block.hip)
+//              f2 = ReLU(BN2(attn))    h3 = f2 fc3^T
+//              y  = ReLU(x + rowscale * BN3(h3))
+//   backward:  the same chain reversed; sums of several products (g_f1 from q/k/v, g_x from fc1 and the
+//              residual) use the GEMM's accumulate epilogue instead of separate adds.
+// Everything is enqueued on the caller's stream; the host never synchronises.  The activations the backward
+// needs live in one caller-owned `saved` buffer (288 GB of HBM: nothing is recomputed), temporaries in the
+// caller's grow-only workspace.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Saved {
+    float *h1, *f1, *hq, *q, *hk, *key, *v, *attn, *f2, *h3;      // (n,c) each
+    float *mean[PTV2_BLK_NBN], *rstd[PTV2_BLK_NBN];                // (c): 0,1,2,5,6 used here
+    // GroupedVectorAttention (ptv2_gva_block "saved" fields)
+    float *a, *b, *rstd_p, *M, *cW, *kW, *qW, *W1, *w, *A, *sw, *sc, *sh;
+    double *mean_w, *rstd_w;
+    size_t bytes;
+};
+
+Saved carve_saved(void *base, int n, int k, int c, int g) {
+    Saved s;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    const size_t nc = sizeof(float) * (size_t)n * c, ng = sizeof(float) * (size_t)n * g;
+    const size_t rows = sizeof(float) * (size_t)n * k * g;
+    s.h1 = (float *)take(nc); s.f1 = (float *)take(nc); s.hq = (float *)take(nc); s.q = (float *)take(nc);
+    s.hk = (float *)take(nc); s.key = (float *)take(nc); s.v = (float *)take(nc); s.attn = (float *)take(nc);
+    s.f2 = (float *)take(nc); s.h3 = (float *)take(nc);
+    for (int i = 0; i < PTV2_BLK_NBN; ++i) {
+        s.mean[i] = (float *)take(sizeof(float) * c);
+        s.rstd[i] = (float *)take(sizeof(float) * c);
+    }
+    s.a = (float *)take(sizeof(float) * 3 * c); s.b = (float *)take(sizeof(float) * c);
+    s.rstd_p = (float *)take(sizeof(float) * c); s.M = (float *)take(sizeof(float) * (size_t)c * g);
+    s.cW = (float *)take(sizeof(float) * g); s.kW = (float *)take(ng); s.qW = (float *)take(ng);
+    s.W1 = (float *)take(rows); s.w = (float *)take(rows); s.A = (float *)take(sizeof(float) * (size_t)n * g * c);
+    s.sw = (float *)take(ng); s.sc = (float *)take(sizeof(float) * g); s.sh = (float *)take(sizeof(float) * g);
+    s.mean_w = (double *)take(sizeof(double) * g); s.rstd_w = (double *)take(sizeof(double) * g);
+    s.bytes = off;
+    return s;
+}
+
+struct Work {
+    char *dense; size_t dense_bytes;
+    char *gva; size_t gva_bytes;
+    float *t[4];  // (n,c) gradient temporaries
+    size_t bytes;
+};
+
+Work carve_work(void *base, int n, int k, int c, int g) {
+    Work w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    w.dense_bytes = dense_workspace_bytes(n, c, c);
+    w.dense = take(w.dense_bytes);
+    w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
+    w.gva = take(w.gva_bytes);
+    for (int i = 0; i < 4; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
+    w.bytes = off;
+    return w;
+}
+
+// eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
+__global__ void bn_eval_stats_kernel(int c, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
+                                     float *__restrict__ mean, float *__restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        mean[i] = rm[i];
+        rstd[i] = 1.0f / sqrtf(rv[i] + eps);
+    }
+}
+
+void param_sizes(int c, int g, long long *sz) {
+    const long long cc = (long long)c * c;
+    sz[PTV2_BLK_FC1_W] = cc; sz[PTV2_BLK_N1_G] = c; sz[PTV2_BLK_N1_B] = c;
+    sz[PTV2_BLK_Q_W] = cc; sz[PTV2_BLK_Q_B] = c; sz[PTV2_BLK_QN_G] = c; sz[PTV2_BLK_QN_B] = c;
+    sz[PTV2_BLK_K_W] = cc; sz[PTV2_BLK_K_B] = c; sz[PTV2_BLK_KN_G] = c; sz[PTV2_BLK_KN_B] = c;
+    sz[PTV2_BLK_V_W] = cc; sz[PTV2_BLK_V_B] = c;
+    sz[PTV2_BLK_P1_W] = 3LL * c; sz[PTV2_BLK_P1_B] = c; sz[PTV2_BLK_PN_G] = c; sz[PTV2_BLK_PN_B] = c;
+    sz[PTV2_BLK_P2_W] = cc; sz[PTV2_BLK_P2_B] = c;
+    sz[PTV2_BLK_W1_W] = (long long)g * c; sz[PTV2_BLK_W1_B] = g; sz[PTV2_BLK_WN_G] = g; sz[PTV2_BLK_WN_B] = g;
+    sz[PTV2_BLK_W2_W] = (long long)g * g; sz[PTV2_BLK_W2_B] = g;
+    sz[PTV2_BLK_N2_G] = c; sz[PTV2_BLK_N2_B] = c; sz[PTV2_BLK_FC3_W] = cc; sz[PTV2_BLK_N3_G] = c; sz[PTV2_BLK_N3_B] = c;
+}
+
+bool args_ok(const ptv2_block *B) {
+    if (!B) return false;
+    if (B->n < 2 || B->k < 1 || B->c < 4 || B->c % 4 != 0 || B->c > 1024 || B->g < 1 || B->c % B->g != 0) return false;
+    if (!B->x || !B->coord || !B->idx || !B->y || !B->saved) return false;
+    if (B->training && (!B->mu || !B->cov)) return false;
+    for (int i = 0; i < PTV2_BLK_NPARAM; ++i) {
+        const bool optional = i == PTV2_BLK_Q_B || i == PTV2_BLK_K_B || i == PTV2_BLK_V_B;
+        if (!B->param[i] && !optional) return false;
+    }
+    return true;
+}
+
+void fill_gva(const ptv2_block *B, const Saved &S, ptv2_gva_block *V) {
+    V->n = B->n; V->k = B->k; V->c = B->c; V->g = B->g; V->training = B->training;
+    V->eps_p = V->eps_w = B->eps; V->momentum_p = V->momentum_w = B->momentum;
+    V->q = S.q; V->key = S.key; V->v = S.v; V->coord = B->coord; V->idx = B->idx; V->mu = B->mu; V->cov = B->cov;
+    V->Wp1 = B->param[PTV2_BLK_P1_W]; V->bp1 = B->param[PTV2_BLK_P1_B]; V->gamma_p = B->param[PTV2_BLK_PN_G];
+    V->beta_p = B->param[PTV2_BLK_PN_B]; V->Wp2 = B->param[PTV2_BLK_P2_W]; V->bp2 = B->param[PTV2_BLK_P2_B];
+    V->Ww1 = B->param[PTV2_BLK_W1_W]; V->bw1 = B->param[PTV2_BLK_W1_B]; V->gamma_w = B->param[PTV2_BLK_WN_G];
+    V->beta_w = B->param[PTV2_BLK_WN_B]; V->Ww2 = B->param[PTV2_BLK_W2_W]; V->bw2 = B->param[PTV2_BLK_W2_B];
+    V->run_mean_p = B->run_mean[3]; V->run_var_p = B->run_var[3]; V->batches_p = B->batches[3];
+    V->run_mean_w = B->run_mean[4]; V->run_var_w = B->run_var[4]; V->batches_w = B->batches[4];
+    V->out = S.attn;
+    V->a = S.a; V->b = S.b; V->rstd_p = S.rstd_p; V->M = S.M; V->cW = S.cW; V->kW = S.kW; V->qW = S.qW; V->W1 = S.W1;
+    V->w = S.w; V->A = S.A; V->sw = S.sw; V->sc = S.sc; V->sh = S.sh; V->mean_w = S.mean_w; V->rstd_w = S.rstd_w;
+}
+
+}  // namespace
+
+#define RUN(call)                        \
+    do {                                 \
+        int rc_ = (call);                \
+        if (rc_ != PTV2_OK) return rc_;  \
+    } while (0)
+
+extern "C" size_t ptv2_block_saved_bytes(int n, int k, int c, int g) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
+    return carve_saved(nullptr, n, k, c, g).bytes + 256;
+}
+
+extern "C" size_t ptv2_block_workspace_bytes(int n, int k, int c, int g) {
+    if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
+    return carve_work(nullptr, n, k, c, g).bytes + 256;
+}
+
+extern "C" int ptv2_block_param_layout(int c, int g, long long *offsets) {
+    if (c < 1 || g < 1 || !offsets) return PTV2_ERR_ARG;
+    long long sz[PTV2_BLK_NPARAM];
+    param_sizes(c, g, sz);
+    long long off = 0;
+    for (int i = 0; i < PTV2_BLK_NPARAM; ++i) {
+        offsets[i] = off;
+        off += (sz[i] + 3) & ~3LL;  // float4-aligned slots
+    }
+    offsets[PTV2_BLK_NPARAM] = off;
+    return PTV2_OK;
+}
+
+// batch statistics (training, or no running buffers) or running statistics (eval) of BatchNorm `i` on x (n,c)
+static int bn_prepare(const ptv2_block *B, int i, const float *x, const Saved &S, const Work &W, void *stream, int *batch) {
+    const bool use_batch = B->training || !B->run_mean[i] || !B->run_var[i];
+    *batch = use_batch ? 1 : 0;
+    if (use_batch) {
+        const bool track = B->training && B->run_mean[i] && B->run_var[i];
+        return bn_stats_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], track ? B->run_mean[i] : nullptr,
+                                     track ? B->run_var[i] : nullptr, track ? B->batches[i] : nullptr, B->eps, B->momentum,
+                                     W.dense, W.dense_bytes, stream);
+    }
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(divup(B->c, 256)), dim3(256), 0, (hipStream_t)stream, B->c,
+                       (const float *)B->run_mean[i], (const float *)B->run_var[i], B->eps, S.mean[i], S.rstd[i]);
+    return PTV2_OK;
+}
+
+extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!args_ok(B)) return PTV2_ERR_ARG;
+    const int n = B->n, k = B->k, c = B->c, g = B->g;
+    const Saved S = carve_saved(B->saved, n, k, c, g);
+    if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;
+    const Work W = carve_work(workspace, n, k, c, g);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    const float *const *P = B->param;
+    int batch;
+    // fc1 -> norm1 -> ReLU
+    RUN(rows_gemm_hip_launcher(n, c, c, B->x, P[PTV2_BLK_FC1_W], 0, nullptr, S.h1, 0, stream));
+    RUN(bn_prepare(B, 0, S.h1, S, W, stream, &batch));
+    RUN(bn_apply_hip_launcher(n, c, S.h1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, S.f1, stream));
+    // linear_q / linear_k (Linear + BN + ReLU), linear_v
+    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_Q_W], 0, P[PTV2_BLK_Q_B], S.hq, 0, stream));
+    RUN(bn_prepare(B, 1, S.hq, S, W, stream, &batch));
+    RUN(bn_apply_hip_launcher(n, c, S.hq, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, S.q, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_K_W], 0, P[PTV2_BLK_K_B], S.hk, 0, stream));
+    RUN(bn_prepare(B, 2, S.hk, S, W, stream, &batch));
+    RUN(bn_apply_hip_launcher(n, c, S.hk, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, S.key, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_V_W], 0, P[PTV2_BLK_V_B], S.v, 0, stream));
+    // grouped vector attention
+    ptv2_gva_block V;
+    fill_gva(B, S, &V);
+    RUN(gva_block_forward_hip_launcher(&V, W.gva, W.gva_bytes, stream));
+    // norm2 -> ReLU -> fc3 -> norm3 -> DropPath -> + identity -> ReLU
+    RUN(bn_prepare(B, 5, S.attn, S, W, stream, &batch));
+    RUN(bn_apply_hip_launcher(n, c, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, S.f2, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, S.f2, P[PTV2_BLK_FC3_W], 0, nullptr, S.h3, 0, stream));
+    RUN(bn_prepare(B, 6, S.h3, S, W, stream, &batch));
+    RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
+                                       B->y, stream));
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_block_grads *G, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    if (!args_ok(B) || !G || !G->gy || !G->gx || !G->gparam) return PTV2_ERR_ARG;
+    const int n = B->n, k = B->k, c = B->c, g = B->g;
+    const Saved S = carve_saved(B->saved, n, k, c, g);
+    if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;
+    const Work W = carve_work(workspace, n, k, c, g);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    const float *const *P = B->param;
+    long long off[PTV2_BLK_NPARAM + 1];
+    (void)ptv2_block_param_layout(c, g, off);
+    auto GP = [&](int i) { return G->gparam + off[i]; };
+    auto GPB = [&](int i) { return P[i] ? G->gparam + off[i] : (float *)nullptr; };  // optional biases
+    int batch[PTV2_BLK_NBN];
+    for (int i = 0; i < PTV2_BLK_NBN; ++i) batch[i] = (B->training || !B->run_mean[i] || !B->run_var[i]) ? 1 : 0;
+    float *T0 = W.t[0], *T1 = W.t[1], *T2 = W.t[2], *T3 = W.t[3];
+
+    // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3 (T0), residual gradient straight into gx
+    RUN(bn_backward_residual_hip_launcher(n, c, S.h3, G->gy, B->y, B->rowscale, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G],
+                                          batch[6], T0, G->gx, GP(PTV2_BLK_N3_G), GP(PTV2_BLK_N3_B), W.dense, W.dense_bytes,
+                                          stream));
+    // fc3
+    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_FC3_W], 1, nullptr, T1, 0, stream));
+    RUN(linear_wgrad_hip_launcher(n, c, c, T0, S.f2, GP(PTV2_BLK_FC3_W), nullptr, W.dense, W.dense_bytes, stream));
+    // norm2 + ReLU -> g_attn (T0)
+    RUN(bn_backward_hip_launcher(n, c, S.attn, T1, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], T0,
+                                 GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
+    // attention: gq (T1), gk (T2), gv (T3)
+    ptv2_gva_block V;
+    fill_gva(B, S, &V);
+    ptv2_gva_block_grads VG;
+    VG.g_out = T0; VG.inv_ptr = G->inv_ptr; VG.inv_rows = G->inv_rows;
+    VG.gq = T1; VG.gk = T2; VG.gv = T3;
+    VG.gWp1 = GP(PTV2_BLK_P1_W); VG.gbp1 = GP(PTV2_BLK_P1_B); VG.ggamma_p = GP(PTV2_BLK_PN_G); VG.gbeta_p = GP(PTV2_BLK_PN_B);
+    VG.gWp2 = GP(PTV2_BLK_P2_W); VG.gbp2 = GP(PTV2_BLK_P2_B); VG.gWw1 = GP(PTV2_BLK_W1_W); VG.gbw1 = GP(PTV2_BLK_W1_B);
+    VG.ggamma_w = GP(PTV2_BLK_WN_G); VG.gbeta_w = GP(PTV2_BLK_WN_B); VG.gWw2 = GP(PTV2_BLK_W2_W); VG.gbw2 = GP(PTV2_BLK_W2_B);
+    if (!G->inv_ptr) (void)hipMemsetAsync(T3, 0, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
+    RUN(gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream));
+    // linear_k / linear_q BatchNorm + ReLU: g_hk (T0), g_hq (T2 after gk is consumed)
+    RUN(bn_backward_hip_launcher(n, c, S.hk, T2, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, batch[2], T0,
+                                 GP(PTV2_BLK_KN_G), GP(PTV2_BLK_KN_B), W.dense, W.dense_bytes, stream));
+    RUN(bn_backward_hip_launcher(n, c, S.hq, T1, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], T2,
+                                 GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
+    // weight / bias gradients of the three projections of f1
+    RUN(linear_wgrad_hip_launcher(n, c, c, T2, S.f1, GP(PTV2_BLK_Q_W), GPB(PTV2_BLK_Q_B), W.dense, W.dense_bytes, stream));
+    RUN(linear_wgrad_hip_launcher(n, c, c, T0, S.f1, GP(PTV2_BLK_K_W), GPB(PTV2_BLK_K_B), W.dense, W.dense_bytes, stream));
+    RUN(linear_wgrad_hip_launcher(n, c, c, T3, S.f1, GP(PTV2_BLK_V_W), GPB(PTV2_BLK_V_B), W.dense, W.dense_bytes, stream));
+    // g_f1 (T1) = g_hq Wq + g_hk Wk + gv Wv
+    RUN(rows_gemm_hip_launcher(n, c, c, T2, P[PTV2_BLK_Q_W], 1, nullptr, T1, 0, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_K_W], 1, nullptr, T1, 1, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, T3, P[PTV2_BLK_V_W], 1, nullptr, T1, 1, stream));
+    // norm1 + ReLU -> g_h1 (T0); fc1: gx += g_h1 fc1
+    RUN(bn_backward_hip_launcher(n, c, S.h1, T1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], T0,
+                                 GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.dense, W.dense_bytes, stream));
+    RUN(linear_wgrad_hip_launcher(n, c, c, T0, B->x, GP(PTV2_BLK_FC1_W), nullptr, W.dense, W.dense_bytes, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_FC1_W], 1, nullptr, G->gx, 1, stream));
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -145,16 +145,21 @@ class Block(nn.Module):
     def forward(self, points, reference_index):
         coord, feat, offset = points
         identity = feat
+        rowscale = None
+        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.0:
+            keep = 1.0 - self.drop_path.drop_prob  # timm DropPath: per-point Bernoulli(keep) / keep
+            rowscale = torch.empty(feat.shape[0], device=feat.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+        if os.environ.get("AO_AMD_BLOCK", "native") == "native" and os.environ.get("AO_AMD_GVA", "fused") == "fused":
+            from . import block as native
+
+            if native.supported(self, feat, reference_index):  # whole block behind one native call per direction
+                return [coord, native.block_forward(self, feat, coord, reference_index, rowscale), offset]
         feat = self.norm1(self.fc1(feat), relu=True)
         if self.enable_checkpoint and self.training:
             feat = torch.utils.checkpoint.checkpoint(self.attn, feat, coord, reference_index, use_reentrant=False)
         else:
             feat = self.attn(feat, coord, reference_index)
         feat = self.norm2(feat, relu=True)
-        rowscale = None
-        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.0:
-            keep = 1.0 - self.drop_path.drop_prob  # timm DropPath: per-point Bernoulli(keep) / keep
-            rowscale = torch.empty(feat.shape[0], device=feat.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
         feat = bn_residual_relu(self.norm3.norm, self.fc3(feat), identity, rowscale)
         return [coord, feat, offset]
 

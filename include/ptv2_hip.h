@@ -357,6 +357,64 @@ int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const
                                       long long sx, float *dW, float *db, void *workspace,
                                       size_t workspace_bytes, void *stream);
 
+/* -------------------------------------------------- fp32 row GEMM (MFMA) --
+ * Y (m,n) [+]= X (m,k) op(W) + bias: the nn.Linear products of a Block on V_MFMA_F32_16X16X4_F32 (true fp32).
+ * w_kmajor == 0: W is (n,k) row-major, y = x W^T (forward); w_kmajor != 0: W is (k,n) row-major, gx = gy W
+ * (input gradient, same weight matrix).  n % 4 == 0, k % 4 == 0, bias (n) or NULL, accumulate != 0 adds onto Y. */
+int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const float *W, int w_kmajor,
+                           const float *bias, float *Y, int accumulate, void *stream);
+
+/* ------------------------------------------------ whole Block, one call --
+ * Block.forward / backward (point_transformer_v2m2_base.py:131-177: fc1, norm1, GroupedVectorAttention with
+ * linear_q/k/v, norm2, fc3, norm3, DropPath, residual, ReLU) behind ONE launcher per direction: ~30 forward and
+ * ~75 backward kernels are enqueued on the caller's stream from native code.  The step was host-bound on the
+ * python / autograd dispatch of those ops; a Block now costs two host calls.
+ * param[] follows PTV2_BLK_* (reference state_dict names in the comments); biases may be NULL (qkv_bias=False).
+ * bn index: 0 norm1, 1 linear_q[1], 2 linear_k[1], 3 linear_p_bias[1], 4 weight_encoding[1], 5 norm2, 6 norm3.
+ * `saved` (ptv2_block_saved_bytes) is written by the forward and read by the backward together with y.
+ * gparam is one flat float buffer laid out by ptv2_block_param_layout (offsets[i] of param i, offsets[30] = total). */
+enum {
+    PTV2_BLK_FC1_W = 0,                                   /* fc1.weight (c,c) */
+    PTV2_BLK_N1_G, PTV2_BLK_N1_B,                         /* norm1.norm.{weight,bias} */
+    PTV2_BLK_Q_W, PTV2_BLK_Q_B, PTV2_BLK_QN_G, PTV2_BLK_QN_B,   /* attn.linear_q.0.*, attn.linear_q.1.norm.* */
+    PTV2_BLK_K_W, PTV2_BLK_K_B, PTV2_BLK_KN_G, PTV2_BLK_KN_B,   /* attn.linear_k.* */
+    PTV2_BLK_V_W, PTV2_BLK_V_B,                           /* attn.linear_v.* */
+    PTV2_BLK_P1_W, PTV2_BLK_P1_B, PTV2_BLK_PN_G, PTV2_BLK_PN_B, PTV2_BLK_P2_W, PTV2_BLK_P2_B, /* attn.linear_p_bias.{0,1.norm,3} */
+    PTV2_BLK_W1_W, PTV2_BLK_W1_B, PTV2_BLK_WN_G, PTV2_BLK_WN_B, PTV2_BLK_W2_W, PTV2_BLK_W2_B, /* attn.weight_encoding.{0,1.norm,3} */
+    PTV2_BLK_N2_G, PTV2_BLK_N2_B,                         /* norm2.norm.* */
+    PTV2_BLK_FC3_W,                                       /* fc3.weight */
+    PTV2_BLK_N3_G, PTV2_BLK_N3_B,                         /* norm3.norm.* */
+    PTV2_BLK_NPARAM
+};
+#define PTV2_BLK_NBN 7
+typedef struct ptv2_block {
+    int n, k, c, g, training;
+    float eps, momentum;
+    const float *x;            /* (n,c) block input, also the residual */
+    const float *coord;        /* (n,3) */
+    const int *idx;            /* (n,k) neighbour table, -1 placeholders */
+    const double *mu, *cov;    /* position moments of the table (gva_pos_stats) */
+    const float *rowscale;     /* (n) per-point DropPath factor or NULL */
+    const float *param[PTV2_BLK_NPARAM];
+    float *run_mean[PTV2_BLK_NBN], *run_var[PTV2_BLK_NBN];
+    long long *batches[PTV2_BLK_NBN];
+    float *y;                  /* (n,c) output */
+    void *saved;
+    size_t saved_bytes;
+} ptv2_block;
+typedef struct ptv2_block_grads {
+    const float *gy;               /* (n,c) */
+    const int *inv_ptr, *inv_rows; /* inverse neighbour table (may be NULL) */
+    float *gx;                     /* (n,c) */
+    float *gparam;                 /* flat parameter gradients */
+} ptv2_block_grads;
+size_t ptv2_block_saved_bytes(int n, int k, int c, int g);
+size_t ptv2_block_workspace_bytes(int n, int k, int c, int g);
+int ptv2_block_param_layout(int c, int g, long long *offsets /* [PTV2_BLK_NPARAM + 1] */);
+int ptv2_block_forward_hip_launcher(const ptv2_block *blk, void *workspace, size_t workspace_bytes, void *stream);
+int ptv2_block_backward_hip_launcher(const ptv2_block *blk, const ptv2_block_grads *grads, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

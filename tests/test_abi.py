@@ -14,13 +14,14 @@ HEADER = os.path.join(ROOT, "include", "ptv2_hip.h")
 def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_version|_info|_enable|_is_on|_kernel_count|_read))\s*\(", txt)))
+    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_param_layout|_version|_info|_enable|_is_on|_kernel_count|_read))\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
 def lib():
     from ao_amd import _lib
     import ao_amd.ptv2.gva  # noqa: F401  (registers the fused-attention entry points)
+    import ao_amd.ptv2.block  # noqa: F401  (registers the block runtime entry points)
 
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()

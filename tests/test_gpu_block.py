@@ -1,0 +1,120 @@
+"""GPU: the fp32 MFMA row GEMM (csrc/gemm.hip) against float64 matmul, and the native Block runtime
+(csrc/block.hip: one call per direction) against the same Block evaluated op by op in python
+(AO_AMD_BLOCK=python: rocBLAS linears + the staged HIP kernels), forward, every gradient, running statistics."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("m,n,k", [(120000, 48, 48), (18905, 96, 96), (4501, 192, 192), (1074, 384, 384), (777, 512, 512),
+                                   (1000, 96, 48), (1000, 48, 96), (63, 64, 32), (65, 16, 4), (1, 48, 48), (3000, 384, 192)])
+@pytest.mark.parametrize("kmajor", [False, True])
+def test_rows_gemm(m, n, k, kmajor):
+    from ao_amd.ptv2.block import rows_gemm
+
+    torch.manual_seed(m + n + k)
+    x = torch.randn(m, k, device="cuda")
+    w = torch.randn((k, n) if kmajor else (n, k), device="cuda") / k ** 0.5
+    b = torch.randn(n, device="cuda")
+    ref = x.double() @ (w.double() if kmajor else w.double().t())
+    y = rows_gemm(x, w, w_kmajor=kmajor)
+    assert rel(y, ref) < 2e-6
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().cpu().numpy(), rtol=0, atol=2e-5)
+    yb = rows_gemm(x, w, bias=b, w_kmajor=kmajor)
+    np.testing.assert_allclose(yb.cpu().numpy(), (ref + b.double()).float().cpu().numpy(), rtol=0, atol=2e-5)
+    acc = torch.randn(m, n, device="cuda")
+    expect = (acc.double() + ref).float()
+    rows_gemm(x, w, w_kmajor=kmajor, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), expect.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def _block_pair(c, g, drop, seed):
+    from ao_amd.ptv2.model import Block
+
+    torch.manual_seed(seed)
+    a = Block(c, g, drop_path_rate=drop).cuda()
+    with torch.no_grad():
+        for name, p in a.named_parameters():
+            if p.dim() == 1 and "norm" in name and name.endswith("weight"):
+                p.uniform_(0.6, 1.4)
+            elif p.dim() == 1:
+                p.normal_(0, 0.2)
+        for name, buf in a.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0, 0.3)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 2.0)
+    return a, copy.deepcopy(a)
+
+
+@pytest.mark.parametrize("n,c,g,k", [(6000, 48, 6, 16), (3000, 96, 12, 16), (1500, 192, 24, 16), (700, 384, 48, 16),
+                                     (2000, 48, 6, 8), (300, 512, 64, 16)])
+@pytest.mark.parametrize("training", [True, False])
+def test_native_block_matches_python_block(monkeypatch, n, c, g, k, training):
+    from ao_amd import pointops, synth
+    from ao_amd.ptv2 import block as native
+
+    cloud = synth.room_cloud(n, seed=n + c)
+    coord = torch.from_numpy(cloud).cuda()
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(k, coord, offset)
+    torch.manual_seed(7)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    go = torch.randn(n, c, device="cuda")
+    blk_n, blk_p = _block_pair(c, g, 0.0, seed=3)
+    outs = {}
+    for tag, blk in (("native", blk_n), ("python", blk_p)):
+        monkeypatch.setenv("AO_AMD_BLOCK", tag)
+        blk.train(training)
+        x = x0.clone().requires_grad_(True)
+        if tag == "native":
+            assert native.supported(blk, x, idx)
+        y = blk([coord, x, offset], idx)[1]
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+        outs[tag] = (y.detach(), grads, {k_: v.clone() for k_, v in blk.state_dict().items()})
+    y_n, g_n, sd_n = outs["native"]
+    y_p, g_p, sd_p = outs["python"]
+    np.testing.assert_allclose(y_n.cpu().numpy(), y_p.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    names = ["x"] + [nm for nm, _ in blk_n.named_parameters()]
+    for nm, a, b in zip(names, g_n, g_p):
+        # biases in front of a training-mode BatchNorm (linear_q/k/v, linear_p_bias, weight_encoding[0]) have an
+        # exactly-zero gradient that both sides compute as O(1e-4) summation noise: absolute floor for those
+        assert rel(a, b) < 5e-3 or float((a - b).abs().max()) < 1e-3, (nm, rel(a, b), float((a - b).abs().max()))
+    for key in sd_p:
+        np.testing.assert_allclose(sd_n[key].cpu().numpy(), sd_p[key].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
+
+
+def test_native_block_droppath_rowscale(monkeypatch):
+    """With DropPath the dropped points pass the identity through unchanged (ReLU of a ReLU output); same draw of
+    the per-point mask -> same output and input gradient as the op-by-op block."""
+    from ao_amd import pointops, synth
+
+    n, c, g, k = 5000, 48, 6, 16
+    coord = torch.from_numpy(synth.room_cloud(n, seed=5)).cuda()
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(k, coord, offset)
+    blk_n, blk_p = _block_pair(c, g, 0.5, seed=11)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    res = {}
+    for tag, blk in (("native", blk_n), ("python", blk_p)):
+        monkeypatch.setenv("AO_AMD_BLOCK", tag)
+        blk.train()
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(99)
+        y = blk([coord, x, offset], idx)[1]
+        (gx,) = torch.autograd.grad((y * y).sum(), [x])
+        res[tag] = (y.detach(), gx)
+    y, gx = res["native"]
+    same = (y == x0).all(dim=1)
+    assert 0.4 < float(same.float().mean()) < 0.6
+    np.testing.assert_allclose(y.cpu().numpy(), res["python"][0].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert rel(gx, res["python"][1]) < 5e-3
