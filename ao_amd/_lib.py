@@ -21,6 +21,7 @@ _SIGNATURES = {
     "ptv2_abi_version": (_c_int, []),
     "ptv2_build_info": (ctypes.c_char_p, []),
     "ptv2_profile_enable": (_c_int, [_c_int]),
+    "ptv2_profile_select": (_c_int, [_c_int]),
     "ptv2_profile_is_on": (_c_int, []),
     "ptv2_profile_kernel_count": (_c_int, []),
     "ptv2_profile_read": (_c_int, [_c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -138,9 +139,22 @@ def workspace(nbytes, device):
     return buf
 
 
-def kernel_timer(enable):
-    """Switch the in-library per-kernel HIP-event timer (include/ptv2_hip.h: ptv2_profile_*)."""
-    lib().ptv2_profile_enable(1 if enable else 0)
+def kernel_timer(enable, only=None):
+    """Switch the in-library per-kernel HIP-event timer (include/ptv2_hip.h: ptv2_profile_*).  `only` = kernel
+    name: bracket that kernel alone (a whole-step measurement is then not perturbed by ~2000 event pairs)."""
+    L = lib()
+    kid = -1
+    if only is not None:
+        name = ctypes.create_string_buffer(64)
+        us, cnt, byt = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_double()
+        for i in range(L.ptv2_profile_kernel_count()):
+            L.ptv2_profile_read(i, name, ctypes.byref(us), ctypes.byref(cnt), ctypes.byref(byt))
+            if name.value.decode() == only:
+                kid = i
+        if kid < 0:
+            raise ValueError("unknown kernel name %r" % only)
+    L.ptv2_profile_select(kid)
+    L.ptv2_profile_enable(1 if enable else 0)
 
 
 def kernel_timer_read():

@@ -24,26 +24,44 @@ const char *kNames[KID_COUNT] = {
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;
+int g_only = -1;                 // >= 0: time this kernel id only (ptv2_profile_select)
+std::vector<hipEvent_t> g_free;  // recycled events: creating one per launch costs more than recording it
+hipEvent_t take_event() {
+    if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 std::vector<Rec> g_recs[KID_COUNT];
 std::vector<hipEvent_t> g_pending[KID_COUNT];
 }  // namespace
 
 extern "C" int ptv2_profile_is_on(void) { return g_on; }
+int ptv2_profile_wants(int kid) { return g_on && (g_only < 0 || g_only == kid); }
+
+// kid >= 0: only that kernel is bracketed with events from now on (keeps the timer out of the way of a
+// whole-step measurement); kid < 0: all kernels
+extern "C" int ptv2_profile_select(int kid) {
+    if (kid >= KID_COUNT) return PTV2_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = kid < 0 ? -1 : kid;
+    return PTV2_OK;
+}
 
 void ptv2_profile_begin(int kid, hipStream_t st) {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, st);
     std::lock_guard<std::mutex> lk(g_mu);
+    hipEvent_t e = take_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
     g_pending[kid].push_back(e);
 }
 
 void ptv2_profile_end(int kid, hipStream_t st, double bytes) {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
-    (void)hipEventRecord(e, st);
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_pending[kid].empty()) { (void)hipEventDestroy(e); return; }
+    hipEvent_t e = take_event();
+    if (!e) return;
+    (void)hipEventRecord(e, st);
+    if (g_pending[kid].empty()) { g_free.push_back(e); return; }
     hipEvent_t a = g_pending[kid].back();
     g_pending[kid].pop_back();
     g_recs[kid].push_back(Rec{a, e, bytes});
@@ -54,9 +72,9 @@ extern "C" int ptv2_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (on) {
         for (int k = 0; k < KID_COUNT; ++k) {
-            for (auto &r : g_recs[k]) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+            for (auto &r : g_recs[k]) { g_free.push_back(r.a); g_free.push_back(r.b); }
             g_recs[k].clear();
-            for (auto e : g_pending[k]) (void)hipEventDestroy(e);
+            for (auto e : g_pending[k]) g_free.push_back(e);
             g_pending[k].clear();
         }
     }

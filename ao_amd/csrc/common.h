@@ -22,11 +22,12 @@ enum PtvKernelId {
     KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_ROWS_GEMM, KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);
+int ptv2_profile_wants(int kid);
 void ptv2_profile_begin(int kid, hipStream_t st);
 void ptv2_profile_end(int kid, hipStream_t st, double algorithmic_bytes);
 struct PtvScopedTimer {
     int kid; hipStream_t st; double bytes; bool on;
-    PtvScopedTimer(int k, hipStream_t s, double b) : kid(k), st(s), bytes(b), on(ptv2_profile_is_on() != 0) {
+    PtvScopedTimer(int k, hipStream_t s, double b) : kid(k), st(s), bytes(b), on(ptv2_profile_wants(k) != 0) {
         if (on) ptv2_profile_begin(kid, st);
     }
     ~PtvScopedTimer() { if (on) ptv2_profile_end(kid, st, bytes); }

@@ -19,6 +19,7 @@
 //                  then the same split-K MFMA reduction as any Linear (dense.hip); gsc / gsh partials.
 //   bwd_gv         grad v through the inverse neighbour table (fixed-order gather, no atomics).
 #include <algorithm>
+#include <cstdlib>
 
 #include "gva_common.h"
 
@@ -429,10 +430,24 @@ extern "C" size_t dense_workspace_bytes(int n, int cout, int cin);
 extern "C" int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
                                          float *db, void *workspace, size_t workspace_bytes, void *stream);
 
+// gva_bwd_point.hip: the fused MFMA backward (one launch) for the (k, c, g) it is instantiated for
+int gva_bwd_point_supported(int k, int c, int g);
+size_t gva_bwd_point_part_floats(int c, int g);
+int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                         const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
+                         const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
+                         float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
+                         hipStream_t st);
+
+static size_t agg_part_bytes(int c, int g) {
+    return align_up(sizeof(float) * std::max({(size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g,
+                                              gva_bwd_point_part_floats(c, g)}));
+}
+
 extern "C" size_t gva_aggregate_workspace_bytes(int n, int k, int c, int g) {
     if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
     const size_t rows = (size_t)n * k;
-    const size_t part = align_up(sizeof(float) * std::max((size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g));
+    const size_t part = agg_part_bytes(c, g);
     return part + 3 * align_up(sizeof(float) * rows * g) + dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g) + 1024;
 }
 
@@ -480,10 +495,26 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
     if (n == 0) return PTV2_OK;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)n * k;
-    const size_t part_bytes = align_up(sizeof(float) * std::max((size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g));
+    const size_t part_bytes = agg_part_bytes(c, g);
     const size_t rows_bytes = align_up(sizeof(float) * (size_t)rows * g);
     char *base = (char *)workspace;
     float *part = (float *)base;
+    if (inv_ptr && gva_bwd_point_supported(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) {
+        // one fused MFMA launch (+ its finalize) instead of tile / rows / finalizes / the G x G weight-gradient GEMM
+        {
+            PtvScopedTimer t(KID_BWD_TILE, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
+            const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
+                                                gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st);
+            if (rc != PTV2_OK) return rc;
+        }
+        {
+            PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
+            hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3((int)std::min<long long>(((long long)n * c + TPB - 1) / TPB, MAX_BLOCKS * 4)),
+                               dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+        }
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     float *gw = (float *)(base + part_bytes);
     float *gz = (float *)(base + part_bytes + rows_bytes);
     float *yb = (float *)(base + part_bytes + 2 * rows_bytes);

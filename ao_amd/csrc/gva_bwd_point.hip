@@ -1,0 +1,489 @@
+// ao_amd/csrc/gva_bwd_point.hip -- backward of the softmax / aggregation stage of grouped vector attention,
+// one point (= its 16 neighbour slots) per wavefront group, every contraction on V_MFMA_F32_16X16X4_F32.
+//
+// The K = 16 neighbour slots of a point are exactly one MFMA dimension, so all per-point products of the
+// backward (gva.py has the algebra; s = slot, g/j = group, ch = channel) are 16-wide matrix products:
+//   z^T  (g,s) = Ww2 (g,j)      y^T (j,s)            logits recomputed (the unmasked softmax is needed)
+//   gw^T (g,s) = g_A (g,ch)     P^T (ch,s)  +  Gm (g,ch) v[idx]^T (ch,s)  + g_sw      Gm = group-masked g_out
+//   gP   (s,ch)= w (s,g)        g_A (g,ch)           -> (ga, gb) partial sums with relu'(P) and pos
+//   gy^T (j,s) = Ww2^T (j,g)    gz^T (g,s)           -> gW1, gsc, gsh partial sums
+//   gWw2 (g,j)+= gz^T (g,s)     y (s,j)              accumulated in registers over all points of the workgroup
+// Results of one product feed the next without leaving registers: with the contraction index of group-sized
+// operands mapped as g = 16 t + 4 (lane >> 4) + r, an MFMA result tile (lane & 15 = column s) IS the B operand
+// of the next product.  Only the last product contracts over s and needs an LDS transpose (G x 16 floats).
+// This replaces four launches (tile / rows / finalize / a G x G weight-gradient GEMM over N*K rows) and the
+// three (N,K,G) scratch tensors between them; the per-thread G x G loops of the row kernel were the slowest
+// code of the deep stages (G = 24, 48: 120-410 us per launch for 2-8 k points).
+//
+// NW wavefronts share a point when C is large (each takes C / NW channels of the channel-parallel phases and a
+// share of the output tiles of the group-parallel ones); a 256-thread workgroup works on 4 / NW points at a time.
+#include <algorithm>
+
+#include "gva_common.h"
+
+namespace gva {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// all-reduce over the 16 lanes of a DPP row (lanes that share lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+
+__host__ __device__ constexpr int ww_pitch(int G) {  // >= G, = 4 mod 16: the 4 lane groups hit disjoint LDS banks
+    int p = G;
+    while (p % 16 != 4) ++p;
+    return p;
+}
+
+template <int G, int C, int NW>
+struct BwdPointCfg {
+    static constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = ww_pitch(G), PW = 4 / NW, CW = C / NW, CS = CW / 4,
+                         UT = CW / 16, I = C / G, PF = 4 * C + 3 * G + G * G;
+    static constexpr int LT = (GT + NW - 1) / NW;            // group tiles per wave in the j-parallel phase
+    static constexpr int NTW = (GT * GT + NW - 1) / NW;      // gWw2 tiles per wave
+    static constexpr size_t lds_floats = 4 * (size_t)C + (size_t)G16 * GPW + 3 * G16 + PW * 16 * 4 + PW * 16 + (size_t)PW * C +
+                                         PW * G16 + (NW > 1 ? (size_t)PW * NW * G16 * 16 : 0) + 2 * (size_t)PW * G16 * 17 + PF;
+};
+
+// part[blockIdx.x][PF]: [4C] (ga.xyz, gb) per channel, [G] gsc, [G] gsh, [G*G] gWw2, [G] gbw2
+template <int G, int C, int NW>
+__global__ __launch_bounds__(256) void attention_bwd_point_kernel(
+    int n, int k, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
+    const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
+    const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
+    const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ g_A,
+    const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ part) {
+    using K = BwdPointCfg<G, C, NW>;
+    constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PW = K::PW, CW = K::CW, CS = K::CS, UT = K::UT, I = K::I,
+                  PF = K::PF, LT = K::LT, NTW = K::NTW;
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;                                   // [C]  (a.xyz, b)
+    float *sWw = (float *)(sAB + C);                      // [G16][GPW]  Ww2, zero padded
+    float *sBw = sWw + G16 * GPW;                         // [G16]
+    float *sSc = sBw + G16;
+    float *sSh = sSc + G16;
+    float4 *sPos = (float4 *)(sSh + G16);                 // [PW][16]
+    int *sSrc = (int *)(sPos + PW * 16);                  // [PW][16]
+    float *sGo = (float *)(sSrc + PW * 16);               // [PW][C]     g_out row of the point
+    float *sGsw = sGo + PW * C;                           // [PW][G16]
+    float *sRed = sGsw + PW * G16;                        // [PW][NW][G16][16]
+    float *sGz = sRed + (NW > 1 ? PW * NW * G16 * 16 : 0);  // [PW][G16][17]
+    float *sY = sGz + PW * G16 * 17;                      // [PW][G16][17]
+    float *sFin = sY + PW * G16 * 17;                     // [PF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = wid / NW, sub = wid % NW;               // point slot of the workgroup, channel part
+    const int l15 = lane & 15, q = lane >> 4;
+    const int c0 = sub * CW;
+
+    for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    for (int e = tid; e < G16 * GPW; e += 256) {
+        const int g = e / GPW, j = e - g * GPW;
+        sWw[e] = (g < G && j < G) ? Ww2[g * G + j] : 0.f;
+    }
+    for (int g = tid; g < G16; g += 256) {
+        sBw[g] = g < G ? bw2[g] : 0.f;
+        sSc[g] = g < G ? sc[g] : 0.f;
+        sSh[g] = g < G ? sh[g] : 0.f;
+    }
+    for (int e = tid; e < PF; e += 256) sFin[e] = 0.f;
+
+    float4 accAB[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) accAB[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float tsc[LT][4], tsh[LT][4], gbw[GT][4];
+#pragma unroll
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tsc[t][r] = tsh[t][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gbw[t][r] = 0.f;
+    v4f accW[NTW];
+#pragma unroll
+    for (int e = 0; e < NTW; ++e) accW[e] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    for (long long base = (long long)blockIdx.x * PW; base < n; base += (long long)gridDim.x * PW) {
+        const long long pt = base + p;
+        const bool act = pt < n;
+        __syncthreads();  // parameter staging (first trip) / readers of the previous point are done
+        if (sub == 0) {
+            if (lane < 16) {
+                Rel r;
+                r.x = r.y = r.z = 0.f;
+                r.src = -1;
+                if (act && lane < k) r = rel_pos(coord, idx, pt * k + lane, (int)pt);
+                sPos[p * 16 + lane] = make_float4(r.x, r.y, r.z, 0.f);
+                sSrc[p * 16 + lane] = r.src;
+            }
+            for (int ch = lane; ch < C; ch += WAVE) sGo[p * C + ch] = act ? g_out[pt * C + ch] : 0.f;
+            if (lane < G16) sGsw[p * G16 + lane] = (act && lane < G) ? g_sw[pt * G + lane] : 0.f;
+        }
+        __syncthreads();
+        const float4 myp = sPos[p * 16 + l15];
+        const int mysrc = sSrc[p * 16 + l15];
+        const bool valid = mysrc >= 0;
+        const bool rowok = act && l15 < k;
+        const long long row = pt * k + l15;
+        float4 rp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rp[r] = sPos[p * 16 + 4 * q + r];
+
+        // ---- y = ReLU(sc W1 + sh) in the layout lane = (s = l15; j = 16 t + 4 q + r)
+        float u1[GT][4], y[GT][4];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int j0 = 16 * t + 4 * q;
+            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowok) {
+                if (G % 4 == 0) {
+                    if (j0 < G) uu = *(const float4 *)(W1 + row * G + j0);
+                } else {
+                    if (j0 < G) { const float2 t2 = *(const float2 *)(W1 + row * G + j0); uu.x = t2.x; uu.y = t2.y; }
+                    if (j0 + 2 < G) { const float2 t2 = *(const float2 *)(W1 + row * G + j0 + 2); uu.z = t2.x; uu.w = t2.y; }
+                }
+            }
+            const float4 s4 = *(const float4 *)(sSc + j0), h4 = *(const float4 *)(sSh + j0);
+            u1[t][0] = uu.x; u1[t][1] = uu.y; u1[t][2] = uu.z; u1[t][3] = uu.w;
+            y[t][0] = fmaxf(__builtin_fmaf(s4.x, uu.x, h4.x), 0.f);
+            y[t][1] = fmaxf(__builtin_fmaf(s4.y, uu.y, h4.y), 0.f);
+            y[t][2] = fmaxf(__builtin_fmaf(s4.z, uu.z, h4.z), 0.f);
+            y[t][3] = fmaxf(__builtin_fmaf(s4.w, uu.w, h4.w), 0.f);
+        }
+        // ---- z^T = Ww2 y^T + bw2, softmax over the 16 slots (= the 16 lanes of a DPP row)
+        float sm[GT][4], wm[GT][4];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) {
+            v4f z = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const float4 w4 = *(const float4 *)(sWw + (16 * tg + l15) * GPW + 16 * t + 4 * q);
+                z = mfma4(w4.x, y[t][0], z);
+                z = mfma4(w4.y, y[t][1], z);
+                z = mfma4(w4.z, y[t][2], z);
+                z = mfma4(w4.w, y[t][3], z);
+            }
+            const float4 b4 = *(const float4 *)(sBw + 16 * tg + 4 * q);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zz = l15 < k ? z[r] + bb[r] : -3.0e38f;
+                const float mx = row16_max(zz);
+                const float e = l15 < k ? expf(zz - mx) : 0.f;
+                const float den = row16_sum(e);
+                sm[tg][r] = e / den;
+                wm[tg][r] = valid ? sm[tg][r] : 0.f;
+            }
+        }
+        // ---- gw^T (g,s) partial over my channels: g_A P^T + Gm v[idx]^T
+        v4f gwT[GT];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) gwT[tg] = (v4f){0.f, 0.f, 0.f, 0.f};
+        {
+            const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
+            const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
+            const float *garow[GT];
+            bool gaok[GT];
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg) {
+                const int g = 16 * tg + l15;
+                gaok[tg] = act && g < G;
+                garow[tg] = g_A + ((pt * G + (gaok[tg] ? g : 0)) * C + chq);
+            }
+#pragma unroll 2
+            for (int s4 = 0; s4 < CS; s4 += 4) {
+                const float4 vv = (valid && act) ? *(const float4 *)(vrow + s4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 go = *(const float4 *)(sGo + p * C + chq + s4);
+                float4 ga4[GT];
+#pragma unroll
+                for (int tg = 0; tg < GT; ++tg)
+                    ga4[tg] = gaok[tg] ? *(const float4 *)(garow[tg] + s4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float vve[4] = {vv.x, vv.y, vv.z, vv.w}, goe[4] = {go.x, go.y, go.z, go.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = chq + s4 + e;
+                    const float4 ab = sAB[ch];
+                    const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
+                    const int gi = ch / I;
+#pragma unroll
+                    for (int tg = 0; tg < GT; ++tg) {
+                        const float gav = e == 0 ? ga4[tg].x : (e == 1 ? ga4[tg].y : (e == 2 ? ga4[tg].z : ga4[tg].w));
+                        gwT[tg] = mfma4(gav, P, gwT[tg]);
+                        gwT[tg] = mfma4(gi == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
+                    }
+                }
+            }
+        }
+        // ---- (ga, gb) partial sums: gP (s,ch) = w g_A for my channel tiles, rows s = 4 q + r
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int ch = c0 + 16 * u + l15;
+            v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * tg + 4 * q + r;
+                    const float bv = (act && g < G) ? g_A[(pt * G + g) * C + ch] : 0.f;
+                    d = mfma4(wm[tg][r], bv, d);
+                }
+            const float4 ab = sAB[ch];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rp[r].x, rp[r].y, rp[r].z);
+                const float gpre = P > 0.f ? d[r] : 0.f;
+                accAB[u].x = __builtin_fmaf(gpre, rp[r].x, accAB[u].x);
+                accAB[u].y = __builtin_fmaf(gpre, rp[r].y, accAB[u].y);
+                accAB[u].z = __builtin_fmaf(gpre, rp[r].z, accAB[u].z);
+                accAB[u].w += gpre;
+            }
+        }
+        // ---- combine the channel parts of gw^T, add g_sw
+        float gw[GT][4];
+        if (NW > 1) {
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sRed[((p * NW + sub) * G16 + 16 * tg + 4 * q + r) * 16 + l15] = gwT[tg][r];
+            __syncthreads();
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) t += sRed[((p * NW + w) * G16 + 16 * tg + 4 * q + r) * 16 + l15];
+                    gw[tg][r] = t;
+                }
+        } else {
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[tg][r] = gwT[tg][r];
+        }
+        // ---- softmax backward: gz = sm * (gm - <sm, gm>_s)
+        float gz[GT][4];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) {
+            const float4 s4 = *(const float4 *)(sGsw + p * G16 + 16 * tg + 4 * q);
+            const float gs[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gm = valid ? gw[tg][r] + gs[r] : 0.f;
+                const float dot = row16_sum(sm[tg][r] * gm);
+                gz[tg][r] = rowok ? sm[tg][r] * (gm - dot) : 0.f;
+            }
+        }
+        // ---- gy^T (j,s) = Ww2^T gz^T for my j tiles -> gW1, gsc, gsh
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) {
+            const int tj = lt * NW + sub;
+            if (tj < GT) {  // wave-uniform
+                v4f gy = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gy = mfma4(sWw[(16 * tg + 4 * q + r) * GPW + 16 * tj + l15], gz[tg][r], gy);
+                const int j0 = 16 * tj + 4 * q;
+                const float4 s4 = *(const float4 *)(sSc + j0);
+                const float scv[4] = {s4.x, s4.y, s4.z, s4.w};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // y / u1 of tile tj (tj is a compile-time function of lt only when NW == 1; select by value)
+                    float yv = 0.f, uv = 0.f;
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+                        if (t == tj) { yv = y[t][r]; uv = u1[t][r]; }
+                    const float gu = yv > 0.f ? gy[r] : 0.f;
+                    tsc[lt][r] = __builtin_fmaf(gu, uv, tsc[lt][r]);
+                    tsh[lt][r] += gu;
+                    o[r] = gu * scv[r];
+                }
+                if (rowok) {
+                    if (G % 4 == 0) {
+                        if (j0 < G) *(float4 *)(gW1 + row * G + j0) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+                        if (j0 < G) *(float2 *)(gW1 + row * G + j0) = make_float2(o[0], o[1]);
+                        if (j0 + 2 < G) *(float2 *)(gW1 + row * G + j0 + 2) = make_float2(o[2], o[3]);
+                    }
+                }
+            }
+        }
+        // ---- gWw2 (g,j) += gz^T y, gbw2 += sum_s gz: contraction over s needs the (g,s) tiles transposed
+        if (sub == 0) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sGz[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = gz[t][r];
+                    sY[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = y[t][r];
+                    gbw[t][r] += gz[t][r];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NTW; ++e) {
+            const int te = e * NW + sub;
+            if (te < GT * GT) {  // wave-uniform
+                const int tg = te / GT, tj = te - tg * GT;
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    accW[e] = mfma4(sGz[(p * G16 + 16 * tg + l15) * 17 + 4 * st + q],
+                                    sY[(p * G16 + 16 * tj + l15) * 17 + 4 * st + q], accW[e]);
+            }
+        }
+    }
+
+    // ---- workgroup record: the four wavefronts add their sums one after another (fixed order)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u].x += __shfl_xor(accAB[u].x, 16, WAVE); accAB[u].x += __shfl_xor(accAB[u].x, 32, WAVE);
+        accAB[u].y += __shfl_xor(accAB[u].y, 16, WAVE); accAB[u].y += __shfl_xor(accAB[u].y, 32, WAVE);
+        accAB[u].z += __shfl_xor(accAB[u].z, 16, WAVE); accAB[u].z += __shfl_xor(accAB[u].z, 32, WAVE);
+        accAB[u].w += __shfl_xor(accAB[u].w, 16, WAVE); accAB[u].w += __shfl_xor(accAB[u].w, 32, WAVE);
+    }
+#pragma unroll
+    for (int t = 0; t < LT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tsc[t][r] = row16_sum(tsc[t][r]); tsh[t][r] = row16_sum(tsh[t][r]); }
+#pragma unroll
+    for (int t = 0; t < GT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gbw[t][r] = row16_sum(gbw[t][r]);
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wid == turn) {
+            if (q == 0) {
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    float *d = sFin + 4 * (c0 + 16 * u + l15);
+                    d[0] += accAB[u].x; d[1] += accAB[u].y; d[2] += accAB[u].z; d[3] += accAB[u].w;
+                }
+            }
+            if (l15 == 0) {
+#pragma unroll
+                for (int lt = 0; lt < LT; ++lt) {
+                    const int tj = lt * NW + sub;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * tj + 4 * q + r;
+                        if (tj < GT && j < G) { sFin[4 * C + j] += tsc[lt][r]; sFin[4 * C + G + j] += tsh[lt][r]; }
+                    }
+                }
+                if (sub == 0) {
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = 16 * t + 4 * q + r;
+                            if (g < G) sFin[4 * C + 2 * G + G * G + g] += gbw[t][r];
+                        }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NTW; ++e) {
+                const int te = e * NW + sub;
+                if (te < GT * GT) {
+                    const int tg = te / GT, tj = te - tg * GT;
+                    const int j = 16 * tj + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int g = 16 * tg + 4 * q + r;
+                        if (g < G && j < G) sFin[4 * C + 2 * G + g * G + j] += accW[e][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < PF; e += 256) part[(size_t)blockIdx.x * PF + e] = sFin[e];
+}
+
+struct MapBwdPoint {  // columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
+    float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
+    int c, g;
+    __device__ void operator()(int e, double v) const {
+        if (e < 4 * c) {
+            const int ch = e >> 2, j = e & 3;
+            if (j < 3) ga[ch * 3 + j] = (float)v; else gb[ch] = (float)v;
+        } else if (e < 4 * c + g) gsc[e - 4 * c] = (float)v;
+        else if (e < 4 * c + 2 * g) gsh[e - 4 * c - g] = (float)v;
+        else if (e < 4 * c + 2 * g + g * g) gWw2[e - 4 * c - 2 * g] = (float)v;
+        else gbw2[e - 4 * c - 2 * g - g * g] = (float)v;
+    }
+};
+
+template <int G, int C, int NW>
+int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2,
+                     const float *v, const float *a, const float *b, const float *coord, const int *idx, const float *g_out,
+                     const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2,
+                     float *ga, float *gb, float *part, size_t part_floats_avail, hipStream_t st) {
+    using K = BwdPointCfg<G, C, NW>;
+    const size_t lds = sizeof(float) * K::lds_floats;
+    // grid: enough workgroups to fill the chip, few enough that the partial records stay a small fraction of the
+    // traffic (<= 8 MB)
+    long long cap = (long long)(8u << 20) / (long long)(sizeof(float) * K::PF);
+    cap = std::max<long long>(256, std::min<long long>(cap / 256 * 256, 2048));
+    const long long groups = ((long long)n + K::PW - 1) / K::PW;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
+    if ((size_t)nblk * K::PF > part_floats_avail) return PTV2_ERR_WORKSPACE;
+    auto kern = attention_bwd_point_kernel<G, C, NW>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw,
+                       gW1, part);
+    launch_finalize(st, (const float *)part, nblk, K::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
+    return PTV2_OK;
+}
+
+}  // namespace gva
+
+// returns 1 when (g, c, k) has a point-kernel instantiation
+int gva_bwd_point_supported(int k, int c, int g) {
+    if (k < 1 || k > 16) return 0;
+    return (g == 6 && c == 48) || (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384) ||
+           (g == 64 && c == 512);
+}
+
+size_t gva_bwd_point_part_floats(int c, int g) {
+    const size_t pf = 4 * (size_t)c + 3 * (size_t)g + (size_t)g * g;
+    return std::max<size_t>((8u << 20) / sizeof(float), 256 * pf) + 1024;
+}
+
+int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                         const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
+                         const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
+                         float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
+                         hipStream_t st) {
+    using namespace gva;
+#define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st
+    if (g == 6 && c == 48) return launch_bwd_point<6, 48, 1>(ARGS);
+    if (g == 12 && c == 96) return launch_bwd_point<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return launch_bwd_point<24, 192, 2>(ARGS);
+    if (g == 48 && c == 384) return launch_bwd_point<48, 384, 4>(ARGS);
+    if (g == 64 && c == 512) return launch_bwd_point<64, 512, 4>(ARGS);
+#undef ARGS
+    return PTV2_ERR_ARG;
+}

@@ -338,6 +338,8 @@ class PointTransformerV2(nn.Module):
     def forward(self, data_dict, geometry=None):
         coord, feat = data_dict["coord"], data_dict["feat"]
         offset = data_dict["offset"].int()
+        if geometry is None:
+            geometry = data_dict.get("geometry")  # prebuilt SceneGeometry (parallel.GeometryPrefetcher)
         geo = geometry if geometry is not None else self.geometry(coord, offset)
         lv = geo.levels
         pe = self.patch_embed

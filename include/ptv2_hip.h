@@ -42,8 +42,11 @@ const char *ptv2_build_info(void);
 /* Optional per-kernel timer (measurement aid, off by default; bench.py's roofline object uses it).
  * enable(1) clears the table and makes every launcher bracket its main kernel with HIP events on the launch
  * stream; read() synchronises on them and returns, for kernel id kid in [0, kernel_count), its name (>= 64
- * bytes), the summed duration in microseconds, the number of launches and the mean algorithmic bytes. */
+ * bytes), the summed duration in microseconds, the number of launches and the mean algorithmic bytes.
+ * select(kid >= 0) restricts the bracketing to one kernel id (so a whole-step timing is not perturbed), select(-1)
+ * restores all. */
 int ptv2_profile_enable(int on);
+int ptv2_profile_select(int kid);
 int ptv2_profile_is_on(void);
 int ptv2_profile_kernel_count(void);
 int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch);

@@ -13,12 +13,20 @@ opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=Tru
 b = synth.scene_batch([0], point_max=pts, room=1)
 data = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
+from ao_amd.ptv2 import parallel
+pre = parallel.GeometryPrefetcher(seg.backbone, dev) if os.environ.get("AO_AMD_PREFETCH", "1") == "1" else None
+if pre:
+    pre.start(data["coord"], data["offset"])
+
 def step(marks=None):
     t = time.perf_counter()
-    loss = seg(data)["loss"]
+    batch = data if pre is None else dict(data, geometry=pre.take())
+    loss = seg(batch)["loss"]
     t1 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
     loss.backward()
+    if pre:
+        pre.start(data["coord"], data["offset"])
     t2 = time.perf_counter()
     opt.step()
     t3 = time.perf_counter()

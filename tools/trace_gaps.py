@@ -5,7 +5,7 @@ Prints the busy time, the idle gaps and, per kernel name, launches and time spli
 import csv, glob, sys, collections
 d = sys.argv[1]
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 rows = rows[int(len(rows) * skip):]  # drop warm-up part
