@@ -53,6 +53,8 @@ _SIGNATURES = {
     "dense_workspace_bytes": (_c_size, [_c_int] * 3),
     "bn_stats_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [ctypes.c_float] * 2 + [_vp, _c_size, _vp]),
     "bn_apply_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 5 + [_c_int, _vp, _vp]),
+    "bn_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 3 + [_c_int] + [_vp] * 5 + [ctypes.c_float] * 2 + [_vp] * 4
+                                + [_c_size, _vp]),
     "bn_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
     "linear_wgrad_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5 + [_c_size, _vp]),
     "bn_apply_residual_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 9),

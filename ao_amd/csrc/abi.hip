@@ -1,5 +1,6 @@
 // ao_amd/csrc/abi.hip -- library identification and the optional per-kernel timer (host only).
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -8,6 +9,26 @@ extern "C" int ptv2_abi_version(void) { return 1; }
 
 extern "C" const char *ptv2_build_info(void) {
     return "libptv2_hip gfx950 (MI355X) hipcc " __VERSION__ " built " __DATE__;
+}
+
+// ------------------------------------------------------- per-stream arrival counters --
+// Kernels that finish their own per-block partial sums ("last block done", gva_common.h) need a zeroed device
+// counter; the last block resets it, so one small array per stream lives for the life of the library (kernels
+// on one stream are serialised, each launcher uses its own slot).
+namespace {
+std::mutex g_cnt_mu;
+std::unordered_map<hipStream_t, unsigned *> g_counters;
+}  // namespace
+
+unsigned *ptv2_stream_counters(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_cnt_mu);
+    auto it = g_counters.find(st);
+    if (it != g_counters.end()) return it->second;
+    unsigned *p = nullptr;
+    if (hipMalloc((void **)&p, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
+    g_counters[st] = p;
+    return p;
 }
 
 // ---------------------------------------------------------------- kernel timer --
@@ -20,7 +41,7 @@ const char *kNames[KID_COUNT] = {
     "peb_bwd_kernel", "aggregate_bwd_tile_kernel", "aggregate_bwd_rows_kernel", "aggregate_bwd_gv_kernel",
     "logits_bwd_rows_kernel", "logits_bwd_gather_kernel", "logits_bwd_params_kernel", "linear_wgrad_kernel",
     "bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "skinny_fwd_kernel",
-    "skinny_bwd_kernel", "rows_gemm_kernel"};
+    "skinny_bwd_kernel", "rows_gemm_kernel", "attention_bwd_point_kernel"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;

@@ -153,19 +153,22 @@ extern "C" int ptv2_block_param_layout(int c, int g, long long *offsets) {
     return PTV2_OK;
 }
 
-// batch statistics (training, or no running buffers) or running statistics (eval) of BatchNorm `i` on x (n,c)
-static int bn_prepare(const ptv2_block *B, int i, const float *x, const Saved &S, const Work &W, void *stream, int *batch) {
+// BatchNorm `i` forward on x (n,c): batch statistics (training, or no running buffers) or running statistics
+// (eval); y = [ReLU](BN(x)), or the Block tail ReLU(residual + rowscale * BN(x)) when residual != NULL
+static int bn_fwd(const ptv2_block *B, int i, const float *x, const float *gamma, const float *beta, int relu,
+                  const float *residual, const float *rowscale, float *y, const Saved &S, const Work &W, void *stream) {
     const bool use_batch = B->training || !B->run_mean[i] || !B->run_var[i];
-    *batch = use_batch ? 1 : 0;
     if (use_batch) {
         const bool track = B->training && B->run_mean[i] && B->run_var[i];
-        return bn_stats_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], track ? B->run_mean[i] : nullptr,
-                                     track ? B->run_var[i] : nullptr, track ? B->batches[i] : nullptr, B->eps, B->momentum,
-                                     W.dense, W.dense_bytes, stream);
+        return bn_forward_hip_launcher(B->n, B->c, x, gamma, beta, relu, S.mean[i], S.rstd[i], track ? B->run_mean[i] : nullptr,
+                                       track ? B->run_var[i] : nullptr, track ? B->batches[i] : nullptr, B->eps, B->momentum,
+                                       residual, rowscale, y, W.dense, W.dense_bytes, stream);
     }
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(divup(B->c, 256)), dim3(256), 0, (hipStream_t)stream, B->c,
                        (const float *)B->run_mean[i], (const float *)B->run_var[i], B->eps, S.mean[i], S.rstd[i]);
-    return PTV2_OK;
+    if (residual)
+        return bn_apply_residual_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], gamma, beta, residual, rowscale, y, stream);
+    return bn_apply_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], gamma, beta, relu, y, stream);
 }
 
 extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *workspace, size_t workspace_bytes, void *stream) {
@@ -176,30 +179,23 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     const Work W = carve_work(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     const float *const *P = B->param;
-    int batch;
     // fc1 -> norm1 -> ReLU
     RUN(rows_gemm_hip_launcher(n, c, c, B->x, P[PTV2_BLK_FC1_W], 0, nullptr, S.h1, 0, stream));
-    RUN(bn_prepare(B, 0, S.h1, S, W, stream, &batch));
-    RUN(bn_apply_hip_launcher(n, c, S.h1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, S.f1, stream));
+    RUN(bn_fwd(B, 0, S.h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, nullptr, nullptr, S.f1, S, W, stream));
     // linear_q / linear_k (Linear + BN + ReLU), linear_v
     RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_Q_W], 0, P[PTV2_BLK_Q_B], S.hq, 0, stream));
-    RUN(bn_prepare(B, 1, S.hq, S, W, stream, &batch));
-    RUN(bn_apply_hip_launcher(n, c, S.hq, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, S.q, stream));
+    RUN(bn_fwd(B, 1, S.hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, nullptr, nullptr, S.q, S, W, stream));
     RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_K_W], 0, P[PTV2_BLK_K_B], S.hk, 0, stream));
-    RUN(bn_prepare(B, 2, S.hk, S, W, stream, &batch));
-    RUN(bn_apply_hip_launcher(n, c, S.hk, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, S.key, stream));
+    RUN(bn_fwd(B, 2, S.hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, nullptr, nullptr, S.key, S, W, stream));
     RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_V_W], 0, P[PTV2_BLK_V_B], S.v, 0, stream));
     // grouped vector attention
     ptv2_gva_block V;
     fill_gva(B, S, &V);
     RUN(gva_block_forward_hip_launcher(&V, W.gva, W.gva_bytes, stream));
     // norm2 -> ReLU -> fc3 -> norm3 -> DropPath -> + identity -> ReLU
-    RUN(bn_prepare(B, 5, S.attn, S, W, stream, &batch));
-    RUN(bn_apply_hip_launcher(n, c, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, S.f2, stream));
+    RUN(bn_fwd(B, 5, S.attn, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, nullptr, nullptr, S.f2, S, W, stream));
     RUN(rows_gemm_hip_launcher(n, c, c, S.f2, P[PTV2_BLK_FC3_W], 0, nullptr, S.h3, 0, stream));
-    RUN(bn_prepare(B, 6, S.h3, S, W, stream, &batch));
-    RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
-                                       B->y, stream));
+    RUN(bn_fwd(B, 6, S.h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], 0, B->x, B->rowscale, B->y, S, W, stream));
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -19,7 +19,7 @@ static inline int divup(long long a, long long b) { return (int)((a + b - 1) / b
 enum PtvKernelId {
     KID_KNN_QUERY = 0, KID_LOGITS_FWD, KID_SOFTMAX_ROWS, KID_AGG_TILE, KID_PEB_FWD, KID_PEB_BWD, KID_BWD_TILE,
     KID_BWD_ROWS, KID_BWD_GV, KID_LOGITS_BWD_ROWS, KID_LOGITS_BWD_GATHER, KID_LOGITS_BWD_PARAMS, KID_WGRAD,
-    KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_ROWS_GEMM, KID_COUNT
+    KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_ROWS_GEMM, KID_BWD_POINT, KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);
 int ptv2_profile_wants(int kid);
@@ -32,6 +32,11 @@ struct PtvScopedTimer {
     }
     ~PtvScopedTimer() { if (on) ptv2_profile_end(kid, st, bytes); }
 };
+
+// Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
+#define PTV2_NUM_COUNTERS 64
+enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS };
+unsigned *ptv2_stream_counters(hipStream_t st);
 
 // Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):
 // fma(dz,dz, fma(dx,dx, dy*dy)), q - p per component.  The only add that could be

@@ -496,6 +496,20 @@ extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *
     return PTV2_OK;
 }
 
+// training-mode forward as one call (statistics + running buffers, then the apply pass; residual != NULL selects
+// the Block tail y = ReLU(residual + rowscale * BN(x)))
+extern "C" int bn_forward_hip_launcher(int n, int c, const float *x, const float *gamma, const float *beta, int relu,
+                                       float *mean, float *rstd, float *running_mean, float *running_var,
+                                       long long *num_batches_tracked, float eps, float momentum, const float *residual,
+                                       const float *rowscale, float *y, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
+    const int rc = bn_stats_hip_launcher(n, c, x, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum,
+                                         workspace, workspace_bytes, stream);
+    if (rc != PTV2_OK) return rc;
+    if (residual) return bn_apply_residual_hip_launcher(n, c, x, mean, rstd, gamma, beta, residual, rowscale, y, stream);
+    return bn_apply_hip_launcher(n, c, x, mean, rstd, gamma, beta, relu, y, stream);
+}
+
 extern "C" int bn_apply_residual_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
                                               const float *gamma, const float *beta, const float *residual,
                                               const float *rowscale, float *y, void *stream) {

@@ -73,7 +73,8 @@ __global__ void add_vec_kernel(int len, float *__restrict__ dst, const float *__
 
 // partial[blk][c] = sum over the block's rows of g_out[n,c] * sw[n, c / I]
 __global__ __launch_bounds__(TPB) void bp2_grad_kernel(int n, int c, int g, const float *__restrict__ g_out,
-                                                       const float *__restrict__ sw, float *__restrict__ part) {
+                                                       const float *__restrict__ sw, float *part, unsigned *counter,
+                                                       float *__restrict__ gbp2) {
     extern __shared__ float lds[];
     const int I = c / g;
     const int rl = TPB / c > 0 ? TPB / c : 1;
@@ -87,15 +88,16 @@ __global__ __launch_bounds__(TPB) void bp2_grad_kernel(int n, int c, int g, cons
         lds[threadIdx.x] = acc;
         __syncthreads();
         if (c >= TPB) {
-            if (ch < c) part[(size_t)blockIdx.x * c + ch] = acc;
+            if (ch < c) part_store(part + (size_t)blockIdx.x * c + ch, acc);
         } else if (threadIdx.x < c) {
             float t = 0.f;
             for (int kk = 0; kk < rl; ++kk) t += lds[kk * c + threadIdx.x];
-            part[(size_t)blockIdx.x * c + threadIdx.x] = t;
+            part_store(part + (size_t)blockIdx.x * c + threadIdx.x, t);
         }
         __syncthreads();
         if (c < TPB) break;
     }
+    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, c, MapVec<float>{gbp2});
 }
 
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -244,8 +246,12 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     {
         const int rl = std::max(1, TPB / c);
         const int nblk = (int)std::min<long long>(((long long)n + rl * 8 - 1) / (rl * 8), MAX_BLOCKS);
-        hipLaunchKernelGGL(bp2_grad_kernel, dim3(nblk), dim3(TPB), sizeof(float) * TPB, st, n, c, g, G->g_out, B->sw, W.part);
-        launch_finalize(st, (const float *)W.part, nblk, c, MapVec<float>{G->gbp2});
+        const bool own_final = (size_t)nblk * c <= FUSED_FINAL_MAX;
+        unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
+        if (own_final && !cnt) return PTV2_ERR_LAUNCH;
+        hipLaunchKernelGGL(bp2_grad_kernel, dim3(nblk), dim3(TPB), sizeof(float) * TPB, st, n, c, g, G->g_out, B->sw, W.part,
+                           cnt ? cnt + CNT_BP2 : nullptr, G->gbp2);
+        if (!own_final) launch_finalize(st, (const float *)W.part, nblk, c, MapVec<float>{G->gbp2});
     }
     // 2. softmax / aggregation stage
     RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,

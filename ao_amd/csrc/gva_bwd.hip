@@ -36,7 +36,7 @@ __global__ __launch_bounds__(TPB) void logits_bwd_rows_kernel(long long rows, co
                                                               const float *__restrict__ gW1,
                                                               const double *__restrict__ gT1,
                                                               const double *__restrict__ gT2, float *__restrict__ gWt,
-                                                              float *__restrict__ part) {
+                                                              float *part, unsigned *counter, float *__restrict__ gcW) {
     __shared__ float s_w[WPB][G];
     float t[G], c1[G], c2[G];
 #pragma unroll
@@ -58,8 +58,9 @@ __global__ __launch_bounds__(TPB) void logits_bwd_rows_kernel(long long rows, co
     if (threadIdx.x < G) {
         float v = 0.f;
         for (int w = 0; w < WPB; ++w) v += s_w[w][threadIdx.x];
-        part[(size_t)blockIdx.x * G + threadIdx.x] = v;
+        part_store(part + (size_t)blockIdx.x * G + threadIdx.x, v);
     }
+    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, G, MapVec<float>{gcW});
 }
 
 // grad qW[j,g] = -sum_s gWt[j,s,g];  grad kW[j,g] = sum over slots that point at j
@@ -221,10 +222,14 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     float *gWt = (float *)((char *)workspace + rows_offset_bytes(c, g));
     const int nb_rows = stage_grid(rows, TPB * 2);
 #define CALL(GG) \
-    hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part)
+    hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part, \
+                       cnt ? cnt + CNT_LOGITS_BWD_ROWS : nullptr, gcW)
+    const bool own_final = (size_t)nb_rows * g <= FUSED_FINAL_MAX;
+    unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
+    if (own_final && !cnt) return PTV2_ERR_LAUNCH;
     GVA_DISPATCH_G(g, CALL)
 #undef CALL
-    launch_finalize(st, (const float *)part, nb_rows, g, MapVec<float>{gcW});
+    if (!own_final) launch_finalize(st, (const float *)part, nb_rows, g, MapVec<float>{gcW});
     hipLaunchKernelGGL(logits_bwd_gather_kernel, dim3(stage_grid((long long)n * g, TPB)), dim3(TPB), 0, st, n, k, g,
                        (const float *)gWt, idx, inv_ptr, inv_rows, gkW, gqW);
     // params kernel: its partials go after the rows-kernel partials (still inside the partial region)

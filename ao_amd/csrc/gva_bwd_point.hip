@@ -61,8 +61,9 @@ struct BwdPointCfg {
                          UT = CW / 16, I = C / G, PF = 4 * C + 3 * G + G * G;
     static constexpr int LT = (GT + NW - 1) / NW;            // group tiles per wave in the j-parallel phase
     static constexpr int NTW = (GT * GT + NW - 1) / NW;      // gWw2 tiles per wave
-    static constexpr size_t lds_floats = 4 * (size_t)C + (size_t)G16 * GPW + 3 * G16 + PW * 16 * 4 + PW * 16 + (size_t)PW * C +
-                                         PW * G16 + (NW > 1 ? (size_t)PW * NW * G16 * 16 : 0) + 2 * (size_t)PW * G16 * 17 + PF;
+    static constexpr size_t lds_floats = 4 * (size_t)C + (size_t)G16 * GPW + 3 * G16 +
+                                         2 * (PW * 16 * 4 + PW * 16 + (size_t)PW * C + PW * G16) +
+                                         (NW > 1 ? (size_t)PW * NW * G16 * 16 : 0) + 2 * (size_t)PW * G16 * 17 + PF;
 };
 
 // part[blockIdx.x][PF]: [4C] (ga.xyz, gb) per channel, [G] gsc, [G] gsh, [G*G] gWw2, [G] gbw2
@@ -82,11 +83,11 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
     float *sBw = sWw + G16 * GPW;                         // [G16]
     float *sSc = sBw + G16;
     float *sSh = sSc + G16;
-    float4 *sPos = (float4 *)(sSh + G16);                 // [PW][16]
-    int *sSrc = (int *)(sPos + PW * 16);                  // [PW][16]
-    float *sGo = (float *)(sSrc + PW * 16);               // [PW][C]     g_out row of the point
-    float *sGsw = sGo + PW * C;                           // [PW][G16]
-    float *sRed = sGsw + PW * G16;                        // [PW][NW][G16][16]
+    float4 *sPos = (float4 *)(sSh + G16);                 // [2][PW][16]   (double-buffered point records)
+    int *sSrc = (int *)(sPos + 2 * PW * 16);              // [2][PW][16]
+    float *sGo = (float *)(sSrc + 2 * PW * 16);           // [2][PW][C]     g_out row of the point
+    float *sGsw = sGo + 2 * PW * C;                       // [2][PW][G16]
+    float *sRed = sGsw + 2 * PW * G16;                    // [PW][NW][G16][16]
     float *sGz = sRed + (NW > 1 ? PW * NW * G16 * 16 : 0);  // [PW][G16][17]
     float *sY = sGz + PW * G16 * 17;                      // [PW][G16][17]
     float *sFin = sY + PW * G16 * 17;                     // [PF]
@@ -124,52 +125,127 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
 #pragma unroll
     for (int e = 0; e < NTW; ++e) accW[e] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    for (long long base = (long long)blockIdx.x * PW; base < n; base += (long long)gridDim.x * PW) {
-        const long long pt = base + p;
-        const bool act = pt < n;
-        __syncthreads();  // parameter staging (first trip) / readers of the previous point are done
+    // Software pipeline over the points of this workgroup: everything of point i+1 whose address does not depend on
+    // computed values (neighbour ids -> relative positions, its g_out / g_sw rows, its logits rows) is requested at
+    // the top of iteration i and lands in registers while point i is processed; the staged part moves to the other
+    // half of a double-buffered LDS record at the end of the iteration.  Without this a point costs four serialised
+    // HBM latencies (idx -> coord -> W1 -> g_A / v) and the kernel is latency-bound at ~3 waves per SIMD.
+    constexpr int GOV = (C + WAVE - 1) / WAVE;
+    struct Stage { float x, y, z; int src; float go[GOV]; float gsw; };
+    auto stage_load = [&](long long ptn, bool actn, Stage &S) {
+        S.x = S.y = S.z = 0.f; S.src = -1; S.gsw = 0.f;
+#pragma unroll
+        for (int i = 0; i < GOV; ++i) S.go[i] = 0.f;
+        if (sub == 0 && actn) {
+            if (lane < 16 && lane < k) {
+                const Rel r = rel_pos(coord, idx, ptn * k + lane, (int)ptn);
+                S.x = r.x; S.y = r.y; S.z = r.z; S.src = r.src;
+            }
+#pragma unroll
+            for (int i = 0; i < GOV; ++i)
+                if (lane + WAVE * i < C) S.go[i] = g_out[ptn * C + lane + WAVE * i];
+            if (lane < G) S.gsw = g_sw[ptn * G + lane];
+        }
+    };
+    auto stage_store = [&](int buf, const Stage &S) {
         if (sub == 0) {
             if (lane < 16) {
-                Rel r;
-                r.x = r.y = r.z = 0.f;
-                r.src = -1;
-                if (act && lane < k) r = rel_pos(coord, idx, pt * k + lane, (int)pt);
-                sPos[p * 16 + lane] = make_float4(r.x, r.y, r.z, 0.f);
-                sSrc[p * 16 + lane] = r.src;
+                sPos[(buf * PW + p) * 16 + lane] = make_float4(S.x, S.y, S.z, 0.f);
+                sSrc[(buf * PW + p) * 16 + lane] = S.src;
             }
-            for (int ch = lane; ch < C; ch += WAVE) sGo[p * C + ch] = act ? g_out[pt * C + ch] : 0.f;
-            if (lane < G16) sGsw[p * G16 + lane] = (act && lane < G) ? g_sw[pt * G + lane] : 0.f;
+#pragma unroll
+            for (int i = 0; i < GOV; ++i)
+                if (lane + WAVE * i < C) sGo[(buf * PW + p) * C + lane + WAVE * i] = S.go[i];
+            if (lane < G16) sGsw[(buf * PW + p) * G16 + lane] = S.gsw;
         }
-        __syncthreads();
-        const float4 myp = sPos[p * 16 + l15];
-        const int mysrc = sSrc[p * 16 + l15];
+    };
+    auto load_w1 = [&](long long ptn, bool actn, float (&u)[GT][4]) {
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int j0 = 16 * t + 4 * q;
+            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (actn && l15 < k) {
+                const float *src = W1 + (ptn * k + l15) * G + j0;
+                if (G % 4 == 0) {
+                    if (j0 < G) uu = *(const float4 *)src;
+                } else {
+                    if (j0 < G) { const float2 t2 = *(const float2 *)src; uu.x = t2.x; uu.y = t2.y; }
+                    if (j0 + 2 < G) { const float2 t2 = *(const float2 *)(src + 2); uu.z = t2.x; uu.w = t2.y; }
+                }
+            }
+            u[t][0] = uu.x; u[t][1] = uu.y; u[t][2] = uu.z; u[t][3] = uu.w;
+        }
+    };
+
+    const long long stride = (long long)gridDim.x * PW;
+    Stage S;
+    float u1n[GT][4];
+    {
+        const long long pt0 = (long long)blockIdx.x * PW + p;
+        stage_load(pt0, pt0 < n, S);
+        stage_store(0, S);
+        load_w1(pt0, pt0 < n, u1n);
+    }
+    int cur = 0;
+    for (long long base = (long long)blockIdx.x * PW; base < n; base += stride, cur ^= 1) {
+        const long long pt = base + p;
+        const bool act = pt < n;
+        __syncthreads();  // record `cur` (and, on the first trip, the parameters) is in LDS; last trip's readers are done
+        const float4 *cPos = sPos + (cur * PW + p) * 16;
+        const int *cSrc = sSrc + (cur * PW + p) * 16;
+        const float *cGo = sGo + (cur * PW + p) * C;
+        const float *cGsw = sGsw + (cur * PW + p) * G16;
+        const float4 myp = cPos[l15];
+        const int mysrc = cSrc[l15];
         const bool valid = mysrc >= 0;
         const bool rowok = act && l15 < k;
         const long long row = pt * k + l15;
         float4 rp[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rp[r] = sPos[p * 16 + 4 * q + r];
+        for (int r = 0; r < 4; ++r) rp[r] = cPos[4 * q + r];
+
+        // operands of the first channel chunks of this point, then the requests for the next point
+        const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
+        const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
+        const float *garow[GT];
+        bool gaok[GT];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) {
+            const int g = 16 * tg + l15;
+            gaok[tg] = act && g < G;
+            garow[tg] = g_A + ((pt * G + (gaok[tg] ? g : 0)) * C + chq);
+        }
+        constexpr int NCH = CS / 4;                                   // channel chunks of 4 contraction steps
+        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (GT == 2 ? 2 : 1);  // chunks in flight
+        float4 rvv[PD], rga[PD][GT];
+        auto fetch_chunk = [&](int ci, int slot) {
+            rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+                rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+#pragma unroll
+        for (int ci = 0; ci < PD; ++ci) fetch_chunk(ci, ci);
+        {
+            const long long ptn = pt + stride;
+            stage_load(ptn, ptn < n, S);
+        }
+        float u1[GT][4], y[GT][4];
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u1[t][r] = u1n[t][r];
+        load_w1(pt + stride, pt + stride < n, u1n);
 
         // ---- y = ReLU(sc W1 + sh) in the layout lane = (s = l15; j = 16 t + 4 q + r)
-        float u1[GT][4], y[GT][4];
 #pragma unroll
         for (int t = 0; t < GT; ++t) {
             const int j0 = 16 * t + 4 * q;
-            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowok) {
-                if (G % 4 == 0) {
-                    if (j0 < G) uu = *(const float4 *)(W1 + row * G + j0);
-                } else {
-                    if (j0 < G) { const float2 t2 = *(const float2 *)(W1 + row * G + j0); uu.x = t2.x; uu.y = t2.y; }
-                    if (j0 + 2 < G) { const float2 t2 = *(const float2 *)(W1 + row * G + j0 + 2); uu.z = t2.x; uu.w = t2.y; }
-                }
-            }
             const float4 s4 = *(const float4 *)(sSc + j0), h4 = *(const float4 *)(sSh + j0);
-            u1[t][0] = uu.x; u1[t][1] = uu.y; u1[t][2] = uu.z; u1[t][3] = uu.w;
-            y[t][0] = fmaxf(__builtin_fmaf(s4.x, uu.x, h4.x), 0.f);
-            y[t][1] = fmaxf(__builtin_fmaf(s4.y, uu.y, h4.y), 0.f);
-            y[t][2] = fmaxf(__builtin_fmaf(s4.z, uu.z, h4.z), 0.f);
-            y[t][3] = fmaxf(__builtin_fmaf(s4.w, uu.w, h4.w), 0.f);
+            y[t][0] = fmaxf(__builtin_fmaf(s4.x, u1[t][0], h4.x), 0.f);
+            y[t][1] = fmaxf(__builtin_fmaf(s4.y, u1[t][1], h4.y), 0.f);
+            y[t][2] = fmaxf(__builtin_fmaf(s4.z, u1[t][2], h4.z), 0.f);
+            y[t][3] = fmaxf(__builtin_fmaf(s4.w, u1[t][3], h4.w), 0.f);
         }
         // ---- z^T = Ww2 y^T + bw2, softmax over the 16 slots (= the 16 lanes of a DPP row)
         float sm[GT][4], wm[GT][4];
@@ -200,38 +276,27 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
         v4f gwT[GT];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) gwT[tg] = (v4f){0.f, 0.f, 0.f, 0.f};
-        {
-            const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
-            const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
-            const float *garow[GT];
-            bool gaok[GT];
 #pragma unroll
-            for (int tg = 0; tg < GT; ++tg) {
-                const int g = 16 * tg + l15;
-                gaok[tg] = act && g < G;
-                garow[tg] = g_A + ((pt * G + (gaok[tg] ? g : 0)) * C + chq);
-            }
-#pragma unroll 2
-            for (int s4 = 0; s4 < CS; s4 += 4) {
-                const float4 vv = (valid && act) ? *(const float4 *)(vrow + s4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 go = *(const float4 *)(sGo + p * C + chq + s4);
-                float4 ga4[GT];
+        for (int ci = 0; ci < NCH; ++ci) {
+            const int slot = ci % PD;
+            const float4 vv = rvv[slot];
+            float4 ga4[GT];
 #pragma unroll
-                for (int tg = 0; tg < GT; ++tg)
-                    ga4[tg] = gaok[tg] ? *(const float4 *)(garow[tg] + s4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float vve[4] = {vv.x, vv.y, vv.z, vv.w}, goe[4] = {go.x, go.y, go.z, go.w};
+            for (int tg = 0; tg < GT; ++tg) ga4[tg] = rga[slot][tg];
+            if (ci + PD < NCH) fetch_chunk(ci + PD, slot);
+            const float4 go = *(const float4 *)(cGo + chq + 4 * ci);
+            const float vve[4] = {vv.x, vv.y, vv.z, vv.w}, goe[4] = {go.x, go.y, go.z, go.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ch = chq + s4 + e;
-                    const float4 ab = sAB[ch];
-                    const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
-                    const int gi = ch / I;
+            for (int e = 0; e < 4; ++e) {
+                const int ch = chq + 4 * ci + e;
+                const float4 ab = sAB[ch];
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
+                const int gi = ch / I;
 #pragma unroll
-                    for (int tg = 0; tg < GT; ++tg) {
-                        const float gav = e == 0 ? ga4[tg].x : (e == 1 ? ga4[tg].y : (e == 2 ? ga4[tg].z : ga4[tg].w));
-                        gwT[tg] = mfma4(gav, P, gwT[tg]);
-                        gwT[tg] = mfma4(gi == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
-                    }
+                for (int tg = 0; tg < GT; ++tg) {
+                    const float gav = e == 0 ? ga4[tg].x : (e == 1 ? ga4[tg].y : (e == 2 ? ga4[tg].z : ga4[tg].w));
+                    gwT[tg] = mfma4(gav, P, gwT[tg]);
+                    gwT[tg] = mfma4(gi == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
                 }
             }
         }
@@ -286,7 +351,7 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
         float gz[GT][4];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) {
-            const float4 s4 = *(const float4 *)(sGsw + p * G16 + 16 * tg + 4 * q);
+            const float4 s4 = *(const float4 *)(cGsw + 16 * tg + 4 * q);
             const float gs[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -332,6 +397,7 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
                 }
             }
         }
+        stage_store(cur ^ 1, S);  // the next point's record (requested at the top of this iteration)
         // ---- gWw2 (g,j) += gz^T y, gbw2 += sum_s gz: contraction over s needs the (g,s) tiles transposed
         if (sub == 0) {
 #pragma unroll

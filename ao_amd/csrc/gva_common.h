@@ -12,7 +12,8 @@ constexpr int WPB = TPB / WAVE;  // waves per block
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int MAX_BLOCKS = 256 * 8;   // grid cap of the row-parallel stages
-constexpr int MAX_PARAM_BLOCKS = 256; // grid cap of the channel-parallel parameter-gradient stage
+constexpr int MAX_PARAM_BLOCKS = 256;
+constexpr size_t FUSED_FINAL_MAX = 16384;  // floats of partial records up to which the last block sums them itself // grid cap of the channel-parallel parameter-gradient stage
 
 // floats of per-block partial sums any stage may write (the workspace's first region)
 inline size_t part_floats(int c, int g) {
@@ -87,6 +88,50 @@ __global__ __launch_bounds__(FIN_COLS *FIN_SLICES) void finalize_kernel(const fl
 #pragma unroll
         for (int t = 0; t < FIN_SLICES; ++t) v += s_acc[t][col];
         map(j, v);
+    }
+}
+
+// ---- the same final reduction inside the producing kernel ("last block done") -----------------------------
+// Small reductions (a few hundred columns, a few hundred blocks) do not deserve a launch of their own: at deep
+// stages the finalize launches were ~360 of ~2000 launches per step, each 5-6 us of pure latency.  Blocks write
+// their record with agent-scope stores (visible across the 8 XCDs' L2s), bump an agent-scope counter, and the
+// block that arrives last sums all records in block order -- the same fixed order as finalize_kernel, so results
+// stay bitwise reproducible and independent of which block happens to be last.
+__device__ __forceinline__ void part_store(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// only after last_block_arrives() (whose acquire fence dropped stale cache lines): plain loads,
+// so that the column sums pipeline instead of paying one memory round trip per record
+__device__ __forceinline__ float part_load(const float *p) { return *p; }
+// call after the block's part_store()s; true in exactly one block (the last to arrive), in all of its threads
+__device__ __forceinline__ bool last_block_arrives(unsigned *counter) {
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my stores have left the wavefront (waitcnt)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == total - 1;
+        if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    }
+    __syncthreads();
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // records of the other XCDs: invalidate, then read
+    return s_last != 0;
+}
+// column sums of part[nblk][len] by the calling block, four independent chains per column, fixed association
+template <class Map>
+__device__ __forceinline__ void finalize_columns(const float *part, int nblk, int len, Map map) {
+    for (int j = threadIdx.x; j < len; j += blockDim.x) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+            a0 += (double)part_load(part + (size_t)b * len + j);
+            a1 += (double)part_load(part + (size_t)(b + 1) * len + j);
+            a2 += (double)part_load(part + (size_t)(b + 2) * len + j);
+            a3 += (double)part_load(part + (size_t)(b + 3) * len + j);
+        }
+        for (; b < nblk; ++b) a0 += (double)part_load(part + (size_t)b * len + j);
+        map(j, (a0 + a1) + (a2 + a3));
     }
 }
 

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
                                                          const float *__restrict__ qW, const float *__restrict__ a,
                                                          const float *__restrict__ b, const float *__restrict__ M,
                                                          const float *__restrict__ cW, const float *__restrict__ coord,
-                                                         const int *__restrict__ idx, float *__restrict__ W1,
-                                                         float *__restrict__ part) {
+                                                         const int *__restrict__ idx, float *__restrict__ W1, float *part,
+                                                         unsigned *counter, double *__restrict__ T1,
+                                                         double *__restrict__ T2) {
     extern __shared__ float4 lds4[];
     constexpr int G4 = (G + 3) & ~3;
     constexpr int RPB = TPB / SPLIT;  // rows per workgroup iteration
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
     if (threadIdx.x < 2 * G) {
         float v = 0.f;
         for (int w = 0; w < WPB; ++w) v += s_w[w][threadIdx.x];
-        part[(size_t)blockIdx.x * 2 * G + threadIdx.x] = v;
+        part_store(part + (size_t)blockIdx.x * 2 * G + threadIdx.x, v);
     }
+    // small grids finish their own column sums (counter != NULL); large ones leave them to finalize_kernel
+    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, 2 * G, MapSplit2<double>{T1, T2, G});
 }
 
 inline int stage_grid(long long work_items, int per_block) {
@@ -214,19 +217,22 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     const size_t lds = lds_base + (split ? lds_red : 0);
     if (lds > 150 * 1024 || g % 2 != 0) return PTV2_ERR_ARG;
     const int nblk = stage_grid(rows, split ? WAVE : TPB);
+    const bool own_final = (size_t)nblk * 2 * g <= FUSED_FINAL_MAX;
+    unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
+    if (own_final && !cnt) return PTV2_ERR_LAUNCH;
 #define CALL(GG)                                                                                                   \
     if (split) {                                                                                                   \
         if (lds > 32 * 1024)                                                                                       \
             (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                   \
         hipLaunchKernelGGL((logits_fwd_kernel<GG, 4>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
-                           idx, W1, part);                                                                         \
+                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                                                                         \
     } else {                                                                                                       \
         if (lds > 32 * 1024)                                                                                       \
             (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                   \
         hipLaunchKernelGGL((logits_fwd_kernel<GG, 1>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
-                           idx, W1, part);                                                                         \
+                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                                                                         \
     }
     {
         // idx, coord, kW (unique rows once), qW in; W1 out
@@ -234,7 +240,7 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
         GVA_DISPATCH_G(g, CALL)
     }
 #undef CALL
-    launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
+    if (!own_final) launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -328,6 +328,12 @@ size_t dense_workspace_bytes(int n, int cout, int cin);
 int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
                           float *running_var, long long *num_batches_tracked, float eps, float momentum,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* training-mode forward as one call: statistics + running buffers + y = [ReLU](BN(x)), or with residual != NULL the
+ * Block tail y = ReLU(residual + rowscale * BN(x)) */
+int bn_forward_hip_launcher(int n, int c, const float *x, const float *gamma, const float *beta, int relu,
+                            float *mean, float *rstd, float *running_mean, float *running_var,
+                            long long *num_batches_tracked, float eps, float momentum, const float *residual,
+                            const float *rowscale, float *y, void *workspace, size_t workspace_bytes, void *stream);
 int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
                           const float *gamma, const float *beta, int relu, float *y, void *stream);
 int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, const float *mean,
