@@ -439,6 +439,9 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
                          hipStream_t st);
 
+int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st);
+
 static size_t agg_part_bytes(int c, int g) {
     return align_up(sizeof(float) * std::max({(size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g,
                                               gva_bwd_point_part_floats(c, g)}));
@@ -462,10 +465,15 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
     const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS * 4);
     {
         PtvScopedTimer t(KID_SOFTMAX_ROWS, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * g));
+        if (k <= 16 && (g == 12 || g == 24 || g == 48 || g == 64) && !getenv("AO_AMD_BWD_STAGED")) {  // g = 6: rows
+            const int rc = gva_softmax_point_launch(n, k, g, W1, sc, sh, Ww2, bw2, idx, w, sw, st);
+            if (rc != PTV2_OK) return rc;
+        } else {
 #define CALL(GG) \
     hipLaunchKernelGGL(softmax_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, w, sw)
-        GVA_DISPATCH_G(g, CALL)
+            GVA_DISPATCH_G(g, CALL)
 #undef CALL
+        }
     }
     const int tp = std::max(1, TPB / c);
     const size_t lds = (size_t)tp * k * (sizeof(float4) + sizeof(float) * G4of(g) + sizeof(int));

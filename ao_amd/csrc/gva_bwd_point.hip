@@ -488,6 +488,204 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
     for (int e = tid; e < PF; e += 256) part[(size_t)blockIdx.x * PF + e] = sFin[e];
 }
 
+// ================================================================== forward ==
+// w = mask * softmax_s(ReLU(sc W1 + sh) Ww2^T + bw2) and sw = sum_s w, one point per wavefront: the G x G product
+// runs on the matrix cores (z^T = Ww2 y^T, slots as the 16 MFMA columns), the softmax over the 16 slots is a DPP
+// row reduction.  Replaces the per-thread G x G loop of softmax_rows_kernel, which took 100-430 us at the deep
+// stages (G = 24, 48) for 2-8 k points.
+template <int G>
+__global__ __launch_bounds__(256) void attention_softmax_point_kernel(int n, int k, const float *__restrict__ W1,
+                                                                      const float *__restrict__ sc,
+                                                                      const float *__restrict__ sh,
+                                                                      const float *__restrict__ Ww2,
+                                                                      const float *__restrict__ bw2,
+                                                                      const int *__restrict__ idx, float *__restrict__ w,
+                                                                      float *__restrict__ sw) {
+    constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = ww_pitch(G);
+    __shared__ __attribute__((aligned(16))) float sWw[G16 * GPW];
+    __shared__ __attribute__((aligned(16))) float sBw[G16], sSc[G16], sSh[G16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    for (int e = tid; e < G16 * GPW; e += 256) {
+        const int g = e / GPW, j = e - g * GPW;
+        sWw[e] = (g < G && j < G) ? Ww2[g * G + j] : 0.f;
+    }
+    for (int g = tid; g < G16; g += 256) {
+        sBw[g] = g < G ? bw2[g] : 0.f;
+        sSc[g] = g < G ? sc[g] : 0.f;
+        sSh[g] = g < G ? sh[g] : 0.f;
+    }
+    __syncthreads();
+    auto load_w1 = [&](long long pt, float (&u)[GT][4], int &src) {
+        src = -1;
+        const bool ok = pt < n && l15 < k;
+        if (ok) src = idx[pt * k + l15];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int j0 = 16 * t + 4 * q;
+            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float *p = W1 + (pt * k + l15) * G + j0;
+                if (G % 4 == 0) {
+                    if (j0 < G) uu = *(const float4 *)p;
+                } else {
+                    if (j0 < G) { const float2 t2 = *(const float2 *)p; uu.x = t2.x; uu.y = t2.y; }
+                    if (j0 + 2 < G) { const float2 t2 = *(const float2 *)(p + 2); uu.z = t2.x; uu.w = t2.y; }
+                }
+            }
+            u[t][0] = uu.x; u[t][1] = uu.y; u[t][2] = uu.z; u[t][3] = uu.w;
+        }
+    };
+    const long long stride = (long long)gridDim.x * 4;
+    long long pt = (long long)blockIdx.x * 4 + wid;
+    float un[GT][4];
+    int srcn;
+    load_w1(pt, un, srcn);
+    for (; pt < n; pt += stride) {
+        float y[GT][4];
+        const int src = srcn;
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int j0 = 16 * t + 4 * q;
+            const float4 s4 = *(const float4 *)(sSc + j0), h4 = *(const float4 *)(sSh + j0);
+            y[t][0] = fmaxf(__builtin_fmaf(s4.x, un[t][0], h4.x), 0.f);
+            y[t][1] = fmaxf(__builtin_fmaf(s4.y, un[t][1], h4.y), 0.f);
+            y[t][2] = fmaxf(__builtin_fmaf(s4.z, un[t][2], h4.z), 0.f);
+            y[t][3] = fmaxf(__builtin_fmaf(s4.w, un[t][3], h4.w), 0.f);
+        }
+        load_w1(pt + stride, un, srcn);  // next point's rows are in flight while this one is processed
+        const bool valid = src >= 0;
+        const bool rowok = l15 < k;
+        float *wrow = w + (pt * k + l15) * G;
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) {
+            v4f z = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const float4 w4 = *(const float4 *)(sWw + (16 * tg + l15) * GPW + 16 * t + 4 * q);
+                z = mfma4(w4.x, y[t][0], z);
+                z = mfma4(w4.y, y[t][1], z);
+                z = mfma4(w4.z, y[t][2], z);
+                z = mfma4(w4.w, y[t][3], z);
+            }
+            const float4 b4 = *(const float4 *)(sBw + 16 * tg + 4 * q);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float o[4], so[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float zz = rowok ? z[r] + bb[r] : -3.0e38f;
+                const float mx = row16_max(zz);
+                const float e = rowok ? expf(zz - mx) : 0.f;
+                const float den = row16_sum(e);
+                o[r] = valid ? e / den : 0.f;
+                so[r] = row16_sum(o[r]);
+            }
+            const int g0 = 16 * tg + 4 * q;
+            if (rowok) {
+                if (G % 4 == 0) {
+                    if (g0 < G) *(float4 *)(wrow + g0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    if (g0 < G) *(float2 *)(wrow + g0) = make_float2(o[0], o[1]);
+                    if (g0 + 2 < G) *(float2 *)(wrow + g0 + 2) = make_float2(o[2], o[3]);
+                }
+            }
+            if (l15 == 0) {
+                float *sp = sw + pt * G + g0;
+                if (G % 4 == 0) {
+                    if (g0 < G) *(float4 *)sp = make_float4(so[0], so[1], so[2], so[3]);
+                } else {
+                    if (g0 < G) *(float2 *)sp = make_float2(so[0], so[1]);
+                    if (g0 + 2 < G) *(float2 *)(sp + 2) = make_float2(so[2], so[3]);
+                }
+            }
+        }
+    }
+}
+
+// W1 (s,g) = P (s,ch) M (ch,g) + kW[idx] - qW + cW per point on the matrix cores (P = ReLU(pos a^T + b) is formed
+// in registers as the A operand, M rows are read as the B operand -- every wavefront reads the same C x G matrix,
+// so it stays in L1/L2), plus the per-column sums T1, T2 that BN_w needs.  One point per wavefront.
+template <int G>
+__global__ __launch_bounds__(256) void attention_logits_point_kernel(int n, int k, int c, const float *__restrict__ kW,
+                                                                     const float *__restrict__ qW,
+                                                                     const float *__restrict__ a, const float *__restrict__ b,
+                                                                     const float *__restrict__ M, const float *__restrict__ cW,
+                                                                     const float *__restrict__ coord,
+                                                                     const int *__restrict__ idx, float *__restrict__ W1,
+                                                                     float *part, unsigned *counter, double *__restrict__ T1,
+                                                                     double *__restrict__ T2) {
+    constexpr int GT = (G + 15) / 16;
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;  // [c]
+    __shared__ float s_w[4][2 * GT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    for (int ch = tid; ch < c; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    __syncthreads();
+    float t1[GT], t2[GT], cw[GT];
+    bool gok[GT];
+#pragma unroll
+    for (int tg = 0; tg < GT; ++tg) {
+        t1[tg] = t2[tg] = 0.f;
+        gok[tg] = 16 * tg + l15 < G;
+        cw[tg] = gok[tg] ? cW[16 * tg + l15] : 0.f;
+    }
+    for (long long pt = (long long)blockIdx.x * 4 + wid; pt < n; pt += (long long)gridDim.x * 4) {
+        Rel rel;
+        rel.x = rel.y = rel.z = 0.f;
+        rel.src = -1;
+        if (l15 < k) rel = rel_pos(coord, idx, pt * k + l15, (int)pt);
+        v4f acc[GT];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) acc[tg] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const float *mrow = M + (size_t)q * G + l15;
+#pragma unroll 4
+        for (int ch0 = 0; ch0 < c; ch0 += 4) {
+            const float4 ab = sAB[ch0 + q];
+            const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rel.x, rel.y, rel.z);
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg) {
+                const float mv = gok[tg] ? mrow[(size_t)ch0 * G + 16 * tg] : 0.f;
+                acc[tg] = mfma4(P, mv, acc[tg]);
+            }
+        }
+        float qv[GT];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) qv[tg] = gok[tg] ? qW[pt * G + 16 * tg + l15] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = 4 * q + r;
+            const int srcs = __shfl(rel.src, s, WAVE);  // lane s (< 16) holds slot s
+            if (s < k) {
+#pragma unroll
+                for (int tg = 0; tg < GT; ++tg)
+                    if (gok[tg]) {
+                        const int g = 16 * tg + l15;
+                        const float kv = srcs >= 0 ? kW[(long long)srcs * G + g] : 0.f;
+                        const float val = acc[tg][r] + (kv - qv[tg]) + cw[tg];
+                        W1[(pt * k + s) * G + g] = val;
+                        t1[tg] += val;
+                        t2[tg] = __builtin_fmaf(val, val, t2[tg]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int tg = 0; tg < GT; ++tg) {
+        t1[tg] += __shfl_xor(t1[tg], 16, WAVE); t1[tg] += __shfl_xor(t1[tg], 32, WAVE);
+        t2[tg] += __shfl_xor(t2[tg], 16, WAVE); t2[tg] += __shfl_xor(t2[tg], 32, WAVE);
+        if (q == 0) { s_w[wid][16 * tg + l15] = t1[tg]; s_w[wid][GT * 16 + 16 * tg + l15] = t2[tg]; }
+    }
+    __syncthreads();
+    if (tid < 2 * G) {
+        const int col = tid < G ? tid : GT * 16 + (tid - G);
+        float v = 0.f;
+        for (int wv = 0; wv < 4; ++wv) v += s_w[wv][col];
+        part_store(part + (size_t)blockIdx.x * 2 * G + tid, v);
+    }
+    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, 2 * G, MapSplit2<double>{T1, T2, G});
+}
+
 struct MapBwdPoint {  // columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
     float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
     int c, g;
@@ -525,6 +723,50 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
 }
 
 }  // namespace gva
+
+// logits stage on the matrix cores; part: >= nblk * 2g floats; returns the grid size through *nblk_out
+int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                            const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
+                            double *T1, double *T2, hipStream_t st) {
+    using namespace gva;
+    if (k < 1 || k > 16 || c % 4 != 0 || c > 2048) return PTV2_ERR_ARG;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(((long long)n + 3) / 4, MAX_BLOCKS));
+    const bool own_final = (size_t)nblk * 2 * g <= FUSED_FINAL_MAX;
+    unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
+    if (own_final && !cnt) return PTV2_ERR_LAUNCH;
+    const size_t lds = sizeof(float4) * (size_t)c;
+    switch (g) {
+#define CASE(GG)                                                                                                        \
+    case GG:                                                                                                            \
+        hipLaunchKernelGGL(attention_logits_point_kernel<GG>, dim3(nblk), dim3(256), lds, st, n, k, c, kW, qW, a, b, M, cW, \
+                           coord, idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                        \
+        break;
+        CASE(6) CASE(12) CASE(24) CASE(48) CASE(64)
+#undef CASE
+        default: return PTV2_ERR_ARG;
+    }
+    if (!own_final) launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
+    return PTV2_OK;
+}
+
+// forward softmax stage on the matrix cores (k <= 16; g one of the instantiated group counts)
+int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st) {
+    using namespace gva;
+    if (k < 1 || k > 16) return PTV2_ERR_ARG;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(((long long)n + 3) / 4, 256 * 8));
+    switch (g) {
+#define CASE(GG)                                                                                                          \
+    case GG:                                                                                                              \
+        hipLaunchKernelGGL(attention_softmax_point_kernel<GG>, dim3(nblk), dim3(256), 0, st, n, k, W1, sc, sh, Ww2, bw2, idx, w, \
+                           sw);                                                                                           \
+        break;
+        CASE(6) CASE(12) CASE(24) CASE(48) CASE(64)
+#undef CASE
+        default: return PTV2_ERR_ARG;
+    }
+    return PTV2_OK;
+}
 
 // returns 1 when (g, c, k) has a point-kernel instantiation
 int gva_bwd_point_supported(int k, int c, int g) {

@@ -9,6 +9,8 @@
 //                       HBM traffic per launch: idx + coord + kW/qW gathers in, W1 out -- the
 //                       (N,K,C) intermediate of the reference never exists.
 // (softmax / aggregation stages: gva_aggregate.hip)
+#include <cstdlib>
+
 #include "gva_common.h"
 
 namespace gva {
@@ -200,6 +202,10 @@ extern "C" int gva_pos_stats_hip_launcher(int n, int k, const float *coord, cons
         default: return PTV2_ERR_ARG;      \
     }
 
+int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                            const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
+                            double *T1, double *T2, hipStream_t st);
+
 extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
                                                const float *a, const float *b, const float *M, const float *cW,
                                                const float *coord, const int *idx, float *W1, double *T1, double *T2,
@@ -209,6 +215,13 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     const long long rows = (long long)n * k;
+    if (k <= 16 && c % 4 == 0 && (g == 48 || g == 64) && !getenv("AO_AMD_BWD_STAGED")) {  // pays for wide G only
+        PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
+        const int rc = gva_logits_point_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, st);
+        if (rc != PTV2_OK) return rc;
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     const int g4 = (g + 3) & ~3;
     const size_t lds_base = sizeof(float4) * (size_t)c + sizeof(float) * (size_t)c * g4;
     const size_t lds_red = sizeof(float) * 4 * WAVE * (g + 1);

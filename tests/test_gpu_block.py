@@ -86,9 +86,13 @@ def test_native_block_matches_python_block(monkeypatch, n, c, g, k, training):
     np.testing.assert_allclose(y_n.cpu().numpy(), y_p.cpu().numpy(), rtol=1e-4, atol=1e-4)
     names = ["x"] + [nm for nm, _ in blk_n.named_parameters()]
     for nm, a, b in zip(names, g_n, g_p):
-        # biases in front of a training-mode BatchNorm (linear_q/k/v, linear_p_bias, weight_encoding[0]) have an
-        # exactly-zero gradient that both sides compute as O(1e-4) summation noise: absolute floor for those
-        assert rel(a, b) < 5e-3 or float((a - b).abs().max()) < 1e-3, (nm, rel(a, b), float((a - b).abs().max()))
+        # biases whose effect a training-mode BatchNorm (or the softmax's shift invariance) removes have an exactly
+        # zero gradient that both sides compute as O(1e-3) summation noise over n*k rows: absolute floor for those
+        zero_grad = training and nm in ("attn.linear_q.0.bias", "attn.linear_k.0.bias", "attn.linear_v.bias",
+                                        "attn.linear_p_bias.0.bias", "attn.linear_p_bias.3.bias",
+                                        "attn.weight_encoding.0.bias", "attn.weight_encoding.3.bias")
+        floor = 5e-3 if zero_grad or nm == "attn.weight_encoding.3.bias" else 1e-4
+        assert rel(a, b) < 5e-3 or float((a - b).abs().max()) < floor, (nm, rel(a, b), float((a - b).abs().max()))
     for key in sd_p:
         np.testing.assert_allclose(sd_n[key].cpu().numpy(), sd_p[key].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
 
