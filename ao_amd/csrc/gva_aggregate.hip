@@ -381,24 +381,53 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
 }
 
 // grad v[j,ch] = sum over slots r that point at j of w[r, g(ch)] * g_out[r / k, ch]
+// one thread per (point j, group, float4 of the group's channels): the slot list and the group weight are read
+// once per 4 channels instead of once per channel
+template <int I>
 __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int c, int g,
                                                                const float *__restrict__ w,
                                                                const float *__restrict__ g_out,
                                                                const int *__restrict__ inv_ptr,
                                                                const int *__restrict__ inv_rows,
                                                                float *__restrict__ gv) {
-    const int I = c / g;
-    const long long total = (long long)n * c;
+    constexpr int V = I >= 4 ? 4 : I;  // channels per thread
+    const int cv = c / V;
+    const long long total = (long long)n * cv;
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
-        const int j = (int)(e / c), ch = (int)(e - (long long)j * c);
+        const int j = (int)(e / cv), ch = (int)(e - (long long)j * cv) * V;
         const int gl = ch / I;
-        float acc = 0.f;
-        for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) {
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
+        for (int p = p0; p < p1; ++p) {
             const int r = inv_rows[p];
-            acc = __builtin_fmaf(w[(long long)r * g + gl], g_out[(long long)(r / k) * c + ch], acc);
+            const float wv = w[(long long)r * g + gl];
+            const float *go = g_out + (long long)(r / k) * c + ch;
+            if (V == 4) {
+                const float4 t = *(const float4 *)go;
+                acc[0] = __builtin_fmaf(wv, t.x, acc[0]); acc[1] = __builtin_fmaf(wv, t.y, acc[1]);
+                acc[2] = __builtin_fmaf(wv, t.z, acc[2]); acc[3] = __builtin_fmaf(wv, t.w, acc[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv, go[i], acc[i]);
+            }
         }
-        gv[e] = acc;
+        if (V == 4) *(float4 *)(gv + (long long)j * c + ch) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else
+#pragma unroll
+            for (int i = 0; i < V; ++i) gv[(long long)j * c + ch + i] = acc[i];
     }
+}
+
+static void launch_bwd_gv(hipStream_t st, int n, int k, int c, int g, const float *w, const float *g_out, const int *inv_ptr,
+                          const int *inv_rows, float *gv) {
+    const int I = c / g;
+    const int V = I >= 4 ? 4 : I;
+    const dim3 grid((unsigned)std::min<long long>(((long long)n * (c / V) + TPB - 1) / TPB, MAX_BLOCKS * 4));
+#define GVCASE(II) case II: hipLaunchKernelGGL(aggregate_bwd_gv_kernel<II>, grid, dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv); break;
+    switch (I) { GVCASE(1) GVCASE(2) GVCASE(4) GVCASE(8) GVCASE(16) GVCASE(32) GVCASE(64) default: break; }
+#undef GVCASE
 }
 
 struct MapAB {  // columns (ch, j): ga (c,3), gb (c)
@@ -518,8 +547,7 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
         }
         {
             PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
-            hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3((int)std::min<long long>(((long long)n * c + TPB - 1) / TPB, MAX_BLOCKS * 4)),
-                               dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+            launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
         }
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
@@ -554,8 +582,7 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
     if (inv_ptr)
     {
         PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
-        hipLaunchKernelGGL(aggregate_bwd_gv_kernel, dim3((int)std::min<long long>(((long long)n * c + TPB - 1) / TPB, MAX_BLOCKS * 4)),
-                           dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+        launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
     }
     const int nb_rows = (int)std::min<long long>((rows + TPB - 1) / TPB, MAX_BLOCKS);
 #define CALL(GG)                                                                                                      \

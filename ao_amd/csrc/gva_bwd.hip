@@ -31,22 +31,46 @@ inline int stage_grid(long long work_items, int per_block, int cap = MAX_BLOCKS)
 inline bool pow2(int k) { return k > 0 && (k & (k - 1)) == 0; }
 
 // ============================================================ logits backward ==
+// gWt = gW1 + gT1 + 2 gT2 W1 (the two BN_w statistics paths folded into the row gradient) and its column sums.
+// Flat float4 streaming: a thread owns whole "units" of lcm(4, G) consecutive floats, so the column of every
+// element of its float4s is a compile-time constant and consecutive lanes touch consecutive memory (the previous
+// row-per-lane form read 4-byte pieces 4 G bytes apart and ran at 1 TB/s).
 template <int G>
 __global__ __launch_bounds__(TPB) void logits_bwd_rows_kernel(long long rows, const float *__restrict__ W1,
                                                               const float *__restrict__ gW1,
                                                               const double *__restrict__ gT1,
                                                               const double *__restrict__ gT2, float *__restrict__ gWt,
                                                               float *part, unsigned *counter, float *__restrict__ gcW) {
+    constexpr int U = (G % 4 == 0) ? G : (G % 2 == 0 ? 2 * G : 4 * G);  // floats per unit = lcm(4, G)
+    constexpr int UQ = U / 4;                                           // float4 per unit
     __shared__ float s_w[WPB][G];
     float t[G], c1[G], c2[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { t[g] = 0.f; c1[g] = (float)gT1[g]; c2[g] = 2.f * (float)gT2[g]; }
-    for (long long row = (long long)blockIdx.x * TPB + threadIdx.x; row < rows; row += (long long)gridDim.x * TPB) {
+    const long long total = rows * G, units = total / U;  // rows * G is a multiple of U whenever rows % (U / G) == 0
+    for (long long u = (long long)blockIdx.x * TPB + threadIdx.x; u < units; u += (long long)gridDim.x * TPB) {
+        const float4 *pw = (const float4 *)(W1 + u * U), *pg = (const float4 *)(gW1 + u * U);
+        float4 *po = (float4 *)(gWt + u * U);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float v = __builtin_fmaf(W1[row * G + g], c2[g], gW1[row * G + g] + c1[g]);
-            gWt[row * G + g] = v;
-            t[g] += v;
+        for (int j = 0; j < UQ; ++j) {
+            const float4 w4 = pw[j], g4 = pg[j];
+            float4 o;
+            o.x = __builtin_fmaf(w4.x, c2[(4 * j) % G], g4.x + c1[(4 * j) % G]);
+            o.y = __builtin_fmaf(w4.y, c2[(4 * j + 1) % G], g4.y + c1[(4 * j + 1) % G]);
+            o.z = __builtin_fmaf(w4.z, c2[(4 * j + 2) % G], g4.z + c1[(4 * j + 2) % G]);
+            o.w = __builtin_fmaf(w4.w, c2[(4 * j + 3) % G], g4.w + c1[(4 * j + 3) % G]);
+            po[j] = o;
+            t[(4 * j) % G] += o.x; t[(4 * j + 1) % G] += o.y; t[(4 * j + 2) % G] += o.z; t[(4 * j + 3) % G] += o.w;
+        }
+    }
+    // tail rows (rows not a multiple of U / G): element-wise by the first threads of block 0
+    if (blockIdx.x == 0) {
+        for (long long e = units * U + threadIdx.x; e < total; e += TPB) {
+            const int g = (int)(e % G);
+            const float v = __builtin_fmaf(W1[e], c2[g], gW1[e] + c1[g]);
+            gWt[e] = v;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) t[gg] += gg == g ? v : 0.f;
         }
     }
 #pragma unroll
@@ -220,7 +244,7 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     const long long rows = (long long)n * k;
     float *part = (float *)workspace;
     float *gWt = (float *)((char *)workspace + rows_offset_bytes(c, g));
-    const int nb_rows = stage_grid(rows, TPB * 2);
+    const int nb_rows = stage_grid(rows * g / 16, TPB);  // ~4 float4 per thread
 #define CALL(GG) \
     hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part, \
                        cnt ? cnt + CNT_LOGITS_BWD_ROWS : nullptr, gcW)

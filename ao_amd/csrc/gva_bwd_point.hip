@@ -68,7 +68,7 @@ struct BwdPointCfg {
 
 // part[blockIdx.x][PF]: [4C] (ga.xyz, gb) per channel, [G] gsc, [G] gsh, [G*G] gWw2, [G] gbw2
 template <int G, int C, int NW>
-__global__ __launch_bounds__(256) void attention_bwd_point_kernel(
+__global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bwd_point_kernel(
     int n, int k, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
     const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void attention_bwd_point_kernel(
             garow[tg] = g_A + ((pt * G + (gaok[tg] ? g : 0)) * C + chq);
         }
         constexpr int NCH = CS / 4;                                   // channel chunks of 4 contraction steps
-        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (GT == 2 ? 2 : 1);  // chunks in flight
+        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : 1;  // chunks in flight (registers: GT >= 2 is at the limit)
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
             rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
