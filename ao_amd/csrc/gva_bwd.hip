@@ -14,6 +14,8 @@
 //   (aggregate backward: gva_aggregate.hip)
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "gva_common.h"
 
 namespace gva {
@@ -219,6 +221,11 @@ struct MapLogitsParams {
 
 using namespace gva;
 
+int gva_bwd_point_supported(int k, int c, int g);
+int gva_logits_params_point_launch(int n, int k, int c, int g, const float *a, const float *b, const float *M,
+                                   const float *coord, const int *idx, const float *gWt, float *part, int max_blocks,
+                                   int *nblk_out, hipStream_t st);
+
 #define GVA_DISPATCH_G(g, CALL)            \
     switch (g) {                           \
         case 6: { CALL(6); break; }        \
@@ -262,6 +269,17 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     const size_t comb_bytes = sizeof(float) * (size_t)nsl * cbk * (g + 4);
     // enough workgroups to hide the tile-load latency (8 per CU), bounded by the partial-sum budget
     const int par_cap = (int)std::max<long long>(64, std::min<long long>(MAX_BLOCKS, ((long long)MAX_PARAM_BLOCKS * 24576) / ((long long)c * (g + 4))));
+    if (g >= 48 && gva_bwd_point_supported(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) {  // pays for wide G only
+        int nb = 0;
+        {
+            PtvScopedTimer t(KID_LOGITS_BWD_PARAMS, st, 4.0 * ((double)rows * (g + 1) + 3.0 * n));
+            const int rc = gva_logits_params_point_launch(n, k, c, g, a, b, M, coord, idx, gWt, ppart, par_cap, &nb, st);
+            if (rc != PTV2_OK) return rc;
+        }
+        launch_finalize(st, (const float *)ppart, nb, c * (g + 4), MapLogitsParams{gM, ga, gb, g});
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     const int nb_par = stage_grid(rows, PR_TILE, par_cap);
 #define CALL(GG)                                                                                                   \
     if (comb_bytes > 32 * 1024)                                                                                    \

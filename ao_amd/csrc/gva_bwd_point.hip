@@ -686,6 +686,179 @@ __global__ __launch_bounds__(256) void attention_logits_point_kernel(int n, int 
     if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, 2 * G, MapSplit2<double>{T1, T2, G});
 }
 
+// Parameter gradients of the logits stage per point on the matrix cores:
+//   dot (s,ch) = gWt (s,g) M^T (g,ch)  -> (ga, gb)[ch] += relu'(P) dot (pos, 1)
+//   gM  (ch,g)+= P^T (ch,s) gWt (s,g)     (16 slots = 4 contraction steps), accumulated in registers over all points
+// Replaces logits_bwd_params_kernel (thread <-> channel with two G-long register rows: VALU-bound, 60-150 us at
+// the deep stages).  NW wavefronts share a point, each owning C / NW channels; record layout per workgroup is the
+// one MapLogitsParams expects: [c][G + 4] = gM row, ga.xyz, gb.
+template <int G, int C, int NW>
+__global__ __launch_bounds__(256) void logits_params_point_kernel(int n, int k, const float *__restrict__ a,
+                                                                  const float *__restrict__ b, const float *__restrict__ M,
+                                                                  const float *__restrict__ coord,
+                                                                  const int *__restrict__ idx,
+                                                                  const float *__restrict__ gWt, float *__restrict__ part) {
+    constexpr int GT = (G + 15) / 16, PW = 4 / NW, CW = C / NW, UT = CW / 16, PER = G + 4;
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;                             // [C]
+    float4 *sPos = sAB + C;                         // [PW][16]
+    float *sFin = (float *)(sPos + PW * 16);        // [C][PER]  (PW > 1 only)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = wid / NW, sub = wid % NW;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int c0 = sub * CW;
+    for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    if (PW > 1)
+        for (int e = tid; e < C * PER; e += 256) sFin[e] = 0.f;
+    float4 accAB[UT];
+    v4f accM[UT][GT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < GT; ++t) accM[u][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+    for (long long base = (long long)blockIdx.x * PW; base < n; base += (long long)gridDim.x * PW) {
+        const long long pt = base + p;
+        const bool act = pt < n;
+        __syncthreads();
+        if (sub == 0 && lane < 16) {
+            Rel r;
+            r.x = r.y = r.z = 0.f;
+            r.src = -1;
+            if (act && lane < k) r = rel_pos(coord, idx, pt * k + lane, (int)pt);
+            sPos[p * 16 + lane] = make_float4(r.x, r.y, r.z, 0.f);
+        }
+        // gWt of the point in both operand layouts
+        float ga_[GT][4];   // A operand of `dot`: lane = (s = l15; g = 16 t + 4 q + r)
+        float gb_[4][GT];   // B operand of gM:   lane = (s = 4 st + q; g = 16 t + l15)
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int g0 = 16 * t + 4 * q;
+            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act && l15 < k) {
+                const float *src = gWt + (pt * k + l15) * G + g0;
+                if (G % 4 == 0) {
+                    if (g0 < G) uu = *(const float4 *)src;
+                } else {
+                    if (g0 < G) { const float2 t2 = *(const float2 *)src; uu.x = t2.x; uu.y = t2.y; }
+                    if (g0 + 2 < G) { const float2 t2 = *(const float2 *)(src + 2); uu.z = t2.x; uu.w = t2.y; }
+                }
+            }
+            ga_[t][0] = uu.x; ga_[t][1] = uu.y; ga_[t][2] = uu.z; ga_[t][3] = uu.w;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int s = 4 * st + q, g = 16 * t + l15;
+                gb_[st][t] = (act && s < k && g < G) ? gWt[(pt * k + s) * G + g] : 0.f;
+            }
+        }
+        __syncthreads();
+        float4 rp[4], pq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rp[r] = sPos[p * 16 + 4 * q + r]; pq[r] = sPos[p * 16 + 4 * r + q]; }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int ch = c0 + 16 * u + l15;
+            const float4 ab = sAB[ch];
+            // dot (s, ch): contraction over g, B operand = M[ch][g]
+            v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const int g0 = 16 * t + 4 * q;
+                float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float *mp = M + (size_t)ch * G + g0;
+                if (G % 4 == 0) {
+                    if (g0 < G) m4 = *(const float4 *)mp;
+                } else {
+                    if (g0 < G) { const float2 t2 = *(const float2 *)mp; m4.x = t2.x; m4.y = t2.y; }
+                    if (g0 + 2 < G) { const float2 t2 = *(const float2 *)(mp + 2); m4.z = t2.x; m4.w = t2.y; }
+                }
+                d = mfma4(ga_[t][0], m4.x, d);
+                d = mfma4(ga_[t][1], m4.y, d);
+                d = mfma4(ga_[t][2], m4.z, d);
+                d = mfma4(ga_[t][3], m4.w, d);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // rows s = 4 q + r of column ch
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rp[r].x, rp[r].y, rp[r].z);
+                const float gpre = (P > 0.f && act && 4 * q + r < k) ? d[r] : 0.f;
+                accAB[u].x = __builtin_fmaf(gpre, rp[r].x, accAB[u].x);
+                accAB[u].y = __builtin_fmaf(gpre, rp[r].y, accAB[u].y);
+                accAB[u].z = __builtin_fmaf(gpre, rp[r].z, accAB[u].z);
+                accAB[u].w += gpre;
+            }
+            // gM (ch, g) += P^T gWt: contraction over the slots s = 4 st + q
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, pq[st].x, pq[st].y, pq[st].z);
+#pragma unroll
+                for (int t = 0; t < GT; ++t) accM[u][t] = mfma4(P, gb_[st][t], accM[u][t]);
+            }
+        }
+    }
+    // record: accM tile (u,t): lane = (g = 16 t + l15; ch = c0 + 16 u + 4 q + r);  accAB: sum over the 4 lane groups
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u].x += __shfl_xor(accAB[u].x, 16, WAVE); accAB[u].x += __shfl_xor(accAB[u].x, 32, WAVE);
+        accAB[u].y += __shfl_xor(accAB[u].y, 16, WAVE); accAB[u].y += __shfl_xor(accAB[u].y, 32, WAVE);
+        accAB[u].z += __shfl_xor(accAB[u].z, 16, WAVE); accAB[u].z += __shfl_xor(accAB[u].z, 32, WAVE);
+        accAB[u].w += __shfl_xor(accAB[u].w, 16, WAVE); accAB[u].w += __shfl_xor(accAB[u].w, 32, WAVE);
+    }
+    float *rec = part + (size_t)blockIdx.x * C * PER;
+    if (PW == 1) {  // every wavefront owns its channels: straight to the record
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * t + l15, ch = c0 + 16 * u + 4 * q + r;
+                    if (g < G) rec[(size_t)ch * PER + g] = accM[u][t][r];
+                }
+            if (q == 0) {
+                float *d = rec + (size_t)(c0 + 16 * u + l15) * PER + G;
+                d[0] = accAB[u].x; d[1] = accAB[u].y; d[2] = accAB[u].z; d[3] = accAB[u].w;
+            }
+        }
+    } else {  // PW point slots share the channels: add up in LDS, one wavefront after the other (fixed order)
+        __syncthreads();
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wid == turn) {
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = 16 * t + l15, ch = c0 + 16 * u + 4 * q + r;
+                            if (g < G) sFin[ch * PER + g] += accM[u][t][r];
+                        }
+                    if (q == 0) {
+                        float *d = sFin + (c0 + 16 * u + l15) * PER + G;
+                        d[0] += accAB[u].x; d[1] += accAB[u].y; d[2] += accAB[u].z; d[3] += accAB[u].w;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < C * PER; e += 256) rec[e] = sFin[e];
+    }
+}
+
+template <int G, int C, int NW>
+int launch_params_point(int n, int k, const float *a, const float *b, const float *M, const float *coord, const int *idx,
+                        const float *gWt, float *part, int max_blocks, int *nblk_out, hipStream_t st) {
+    constexpr int PW = 4 / NW;
+    const size_t lds = sizeof(float4) * (C + PW * 16) + (PW > 1 ? sizeof(float) * (size_t)C * (G + 4) : 0);
+    const long long groups = ((long long)n + PW - 1) / PW;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, max_blocks));
+    auto kern = logits_params_point_kernel<G, C, NW>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, a, b, M, coord, idx, gWt, part);
+    *nblk_out = nblk;
+    return PTV2_OK;
+}
+
 struct MapBwdPoint {  // columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
     float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
     int c, g;
@@ -723,6 +896,21 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
 }
 
 }  // namespace gva
+
+// parameter gradients of the logits stage on the matrix cores; writes nblk records of c (g + 4) floats to part
+int gva_logits_params_point_launch(int n, int k, int c, int g, const float *a, const float *b, const float *M,
+                                   const float *coord, const int *idx, const float *gWt, float *part, int max_blocks,
+                                   int *nblk_out, hipStream_t st) {
+    using namespace gva;
+#define ARGS n, k, a, b, M, coord, idx, gWt, part, max_blocks, nblk_out, st
+    if (g == 6 && c == 48) return launch_params_point<6, 48, 1>(ARGS);
+    if (g == 12 && c == 96) return launch_params_point<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return launch_params_point<24, 192, 2>(ARGS);
+    if (g == 48 && c == 384) return launch_params_point<48, 384, 4>(ARGS);
+    if (g == 64 && c == 512) return launch_params_point<64, 512, 4>(ARGS);
+#undef ARGS
+    return PTV2_ERR_ARG;
+}
 
 // logits stage on the matrix cores; part: >= nblk * 2g floats; returns the grid size through *nblk_out
 int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
