@@ -63,7 +63,7 @@ Work carve_work(void *base, int n, int k, int c, int g) {
     char *p = (char *)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
-    w.dense_bytes = dense_workspace_bytes(n, c, c);
+    w.dense_bytes = dense_workspace_bytes(n, 3 * c, c);  // three weight gradients in one launch
     w.dense = take(w.dense_bytes);
     w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
     w.gva = take(w.gva_bytes);
@@ -244,9 +244,12 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     RUN(bn_backward_hip_launcher(n, c, S.hq, T1, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], T2,
                                  GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
     // weight / bias gradients of the three projections of f1
-    RUN(linear_wgrad_hip_launcher(n, c, c, T2, S.f1, GP(PTV2_BLK_Q_W), GPB(PTV2_BLK_Q_B), W.dense, W.dense_bytes, stream));
-    RUN(linear_wgrad_hip_launcher(n, c, c, T0, S.f1, GP(PTV2_BLK_K_W), GPB(PTV2_BLK_K_B), W.dense, W.dense_bytes, stream));
-    RUN(linear_wgrad_hip_launcher(n, c, c, T3, S.f1, GP(PTV2_BLK_V_W), GPB(PTV2_BLK_V_B), W.dense, W.dense_bytes, stream));
+    {
+        const float *gys[3] = {T2, T0, T3}, *xs[3] = {S.f1, S.f1, S.f1};
+        float *dws[3] = {GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W)};
+        float *dbs[3] = {GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B)};
+        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 3, gys, xs, dws, dbs, W.dense, W.dense_bytes, stream));
+    }
     // g_f1 (T1) = g_hq Wq + g_hk Wk + gv Wv
     RUN(rows_gemm_hip_launcher(n, c, c, T2, P[PTV2_BLK_Q_W], 1, nullptr, T1, 0, stream));
     RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_K_W], 1, nullptr, T1, 1, stream));

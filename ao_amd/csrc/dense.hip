@@ -318,16 +318,24 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int WG_MT = 3, WG_TILE = 16 * WG_MT, WG_CHUNK = 256;
 
+// several independent products of one shape in one launch (blockIdx.z selects the operand pair)
+struct WgradMulti {
+    const float *gY[4], *X[4];
+    float *dW[4], *db[4];
+    int count;  // 0: the strided form (gY + z * sy, X + z * sx)
+};
+
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
                                                            const float *__restrict__ gY, long long ldy, long long sy,
                                                            const float *__restrict__ X, long long ldx, long long sx,
                                                            float *__restrict__ part, float *__restrict__ part_b,
-                                                           int batch) {
+                                                           int batch, WgradMulti multi) {
     __shared__ float sRed[TPB / WAVE][WG_MT * WG_MT * 4 + WG_MT][WAVE + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int bz = blockIdx.z;
     const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
-    const float *A = gY + (long long)bz * sy, *B = X + (long long)bz * sx;
+    const float *A = multi.count ? multi.gY[bz] : gY + (long long)bz * sy;
+    const float *B = multi.count ? multi.X[bz] : X + (long long)bz * sx;
     const long long r0 = (long long)blockIdx.x * WG_CHUNK;
     const long long r1 = (r0 + WG_CHUNK) < (long long)n ? (r0 + WG_CHUNK) : (long long)n;
     const int lr = lane >> 4, lc = lane & 15;
@@ -342,7 +350,8 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
     bool mo[WG_MT], mi[WG_MT];
 #pragma unroll
     for (int m = 0; m < WG_MT; ++m) { mo[m] = to + m * 16 + lc < cout; mi[m] = ti + m * 16 + lc < cin; }
-    for (long long rb = r0 + 4 * wid; rb < r1; rb += 4 * (TPB / WAVE)) {
+#pragma unroll 8
+    for (long long rb = r0 + 4 * wid; rb < r1; rb += 4 * (TPB / WAVE)) {  // unrolled: 48 fragment loads in flight per wave
         const long long row = rb + lr;
         const bool rok = row < r1;
         float a[WG_MT], b[WG_MT];
@@ -626,11 +635,55 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     {
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)chunks * cout * cin));
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
-                           db ? part_b : (float *)nullptr, batch);
+                           db ? part_b : (float *)nullptr, batch, WgradMulti{});
     }
     if (db) launch_finalize(st, (const float *)part, chunks, batch * cout * cin + batch * cout,
                             gva::MapSplit2<float>{dW, db, batch * cout * cin});
     else launch_finalize(st, (const float *)part, chunks, batch * cout * cin, gva::MapVec<float>{dW});
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+struct MapWgradMulti {  // record = [count][cout*cin] weights, then [count][cout] bias sums
+    WgradMulti m;
+    int wlen, cout;
+    __device__ void operator()(int e, double v) const {
+        const int wtot = m.count * wlen;
+        if (e < wtot) {
+            const int b = e / wlen;
+            m.dW[b][e - b * wlen] = (float)v;
+        } else {
+            const int r = e - wtot, b = r / cout;
+            if (m.db[b]) m.db[b][r - b * cout] = (float)v;
+        }
+    }
+};
+
+// count (<= 4) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
+// shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))
+extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
+                                               const float *const *X, float *const *dW, float *const *db, void *workspace,
+                                               size_t workspace_bytes, void *stream) {
+    if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 4 || !gY || !X || !dW) return PTV2_ERR_ARG;
+    const int chunks = (n + WG_CHUNK - 1) / WG_CHUNK;
+    const size_t rec = (size_t)count * ((size_t)cout * cin + cout);
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)chunks * rec) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    WgradMulti m{};
+    m.count = count;
+    for (int i = 0; i < count; ++i) {
+        if (!gY[i] || !X[i] || !dW[i]) return PTV2_ERR_ARG;
+        m.gY[i] = gY[i]; m.X[i] = X[i]; m.dW[i] = dW[i]; m.db[i] = db ? db[i] : nullptr;
+    }
+    float *part = (float *)workspace;
+    const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
+    dim3 grid(chunks, tiles_o * tiles_i, count);
+    {
+        PtvScopedTimer t(KID_WGRAD, st, 4.0 * count * ((double)n * (cout + cin) + (double)chunks * cout * cin));
+        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
+                           (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m);
+    }
+    launch_finalize(st, (const float *)part, chunks, (int)rec, MapWgradMulti{m, cout * cin, cout});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

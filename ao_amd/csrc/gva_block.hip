@@ -160,7 +160,8 @@ BlockWs carve(void *base, int n, int k, int c, int g) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
     const size_t rows = (size_t)n * k;
     w.stage_bytes = std::max({gva_workspace_bytes(n, k, c, g), gva_aggregate_workspace_bytes(n, k, c, g),
-                              dense_workspace_bytes(n, c, c), dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g)});
+                              dense_workspace_bytes(n, c, c), dense_workspace_bytes(n, 2 * g, c),
+                              dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g)});
     w.stage = take(w.stage_bytes);
     w.out_v = (float *)take(sizeof(float) * (size_t)n * c);
     w.gA = (float *)take(sizeof(float) * (size_t)n * g * c);
@@ -273,8 +274,11 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     // 6. projections kW = k Ww1^T, qW = q Ww1^T
     RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gkW, B->Ww1, G->gk, stream));
     RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gqW, B->Ww1, G->gq, stream));
-    RUN(linear_wgrad_hip_launcher(n, g, c, W.gkW, B->key, W.gWw1_k, nullptr, W.stage, W.stage_bytes, stream));
-    RUN(linear_wgrad_hip_launcher(n, g, c, W.gqW, B->q, W.gWw1_q, nullptr, W.stage, W.stage_bytes, stream));
+    {
+        const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
+        float *dws[2] = {W.gWw1_k, W.gWw1_q};
+        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, W.stage, W.stage_bytes, stream));
+    }
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1
     hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c + (long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,
                        g, B->Wp2, B->bp2, B->Ww1, (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k,

@@ -353,6 +353,11 @@ int bn_backward_residual_hip_launcher(int n, int c, const float *x, const float 
                                       void *stream);
 int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
                               float *db, void *workspace, size_t workspace_bytes, void *stream);
+/* count (<= 4) weight gradients of one shape in one launch: dW[i] = gY[i]^T X[i], db[i] = column sums (db or db[i]
+ * may be NULL); workspace: dense_workspace_bytes(n, count * cout, cin) */
+int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
+                                    const float *const *X, float *const *dW, float *const *db, void *workspace,
+                                    size_t workspace_bytes, void *stream);
 /* skinny projection y (n,cout) = x (n,cin) W^T (cout,cin), cout <= 64, cin % 4 == 0, and its input gradient
  * gx = gy W (the weight gradient is linear_wgrad) */
 int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
