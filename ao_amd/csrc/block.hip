@@ -183,11 +183,14 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     RUN(rows_gemm_hip_launcher(n, c, c, B->x, P[PTV2_BLK_FC1_W], 0, nullptr, S.h1, 0, stream));
     RUN(bn_fwd(B, 0, S.h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, nullptr, nullptr, S.f1, S, W, stream));
     // linear_q / linear_k (Linear + BN + ReLU), linear_v
-    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_Q_W], 0, P[PTV2_BLK_Q_B], S.hq, 0, stream));
+    {
+        const float *xs[3] = {S.f1, S.f1, S.f1}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
+        const float *bs[3] = {P[PTV2_BLK_Q_B], P[PTV2_BLK_K_B], P[PTV2_BLK_V_B]};
+        float *ys[3] = {S.hq, S.hk, S.v};
+        RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, stream));
+    }
     RUN(bn_fwd(B, 1, S.hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, nullptr, nullptr, S.q, S, W, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_K_W], 0, P[PTV2_BLK_K_B], S.hk, 0, stream));
     RUN(bn_fwd(B, 2, S.hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, nullptr, nullptr, S.key, S, W, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, S.f1, P[PTV2_BLK_V_W], 0, P[PTV2_BLK_V_B], S.v, 0, stream));
     // grouped vector attention
     ptv2_gva_block V;
     fill_gva(B, S, &V);
@@ -251,9 +254,11 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
         RUN(linear_wgrad_multi_hip_launcher(n, c, c, 3, gys, xs, dws, dbs, W.dense, W.dense_bytes, stream));
     }
     // g_f1 (T1) = g_hq Wq + g_hk Wk + gv Wv
-    RUN(rows_gemm_hip_launcher(n, c, c, T2, P[PTV2_BLK_Q_W], 1, nullptr, T1, 0, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_K_W], 1, nullptr, T1, 1, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, T3, P[PTV2_BLK_V_W], 1, nullptr, T1, 1, stream));
+    {
+        const float *xs[3] = {T2, T0, T3}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
+        float *ys[3] = {T1, nullptr, nullptr};
+        RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 1, xs, ws, 1, nullptr, ys, 0, stream));
+    }
     // norm1 + ReLU -> g_h1 (T0); fc1: gx += g_h1 fc1
     RUN(bn_backward_hip_launcher(n, c, S.h1, T1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], T0,
                                  GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.dense, W.dense_bytes, stream));

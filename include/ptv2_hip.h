@@ -378,6 +378,12 @@ int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const
 int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const float *W, int w_kmajor,
                            const float *bias, float *Y, int accumulate, void *stream);
 
+/* count (<= 3) products of one shape in one launch.  sum == 0: Y[i] = X[i] op(W[i]) + bias[i] (e.g. the q, k, v
+ * projections of one input); sum != 0: Y[0] (+)= sum_i X[i] op(W[i]) (the input gradient through all three). */
+int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
+                                 const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
+                                 int accumulate, void *stream);
+
 /* ------------------------------------------------ whole Block, one call --
  * Block.forward / backward (point_transformer_v2m2_base.py:131-177: fc1, norm1, GroupedVectorAttention with
  * linear_q/k/v, norm2, fc3, norm3, DropPath, residual, ReLU) behind ONE launcher per direction: ~30 forward and
