@@ -37,6 +37,60 @@ def test_rows_gemm(m, n, k, kmajor):
     np.testing.assert_allclose(acc.cpu().numpy(), expect.cpu().numpy(), rtol=0, atol=2e-5)
 
 
+def _ptr_array(tensors):
+    import ctypes
+
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+@pytest.mark.parametrize("m,c", [(120000, 48), (7500, 192), (1900, 384), (333, 512)])
+def test_rows_gemm_multi(m, c):
+    """q/k/v form (three independent outputs) and the summed form (g_f1 = sum_i gY_i W_i) of one launch."""
+    from ao_amd import _lib
+    import ao_amd.ptv2.block  # noqa: F401
+
+    torch.manual_seed(c)
+    L = _lib.lib()
+    x = torch.randn(m, c, device="cuda")
+    ws = [torch.randn(c, c, device="cuda") / c ** 0.5 for _ in range(3)]
+    bs = [torch.randn(c, device="cuda") for _ in range(3)]
+    ys = [torch.empty(m, c, device="cuda") for _ in range(3)]
+    rc = L.rows_gemm_multi_hip_launcher(m, c, c, 3, 0, _ptr_array([x, x, x]), _ptr_array(ws), 0, _ptr_array(bs), _ptr_array(ys),
+                                        0, _lib.stream_ptr())
+    _lib.check(rc, "rows_gemm_multi_hip_launcher")
+    for w, b, y in zip(ws, bs, ys):
+        ref = (x.double() @ w.double().t() + b.double()).float()
+        np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=3e-5)
+    gys = [torch.randn(m, c, device="cuda") for _ in range(3)]
+    out = torch.empty(m, c, device="cuda")
+    rc = L.rows_gemm_multi_hip_launcher(m, c, c, 3, 1, _ptr_array(gys), _ptr_array(ws), 1, None, _ptr_array([out, None, None]), 0,
+                                        _lib.stream_ptr())
+    _lib.check(rc, "rows_gemm_multi_hip_launcher")
+    ref = sum(g.double() @ w.double() for g, w in zip(gys, ws)).float()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=6e-5)
+
+
+@pytest.mark.parametrize("n,cout,cin,count", [(120000, 48, 48, 3), (7500, 24, 192, 2), (1900, 384, 384, 3), (4097, 6, 48, 2)])
+def test_linear_wgrad_multi(n, cout, cin, count):
+    from ao_amd import _lib
+
+    torch.manual_seed(n)
+    L = _lib.lib()
+    gys = [torch.randn(n, cout, device="cuda") for _ in range(count)]
+    xs = [torch.randn(n, cin, device="cuda") for _ in range(count)]
+    dws = [torch.empty(cout, cin, device="cuda") for _ in range(count)]
+    dbs = [torch.empty(cout, device="cuda") if i != 1 else None for i in range(count)]
+    ws = _lib.workspace(L.dense_workspace_bytes(n, count * cout, cin), xs[0].device)
+    rc = L.linear_wgrad_multi_hip_launcher(n, cout, cin, count, _ptr_array(gys), _ptr_array(xs), _ptr_array(dws), _ptr_array(dbs),
+                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "linear_wgrad_multi_hip_launcher")
+    for gy, x, dw, db in zip(gys, xs, dws, dbs):
+        ref = gy.double().t() @ x.double()
+        assert rel(dw, ref) < 1e-5
+        if db is not None:
+            assert rel(db, gy.double().sum(0)) < 1e-5
+
+
 def _block_pair(c, g, drop, seed):
     from ao_amd.ptv2.model import Block
 
