@@ -6,7 +6,7 @@ usage: tools/pmc_traffic.py <dir_fetch> <dir_write> [name substrings...]"""
 import csv, glob, sys, collections, json
 
 def load(d, counter):
-    f = glob.glob(d + '/*/*_counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter: continue
