@@ -41,7 +41,9 @@ const char *kNames[KID_COUNT] = {
     "peb_bwd_kernel", "aggregate_bwd_tile_kernel", "aggregate_bwd_rows_kernel", "aggregate_bwd_gv_kernel",
     "logits_bwd_rows_kernel", "logits_bwd_gather_kernel", "logits_bwd_params_kernel", "linear_wgrad_kernel",
     "bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "skinny_fwd_kernel",
-    "skinny_bwd_kernel", "rows_gemm_kernel", "attention_bwd_point_kernel"};
+    "skinny_bwd_kernel", "rows_gemm_kernel", "attention_bwd_point_kernel<6, 48, 1>",
+    "attention_bwd_point_kernel<12, 96, 1>", "attention_bwd_point_kernel<24, 192, 2>",
+    "attention_bwd_point_kernel<48, 384, 4>", "attention_bwd_point_kernel<64, 512, 4>"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;

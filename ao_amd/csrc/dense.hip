@@ -38,6 +38,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
     // E[x^2] - E[x]^2 when |mean| >> std, at no extra pass
     const float4 sft = ((const float4 *)x)[q];
     if (r < rl)
+#pragma unroll 4
         for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
             float4 v = ((const float4 *)x)[row * cq + q];
             v.x -= sft.x; v.y -= sft.y; v.z -= sft.z; v.w -= sft.w;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_residual_kernel(int n, int 
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (r < rl) {
         const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q];
+#pragma unroll 4
         for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
             const float4 v = ((const float4 *)x)[row * cq + q], o = ((const float4 *)y)[row * cq + q];
             float4 d = ((const float4 *)gy)[row * cq + q];
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const 
     if (r < rl) {
         const float4 m = ((const float4 *)mean)[q], rs = ((const float4 *)rstd)[q];
         const float4 g = ((const float4 *)gamma)[q], b = ((const float4 *)beta)[q];
+#pragma unroll 4
         for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)gridDim.x * rl) {
             const float4 v = ((const float4 *)x)[row * cq + q];
             float4 d = ((const float4 *)gy)[row * cq + q];

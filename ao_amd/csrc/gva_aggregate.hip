@@ -540,7 +540,7 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
         // one fused MFMA launch (+ its finalize) instead of tile / rows / finalizes / the G x G weight-gradient GEMM
         {
             // W1, idx, coord, g_out, g_sw, v rows (unique once), g_A in; gW1 out
-            PtvScopedTimer t(KID_BWD_POINT, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
+            PtvScopedTimer t(KID_BWD_POINT + (g == 6 ? 0 : g == 12 ? 1 : g == 24 ? 2 : g == 48 ? 3 : 4), st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
             const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
                                                 gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st);
             if (rc != PTV2_OK) return rc;
