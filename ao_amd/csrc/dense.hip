@@ -15,6 +15,7 @@
 //                                  staged through LDS, 3x3 register patch per lane), partial tiles
 //                                  summed in fixed order; the bias gradient falls out of the same pass
 #include <algorithm>
+#include <cstdlib>
 
 #include "gva_common.h"
 
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int
 // i.e. four 64-byte row segments per load, no LDS staging.  A workgroup = 4 waves = one (up to) 48x48
 // output tile for one chunk of rows; the waves interleave k-steps and are summed through LDS.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int WG_MT = 3, WG_TILE = 16 * WG_MT, WG_CHUNK = 256;
+constexpr int WG_MT = 3, WG_TILE = 16 * WG_MT, WG_CHUNK = 256, WG_CHUNK_MIN = 128;
 
 // several independent products of one shape in one launch (blockIdx.z selects the operand pair)
 struct WgradMulti {
@@ -332,15 +333,15 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
                                                            const float *__restrict__ gY, long long ldy, long long sy,
                                                            const float *__restrict__ X, long long ldx, long long sx,
                                                            float *__restrict__ part, float *__restrict__ part_b,
-                                                           int batch, WgradMulti multi) {
+                                                           int batch, WgradMulti multi, int chunk) {
     __shared__ float sRed[TPB / WAVE][WG_MT * WG_MT * 4 + WG_MT][WAVE + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int bz = blockIdx.z;
     const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
     const float *A = multi.count ? multi.gY[bz] : gY + (long long)bz * sy;
     const float *B = multi.count ? multi.X[bz] : X + (long long)bz * sx;
-    const long long r0 = (long long)blockIdx.x * WG_CHUNK;
-    const long long r1 = (r0 + WG_CHUNK) < (long long)n ? (r0 + WG_CHUNK) : (long long)n;
+    const long long r0 = (long long)blockIdx.x * chunk;
+    const long long r1 = (r0 + chunk) < (long long)n ? (r0 + chunk) : (long long)n;
     const int lr = lane >> 4, lc = lane & 15;
     f32x4 acc[WG_MT][WG_MT];
     float bsum[WG_MT];
@@ -353,22 +354,30 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
     bool mo[WG_MT], mi[WG_MT];
 #pragma unroll
     for (int m = 0; m < WG_MT; ++m) { mo[m] = to + m * 16 + lc < cout; mi[m] = ti + m * 16 + lc < cin; }
-#pragma unroll 8
-    for (long long rb = r0 + 4 * wid; rb < r1; rb += 4 * (TPB / WAVE)) {  // unrolled: 48 fragment loads in flight per wave
-        const long long row = rb + lr;
-        const bool rok = row < r1;
-        float a[WG_MT], b[WG_MT];
+    // U k-steps per trip: all 6 U fragment loads are issued before the first MFMA consumes one (a step-by-step loop
+    // paid one memory latency per 4 rows: 2.5 us per 100 rows of chunk, independent of the problem size)
+    constexpr int U = 8;
+    for (long long rb = r0 + 4 * wid; rb < r1; rb += 4 * (TPB / WAVE) * U) {
+        float a[U][WG_MT], b[U][WG_MT];
 #pragma unroll
-        for (int m = 0; m < WG_MT; ++m) {
-            a[m] = (rok && mo[m]) ? A[row * ldy + to + m * 16 + lc] : 0.f;
-            b[m] = (rok && mi[m]) ? B[row * ldx + ti + m * 16 + lc] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const long long row = rb + (long long)u * 4 * (TPB / WAVE) + lr;
+            const bool rok = row < r1;
+#pragma unroll
+            for (int m = 0; m < WG_MT; ++m) {
+                a[u][m] = (rok && mo[m]) ? A[row * ldy + to + m * 16 + lc] : 0.f;
+                b[u][m] = (rok && mi[m]) ? B[row * ldx + ti + m * 16 + lc] : 0.f;
+            }
         }
 #pragma unroll
-        for (int m = 0; m < WG_MT; ++m) {
-            bsum[m] += a[m];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < WG_MT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
-        }
+            for (int m = 0; m < WG_MT; ++m) {
+                bsum[m] += a[u][m];
+#pragma unroll
+                for (int t = 0; t < WG_MT; ++t)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], b[u][t], acc[m][t], 0, 0, 0);
+            }
     }
     // combine the 4 waves (fixed order) and write the partial tile
 #pragma unroll
@@ -462,10 +471,18 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 using namespace dense;
 
 extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin = total outputs over all batches
-    const size_t chunks = (size_t)(n + WG_CHUNK - 1) / WG_CHUNK + 1;
+    const size_t chunks = (size_t)(n + WG_CHUNK_MIN - 1) / WG_CHUNK_MIN + 1;
     const size_t wg = sizeof(float) * chunks * ((size_t)cout * cin + cout);
     const size_t bn = sizeof(float) * (size_t)MAX_BLK * 2 * (size_t)std::max(cout, cin);
     return align_up(std::max(wg, bn)) + 1024;
+}
+
+// rows per split-K workgroup of the weight gradient
+static int wg_chunk(int n) {
+    static const int forced = [] { const char *e = getenv("AO_AMD_WG_CHUNK"); return e ? atoi(e) : 0; }();
+    if (forced >= WG_CHUNK_MIN) return forced;
+    (void)n;
+    return WG_CHUNK;
 }
 
 static int bn_grid(int n, int c) {
@@ -627,7 +644,8 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
                                                  long long sy, const float *X, long long ldx, long long sx, float *dW,
                                                  float *db, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || batch < 1) return PTV2_ERR_ARG;
-    const int chunks = (n + WG_CHUNK - 1) / WG_CHUNK;
+    const int chunk = wg_chunk(n);
+    const int chunks = (n + chunk - 1) / chunk;
     const size_t need = sizeof(float) * (size_t)chunks * batch * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < need) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -638,7 +656,7 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     {
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)chunks * cout * cin));
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
-                           db ? part_b : (float *)nullptr, batch, WgradMulti{});
+                           db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
     }
     if (db) launch_finalize(st, (const float *)part, chunks, batch * cout * cin + batch * cout,
                             gva::MapSplit2<float>{dW, db, batch * cout * cin});
@@ -668,7 +686,8 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                                                const float *const *X, float *const *dW, float *const *db, void *workspace,
                                                size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 4 || !gY || !X || !dW) return PTV2_ERR_ARG;
-    const int chunks = (n + WG_CHUNK - 1) / WG_CHUNK;
+    const int chunk = wg_chunk(n);
+    const int chunks = (n + chunk - 1) / chunk;
     const size_t rec = (size_t)count * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)chunks * rec) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -684,7 +703,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
     {
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * count * ((double)n * (cout + cin) + (double)chunks * cout * cin));
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
-                           (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m);
+                           (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
     }
     launch_finalize(st, (const float *)part, chunks, (int)rec, MapWgradMulti{m, cout * cin, cout});
     PTV2_CHECK_LAUNCH();
