@@ -19,9 +19,10 @@
 namespace gemm {
 
 constexpr int BM = 64;        // rows per workgroup (4 wavefronts x 16)
-constexpr int KC = 32;        // reduction indices per LDS chunk
-constexpr int PITCH = KC + 4; // LDS row pitch in floats
 constexpr int THREADS = 256;
+// KC = reduction indices per LDS chunk (32, or 64 for k >= 192: half as many chunk hand-offs, twice the loads in
+// flight -- with 24 MFMAs per chunk the prefetch distance of one chunk did not cover the memory latency and every
+// chunk of the deep stages' k = 192 / 384 cost ~1 us); LDS row pitch KC + 4 floats keeps ds_read_b128 conflict-free
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -34,16 +35,20 @@ struct GemmMulti {
     int sum;    // != 0: Y[0] = sum_i X[i] op(W[i])
 };
 
-template <int BN, bool W_KMAJOR>
+template <int BN, bool W_KMAJOR, int KC>
 __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k, const float *__restrict__ X0,
                                                             const float *__restrict__ W0,
                                                             const float *__restrict__ bias0, float *__restrict__ Y0,
                                                             int accumulate, int ncb, GemmMulti multi) {
+    constexpr int PITCH = KC + 4;
     __shared__ __attribute__((aligned(16))) float sX[BM * PITCH];
     __shared__ __attribute__((aligned(16))) float sW[BN * PITCH];
     constexpr int NT = BN / 16;            // MFMA column tiles per wavefront
-    constexpr int WQ = BN * KC / 4;        // float4 slots of the W chunk
+    constexpr int KQ = KC / 4;             // float4 per row of a chunk
+    constexpr int XLOADS = BM * KQ / THREADS;
+    constexpr int WQ = BN * KQ;            // float4 slots of the W chunk
     constexpr int WLOADS = (WQ + THREADS - 1) / THREADS;
+    constexpr int RUN = KC / 16;           // float4 per lane and chunk (a lane owns KC / 4 consecutive reduction indices)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
     const long long row0 = (long long)rb * BM;
@@ -56,11 +61,11 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
     const float *X = multi.count ? multi.X[indep ? z : 0] : X0;
     const float *W = multi.count ? multi.W[indep ? z : 0] : W0;
 
-    float4 rx[2], rw[WLOADS];
+    float4 rx[XLOADS], rw[WLOADS];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + j * THREADS, r = q >> 3, kq = (q & 7) * 4;
+        for (int j = 0; j < XLOADS; ++j) {
+            const int q = tid + j * THREADS, r = q / KQ, kq = (q % KQ) * 4;
             const long long row = row0 + r;
             rx[j] = (row < m && k0 + kq < k) ? *(const float4 *)(X + row * k + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < WQ) {
                 if (!W_KMAJOR) {
-                    const int r = q >> 3, kq = (q & 7) * 4;
+                    const int r = q / KQ, kq = (q % KQ) * 4;
                     if (n0 + r < n && k0 + kq < k) rw[j] = *(const float4 *)(W + (long long)(n0 + r) * k + k0 + kq);
                 } else {
                     const int kk = q / (BN / 4), cq = (q - kk * (BN / 4)) * 4;
@@ -81,8 +86,8 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = tid + j * THREADS, r = q >> 3, kq = (q & 7) * 4;
+        for (int j = 0; j < XLOADS; ++j) {
+            const int q = tid + j * THREADS, r = q / KQ, kq = (q % KQ) * 4;
             *(float4 *)(sX + r * PITCH + kq) = rx[j];
         }
 #pragma unroll
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             const int q = tid + j * THREADS;
             if (q < WQ) {
                 if (!W_KMAJOR) {
-                    const int r = q >> 3, kq = (q & 7) * 4;
+                    const int r = q / KQ, kq = (q % KQ) * 4;
                     *(float4 *)(sW + r * PITCH + kq) = rw[j];
                 } else {
                     const int kk = q / (BN / 4), cq = (q - kk * (BN / 4)) * 4;
@@ -105,10 +110,10 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // lane (i = lane & 15, s = lane >> 4) owns reduction indices s*8 .. s*8+7 of row / column i in each chunk:
-    // the contraction order differs from k-ascending, identically for both operands
-    const float *px = sX + (wid * 16 + (lane & 15)) * PITCH + (lane >> 4) * 8;
-    const float *pw = sW + (lane & 15) * PITCH + (lane >> 4) * 8;
+    // lane (i = lane & 15, s = lane >> 4) owns reduction indices s*KC/4 .. (s+1)*KC/4-1 of row / column i in each
+    // chunk: the contraction order differs from k-ascending, identically for both operands
+    const float *px = sX + (wid * 16 + (lane & 15)) * PITCH + (lane >> 4) * (KC / 4);
+    const float *pw = sW + (lane & 15) * PITCH + (lane >> 4) * (KC / 4);
     for (int pair = 0; pair < npair; ++pair) {
         if (pair > 0) {
             X = multi.X[pair];
@@ -121,18 +126,19 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
         for (int k0 = 0; k0 < k; k0 += KC) {
             const bool more = k0 + KC < k;
             if (more) fetch(k0 + KC);
-            const float4 x0 = *(const float4 *)px, x1 = *(const float4 *)(px + 4);
+            float4 xr[RUN];
+#pragma unroll
+            for (int j = 0; j < RUN; ++j) xr[j] = *(const float4 *)(px + 4 * j);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float4 w0 = *(const float4 *)(pw + t * 16 * PITCH), w1 = *(const float4 *)(pw + t * 16 * PITCH + 4);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < RUN; ++j) {
+                    const float4 w4 = *(const float4 *)(pw + t * 16 * PITCH + 4 * j);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, xr[j].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, xr[j].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, xr[j].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, xr[j].w, acc[t], 0, 0, 0);
+                }
             }
             if (more) {
                 __syncthreads();
@@ -166,6 +172,26 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
 
 }  // namespace gemm
 
+template <int BN, bool KM, int KC>
+static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const float *X, const float *W, const float *bias, float *Y,
+                       int accumulate, int ncb, const gemm::GemmMulti &gm) {
+    hipLaunchKernelGGL((gemm::rows_gemm_kernel<BN, KM, KC>), grid, dim3(gemm::THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate,
+                       ncb, gm);
+}
+
+static void launch_gemm(bool n48, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
+                        const float *W, const float *bias, float *Y, int accumulate, int ncb, const gemm::GemmMulti &gm) {
+#define GO(BN, KM, KC) launch_one<BN, KM, KC>(grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, gm)
+    if (n48) {
+        if (kmajor) { if (wide_k) GO(48, true, 64); else GO(48, true, 32); }
+        else { if (wide_k) GO(48, false, 64); else GO(48, false, 32); }
+    } else {
+        if (kmajor) { if (wide_k) GO(64, true, 64); else GO(64, true, 32); }
+        else { if (wide_k) GO(64, false, 64); else GO(64, false, 32); }
+    }
+#undef GO
+}
+
 // Y (m,n) [+]= X (m,k) op(W) + bias.  w_kmajor == 0: W is (n,k) row-major (y = x W^T, nn.Linear forward);
 // w_kmajor != 0: W is (k,n) row-major (gx = gy W).  n % 4 == 0, k % 4 == 0; bias may be NULL.
 extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const float *W, int w_kmajor,
@@ -182,13 +208,7 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
     const dim3 grid((unsigned)(nrb * ncb));
     {
         PtvScopedTimer t(KID_ROWS_GEMM, st, 4.0 * ((double)m * (n + k) + (double)n * k));
-        if (n48) {
-            if (w_kmajor) hipLaunchKernelGGL((rows_gemm_kernel<48, true>), grid, dim3(THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
-            else hipLaunchKernelGGL((rows_gemm_kernel<48, false>), grid, dim3(THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
-        } else {
-            if (w_kmajor) hipLaunchKernelGGL((rows_gemm_kernel<64, true>), grid, dim3(THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
-            else hipLaunchKernelGGL((rows_gemm_kernel<64, false>), grid, dim3(THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
-        }
+        launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -219,13 +239,7 @@ extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int 
     const float *b0 = sum ? gm.bias[0] : nullptr;
     {
         PtvScopedTimer t(KID_ROWS_GEMM, st, 4.0 * count * ((double)m * (n + k) + (double)n * k));
-        if (n48) {
-            if (w_kmajor) hipLaunchKernelGGL((rows_gemm_kernel<48, true>), grid, dim3(THREADS), 0, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
-            else hipLaunchKernelGGL((rows_gemm_kernel<48, false>), grid, dim3(THREADS), 0, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
-        } else {
-            if (w_kmajor) hipLaunchKernelGGL((rows_gemm_kernel<64, true>), grid, dim3(THREADS), 0, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
-            else hipLaunchKernelGGL((rows_gemm_kernel<64, false>), grid, dim3(THREADS), 0, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
-        }
+        launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
