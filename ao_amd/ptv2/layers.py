@@ -224,3 +224,86 @@ def skinny_linear(x, weight):
             and x.shape[1] % 4 == 0 and weight.shape[0] <= 64 and x.shape[0] >= 256):
         return _SkinnyLinear.apply(x, weight)
     return x @ weight.t()
+
+
+class _LinBnRelu(torch.autograd.Function):
+    """ReLU(BatchNorm(x W^T + b)) as one autograd node on the library's row GEMM / BatchNorm / weight-gradient
+    kernels (the per-stage projections around the Blocks: GridPool.fc, Unpool.proj / proj_skip, the head)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias, gamma, beta, bn):
+        x = x.contiguous()
+        n, cin = x.shape
+        cout = weight.shape[0]
+        L = _lib.lib()
+        dev = x.device
+        st = _lib.stream_ptr()
+        h = torch.empty((n, cout), dtype=torch.float32, device=dev)
+        rc = L.rows_gemm_hip_launcher(n, cout, cin, x.data_ptr(), weight.data_ptr(), 0, _lib.ptr(bias), h.data_ptr(), 0, st)
+        _lib.check(rc, "rows_gemm_hip_launcher")
+        training = bn.training or bn.running_mean is None
+        y = torch.empty_like(h)
+        if training:
+            mean = torch.empty(cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(cout, dtype=torch.float32, device=dev)
+            track = bn.track_running_stats and bn.training and bn.running_mean is not None
+            ws = _ws(n, cout, cout, dev)
+            rc = L.bn_forward_hip_launcher(
+                n, cout, h.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, mean.data_ptr(), rstd.data_ptr(),
+                bn.running_mean.data_ptr() if track else 0, bn.running_var.data_ptr() if track else 0,
+                bn.num_batches_tracked.data_ptr() if track else 0, float(bn.eps), float(bn.momentum), 0, 0, y.data_ptr(),
+                ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "bn_forward_hip_launcher")
+        else:
+            mean = bn.running_mean
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            rc = L.bn_apply_hip_launcher(n, cout, h.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), 1, y.data_ptr(), st)
+            _lib.check(rc, "bn_apply_hip_launcher")
+        ctx.save_for_backward(x, weight, h, mean, rstd, gamma, beta)
+        ctx.training, ctx.has_bias = bool(training), bias is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        x, weight, h, mean, rstd, gamma, beta = ctx.saved_tensors
+        n, cin = x.shape
+        cout = weight.shape[0]
+        L = _lib.lib()
+        dev = x.device
+        st = _lib.stream_ptr()
+        gy = gy.contiguous()
+        gh = torch.empty_like(h)
+        dgamma = torch.empty(cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(cout, dtype=torch.float32, device=dev)
+        ws = _ws(n, max(cout, cin), max(cout, cin), dev)
+        rc = L.bn_backward_hip_launcher(n, cout, h.data_ptr(), gy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), 1, int(ctx.training), gh.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "bn_backward_hip_launcher")
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            rc = L.rows_gemm_hip_launcher(n, cin, cout, gh.data_ptr(), weight.data_ptr(), 1, 0, gx.data_ptr(), 0, st)
+            _lib.check(rc, "rows_gemm_hip_launcher")
+        dW = torch.empty_like(weight)
+        db = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        rc = L.linear_wgrad_hip_launcher(n, cout, cin, gh.data_ptr(), x.data_ptr(), dW.data_ptr(), _lib.ptr(db), ws.data_ptr(),
+                                         ws.numel(), st)
+        _lib.check(rc, "linear_wgrad_hip_launcher")
+        return gx, dW, db, dgamma, dbeta, None
+
+
+def lin_bn_relu(linear, bn, x):
+    """ReLU(bn(linear(x))) for nn.Linear `linear` and RowBatchNorm1d `bn`; one fused autograd node when the row
+    kernels cover the shape (fp32 CUDA rows, channel counts multiples of 4), the two-module path otherwise."""
+    cout, cin = linear.weight.shape
+    if (isinstance(bn, RowBatchNorm1d) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and cin % 4 == 0
+            and cout % 4 == 0 and bn._fast(x.new_empty((2, cout))) and linear.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and linear.weight.is_contiguous()):
+        from . import block  # noqa: F401  (registers rows_gemm_hip_launcher)
+
+        return _LinBnRelu.apply(x, linear.weight, linear.bias, bn.weight, bn.bias, bn)
+    return bn(linear(x), relu=True)

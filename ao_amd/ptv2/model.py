@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import _lib, pointops
 from ..pointops.interpolation import _InterpolateRows
 from .geometry import build_geometry
-from .layers import RowBatchNorm1d, RowLinear, bn_residual_relu
+from .layers import RowBatchNorm1d, RowLinear, bn_residual_relu, lin_bn_relu
 
 
 class PointBatchNorm(nn.Module):
@@ -50,6 +50,8 @@ class LinBnRelu(nn.Sequential):
         super().__init__(RowLinear(cin, cout, bias=bias), PointBatchNorm(cout), nn.ReLU(inplace=True))
 
     def forward(self, x):
+        if x.dim() == 2:
+            return lin_bn_relu(self[0], self[1].norm, x)
         return self[1](self[0](x), relu=True)
 
 
@@ -232,7 +234,7 @@ class GridPool(nn.Module):
         self.act = nn.ReLU(inplace=True)
 
     def forward(self, feat, fine_level, coarse_level):
-        feat = self.norm(self.fc(feat), relu=True)
+        feat = lin_bn_relu(self.fc, self.norm.norm, feat)
         return _SegmentMax.apply(feat, fine_level.order32, fine_level.idx_ptr32)
 
 
@@ -354,6 +356,8 @@ class PointTransformerV2(nn.Module):
             dec = self.dec_stages[i]
             feat = dec.up(feat, skips.pop(), lv[i])
             feat = dec.blocks([lv[i].coord, feat, lv[i].offset], lv[i].neighbours(dec.blocks.neighbours))[1]
+        if isinstance(self.seg_head, nn.Sequential):
+            return self.seg_head[3](lin_bn_relu(self.seg_head[0], self.seg_head[1].norm, feat))
         return self.seg_head(feat)
 
 
