@@ -42,13 +42,22 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
                                                          const float *__restrict__ gWw1_k,
                                                          const float *__restrict__ gWw1_q, float *__restrict__ gWw1,
                                                          float *gWp2, float *gbp2, float *__restrict__ gbw1) {
-    const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
     const long long n1 = (long long)g * c, n2 = (long long)c * c;
-    if (e < n1) {
-        const int gi = (int)(e / c), ci = (int)(e - (long long)gi * c);
-        float acc = gcW[gi] * bp2[ci] + gWw1_k[e] + gWw1_q[e];
-        for (int cp = 0; cp < c; ++cp) acc = __builtin_fmaf(gM[(size_t)cp * g + gi], Wp2[(size_t)ci * c + cp], acc);
-        gWw1[e] = acc;
+    const int wblocks = (int)((n1 + WPB - 1) / WPB);  // the first blocks: one wavefront per gWw1 output (a length-c dot
+    if ((int)blockIdx.x < wblocks) {                  // product whose Wp2 row is read coalesced across the lanes)
+        const long long o = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
+        if (o < n1) {
+            const int lane = threadIdx.x & 63;
+            const int gi = (int)(o / c), ci = (int)(o - (long long)gi * c);
+            float acc = 0.f;
+            for (int cp = lane; cp < c; cp += WAVE) acc = __builtin_fmaf(gM[(size_t)cp * g + gi], Wp2[(size_t)ci * c + cp], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) gWw1[o] = acc + gcW[gi] * bp2[ci] + gWw1_k[o] + gWw1_q[o];
+        }
+        return;
+    }
+    const long long e = n1 + (long long)(blockIdx.x - wblocks) * TPB + threadIdx.x;
+    if (false) {
     } else if (e < n1 + n2) {
         const long long r = e - n1;
         const int ci = (int)(r / c), cp = (int)(r - (long long)ci * c);
@@ -280,7 +289,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, W.stage, W.stage_bytes, stream));
     }
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1
-    hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c + (long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,
+    hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c, WPB) + divup((long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,
                        g, B->Wp2, B->bp2, B->Ww1, (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k,
                        (const float *)W.gWw1_q, G->gWw1, G->gWp2, G->gbp2, G->gbw1);
     PTV2_CHECK_LAUNCH();
