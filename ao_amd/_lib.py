@@ -57,7 +57,11 @@ _SIGNATURES = {
                                 + [_c_size, _vp]),
     "bn_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
     "linear_wgrad_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5 + [_c_size, _vp]),
-    "linear_wgrad_multi_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 5 + [_c_size, _vp]),
+    "linear_wgrad_multi_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 7 + [_c_size, _vp]),
+    "skinny_linear_forward_xf_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),
+    "bn_tiles_floats": (_c_size, [_c_int] * 2),
+    "bn_tiles_finalize_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 10 + [ctypes.c_float] * 2 + [_vp]),
+    "bn_stats_affine_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 10 + [ctypes.c_float] * 2 + [_vp, _c_size, _vp]),
     "bn_apply_residual_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 9),
     "bn_backward_residual_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 7 + [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "skinny_linear_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),

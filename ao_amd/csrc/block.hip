@@ -5,6 +5,9 @@
 //              attn = GVA(q,k,v,coord,idx)                       (gva_block.hip)
 //              f2 = ReLU(BN2(attn))    h3 = f2 fc3^T
 //              y  = ReLU(x + rowscale * BN3(h3))
+//   BatchNorm is fused into the Linears around it: the GEMM that produces h1 / hq / hk / h3 leaves per-row-block
+//   column statistics in its epilogue (one tiny finalize each), and f1, q, k, f2 are never materialised -- their
+//   consumers (GEMM, weight gradient, the G-wide projections) apply ReLU(x * sc + sh) on the operand load.
 //   backward:  the same chain reversed; sums of several products (g_f1 from q/k/v, g_x from fc1 and the
 //              residual) use the GEMM's accumulate epilogue instead of separate adds.
 // Everything is enqueued on the caller's stream; the host never synchronises.  The activations the backward
@@ -19,8 +22,9 @@ namespace {
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Saved {
-    float *h1, *f1, *hq, *q, *hk, *key, *v, *attn, *f2, *h3;      // (n,c) each
+    float *h1, *hq, *hk, *v, *attn, *h3;                          // (n,c) each
     float *mean[PTV2_BLK_NBN], *rstd[PTV2_BLK_NBN];                // (c): 0,1,2,5,6 used here
+    float *bsc[PTV2_BLK_NBN], *bsh[PTV2_BLK_NBN];                  // (c): folded affine of BatchNorm 0,1,2,5
     // GroupedVectorAttention (ptv2_gva_block "saved" fields)
     float *a, *b, *rstd_p, *M, *cW, *kW, *qW, *W1, *w, *A, *sw, *sc, *sh;
     double *mean_w, *rstd_w;
@@ -34,12 +38,13 @@ Saved carve_saved(void *base, int n, int k, int c, int g) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
     const size_t nc = sizeof(float) * (size_t)n * c, ng = sizeof(float) * (size_t)n * g;
     const size_t rows = sizeof(float) * (size_t)n * k * g;
-    s.h1 = (float *)take(nc); s.f1 = (float *)take(nc); s.hq = (float *)take(nc); s.q = (float *)take(nc);
-    s.hk = (float *)take(nc); s.key = (float *)take(nc); s.v = (float *)take(nc); s.attn = (float *)take(nc);
-    s.f2 = (float *)take(nc); s.h3 = (float *)take(nc);
+    s.h1 = (float *)take(nc); s.hq = (float *)take(nc); s.hk = (float *)take(nc); s.v = (float *)take(nc);
+    s.attn = (float *)take(nc); s.h3 = (float *)take(nc);
     for (int i = 0; i < PTV2_BLK_NBN; ++i) {
         s.mean[i] = (float *)take(sizeof(float) * c);
         s.rstd[i] = (float *)take(sizeof(float) * c);
+        s.bsc[i] = (float *)take(sizeof(float) * c);
+        s.bsh[i] = (float *)take(sizeof(float) * c);
     }
     s.a = (float *)take(sizeof(float) * 3 * c); s.b = (float *)take(sizeof(float) * c);
     s.rstd_p = (float *)take(sizeof(float) * c); s.M = (float *)take(sizeof(float) * (size_t)c * g);
@@ -55,6 +60,7 @@ struct Work {
     char *dense; size_t dense_bytes;
     char *gva; size_t gva_bytes;
     float *t[4];  // (n,c) gradient temporaries
+    float *stat[4];  // GEMM-epilogue statistics records of h1, hq, hk, h3: ceil(n / 64) x [2][c]
     size_t bytes;
 };
 
@@ -68,17 +74,23 @@ Work carve_work(void *base, int n, int k, int c, int g) {
     w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
     w.gva = take(w.gva_bytes);
     for (int i = 0; i < 4; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
+    for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * bn_tiles_floats(n, c));
     w.bytes = off;
     return w;
 }
 
-// eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps)
+// eval-mode statistics: mean = running_mean, rstd = 1/sqrt(running_var + eps), and the folded affine
 __global__ void bn_eval_stats_kernel(int c, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
-                                     float *__restrict__ mean, float *__restrict__ rstd) {
+                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ sc,
+                                     float *__restrict__ sh) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < c) {
-        mean[i] = rm[i];
-        rstd[i] = 1.0f / sqrtf(rv[i] + eps);
+        const float m = rm[i], r = 1.0f / sqrtf(rv[i] + eps);
+        mean[i] = m;
+        rstd[i] = r;
+        sc[i] = r * gamma[i];
+        sh[i] = beta[i] - m * r * gamma[i];
     }
 }
 
@@ -110,7 +122,8 @@ bool args_ok(const ptv2_block *B) {
 void fill_gva(const ptv2_block *B, const Saved &S, ptv2_gva_block *V) {
     V->n = B->n; V->k = B->k; V->c = B->c; V->g = B->g; V->training = B->training;
     V->eps_p = V->eps_w = B->eps; V->momentum_p = V->momentum_w = B->momentum;
-    V->q = S.q; V->key = S.key; V->v = S.v; V->coord = B->coord; V->idx = B->idx; V->mu = B->mu; V->cov = B->cov;
+    V->q = S.hq; V->key = S.hk; V->v = S.v;  // pre-BatchNorm projections + the folded affine (applied on operand load)
+    V->q_sc = S.bsc[1]; V->q_sh = S.bsh[1]; V->k_sc = S.bsc[2]; V->k_sh = S.bsh[2]; V->coord = B->coord; V->idx = B->idx; V->mu = B->mu; V->cov = B->cov;
     V->Wp1 = B->param[PTV2_BLK_P1_W]; V->bp1 = B->param[PTV2_BLK_P1_B]; V->gamma_p = B->param[PTV2_BLK_PN_G];
     V->beta_p = B->param[PTV2_BLK_PN_B]; V->Wp2 = B->param[PTV2_BLK_P2_W]; V->bp2 = B->param[PTV2_BLK_P2_B];
     V->Ww1 = B->param[PTV2_BLK_W1_W]; V->bw1 = B->param[PTV2_BLK_W1_B]; V->gamma_w = B->param[PTV2_BLK_WN_G];
@@ -153,22 +166,26 @@ extern "C" int ptv2_block_param_layout(int c, int g, long long *offsets) {
     return PTV2_OK;
 }
 
-// BatchNorm `i` forward on x (n,c): batch statistics (training, or no running buffers) or running statistics
-// (eval); y = [ReLU](BN(x)), or the Block tail ReLU(residual + rowscale * BN(x)) when residual != NULL
-static int bn_fwd(const ptv2_block *B, int i, const float *x, const float *gamma, const float *beta, int relu,
-                  const float *residual, const float *rowscale, float *y, const Saved &S, const Work &W, void *stream) {
-    const bool use_batch = B->training || !B->run_mean[i] || !B->run_var[i];
-    if (use_batch) {
+static bool use_batch(const ptv2_block *B, int i) { return B->training || !B->run_mean[i] || !B->run_var[i]; }
+
+// statistics of BatchNorm `i` (input h, (n,c)) -> S.mean / S.rstd / S.sc / S.sh: from the producing GEMM's epilogue
+// records (`part` != NULL), from a pass over h (`part` == NULL, batch statistics), or from the running buffers (eval)
+static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, const float *gamma, const float *beta,
+                      const Saved &S, const Work &W, void *stream) {
+    if (use_batch(B, i)) {
         const bool track = B->training && B->run_mean[i] && B->run_var[i];
-        return bn_forward_hip_launcher(B->n, B->c, x, gamma, beta, relu, S.mean[i], S.rstd[i], track ? B->run_mean[i] : nullptr,
-                                       track ? B->run_var[i] : nullptr, track ? B->batches[i] : nullptr, B->eps, B->momentum,
-                                       residual, rowscale, y, W.dense, W.dense_bytes, stream);
+        float *rm = track ? B->run_mean[i] : nullptr, *rv = track ? B->run_var[i] : nullptr;
+        long long *nb = track ? B->batches[i] : nullptr;
+        if (part)
+            return bn_tiles_finalize_hip_launcher(B->n, B->c, part, gamma, beta, S.mean[i], S.rstd[i], S.bsc[i], S.bsh[i], rm, rv,
+                                                  nb, B->eps, B->momentum, stream);
+        return bn_stats_affine_hip_launcher(B->n, B->c, h, gamma, beta, S.mean[i], S.rstd[i], S.bsc[i], S.bsh[i], rm, rv, nb, B->eps,
+                                            B->momentum, W.dense, W.dense_bytes, stream);
     }
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(divup(B->c, 256)), dim3(256), 0, (hipStream_t)stream, B->c,
-                       (const float *)B->run_mean[i], (const float *)B->run_var[i], B->eps, S.mean[i], S.rstd[i]);
-    if (residual)
-        return bn_apply_residual_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], gamma, beta, residual, rowscale, y, stream);
-    return bn_apply_hip_launcher(B->n, B->c, x, S.mean[i], S.rstd[i], gamma, beta, relu, y, stream);
+                       (const float *)B->run_mean[i], (const float *)B->run_var[i], B->eps, gamma, beta, S.mean[i], S.rstd[i],
+                       S.bsc[i], S.bsh[i]);
+    return PTV2_OK;
 }
 
 extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *workspace, size_t workspace_bytes, void *stream) {
@@ -179,26 +196,38 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     const Work W = carve_work(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     const float *const *P = B->param;
-    // fc1 -> norm1 -> ReLU
-    RUN(rows_gemm_hip_launcher(n, c, c, B->x, P[PTV2_BLK_FC1_W], 0, nullptr, S.h1, 0, stream));
-    RUN(bn_fwd(B, 0, S.h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, nullptr, nullptr, S.f1, S, W, stream));
-    // linear_q / linear_k (Linear + BN + ReLU), linear_v
+    float *st_h1 = use_batch(B, 0) ? W.stat[0] : nullptr, *st_hq = use_batch(B, 1) ? W.stat[1] : nullptr;
+    float *st_hk = use_batch(B, 2) ? W.stat[2] : nullptr, *st_h3 = use_batch(B, 6) ? W.stat[3] : nullptr;
+    // fc1 (+ statistics of h1) -> norm1
     {
-        const float *xs[3] = {S.f1, S.f1, S.f1}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
-        const float *bs[3] = {P[PTV2_BLK_Q_B], P[PTV2_BLK_K_B], P[PTV2_BLK_V_B]};
-        float *ys[3] = {S.hq, S.hk, S.v};
-        RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, stream));
+        const float *xs[1] = {B->x}, *ws[1] = {P[PTV2_BLK_FC1_W]};
+        float *ys[1] = {S.h1}, *sts[1] = {st_h1};
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, nullptr, nullptr, sts, stream));
     }
-    RUN(bn_fwd(B, 1, S.hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, nullptr, nullptr, S.q, S, W, stream));
-    RUN(bn_fwd(B, 2, S.hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, nullptr, nullptr, S.key, S, W, stream));
-    // grouped vector attention
+    RUN(bn_prepare(B, 0, S.h1, st_h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S, W, stream));
+    // linear_q / linear_k / linear_v on f1 = ReLU(BN1(h1)) (applied on the operand load), statistics of hq, hk
+    {
+        const float *xs[3] = {S.h1, S.h1, S.h1}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
+        const float *bs[3] = {P[PTV2_BLK_Q_B], P[PTV2_BLK_K_B], P[PTV2_BLK_V_B]};
+        float *ys[3] = {S.hq, S.hk, S.v}, *sts[3] = {st_hq, st_hk, nullptr};
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, S.bsc[0], S.bsh[0], sts, stream));
+    }
+    RUN(bn_prepare(B, 1, S.hq, st_hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S, W, stream));
+    RUN(bn_prepare(B, 2, S.hk, st_hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S, W, stream));
+    // grouped vector attention (q, k enter as hq, hk + folded affine)
     ptv2_gva_block V;
     fill_gva(B, S, &V);
     RUN(gva_block_forward_hip_launcher(&V, W.gva, W.gva_bytes, stream));
-    // norm2 -> ReLU -> fc3 -> norm3 -> DropPath -> + identity -> ReLU
-    RUN(bn_fwd(B, 5, S.attn, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, nullptr, nullptr, S.f2, S, W, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, S.f2, P[PTV2_BLK_FC3_W], 0, nullptr, S.h3, 0, stream));
-    RUN(bn_fwd(B, 6, S.h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], 0, B->x, B->rowscale, B->y, S, W, stream));
+    // norm2 (statistics by a pass over attn) -> fc3 on f2 = ReLU(BN2(attn)) (+ statistics of h3) -> norm3 -> tail
+    RUN(bn_prepare(B, 5, S.attn, nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
+    {
+        const float *xs[1] = {S.attn}, *ws[1] = {P[PTV2_BLK_FC3_W]};
+        float *ys[1] = {S.h3}, *sts[1] = {st_h3};
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, S.bsc[5], S.bsh[5], sts, stream));
+    }
+    RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
+    RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
+                                       B->y, stream));
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -226,7 +255,11 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                           stream));
     // fc3
     RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_FC3_W], 1, nullptr, T1, 0, stream));
-    RUN(linear_wgrad_hip_launcher(n, c, c, T0, S.f2, GP(PTV2_BLK_FC3_W), nullptr, W.dense, W.dense_bytes, stream));
+    {
+        const float *gys[1] = {T0}, *xs[1] = {S.attn}, *xsc[1] = {S.bsc[5]}, *xsh[1] = {S.bsh[5]};  // X = f2 = ReLU(BN2(attn))
+        float *dws[1] = {GP(PTV2_BLK_FC3_W)};
+        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 1, gys, xs, dws, nullptr, xsc, xsh, W.dense, W.dense_bytes, stream));
+    }
     // norm2 + ReLU -> g_attn (T0)
     RUN(bn_backward_hip_launcher(n, c, S.attn, T1, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], T0,
                                  GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
@@ -248,10 +281,11 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                  GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
     // weight / bias gradients of the three projections of f1
     {
-        const float *gys[3] = {T2, T0, T3}, *xs[3] = {S.f1, S.f1, S.f1};
+        const float *gys[3] = {T2, T0, T3}, *xs[3] = {S.h1, S.h1, S.h1};  // X = f1 = ReLU(BN1(h1)) on the operand load
+        const float *xsc[3] = {S.bsc[0], S.bsc[0], S.bsc[0]}, *xsh[3] = {S.bsh[0], S.bsh[0], S.bsh[0]};
         float *dws[3] = {GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W)};
         float *dbs[3] = {GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B)};
-        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 3, gys, xs, dws, dbs, W.dense, W.dense_bytes, stream));
+        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 3, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
     }
     // g_f1 (T1) = g_hq Wq + g_hk Wk + gv Wv
     {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
 // finalize: column sums of (x-x0) and (x-x0)^2 over the per-block partials -> mean, rstd, running statistics
 __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_kernel(
     const float *__restrict__ part, int nblk, int c, int n, const float *__restrict__ x0, float eps, float momentum,
-    float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches) {
+    float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ sc, float *__restrict__ sh) {
     __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
     const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
     const int ch = blockIdx.x * gva::FIN_COLS + col;
@@ -98,6 +99,55 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_ke
         var = var > 0.0 ? var : 0.0;
         mean[ch] = (float)m;
         rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+        if (sc) {  // y = x * sc + sh is the whole normalisation: consumers apply it on their operand load
+            const float scale = rstd[ch] * gamma[ch];
+            sc[ch] = scale;
+            sh[ch] = beta[ch] - mean[ch] * scale;
+        }
+        if (run_mean) {
+            const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+            run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
+            run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
+            if (ch == 0 && batches) *batches += 1;
+        }
+    }
+}
+
+// the same from the row GEMM's epilogue records part[nrb][2][c] (per 64-row block: column sums and sums of squares
+// about the block mean), merged with the parallel-variance identity  M2 = sum_b (M2_b + S_b^2 / n_b) - n mean^2
+__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_tiles_kernel(
+    const float *__restrict__ part, int nrb, int c, int n, float eps, float momentum, float *__restrict__ mean,
+    float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ sc, float *__restrict__ sh) {
+    __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+    const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
+    const int ch = blockIdx.x * gva::FIN_COLS + col;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        for (int k = sl; k < nrb; k += gva::FIN_SLICES) {
+            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const double sb = (double)part[(size_t)k * 2 * c + ch];
+            a += sb;
+            b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
+        }
+    }
+    s1[sl][col] = a;
+    s2[sl][col] = b;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        const double m = t1 / n;
+        double var = t2 / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        mean[ch] = (float)m;
+        rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+        if (sc) {
+            const float scale = rstd[ch] * gamma[ch];
+            sc[ch] = scale;
+            sh[ch] = beta[ch] - mean[ch] * scale;
+        }
         if (run_mean) {
             const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
             run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
@@ -327,6 +377,7 @@ struct WgradMulti {
     const float *gY[4], *X[4];
     float *dW[4], *db[4];
     int count;  // 0: the strided form (gY + z * sy, X + z * sx)
+    const float *xsc[4], *xsh[4];  // != NULL: the X operand of pair z is ReLU(x * xsc + xsh) (fused BatchNorm + ReLU)
 };
 
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
@@ -352,8 +403,15 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
         for (int t = 0; t < WG_MT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     bool mo[WG_MT], mi[WG_MT];
+    const float *xs = multi.count ? multi.xsc[bz] : nullptr, *xh = multi.count ? multi.xsh[bz] : nullptr;
+    float xsc_[WG_MT], xsh_[WG_MT];
 #pragma unroll
-    for (int m = 0; m < WG_MT; ++m) { mo[m] = to + m * 16 + lc < cout; mi[m] = ti + m * 16 + lc < cin; }
+    for (int m = 0; m < WG_MT; ++m) {
+        mo[m] = to + m * 16 + lc < cout;
+        mi[m] = ti + m * 16 + lc < cin;
+        xsc_[m] = (xs && mi[m]) ? xs[ti + m * 16 + lc] : 1.f;
+        xsh_[m] = (xs && mi[m]) ? xh[ti + m * 16 + lc] : 0.f;
+    }
     // U k-steps per trip: all 6 U fragment loads are issued before the first MFMA consumes one (a step-by-step loop
     // paid one memory latency per 4 rows: 2.5 us per 100 rows of chunk, independent of the problem size)
     constexpr int U = 8;
@@ -368,6 +426,12 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
                 a[u][m] = (rok && mo[m]) ? A[row * ldy + to + m * 16 + lc] : 0.f;
                 b[u][m] = (rok && mi[m]) ? B[row * ldx + ti + m * 16 + lc] : 0.f;
             }
+        }
+        if (xs) {  // fused BatchNorm + ReLU on the X operand; rows past the end meet a == 0, so no masking is needed
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < WG_MT; ++m) b[u][m] = fmaxf(__builtin_fmaf(b[u][m], xsc_[m], xsh_[m]), 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -420,15 +484,21 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 // y[n,o] = sum_i x[n,i] W[o,i] for cout <= 64 (the G-wide projections kW, qW of the attention logits); the
 // BLAS kernel chosen for an N x 48 x 6 product runs 190 us (profiles/r01_fused_v5_*).  One lane per output,
 // W in LDS, the x row is shared by the cout lanes of a point.
+// xsc / xsh != NULL: the input row passes through ReLU(x * xsc + xsh) first (BatchNorm + ReLU of linear_q / linear_k
+// fused into the projection that consumes them)
 __global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, int cout, const float *__restrict__ x,
-                                                         const float *__restrict__ W, float *__restrict__ y) {
+                                                         const float *__restrict__ W, const float *__restrict__ xsc,
+                                                         const float *__restrict__ xsh, float *__restrict__ y) {
     extern __shared__ float4 lds4[];
-    float *sW = (float *)lds4;  // [cout][cin + 4]
+    float *sW = (float *)lds4;  // [cout][cin + 4], then [2][cin] scale / shift
     const int ldw = cin + 4, cq = cin >> 2;
+    float *sSc = sW + (size_t)cout * ldw, *sSh = sSc + cin;
     for (int e = threadIdx.x; e < cout * cq; e += TPB) {
         const int r = e / cq, q = e - r * cq;
         *(float4 *)(sW + (size_t)r * ldw + 4 * q) = *(const float4 *)(W + (size_t)r * cin + 4 * q);
     }
+    if (xsc)
+        for (int e = threadIdx.x; e < cin; e += TPB) { sSc[e] = xsc[e]; sSh[e] = xsh[e]; }
     __syncthreads();
     const long long total = n * cout;
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
@@ -436,10 +506,21 @@ __global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, i
         const int o = (int)(e - row * cout);
         const float4 *xr = (const float4 *)(x + row * cin), *wr = (const float4 *)(sW + (size_t)o * ldw);
         float acc = 0.f;
-        for (int q = 0; q < cq; ++q) {
-            const float4 a = xr[q], w = wr[q];
-            acc = __builtin_fmaf(a.x, w.x, acc); acc = __builtin_fmaf(a.y, w.y, acc);
-            acc = __builtin_fmaf(a.z, w.z, acc); acc = __builtin_fmaf(a.w, w.w, acc);
+        if (xsc) {
+            for (int q = 0; q < cq; ++q) {
+                float4 a = xr[q];
+                const float4 w = wr[q], s4 = ((const float4 *)sSc)[q], h4 = ((const float4 *)sSh)[q];
+                a.x = fmaxf(__builtin_fmaf(a.x, s4.x, h4.x), 0.f); a.y = fmaxf(__builtin_fmaf(a.y, s4.y, h4.y), 0.f);
+                a.z = fmaxf(__builtin_fmaf(a.z, s4.z, h4.z), 0.f); a.w = fmaxf(__builtin_fmaf(a.w, s4.w, h4.w), 0.f);
+                acc = __builtin_fmaf(a.x, w.x, acc); acc = __builtin_fmaf(a.y, w.y, acc);
+                acc = __builtin_fmaf(a.z, w.z, acc); acc = __builtin_fmaf(a.w, w.w, acc);
+            }
+        } else {
+            for (int q = 0; q < cq; ++q) {
+                const float4 a = xr[q], w = wr[q];
+                acc = __builtin_fmaf(a.x, w.x, acc); acc = __builtin_fmaf(a.y, w.y, acc);
+                acc = __builtin_fmaf(a.z, w.z, acc); acc = __builtin_fmaf(a.w, w.w, acc);
+            }
         }
         y[e] = acc;
     }
@@ -491,6 +572,11 @@ static int bn_grid(int n, int c) {
     return (int)std::max<long long>(1, std::min<long long>(b, MAX_BLK));
 }
 
+namespace {
+struct BnAffine { const float *gamma = nullptr, *beta = nullptr; float *sc = nullptr, *sh = nullptr; };
+thread_local BnAffine g_affine;  // set by bn_stats_affine_hip_launcher around its call of bn_stats_hip_launcher
+}  // namespace
+
 extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
                                      float *running_var, long long *num_batches_tracked, float eps, float momentum,
                                      void *workspace, size_t workspace_bytes, void *stream) {
@@ -505,7 +591,107 @@ extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, 
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
                        dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, st, (const float *)part, nblk, c, n, x, eps, momentum, mean,
-                       rstd, running_mean, running_var, num_batches_tracked);
+                       rstd, running_mean, running_var, num_batches_tracked, g_affine.gamma, g_affine.beta, g_affine.sc,
+                       g_affine.sh);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// bn_stats that also emits the folded affine (sc = rstd * gamma, sh = beta - mean * sc) for consumers that apply the
+// normalisation on their operand load (rows_gemm_fused, linear_wgrad_multi, skinny_linear_forward)
+extern "C" int bn_stats_affine_hip_launcher(int n, int c, const float *x, const float *gamma, const float *beta, float *mean,
+                                            float *rstd, float *sc, float *sh, float *running_mean, float *running_var,
+                                            long long *num_batches_tracked, float eps, float momentum, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+    if (!gamma || !beta || !sc || !sh) return PTV2_ERR_ARG;
+    g_affine = BnAffine{gamma, beta, sc, sh};
+    const int rc = bn_stats_hip_launcher(n, c, x, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum,
+                                         workspace, workspace_bytes, stream);
+    g_affine = BnAffine{};
+    return rc;
+}
+
+// first level for many records: block (x, y) folds records y, y + gridDim.y, ... of 64 columns into ONE record of
+// the same form (sum; centred sum of squares; its row count is implied by the records it covers)
+__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_fold_tiles_kernel(const float *__restrict__ part, int nrb,
+                                                                                       int c, int n, double *__restrict__ out) {
+    __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+    const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
+    const int ch = blockIdx.x * gva::FIN_COLS + col;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        for (int k = blockIdx.y * gva::FIN_SLICES + sl; k < nrb; k += gridDim.y * gva::FIN_SLICES) {
+            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const double sb = (double)part[(size_t)k * 2 * c + ch];
+            a += sb;
+            b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
+        }
+    }
+    s1[sl][col] = a;
+    s2[sl][col] = b;
+    __syncthreads();
+    if (sl == 0 && ch < c) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        out[(size_t)blockIdx.y * 2 * c + ch] = t1;       // sum
+        out[(size_t)blockIdx.y * 2 * c + c + ch] = t2;   // sum_b (M2_b + S_b^2 / n_b): only "- n mean^2" is missing
+    }
+}
+
+// second level: nrec folded records (float64) -> mean, rstd, folded affine, running buffers
+__global__ void bn_finalize_folded_kernel(const double *__restrict__ rec, int nrec, int c, int n, float eps, float momentum,
+                                          float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var,
+                                          long long *batches, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                          float *__restrict__ sc, float *__restrict__ sh) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < nrec; ++k) { t1 += rec[(size_t)k * 2 * c + ch]; t2 += rec[(size_t)k * 2 * c + c + ch]; }
+    const double m = t1 / n;
+    double var = t2 / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    mean[ch] = (float)m;
+    rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (sc) {
+        const float scale = rstd[ch] * gamma[ch];
+        sc[ch] = scale;
+        sh[ch] = beta[ch] - mean[ch] * scale;
+    }
+    if (run_mean) {
+        const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+        run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
+        run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
+        if (ch == 0 && batches) *batches += 1;
+    }
+}
+
+// statistics of a (n,c) tensor from the records its producing rows_gemm_fused launch left in `part`
+extern "C" size_t bn_tiles_floats(int n, int c) {  // floats of a statistics record buffer (incl. the folding scratch)
+    return (size_t)((n + 63) / 64) * 2 * c + 2 + 2 * (size_t)16 * 2 * c;
+}
+
+extern "C" int bn_tiles_finalize_hip_launcher(int n, int c, float *part, const float *gamma, const float *beta,
+                                              float *mean, float *rstd, float *sc, float *sh, float *running_mean,
+                                              float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                                              void *stream) {
+    if (n < 1 || c < 4 || !part || !mean || !rstd || ((sc != nullptr) && (!gamma || !beta || !sh))) return PTV2_ERR_ARG;
+    const int nrb_all = (n + 63) / 64;
+    if (nrb_all > 512) {  // two levels: 16 folding blocks per 64 columns, then a one-thread-per-column finish.  The folded
+        // records live behind the tile records (the GEMM wrote nrb * 2c floats; 16 * 2c doubles more are reserved)
+        double *fold = (double *)(part + (((size_t)nrb_all * 2 * c + 1) & ~(size_t)1));
+        const int ny = 16;
+        hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS, ny),
+                           dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, part, nrb_all, c, n, fold);
+        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                           (const double *)fold, ny, c, n, eps, momentum, mean, rstd, running_mean, running_var,
+                           num_batches_tracked, gamma, beta, sc, sh);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
+                       dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, part, (n + 63) / 64, c, n, eps, momentum,
+                       mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -608,11 +794,11 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     return PTV2_OK;
 }
 
-extern "C" int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
-                                                 void *stream) {
-    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1 || cout > 64) return PTV2_ERR_ARG;
+extern "C" int skinny_linear_forward_xf_hip_launcher(int n, int cin, int cout, const float *x, const float *W,
+                                                    const float *xsc, const float *xsh, float *y, void *stream) {
+    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1 || cout > 64 || (xsc == nullptr) != (xsh == nullptr)) return PTV2_ERR_ARG;
     if (n == 0) return PTV2_OK;
-    const size_t lds = sizeof(float) * (size_t)cout * (cin + 4);
+    const size_t lds = sizeof(float) * ((size_t)cout * (cin + 4) + 2 * (size_t)cin);
     if (lds > 160 * 1024) return PTV2_ERR_ARG;
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void *)skinny_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -620,10 +806,16 @@ extern "C" int skinny_linear_forward_hip_launcher(int n, int cin, int cout, cons
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 8);
     {
         PtvScopedTimer t(KID_SKINNY_FWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
-        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, y);
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, xsc,
+                           xsh, y);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
+}
+
+extern "C" int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
+                                                 void *stream) {
+    return skinny_linear_forward_xf_hip_launcher(n, cin, cout, x, W, nullptr, nullptr, y, stream);
 }
 
 extern "C" int skinny_linear_backward_hip_launcher(int n, int cin, int cout, const float *gy, const float *W, float *gx,
@@ -683,7 +875,8 @@ struct MapWgradMulti {  // record = [count][cout*cin] weights, then [count][cout
 // count (<= 4) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
 // shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))
 extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
-                                               const float *const *X, float *const *dW, float *const *db, void *workspace,
+                                               const float *const *X, float *const *dW, float *const *db,
+                                               const float *const *xsc, const float *const *xsh, void *workspace,
                                                size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 4 || !gY || !X || !dW) return PTV2_ERR_ARG;
     const int chunk = wg_chunk(n);
@@ -696,6 +889,9 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
     for (int i = 0; i < count; ++i) {
         if (!gY[i] || !X[i] || !dW[i]) return PTV2_ERR_ARG;
         m.gY[i] = gY[i]; m.X[i] = X[i]; m.dW[i] = dW[i]; m.db[i] = db ? db[i] : nullptr;
+        m.xsc[i] = xsc ? xsc[i] : nullptr;
+        m.xsh[i] = xsh ? xsh[i] : nullptr;
+        if ((m.xsc[i] == nullptr) != (m.xsh[i] == nullptr)) return PTV2_ERR_ARG;
     }
     float *part = (float *)workspace;
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;

@@ -33,7 +33,25 @@ struct GemmMulti {
     float *Y[3];
     int count;  // 0: single product from the plain arguments
     int sum;    // != 0: Y[0] = sum_i X[i] op(W[i])
+    // BatchNorm fused on either side (block.hip): the X operand passes through ReLU(x * xsc[k] + xsh[k]) on its way
+    // into LDS (the normalise + ReLU of the BatchNorm in front of this Linear, never materialised), and/or the
+    // epilogue leaves per-row-block column statistics of the output in stats[z] (records [row block][2][n]: sum and
+    // centred sum of squares of the block's rows) for the BatchNorm behind it
+    const float *xsc, *xsh;
+    float *stats[3];
 };
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16 lanes that share lane >> 4
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
 
 template <int BN, bool W_KMAJOR, int KC>
 __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k, const float *__restrict__ X0,
@@ -68,6 +86,13 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             const int q = tid + j * THREADS, r = q / KQ, kq = (q % KQ) * 4;
             const long long row = row0 + r;
             rx[j] = (row < m && k0 + kq < k) ? *(const float4 *)(X + row * k + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (multi.xsc && k0 + kq < k) {
+                const float4 s4 = *(const float4 *)(multi.xsc + k0 + kq), h4 = *(const float4 *)(multi.xsh + k0 + kq);
+                rx[j].x = fmaxf(__builtin_fmaf(rx[j].x, s4.x, h4.x), 0.f);
+                rx[j].y = fmaxf(__builtin_fmaf(rx[j].y, s4.y, h4.y), 0.f);
+                rx[j].z = fmaxf(__builtin_fmaf(rx[j].z, s4.z, h4.z), 0.f);
+                rx[j].w = fmaxf(__builtin_fmaf(rx[j].w, s4.w, h4.w), 0.f);
+            }
         }
 #pragma unroll
         for (int j = 0; j < WLOADS; ++j) {
@@ -149,22 +174,77 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
     }
     // D[i][j]: i = output column within the tile = (lane >> 4) * 4 + reg, j = row within the strip = lane & 15
     const long long row = row0 + wid * 16 + (lane & 15);
-    if (row < m) {
+    float4 val[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n0 + t * 16 + (lane >> 4) * 4;
+        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (bias && col < n) {
+            const float4 bb = *(const float4 *)(bias + col);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        val[t] = v;
+        if (row < m && col < n) {
+            float4 *dst = (float4 *)(Y + row * n + col);
+            if (accumulate) {
+                const float4 o = *dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+        }
+    }
+    float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
+    if (stats) {
+        // column statistics of this 64-row block: sum, then sum of squares about the block mean (two passes over
+        // the register tile; the finalize merges blocks with the parallel-variance formula in double)
+        float *sS = sX;  // [4 waves][BN]: the operand staging is no longer needed
+        const bool rv = row < m;
+        const int cnt = (int)((m - row0) < BM ? (m - row0) : BM);
+        const int cl = (lane >> 4) * 4;  // my 4 columns within a 16-wide tile
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int col = n0 + t * 16 + (lane >> 4) * 4;
-            if (col < n) {
-                float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-                if (bias) {
-                    const float4 bb = *(const float4 *)(bias + col);
-                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            const float sx = row16_sum(rv ? val[t].x : 0.f), sy = row16_sum(rv ? val[t].y : 0.f);
+            const float sz = row16_sum(rv ? val[t].z : 0.f), sw = row16_sum(rv ? val[t].w : 0.f);
+            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(sx, sy, sz, sw);
+        }
+        __syncthreads();
+        float4 mean[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 a = *(const float4 *)(sS + t * 16 + cl);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
+            mean[t] = a;  // block sums for now
+        }
+        __syncthreads();
+        const float inv = 1.0f / (float)cnt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + t * 16 + cl;
+            if (wid == 0 && (lane & 15) == 0 && col < n) *(float4 *)(stats + (size_t)rb * 2 * n + col) = mean[t];
+            const float dx = rv ? val[t].x - mean[t].x * inv : 0.f, dy = rv ? val[t].y - mean[t].y * inv : 0.f;
+            const float dz = rv ? val[t].z - mean[t].z * inv : 0.f, dw = rv ? val[t].w - mean[t].w * inv : 0.f;
+            const float qx = row16_sum(dx * dx), qy = row16_sum(dy * dy), qz = row16_sum(dz * dz), qw = row16_sum(dw * dw);
+            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(qx, qy, qz, qw);
+        }
+        __syncthreads();
+        if (wid == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = n0 + t * 16 + cl;
+                if (col < n) {
+                    float4 a = *(const float4 *)(sS + t * 16 + cl);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) {
+                        const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
+                        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                    }
+                    *(float4 *)(stats + (size_t)rb * 2 * n + n + col) = a;
                 }
-                float4 *dst = (float4 *)(Y + row * n + col);
-                if (accumulate) {
-                    const float4 o = *dst;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                *dst = v;
             }
         }
     }
@@ -216,9 +296,13 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
 
 // count (<= 3) products of one shape in one launch.  sum == 0: Y[i] = X[i] op(W[i]) + bias[i] (independent outputs);
 // sum != 0: Y[0] (+)= sum_i X[i] op(W[i]) (+ bias[0]).
-extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
+// as rows_gemm_multi, with BatchNorm fused on either side: xsc / xsh (k) != NULL: the X operand is ReLU(x * xsc + xsh);
+// stats != NULL: stats[i] != NULL receives the per-row-block column statistics of Y[i] (ceil(m / 64) records of
+// [2][n] floats: sum, centred sum of squares), to be merged by bn_tiles_finalize_hip_launcher
+extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
                                             const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
-                                            int accumulate, void *stream) {
+                                            int accumulate, const float *xsc, const float *xsh, float *const *stats,
+                                            void *stream) {
     using namespace gemm;
     if (m < 0 || n < 4 || k < 4 || n % 4 != 0 || k % 4 != 0 || count < 1 || count > 3 || !X || !W || !Y) return PTV2_ERR_ARG;
     if (m == 0) return PTV2_OK;
@@ -228,7 +312,11 @@ extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int 
     for (int i = 0; i < count; ++i) {
         if (!X[i] || !W[i] || (!Y[i] && (i == 0 || !sum))) return PTV2_ERR_ARG;
         gm.X[i] = X[i]; gm.W[i] = W[i]; gm.bias[i] = bias ? bias[i] : nullptr; gm.Y[i] = Y[i];
+        gm.stats[i] = stats ? stats[i] : nullptr;
     }
+    if ((xsc == nullptr) != (xsh == nullptr)) return PTV2_ERR_ARG;
+    gm.xsc = xsc;
+    gm.xsh = xsh;
     hipStream_t st = (hipStream_t)stream;
     const bool n48 = n % 48 == 0;
     const int bn = n48 ? 48 : 64;
@@ -243,4 +331,11 @@ extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int 
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
+}
+
+extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
+                                            const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
+                                            int accumulate, void *stream) {
+    return rows_gemm_fused_hip_launcher(m, n, k, count, sum, X, W, w_kmajor, bias, Y, accumulate, nullptr, nullptr, nullptr,
+                                        stream);
 }

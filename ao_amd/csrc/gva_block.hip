@@ -224,8 +224,8 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
                                         B->rstd_p, stream));
     hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup(((long long)c * g + g) * WAVE, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
                        B->Ww1, B->bw1, B->M, B->cW);
-    RUN(skinny_linear_forward_hip_launcher(n, c, g, B->key, B->Ww1, B->kW, stream));
-    RUN(skinny_linear_forward_hip_launcher(n, c, g, B->q, B->Ww1, B->qW, stream));
+    RUN(skinny_linear_forward_xf_hip_launcher(n, c, g, B->key, B->Ww1, B->k_sc, B->k_sh, B->kW, stream));
+    RUN(skinny_linear_forward_xf_hip_launcher(n, c, g, B->q, B->Ww1, B->q_sc, B->q_sh, B->qW, stream));
     RUN(gva_logits_forward_hip_launcher(n, k, c, g, B->kW, B->qW, B->a, B->b, B->M, B->cW, B->coord, B->idx, B->W1, W.T1,
                                         W.T2, W.stage, W.stage_bytes, stream));
     RUN(gva_fold_w_forward_hip_launcher(g, W.T1, W.T2, B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w,
@@ -286,7 +286,8 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     {
         const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
         float *dws[2] = {W.gWw1_k, W.gWw1_q};
-        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, W.stage, W.stage_bytes, stream));
+        const float *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
+        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.stage, W.stage_bytes, stream));
     }
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1
     hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c, WPB) + divup((long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,

@@ -22,6 +22,8 @@ _lib.register({
                                                                  _lib._c_int, _lib._vp]),
     "rows_gemm_multi_hip_launcher": (_lib._c_int, [_lib._c_int] * 5 + [_lib._vp, _lib._vp, _lib._c_int, _lib._vp, _lib._vp,
                                                                        _lib._c_int, _lib._vp]),
+    "rows_gemm_fused_hip_launcher": (_lib._c_int, [_lib._c_int] * 5 + [_lib._vp, _lib._vp, _lib._c_int, _lib._vp, _lib._vp,
+                                                                       _lib._c_int, _lib._vp, _lib._vp, _lib._vp, _lib._vp]),
     "ptv2_block_saved_bytes": (_lib._c_size, [_lib._c_int] * 4),
     "ptv2_block_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
     "ptv2_block_param_layout": (_lib._c_int, [_lib._c_int, _lib._c_int, _lib._vp]),

@@ -385,7 +385,7 @@ class _BlockArgs(ctypes.Structure):  # mirrors ptv2_gva_block (include/ptv2_hip.
                     "Wp1", "bp1", "gamma_p", "beta_p", "Wp2", "bp2", "Ww1", "bw1", "gamma_w", "beta_w", "Ww2", "bw2",
                     "run_mean_p", "run_var_p", "run_mean_w", "run_var_w", "batches_p", "batches_w",
                     "out", "a", "b", "rstd_p", "M", "cW", "kW", "qW", "W1", "w", "A", "sw", "sc", "sh",
-                    "mean_w", "rstd_w")])
+                    "mean_w", "rstd_w", "q_sc", "q_sh", "k_sc", "k_sh")])
 
 
 class _BlockGrads(ctypes.Structure):  # mirrors ptv2_gva_block_grads

@@ -271,6 +271,9 @@ typedef struct ptv2_gva_block {
     float *a, *b, *rstd_p, *M, *cW;               /* (c,3) (c) (c) (c,g) (g) */
     float *kW, *qW, *W1, *w, *A, *sw, *sc, *sh;   /* (n,g) (n,g) (n,k,g) (n,k,g) (n,g,c) (n,g) (g) (g) */
     double *mean_w, *rstd_w;                      /* (g) (g) */
+    /* optional (all four or none): q / key are the pre-BatchNorm outputs of linear_q[0] / linear_k[0] and the
+     * BatchNorm + ReLU is applied as ReLU(x * sc + sh) on the operand load of the consumers (block.hip) */
+    const float *q_sc, *q_sh, *k_sc, *k_sh;       /* (c) each */
 } ptv2_gva_block;
 
 typedef struct ptv2_gva_block_grads {
@@ -356,12 +359,18 @@ int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const f
 /* count (<= 4) weight gradients of one shape in one launch: dW[i] = gY[i]^T X[i], db[i] = column sums (db or db[i]
  * may be NULL); workspace: dense_workspace_bytes(n, count * cout, cin) */
 int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
-                                    const float *const *X, float *const *dW, float *const *db, void *workspace,
+                                    const float *const *X, float *const *dW, float *const *db,
+                                    const float *const *xsc, const float *const *xsh, void *workspace,
                                     size_t workspace_bytes, void *stream);
+/* xsc[i] / xsh[i] (cin) != NULL (arrays may be NULL): the X operand of product i is ReLU(x * xsc + xsh), i.e. the
+ * BatchNorm + ReLU in front of that Linear applied on the operand load instead of in a pass of its own. */
 /* skinny projection y (n,cout) = x (n,cin) W^T (cout,cin), cout <= 64, cin % 4 == 0, and its input gradient
  * gx = gy W (the weight gradient is linear_wgrad) */
 int skinny_linear_forward_hip_launcher(int n, int cin, int cout, const float *x, const float *W, float *y,
                                        void *stream);
+/* the same with the input passed through ReLU(x * xsc + xsh) first (xsc, xsh (cin), both or neither) */
+int skinny_linear_forward_xf_hip_launcher(int n, int cin, int cout, const float *x, const float *W, const float *xsc,
+                                          const float *xsh, float *y, void *stream);
 int skinny_linear_backward_hip_launcher(int n, int cin, int cout, const float *gy, const float *W,
                                         float *gx, void *stream);
 /* batched / strided form: dW[b][o][i] = sum_n gY[n*ldy + b*sy + o] * X[n*ldx + b*sx + i], b < batch
@@ -383,6 +392,25 @@ int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const float *W, 
 int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
                                  const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
                                  int accumulate, void *stream);
+
+/* BatchNorm fused into the Linear on either side of it (block.hip):
+ *   rows_gemm_fused: as rows_gemm_multi; xsc / xsh (k) != NULL: the X operand is ReLU(x * xsc + xsh) (normalise + ReLU of
+ *     the BatchNorm in front, folded to one multiply-add per element); stats != NULL and stats[i] != NULL: per-row-block
+ *     column statistics of Y[i], ceil(m / 64) records of [2][n] floats (sum; sum of squares about the block mean)
+ *   bn_tiles_finalize: merges those records (parallel-variance identity, float64) into mean / rstd, updates the running
+ *     buffers, and (sc != NULL) emits the folded affine sc = rstd * gamma, sh = beta - mean * sc
+ *   bn_stats_affine: bn_stats that also emits sc, sh */
+int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
+                                 const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
+                                 int accumulate, const float *xsc, const float *xsh, float *const *stats, void *stream);
+size_t bn_tiles_floats(int n, int c); /* floats to reserve for one statistics record buffer */
+int bn_tiles_finalize_hip_launcher(int n, int c, float *part, const float *gamma, const float *beta, float *mean,
+                                   float *rstd, float *sc, float *sh, float *running_mean, float *running_var,
+                                   long long *num_batches_tracked, float eps, float momentum, void *stream);
+int bn_stats_affine_hip_launcher(int n, int c, const float *x, const float *gamma, const float *beta, float *mean,
+                                 float *rstd, float *sc, float *sh, float *running_mean, float *running_var,
+                                 long long *num_batches_tracked, float eps, float momentum, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------ whole Block, one call --
  * Block.forward / backward (point_transformer_v2m2_base.py:131-177: fc1, norm1, GroupedVectorAttention with

@@ -81,7 +81,7 @@ def test_linear_wgrad_multi(n, cout, cin, count):
     dws = [torch.empty(cout, cin, device="cuda") for _ in range(count)]
     dbs = [torch.empty(cout, device="cuda") if i != 1 else None for i in range(count)]
     ws = _lib.workspace(L.dense_workspace_bytes(n, count * cout, cin), xs[0].device)
-    rc = L.linear_wgrad_multi_hip_launcher(n, cout, cin, count, _ptr_array(gys), _ptr_array(xs), _ptr_array(dws), _ptr_array(dbs),
+    rc = L.linear_wgrad_multi_hip_launcher(n, cout, cin, count, _ptr_array(gys), _ptr_array(xs), _ptr_array(dws), _ptr_array(dbs), None, None,
                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "linear_wgrad_multi_hip_launcher")
     for gy, x, dw, db in zip(gys, xs, dws, dbs):
