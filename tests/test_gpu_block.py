@@ -91,6 +91,68 @@ def test_linear_wgrad_multi(n, cout, cin, count):
             assert rel(db, gy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("n,c", [(120000, 48), (30001, 96), (4501, 192), (1074, 384), (70, 512)])
+def test_batchnorm_fused_into_gemm(n, c):
+    """GEMM-epilogue statistics + bn_tiles_finalize against nn.BatchNorm1d on the GEMM output, and the normalise +
+    ReLU applied on the operand load of the next GEMM / weight gradient / G-wide projection against the explicit
+    sequence."""
+    import ctypes
+
+    from ao_amd import _lib
+    import ao_amd.ptv2.block  # noqa: F401
+
+    torch.manual_seed(n)
+    L = _lib.lib()
+    s = _lib.stream_ptr()
+    x = torch.randn(n, c, device="cuda")
+    w1 = torch.randn(c, c, device="cuda") / c ** 0.5
+    b1 = torch.randn(c, device="cuda") * 3          # |mean| >> std in some columns: the variance must survive
+    h = torch.empty(n, c, device="cuda")
+    st = torch.empty(L.bn_tiles_floats(n, c), device="cuda")
+    rc = L.rows_gemm_fused_hip_launcher(n, c, c, 1, 0, _ptr_array([x]), _ptr_array([w1]), 0, _ptr_array([b1]), _ptr_array([h]), 0,
+                                        None, None, _ptr_array([st]), s)
+    _lib.check(rc, "rows_gemm_fused_hip_launcher")
+    bn = torch.nn.BatchNorm1d(c).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    ref_rm, ref_rv = bn.running_mean.clone(), bn.running_var.clone()
+    mean, rstd, sc, sh = (torch.empty(c, device="cuda") for _ in range(4))
+    rm, rv = ref_rm.clone(), ref_rv.clone()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    rc = L.bn_tiles_finalize_hip_launcher(n, c, st.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), mean.data_ptr(),
+                                          rstd.data_ptr(), sc.data_ptr(), sh.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                          nbt.data_ptr(), float(bn.eps), float(bn.momentum), s)
+    _lib.check(rc, "bn_tiles_finalize_hip_launcher")
+    f_ref = torch.relu(bn(h))                       # also updates bn.running_*
+    hd = h.double()
+    np.testing.assert_allclose(mean.cpu().numpy(), hd.mean(0).float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (hd.var(0, unbiased=False) + bn.eps).rsqrt().float().cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(nbt) == 1
+    # consumers with the fused normalise + ReLU
+    w2 = torch.randn(c, c, device="cuda") / c ** 0.5
+    y = torch.empty(n, c, device="cuda")
+    rc = L.rows_gemm_fused_hip_launcher(n, c, c, 1, 0, _ptr_array([h]), _ptr_array([w2]), 0, None, _ptr_array([y]), 0,
+                                        sc.data_ptr(), sh.data_ptr(), None, s)
+    _lib.check(rc, "rows_gemm_fused_hip_launcher")
+    np.testing.assert_allclose(y.cpu().numpy(), (f_ref.detach() @ w2.t()).cpu().numpy(), rtol=1e-4, atol=2e-4)
+    gy = torch.randn(n, c, device="cuda")
+    dW = torch.empty(c, c, device="cuda")
+    ws = _lib.workspace(L.dense_workspace_bytes(n, c, c), x.device)
+    rc = L.linear_wgrad_multi_hip_launcher(n, c, c, 1, _ptr_array([gy]), _ptr_array([h]), _ptr_array([dW]), None, _ptr_array([sc]),
+                                           _ptr_array([sh]), ws.data_ptr(), ws.numel(), s)
+    _lib.check(rc, "linear_wgrad_multi_hip_launcher")
+    assert rel(dW, gy.double().t() @ f_ref.detach().double()) < 1e-5
+    g = max(c // 8, 4)
+    ww = torch.randn(g, c, device="cuda") / c ** 0.5
+    kw = torch.empty(n, g, device="cuda")
+    rc = L.skinny_linear_forward_xf_hip_launcher(n, c, g, h.data_ptr(), ww.data_ptr(), sc.data_ptr(), sh.data_ptr(), kw.data_ptr(), s)
+    _lib.check(rc, "skinny_linear_forward_xf_hip_launcher")
+    np.testing.assert_allclose(kw.cpu().numpy(), (f_ref.detach() @ ww.t()).cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
 def _block_pair(c, g, drop, seed):
     from ao_amd.ptv2.model import Block
 
