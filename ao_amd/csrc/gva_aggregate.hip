@@ -466,7 +466,8 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                          const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
-                         hipStream_t st);
+                         hipStream_t st, const float *Wp2, const float *bp2);
+int gva_bwd_point_local(int k, int c, int g);
 
 int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
                              const float *bw2, const int *idx, float *w, float *sw, hipStream_t st);
@@ -519,6 +520,10 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
     return PTV2_OK;
 }
 
+// set by gva_aggregate_backward_fused_peb around its call: the backward of the grouped projection is then done
+// inside the point kernel (g_A, g_sw are not read)
+static thread_local const float *g_fused_Wp2 = nullptr, *g_fused_bp2 = nullptr;
+
 extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
                                                    const float *sh, const float *Ww2, const float *bw2,
                                                    const float *v, const float *a, const float *b,
@@ -542,7 +547,8 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
             // W1, idx, coord, g_out, g_sw, v rows (unique once), g_A in; gW1 out
             PtvScopedTimer t(KID_BWD_POINT + (g == 6 ? 0 : g == 12 ? 1 : g == 24 ? 2 : g == 48 ? 3 : 4), st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
             const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
-                                                gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st);
+                                                gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st, g_fused_Wp2,
+                                                g_fused_bp2);
             if (rc != PTV2_OK) return rc;
         }
         {
@@ -597,4 +603,22 @@ extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, c
     PTV2_CHECK_LAUNCH();
     // grad Ww2[g][g'] = sum_rows gz[r,g] y[r,g'],  grad bw2 = column sums of gz: the Linear weight-gradient reduction
     return linear_wgrad_hip_launcher((int)rows, g, g, gz, yb, gWw2, gbw2, dense_ws, dense_bytes, stream);
+}
+
+// gva_aggregate_backward with the backward of the grouped projection (gva_peb_backward) folded into the point kernel:
+// for the instances gva_bwd_point_local() names, g_A (N,G,C) and g_sw are never materialised.  Internal to block runtime.
+int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                     const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
+                                     const float *coord, const int *idx, const float *w, const float *g_out, const float *Wp2,
+                                     const float *bp2, const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
+                                     float *gsh, float *gWw2, float *gbw2, float *gv, float *ga, float *gb, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!inv_ptr || !gva_bwd_point_local(k, c, g) || !Wp2 || !bp2) return PTV2_ERR_ARG;
+    g_fused_Wp2 = Wp2;
+    g_fused_bp2 = bp2;
+    const int rc = gva_aggregate_backward_hip_launcher(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, nullptr,
+                                                       nullptr, inv_ptr, inv_rows, gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace,
+                                                       workspace_bytes, stream);
+    g_fused_Wp2 = g_fused_bp2 = nullptr;
+    return rc;
 }

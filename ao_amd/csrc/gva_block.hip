@@ -6,6 +6,7 @@
 // With ~35 python-level ops per block the step was host-bound (profiles/r01_*: 2 350 launches, 32 ms of host
 // time vs 30 ms of kernel time); behind this entry point a block costs two host calls.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gva_common.h"
 
@@ -154,6 +155,14 @@ int gva_peb_forward_hip_launcher(int, int, int, const float *, const float *, co
 int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, const float *, float *, float *, void *);
 }
 
+int gva_bwd_point_local(int k, int c, int g);
+int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                     const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
+                                     const float *coord, const int *idx, const float *w, const float *g_out, const float *Wp2,
+                                     const float *bp2, const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
+                                     float *gsh, float *gWw2, float *gbw2, float *gv, float *ga, float *gb, void *workspace,
+                                     size_t workspace_bytes, void *stream);
+
 namespace {
 struct BlockWs {  // carve the block workspace
     char *stage; size_t stage_bytes;       // scratch handed to the stage launchers
@@ -249,8 +258,10 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
-    // 1. projection after the neighbour sum: g_A, g_sw, grad Wp2 (direct part), grad bp2 (direct part)
-    RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
+    // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
+    //    grad Wp2 (direct part), grad bp2 (direct part)
+    const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");
+    if (!fused_peb) RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
     RUN(linear_wgrad_strided_hip_launcher(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, nullptr, W.stage,
                                           W.stage_bytes, stream));
     {
@@ -264,9 +275,14 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         if (!own_final) launch_finalize(st, (const float *)W.part, nblk, c, MapVec<float>{G->gbp2});
     }
     // 2. softmax / aggregation stage
-    RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
-                                            B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
-                                            W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
+    if (fused_peb)
+        RUN(gva_aggregate_backward_fused_peb(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx,
+                                             B->w, G->g_out, B->Wp2, B->bp2, G->inv_ptr, G->inv_rows, W.gW1, W.gsc, W.gsh,
+                                             G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
+    else
+        RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
+                                                B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
+                                                W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
     // 3. BatchNorm over the logits
     RUN(gva_fold_w_backward_hip_launcher(g, B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, W.gT1, W.gT2,
                                          G->ggamma_w, G->gbeta_w, stream));

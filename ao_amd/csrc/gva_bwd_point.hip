@@ -21,6 +21,8 @@
 
 #include "gva_common.h"
 
+int gva_bwd_point_local(int k, int c, int g);
+
 namespace gva {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -73,8 +75,14 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
     const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
     const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ g_A,
-    const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ part) {
+    const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ part, const float *__restrict__ Wp2,
+    const float *__restrict__ bp2) {
     using K = BwdPointCfg<G, C, NW>;
+    // Wp2 != NULL (narrow instances, one wavefront per point): g_A (g,ch) = sum_i g_out[gI+i] Wp2[gI+i,ch] and
+    // g_sw = <g_out, bp2>_group -- the backward of the grouped projection -- are formed per point in LDS instead of
+    // being read from the (N,G,C) tensor a separate launch would have to write (276 of this kernel's ~600 MB at
+    // 120 k points, plus that launch)
+    const bool local = NW == 1 && Wp2 != nullptr;
     constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PW = K::PW, CW = K::CW, CS = K::CS, UT = K::UT, I = K::I,
                   PF = K::PF, LT = K::LT, NTW = K::NTW;
     extern __shared__ float4 lds4[];
@@ -91,6 +99,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     float *sGz = sRed + (NW > 1 ? PW * NW * G16 * 16 : 0);  // [PW][G16][17]
     float *sY = sGz + PW * G16 * 17;                      // [PW][G16][17]
     float *sFin = sY + PW * G16 * 17;                     // [PF]
+    float *sWp2 = sFin + PF;                              // [C][C] + [C] bp2            (local only)
+    float *sGA = sWp2 + (size_t)C * C + C;                // [4 waves][G16][C] + [4][G16] (local only)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int p = wid / NW, sub = wid % NW;               // point slot of the workgroup, channel part
@@ -108,6 +118,12 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         sSh[g] = g < G ? sh[g] : 0.f;
     }
     for (int e = tid; e < PF; e += 256) sFin[e] = 0.f;
+    if (local) {
+        for (int e = tid; e < C * C; e += 256) sWp2[e] = Wp2[e];
+        for (int e = tid; e < C; e += 256) sWp2[C * C + e] = bp2[e];
+        for (int e = tid; e < 4 * G16 * C + 4 * G16; e += 256) sGA[e] = 0.f;
+    }
+    float *myGA = sGA + (size_t)wid * G16 * C, *myGsw = sGA + (size_t)4 * G16 * C + wid * G16;
 
     float4 accAB[UT];
 #pragma unroll
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
             for (int i = 0; i < GOV; ++i)
                 if (lane + WAVE * i < C) S.go[i] = g_out[ptn * C + lane + WAVE * i];
-            if (lane < G) S.gsw = g_sw[ptn * G + lane];
+            if (lane < G && g_sw) S.gsw = g_sw[ptn * G + lane];
         }
     };
     auto stage_store = [&](int buf, const Stage &S) {
@@ -204,6 +220,24 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int r = 0; r < 4; ++r) rp[r] = cPos[4 * q + r];
 
+        if (local) {  // g_A and g_sw of my point from its g_out row (in LDS) and Wp2 / bp2 (in LDS)
+            for (int cp = lane; cp < C; cp += WAVE) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < I; ++i) acc = __builtin_fmaf(cGo[g * I + i], sWp2[(g * I + i) * C + cp], acc);
+                    myGA[g * C + cp] = acc;
+                }
+            }
+            if (lane < G) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < I; ++i) acc = __builtin_fmaf(cGo[lane * I + i], sWp2[C * C + lane * I + i], acc);
+                myGsw[lane] = acc;
+            }
+            __syncthreads();
+        }
         // operands of the first channel chunks of this point, then the requests for the next point
         const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
         const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
@@ -221,8 +255,10 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         auto fetch_chunk = [&](int ci, int slot) {
             rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int tg = 0; tg < GT; ++tg)
-                rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tg = 0; tg < GT; ++tg) {
+                if (local) rga[slot][tg] = *(const float4 *)(myGA + (16 * tg + l15) * C + chq + 4 * ci);
+                else rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         };
 #pragma unroll
         for (int ci = 0; ci < PD; ++ci) fetch_chunk(ci, ci);
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int g = 16 * tg + 4 * q + r;
-                    const float bv = (act && g < G) ? g_A[(pt * G + g) * C + ch] : 0.f;
+                    const float bv = local ? myGA[g * C + ch] : ((act && g < G) ? g_A[(pt * G + g) * C + ch] : 0.f);
                     d = mfma4(wm[tg][r], bv, d);
                 }
             const float4 ab = sAB[ch];
@@ -351,7 +387,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         float gz[GT][4];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) {
-            const float4 s4 = *(const float4 *)(cGsw + 16 * tg + 4 * q);
+            const float4 s4 = *(const float4 *)((local ? myGsw : cGsw) + 16 * tg + 4 * q);
             const float gs[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -877,9 +913,11 @@ template <int G, int C, int NW>
 int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2,
                      const float *v, const float *a, const float *b, const float *coord, const int *idx, const float *g_out,
                      const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2,
-                     float *ga, float *gb, float *part, size_t part_floats_avail, hipStream_t st) {
+                     float *ga, float *gb, float *part, size_t part_floats_avail, hipStream_t st, const float *Wp2,
+                     const float *bp2) {
     using K = BwdPointCfg<G, C, NW>;
-    const size_t lds = sizeof(float) * K::lds_floats;
+    const bool local = NW == 1 && Wp2 != nullptr;
+    const size_t lds = sizeof(float) * (K::lds_floats + (local ? (size_t)C * C + C + 4 * (size_t)K::G16 * C + 4 * K::G16 : 0));
     // grid: enough workgroups to fill the chip, few enough that the partial records stay a small fraction of the
     // traffic (<= 8 MB)
     long long cap = (long long)(8u << 20) / (long long)(sizeof(float) * K::PF);
@@ -890,7 +928,7 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
     auto kern = attention_bwd_point_kernel<G, C, NW>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw,
-                       gW1, part);
+                       gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr);
     launch_finalize(st, (const float *)part, nblk, K::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
     return PTV2_OK;
 }
@@ -956,6 +994,11 @@ int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *
     return PTV2_OK;
 }
 
+// 1 when the instance forms g_A / g_sw itself from Wp2, bp2 (possible for the one-wavefront-per-point instances)
+int gva_bwd_point_local(int k, int c, int g) {  // measured: pays at (6, 48) only (at (12, 96) the kernel grows by 115 us to save a 45 us launch)
+    return k >= 1 && k <= 16 && g == 6 && c == 48;
+}
+
 // returns 1 when (g, c, k) has a point-kernel instantiation
 int gva_bwd_point_supported(int k, int c, int g) {
     if (k < 1 || k > 16) return 0;
@@ -972,9 +1015,10 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                          const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
-                         hipStream_t st) {
+                         hipStream_t st, const float *Wp2, const float *bp2) {
     using namespace gva;
-#define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st
+    if (!g_A && !(Wp2 && bp2 && gva_bwd_point_local(k, c, g))) return PTV2_ERR_ARG;
+#define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st, Wp2, bp2
     if (g == 6 && c == 48) return launch_bwd_point<6, 48, 1>(ARGS);
     if (g == 12 && c == 96) return launch_bwd_point<12, 96, 1>(ARGS);
     if (g == 24 && c == 192) return launch_bwd_point<24, 192, 2>(ARGS);
