@@ -22,6 +22,7 @@ _SIGNATURES = {
     "ptv2_build_info": (ctypes.c_char_p, []),
     "ptv2_profile_enable": (_c_int, [_c_int]),
     "ptv2_profile_select": (_c_int, [_c_int]),
+    "ptv2_profile_stride": (_c_int, [_c_int]),
     "ptv2_profile_is_on": (_c_int, []),
     "ptv2_profile_kernel_count": (_c_int, []),
     "ptv2_profile_read": (_c_int, [_c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
@@ -146,7 +147,7 @@ def workspace(nbytes, device):
     return buf
 
 
-def kernel_timer(enable, only=None):
+def kernel_timer(enable, only=None, stride=1):
     """Switch the in-library per-kernel HIP-event timer (include/ptv2_hip.h: ptv2_profile_*).  `only` = kernel
     name: bracket that kernel alone (a whole-step measurement is then not perturbed by ~2000 event pairs)."""
     L = lib()
@@ -161,6 +162,7 @@ def kernel_timer(enable, only=None):
         if kid < 0:
             raise ValueError("unknown kernel name %r" % only)
     L.ptv2_profile_select(kid)
+    L.ptv2_profile_stride(int(stride))
     L.ptv2_profile_enable(1 if enable else 0)
 
 

@@ -41,13 +41,18 @@ const char *kNames[KID_COUNT] = {
     "peb_bwd_kernel", "aggregate_bwd_tile_kernel", "aggregate_bwd_rows_kernel", "aggregate_bwd_gv_kernel",
     "logits_bwd_rows_kernel", "logits_bwd_gather_kernel", "logits_bwd_params_kernel", "linear_wgrad_kernel",
     "bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "skinny_fwd_kernel",
-    "skinny_bwd_kernel", "rows_gemm_kernel", "attention_bwd_point_kernel<6, 48, 1>",
+    "skinny_bwd_kernel", "rows_gemm_kernel<48, false, 32>", "rows_gemm_kernel<48, false, 64>",
+    "rows_gemm_kernel<48, true, 32>", "rows_gemm_kernel<48, true, 64>", "rows_gemm_kernel<64, false, 32>",
+    "rows_gemm_kernel<64, false, 64>", "rows_gemm_kernel<64, true, 32>", "rows_gemm_kernel<64, true, 64>",
+    "attention_bwd_point_kernel<6, 48, 1>",
     "attention_bwd_point_kernel<12, 96, 1>", "attention_bwd_point_kernel<24, 192, 2>",
     "attention_bwd_point_kernel<48, 384, 4>", "attention_bwd_point_kernel<64, 512, 4>"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;
 int g_only = -1;                 // >= 0: time this kernel id only (ptv2_profile_select)
+int g_stride = 1;                // bracket every g_stride-th launch of a timed kernel (ptv2_profile_stride)
+unsigned g_seen[KID_COUNT];      // launches seen per kernel id since enable
 std::vector<hipEvent_t> g_free;  // recycled events: creating one per launch costs more than recording it
 hipEvent_t take_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
@@ -60,7 +65,20 @@ std::vector<hipEvent_t> g_pending[KID_COUNT];
 }  // namespace
 
 extern "C" int ptv2_profile_is_on(void) { return g_on; }
-int ptv2_profile_wants(int kid) { return g_on && (g_only < 0 || g_only == kid); }
+int ptv2_profile_wants(int kid) {
+    if (!g_on || (g_only >= 0 && g_only != kid)) return 0;
+    if (g_stride <= 1) return 1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (g_seen[kid]++ % (unsigned)g_stride) == 0;
+}
+
+// bracket only every n-th launch of the timed kernels (n >= 1): a uniform sample of the launches in a timed region
+extern "C" int ptv2_profile_stride(int n) {
+    if (n < 1) return PTV2_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_stride = n;
+    return PTV2_OK;
+}
 
 // kid >= 0: only that kernel is bracketed with events from now on (keeps the timer out of the way of a
 // whole-step measurement); kid < 0: all kernels
@@ -94,6 +112,7 @@ void ptv2_profile_end(int kid, hipStream_t st, double bytes) {
 extern "C" int ptv2_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (on) {
+        for (int k = 0; k < KID_COUNT; ++k) g_seen[k] = 0;
         for (int k = 0; k < KID_COUNT; ++k) {
             for (auto &r : g_recs[k]) { g_free.push_back(r.a); g_free.push_back(r.b); }
             g_recs[k].clear();

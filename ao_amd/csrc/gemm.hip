@@ -287,7 +287,8 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
     const dim3 grid((unsigned)(nrb * ncb));
     {
-        PtvScopedTimer t(KID_ROWS_GEMM, st, 4.0 * ((double)m * (n + k) + (double)n * k));
+        PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
+                         4.0 * ((double)m * (n + k) + (double)n * k));
         launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
     }
     PTV2_CHECK_LAUNCH();
@@ -326,7 +327,8 @@ extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int 
     const dim3 grid((unsigned)(nrb * ncb), sum ? 1 : count);
     const float *b0 = sum ? gm.bias[0] : nullptr;
     {
-        PtvScopedTimer t(KID_ROWS_GEMM, st, 4.0 * count * ((double)m * (n + k) + (double)n * k));
+        PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
+                         4.0 * count * ((double)m * (n + k) + (double)n * k));
         launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
     }
     PTV2_CHECK_LAUNCH();

@@ -47,6 +47,7 @@ const char *ptv2_build_info(void);
  * restores all. */
 int ptv2_profile_enable(int on);
 int ptv2_profile_select(int kid);
+int ptv2_profile_stride(int n); /* bracket every n-th launch only (uniform sample), n >= 1 */
 int ptv2_profile_is_on(void);
 int ptv2_profile_kernel_count(void);
 int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch);
