@@ -572,14 +572,10 @@ static int bn_grid(int n, int c) {
     return (int)std::max<long long>(1, std::min<long long>(b, MAX_BLK));
 }
 
-namespace {
-struct BnAffine { const float *gamma = nullptr, *beta = nullptr; float *sc = nullptr, *sh = nullptr; };
-thread_local BnAffine g_affine;  // set by bn_stats_affine_hip_launcher around its call of bn_stats_hip_launcher
-}  // namespace
-
-extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
-                                     float *running_var, long long *num_batches_tracked, float eps, float momentum,
-                                     void *workspace, size_t workspace_bytes, void *stream) {
+// statistics pass + finalize; gamma / beta / sc / sh != NULL additionally emit the folded affine
+static int bn_stats_impl(int n, int c, const float *x, float *mean, float *rstd, float *running_mean, float *running_var,
+                         long long *num_batches_tracked, float eps, float momentum, const float *gamma, const float *beta,
+                         float *sc, float *sh, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 1 || c < 4 || c % 4 != 0 || c > 1024) return PTV2_ERR_ARG;
     if (!workspace || workspace_bytes < dense_workspace_bytes(n, c, c)) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -591,10 +587,16 @@ extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, 
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
                        dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, st, (const float *)part, nblk, c, n, x, eps, momentum, mean,
-                       rstd, running_mean, running_var, num_batches_tracked, g_affine.gamma, g_affine.beta, g_affine.sc,
-                       g_affine.sh);
+                       rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
+}
+
+extern "C" int bn_stats_hip_launcher(int n, int c, const float *x, float *mean, float *rstd, float *running_mean,
+                                     float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    return bn_stats_impl(n, c, x, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum, nullptr, nullptr,
+                         nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 // bn_stats that also emits the folded affine (sc = rstd * gamma, sh = beta - mean * sc) for consumers that apply the
@@ -604,11 +606,8 @@ extern "C" int bn_stats_affine_hip_launcher(int n, int c, const float *x, const 
                                             long long *num_batches_tracked, float eps, float momentum, void *workspace,
                                             size_t workspace_bytes, void *stream) {
     if (!gamma || !beta || !sc || !sh) return PTV2_ERR_ARG;
-    g_affine = BnAffine{gamma, beta, sc, sh};
-    const int rc = bn_stats_hip_launcher(n, c, x, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum,
-                                         workspace, workspace_bytes, stream);
-    g_affine = BnAffine{};
-    return rc;
+    return bn_stats_impl(n, c, x, mean, rstd, running_mean, running_var, num_batches_tracked, eps, momentum, gamma, beta, sc, sh,
+                         workspace, workspace_bytes, stream);
 }
 
 // first level for many records: block (x, y) folds records y, y + gridDim.y, ... of 64 columns into ONE record of

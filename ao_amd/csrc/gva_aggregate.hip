@@ -520,18 +520,13 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
     return PTV2_OK;
 }
 
-// set by gva_aggregate_backward_fused_peb around its call: the backward of the grouped projection is then done
-// inside the point kernel (g_A, g_sw are not read)
-static thread_local const float *g_fused_Wp2 = nullptr, *g_fused_bp2 = nullptr;
-
-extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
-                                                   const float *sh, const float *Ww2, const float *bw2,
-                                                   const float *v, const float *a, const float *b,
-                                                   const float *coord, const int *idx, const float *w,
-                                                   const float *g_out, const float *g_A, const float *g_sw,
-                                                   const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
-                                                   float *gsh, float *gWw2, float *gbw2, float *gv, float *ga,
-                                                   float *gb, void *workspace, size_t workspace_bytes, void *stream) {
+// Wp2 / bp2 != NULL: the backward of the grouped projection is done inside the point kernel (g_A, g_sw are not read)
+static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                   const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
+                                   const float *coord, const int *idx, const float *w, const float *g_out, const float *g_A,
+                                   const float *g_sw, const float *g_fused_Wp2, const float *g_fused_bp2, const int *inv_ptr,
+                                   const int *inv_rows, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2, float *gv,
+                                   float *ga, float *gb, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0 || !pow2(c / g) || c / g > 64) return PTV2_ERR_ARG;
     if (!workspace || workspace_bytes < gva_aggregate_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
     if (n == 0) return PTV2_OK;
@@ -614,11 +609,19 @@ int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1
                                      float *gsh, float *gWw2, float *gbw2, float *gv, float *ga, float *gb, void *workspace,
                                      size_t workspace_bytes, void *stream) {
     if (!inv_ptr || !gva_bwd_point_local(k, c, g) || !Wp2 || !bp2) return PTV2_ERR_ARG;
-    g_fused_Wp2 = Wp2;
-    g_fused_bp2 = bp2;
-    const int rc = gva_aggregate_backward_hip_launcher(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, nullptr,
-                                                       nullptr, inv_ptr, inv_rows, gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace,
-                                                       workspace_bytes, stream);
-    g_fused_Wp2 = g_fused_bp2 = nullptr;
-    return rc;
+    return aggregate_backward_impl(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, nullptr, nullptr, Wp2, bp2,
+                                   inv_ptr, inv_rows, gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,
+                                                   const float *sh, const float *Ww2, const float *bw2,
+                                                   const float *v, const float *a, const float *b,
+                                                   const float *coord, const int *idx, const float *w,
+                                                   const float *g_out, const float *g_A, const float *g_sw,
+                                                   const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
+                                                   float *gsh, float *gWw2, float *gbw2, float *gv, float *ga,
+                                                   float *gb, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!g_A || !g_sw) return PTV2_ERR_ARG;
+    return aggregate_backward_impl(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, g_A, g_sw, nullptr, nullptr,
+                                   inv_ptr, inv_rows, gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace, workspace_bytes, stream);
 }

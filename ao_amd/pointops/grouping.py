@@ -8,7 +8,6 @@ import torch
 from torch.autograd import Function
 
 from .. import _lib
-from ..profiling import clock
 
 
 class Grouping(Function):

@@ -29,7 +29,6 @@ import os
 import torch
 
 from .. import _lib
-from ..profiling import clock
 from .layers import skinny_linear
 
 _SIG = {

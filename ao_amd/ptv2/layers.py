@@ -13,7 +13,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from ..profiling import clock
 
 WGRAD_MIN_ROWS = 2048
 
