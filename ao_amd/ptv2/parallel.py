@@ -28,6 +28,36 @@ def wrap_ddp(module, device):
                                                      gradient_as_bucket_view=True)
 
 
+class FlatGradSync:
+    """Gradient averaging as ONE all-reduce of one flat buffer after backward (RCCL over xGMI on GPUs).
+
+    DistributedDataParallel copies every parameter gradient into its buckets with one small kernel each; with the
+    840 parameters of PT-v2m2 that is ~2.4 ms of a 17 ms step on one MI355X (measured with a 1-rank group), more
+    than the 15.6 MB exchange itself costs on xGMI.  Here the gradients are flattened by one multi-tensor copy,
+    reduced once, and written back by one multi-tensor copy.  Parameters are broadcast from rank 0 once, BatchNorm
+    buffers stay per process (the reference runs DDP with broadcast_buffers=False and sync_bn=False)."""
+
+    def __init__(self, module, force=False):
+        self.force = force  # run the flatten / all-reduce / write-back even in a 1-rank group (overhead measurement)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.world > 1:
+            flat = torch._utils._flatten_dense_tensors([p.data for p in self.params])
+            dist.broadcast(flat, 0)
+            for p, f in zip(self.params, torch._utils._unflatten_dense_tensors(flat, [p.data for p in self.params])):
+                p.data.copy_(f)
+
+    def sync(self):
+        """Average `.grad` over the ranks (call between backward and the optimizer step)."""
+        if self.world == 1 and not self.force:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat)
+        flat.div_(self.world)
+        torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
+
+
 def fence(device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

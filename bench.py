@@ -6,7 +6,8 @@
 One "step" = one full training step of the hot path on one batch that is already resident in HBM:
 geometry (kNN tables, grid pooling, interpolation tables) + PT-v2m2 forward + cross-entropy +
 backward + AdamW.  One process per GPU; data parallel by scene (one scene per rank, weak scaling);
-gradients all-reduced by torch DDP over RCCL (backend "nccl" on ROCm).  Rank 0 prints ONE JSON line.
+gradients averaged over RCCL (backend "nccl" on ROCm) by one flat all-reduce per step (or torch DDP,
+AO_AMD_GRAD_SYNC=ddp).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line (task section 4):
   roofline      the dominant hand-written kernel, timed live with HIP events on the launch stream
@@ -112,12 +113,20 @@ def main():
     cfg = dict(ptv2.S3DIS_BACKBONE)
     seg = ptv2.DefaultSegmentor(cfg).to(device).train()
     net = seg
-    if world > 1 or os.environ.get("AO_AMD_FORCE_DDP") == "1":  # the env switch lets a 1-GPU box exercise the DDP path
+    # gradient exchange: one flat all-reduce after backward (parallel.FlatGradSync, default) or torch DDP
+    # (AO_AMD_GRAD_SYNC=ddp; AO_AMD_FORCE_DDP=1 also wraps a 1-rank run so that a 1-GPU box exercises that path)
+    sync = None
+    use_ddp = os.environ.get("AO_AMD_GRAD_SYNC", "flat") == "ddp" or os.environ.get("AO_AMD_FORCE_DDP") == "1"
+    force_sync = os.environ.get("AO_AMD_FORCE_SYNC") == "1"  # 1-GPU box: run the flat exchange in a 1-rank group
+    if world > 1 or os.environ.get("AO_AMD_FORCE_DDP") == "1" or force_sync:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        net = parallel.wrap_ddp(seg, device)
+        if use_ddp:
+            net = parallel.wrap_ddp(seg, device)
+        else:
+            sync = parallel.FlatGradSync(seg, force=force_sync)
     opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     data = make_batch(rank, args.scenes, args.points, device)
     n_points = int(data["coord"].shape[0])
@@ -139,6 +148,8 @@ def main():
             loss = net(batch)["loss"]
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if sync is not None:
+            sync.sync()
         if prefetch is not None:
             prefetch.start(data["coord"], data["offset"])
         opt.step()
@@ -179,7 +190,8 @@ def main():
             "config": {"workload": "s3dis semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
-                       "parallelism": "dp%d" % world, "loss": float(loss.detach())},
+                       "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
+                       "loss": float(loss.detach())},
         }
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9

@@ -56,6 +56,15 @@ def _worker(rank, world, port, out_dir):
     opt.zero_grad(set_to_none=True)
     _loss(net, data).backward()
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # the same through the flat all-reduce on an unwrapped copy of the model
+    import copy
+
+    twin = copy.deepcopy(model)
+    sync = parallel.FlatGradSync(twin)
+    twin.zero_grad(set_to_none=True)
+    _loss(twin, data).backward()
+    sync.sync()
+    flat_grads = {k: p.grad.clone() for k, p in twin.named_parameters()}
 
     def step():
         loss = _loss(net, data)
@@ -65,7 +74,7 @@ def _worker(rank, world, port, out_dir):
         return loss
 
     elapsed, pts, loss = parallel.timed_steps(step, 2, device, data["coord"].shape[0])
-    torch.save(dict(seeds=seeds, grads=grads, params={k: p.detach().clone() for k, p in model.named_parameters()},
+    torch.save(dict(seeds=seeds, grads=grads, flat_grads=flat_grads, params={k: p.detach().clone() for k, p in model.named_parameters()},
                     elapsed=elapsed, pts=pts, n=data["coord"].shape[0], loss=float(loss.detach())),
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
@@ -98,3 +107,4 @@ def test_two_rank_data_parallel_step(tmp_path):
             ref[k] = ref.get(k, 0) + p.grad / 2
     for k, g in ref.items():
         np.testing.assert_allclose(r0["grads"][k].numpy(), g.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)  # pre-BN biases: zero gradient + noise
+        np.testing.assert_allclose(r0["flat_grads"][k].numpy(), r0["grads"][k].numpy(), rtol=1e-5, atol=2e-6, err_msg=k)
