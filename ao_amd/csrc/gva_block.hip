@@ -76,11 +76,6 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
     }
 }
 
-__global__ void add_vec_kernel(int len, float *__restrict__ dst, const float *__restrict__ src) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < len) dst[e] += src[e];
-}
-
 // partial[blk][c] = sum over the block's rows of g_out[n,c] * sw[n, c / I]
 __global__ __launch_bounds__(TPB) void bp2_grad_kernel(int n, int c, int g, const float *__restrict__ g_out,
                                                        const float *__restrict__ sw, float *part, unsigned *counter,
@@ -155,6 +150,10 @@ int gva_peb_forward_hip_launcher(int, int, int, const float *, const float *, co
 int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, const float *, float *, float *, void *);
 }
 
+int gva_fold_p_backward2(int c, const float *Wp1, const float *bp1, const float *gamma, const double *mu, const double *cov,
+                         const float *running_mean, const float *rstd, int training, const float *ga, const float *gb,
+                         const float *ga2, const float *gb2, float *gWp1, float *gbp1, float *ggamma, float *gbeta,
+                         void *stream);
 int gva_bwd_point_local(int k, int c, int g);
 int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
                                      const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
@@ -292,10 +291,8 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
                                          G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage,
                                          W.stage_bytes, stream));
     // 5. folded BN_p: both stages contribute to (a, b)
-    hipLaunchKernelGGL(add_vec_kernel, dim3(divup(3 * c, 256)), dim3(256), 0, st, 3 * c, W.ga1, (const float *)W.ga2);
-    hipLaunchKernelGGL(add_vec_kernel, dim3(divup(c, 256)), dim3(256), 0, st, c, W.gb1, (const float *)W.gb2);
-    RUN(gva_fold_p_backward_hip_launcher(c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p,
-                                         B->training, W.ga1, W.gb1, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p, stream));
+    RUN(gva_fold_p_backward2(c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1, W.gb1,
+                             W.ga2, W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p, stream));
     // 6. projections kW = k Ww1^T, qW = q Ww1^T
     RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gkW, B->Ww1, G->gk, stream));
     RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gqW, B->Ww1, G->gq, stream));

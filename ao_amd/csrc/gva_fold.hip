@@ -55,13 +55,19 @@ __global__ void fold_p_bwd_kernel(int c, const float *__restrict__ Wp1, const fl
                                   const float *__restrict__ gamma, const double *__restrict__ mu,
                                   const double *__restrict__ cov, const float *__restrict__ run_mean,
                                   const float *__restrict__ rstd_in, int training, const float *__restrict__ ga,
-                                  const float *__restrict__ gb, float *__restrict__ gWp1, float *__restrict__ gbp1,
+                                  const float *__restrict__ gb, const float *__restrict__ ga2,
+                                  const float *__restrict__ gb2, float *__restrict__ gWp1, float *__restrict__ gbp1,
                                   float *__restrict__ ggamma, float *__restrict__ gbeta) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     const double w[3] = {Wp1[3 * ch], Wp1[3 * ch + 1], Wp1[3 * ch + 2]};
-    const double g[3] = {ga[3 * ch], ga[3 * ch + 1], ga[3 * ch + 2]};
-    const double gbv = gb[ch], rstd = rstd_in[ch], gam = gamma[ch];
+    double g[3] = {ga[3 * ch], ga[3 * ch + 1], ga[3 * ch + 2]};
+    double gbv = gb[ch];
+    if (ga2) {  // (a, b) feed two stages (logits and aggregation): their gradients are summed here
+        g[0] += ga2[3 * ch]; g[1] += ga2[3 * ch + 1]; g[2] += ga2[3 * ch + 2];
+        gbv += gb2[ch];
+    }
+    const double rstd = rstd_in[ch], gam = gamma[ch];
     const double s = gam * rstd;
     gbeta[ch] = (float)gbv;
     if (training) {
@@ -158,7 +164,20 @@ extern "C" int gva_fold_p_backward_hip_launcher(int c, const float *Wp1, const f
                                                 float *gWp1, float *gbp1, float *ggamma, float *gbeta, void *stream) {
     if (c < 1) return PTV2_ERR_ARG;
     hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, mu,
-                       cov, running_mean, rstd, training, ga, gb, gWp1, gbp1, ggamma, gbeta);
+                       cov, running_mean, rstd, training, ga, gb, (const float *)nullptr, (const float *)nullptr, gWp1, gbp1,
+                       ggamma, gbeta);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// the same with the gradient of (a, b) given as the sum of two contributions (internal to the block runtime)
+int gva_fold_p_backward2(int c, const float *Wp1, const float *bp1, const float *gamma, const double *mu, const double *cov,
+                         const float *running_mean, const float *rstd, int training, const float *ga, const float *gb,
+                         const float *ga2, const float *gb2, float *gWp1, float *gbp1, float *ggamma, float *gbeta,
+                         void *stream) {
+    if (c < 1) return PTV2_ERR_ARG;
+    hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, mu,
+                       cov, running_mean, rstd, training, ga, gb, ga2, gb2, gWp1, gbp1, ggamma, gbeta);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
