@@ -59,7 +59,7 @@ Saved carve_saved(void *base, int n, int k, int c, int g) {
 struct Work {
     char *dense; size_t dense_bytes;
     char *gva; size_t gva_bytes;
-    float *t[4];  // (n,c) gradient temporaries
+    float *t[7];  // (n,c) gradient temporaries: the five that feed the batched weight gradient stay alive to the end
     float *stat[4];  // GEMM-epilogue statistics records of h1, hq, hk, h3: ceil(n / 64) x [2][c]
     size_t bytes;
 };
@@ -69,11 +69,11 @@ Work carve_work(void *base, int n, int k, int c, int g) {
     char *p = (char *)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
-    w.dense_bytes = dense_workspace_bytes(n, 3 * c, c);  // three weight gradients in one launch
+    w.dense_bytes = dense_workspace_bytes(n, 5 * c, c);  // five weight gradients in one launch
     w.dense = take(w.dense_bytes);
     w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
     w.gva = take(w.gva_bytes);
-    for (int i = 0; i < 4; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
+    for (int i = 0; i < 7; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
     for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * bn_tiles_floats(n, c));
     w.bytes = off;
     return w;
@@ -247,57 +247,54 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     auto GPB = [&](int i) { return P[i] ? G->gparam + off[i] : (float *)nullptr; };  // optional biases
     int batch[PTV2_BLK_NBN];
     for (int i = 0; i < PTV2_BLK_NBN; ++i) batch[i] = (B->training || !B->run_mean[i] || !B->run_var[i]) ? 1 : 0;
-    float *T0 = W.t[0], *T1 = W.t[1], *T2 = W.t[2], *T3 = W.t[3];
+    // gradient tensors; g_h3, g_hq, g_hk, gv, g_h1 are also the gY operands of the five (c,c) weight gradients, which run
+    // as ONE launch + one finalize at the end of the block instead of three launches spread along the chain
+    float *g_h3 = W.t[0], *g_hq = W.t[1], *g_hk = W.t[2], *gv = W.t[3], *g_h1 = W.t[4], *ta = W.t[5], *tb = W.t[6];
 
-    // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3 (T0), residual gradient straight into gx
+    // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3, residual gradient straight into gx
     RUN(bn_backward_residual_hip_launcher(n, c, S.h3, G->gy, B->y, B->rowscale, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G],
-                                          batch[6], T0, G->gx, GP(PTV2_BLK_N3_G), GP(PTV2_BLK_N3_B), W.dense, W.dense_bytes,
+                                          batch[6], g_h3, G->gx, GP(PTV2_BLK_N3_G), GP(PTV2_BLK_N3_B), W.dense, W.dense_bytes,
                                           stream));
-    // fc3
-    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_FC3_W], 1, nullptr, T1, 0, stream));
-    {
-        const float *gys[1] = {T0}, *xs[1] = {S.attn}, *xsc[1] = {S.bsc[5]}, *xsh[1] = {S.bsh[5]};  // X = f2 = ReLU(BN2(attn))
-        float *dws[1] = {GP(PTV2_BLK_FC3_W)};
-        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 1, gys, xs, dws, nullptr, xsc, xsh, W.dense, W.dense_bytes, stream));
-    }
-    // norm2 + ReLU -> g_attn (T0)
-    RUN(bn_backward_hip_launcher(n, c, S.attn, T1, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], T0,
+    // fc3 input gradient -> g_f2 (ta); norm2 + ReLU -> g_attn (tb)
+    RUN(rows_gemm_hip_launcher(n, c, c, g_h3, P[PTV2_BLK_FC3_W], 1, nullptr, ta, 0, stream));
+    RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], tb,
                                  GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
-    // attention: gq (T1), gk (T2), gv (T3)
+    // attention: gq (ta), gk (g_h1's buffer, free until the end of the chain), gv
+    float *gq = ta, *gk = g_h1;
     ptv2_gva_block V;
     fill_gva(B, S, &V);
     ptv2_gva_block_grads VG;
-    VG.g_out = T0; VG.inv_ptr = G->inv_ptr; VG.inv_rows = G->inv_rows;
-    VG.gq = T1; VG.gk = T2; VG.gv = T3;
+    VG.g_out = tb; VG.inv_ptr = G->inv_ptr; VG.inv_rows = G->inv_rows;
+    VG.gq = gq; VG.gk = gk; VG.gv = gv;
     VG.gWp1 = GP(PTV2_BLK_P1_W); VG.gbp1 = GP(PTV2_BLK_P1_B); VG.ggamma_p = GP(PTV2_BLK_PN_G); VG.gbeta_p = GP(PTV2_BLK_PN_B);
     VG.gWp2 = GP(PTV2_BLK_P2_W); VG.gbp2 = GP(PTV2_BLK_P2_B); VG.gWw1 = GP(PTV2_BLK_W1_W); VG.gbw1 = GP(PTV2_BLK_W1_B);
     VG.ggamma_w = GP(PTV2_BLK_WN_G); VG.gbeta_w = GP(PTV2_BLK_WN_B); VG.gWw2 = GP(PTV2_BLK_W2_W); VG.gbw2 = GP(PTV2_BLK_W2_B);
-    if (!G->inv_ptr) (void)hipMemsetAsync(T3, 0, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
+    if (!G->inv_ptr) (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
     RUN(gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream));
-    // linear_k / linear_q BatchNorm + ReLU: g_hk (T0), g_hq (T2 after gk is consumed)
-    RUN(bn_backward_hip_launcher(n, c, S.hk, T2, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, batch[2], T0,
+    // linear_k / linear_q BatchNorm + ReLU
+    RUN(bn_backward_hip_launcher(n, c, S.hk, gk, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, batch[2], g_hk,
                                  GP(PTV2_BLK_KN_G), GP(PTV2_BLK_KN_B), W.dense, W.dense_bytes, stream));
-    RUN(bn_backward_hip_launcher(n, c, S.hq, T1, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], T2,
+    RUN(bn_backward_hip_launcher(n, c, S.hq, gq, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], g_hq,
                                  GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
-    // weight / bias gradients of the three projections of f1
+    // g_f1 (tb) = g_hq Wq + g_hk Wk + gv Wv
     {
-        const float *gys[3] = {T2, T0, T3}, *xs[3] = {S.h1, S.h1, S.h1};  // X = f1 = ReLU(BN1(h1)) on the operand load
-        const float *xsc[3] = {S.bsc[0], S.bsc[0], S.bsc[0]}, *xsh[3] = {S.bsh[0], S.bsh[0], S.bsh[0]};
-        float *dws[3] = {GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W)};
-        float *dbs[3] = {GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B)};
-        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 3, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
-    }
-    // g_f1 (T1) = g_hq Wq + g_hk Wk + gv Wv
-    {
-        const float *xs[3] = {T2, T0, T3}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
-        float *ys[3] = {T1, nullptr, nullptr};
+        const float *xs[3] = {g_hq, g_hk, gv}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
+        float *ys[3] = {tb, nullptr, nullptr};
         RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 1, xs, ws, 1, nullptr, ys, 0, stream));
     }
-    // norm1 + ReLU -> g_h1 (T0); fc1: gx += g_h1 fc1
-    RUN(bn_backward_hip_launcher(n, c, S.h1, T1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], T0,
+    // norm1 + ReLU -> g_h1; fc1: gx += g_h1 fc1
+    RUN(bn_backward_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], g_h1,
                                  GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.dense, W.dense_bytes, stream));
-    RUN(linear_wgrad_hip_launcher(n, c, c, T0, B->x, GP(PTV2_BLK_FC1_W), nullptr, W.dense, W.dense_bytes, stream));
-    RUN(rows_gemm_hip_launcher(n, c, c, T0, P[PTV2_BLK_FC1_W], 1, nullptr, G->gx, 1, stream));
+    RUN(rows_gemm_hip_launcher(n, c, c, g_h1, P[PTV2_BLK_FC1_W], 1, nullptr, G->gx, 1, stream));
+    // the five (c,c) weight gradients: fc3 (X = f2 = ReLU(BN2(attn))), linear_q / k / v (X = f1 = ReLU(BN1(h1))), fc1 (X = x)
+    {
+        const float *gys[5] = {g_h3, g_hq, g_hk, gv, g_h1}, *xs[5] = {S.attn, S.h1, S.h1, S.h1, B->x};
+        const float *xsc[5] = {S.bsc[5], S.bsc[0], S.bsc[0], S.bsc[0], nullptr};
+        const float *xsh[5] = {S.bsh[5], S.bsh[0], S.bsh[0], S.bsh[0], nullptr};
+        float *dws[5] = {GP(PTV2_BLK_FC3_W), GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W), GP(PTV2_BLK_FC1_W)};
+        float *dbs[5] = {nullptr, GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B), nullptr};
+        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

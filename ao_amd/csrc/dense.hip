@@ -374,10 +374,10 @@ constexpr int WG_MT = 3, WG_TILE = 16 * WG_MT, WG_CHUNK = 256, WG_CHUNK_MIN = 12
 
 // several independent products of one shape in one launch (blockIdx.z selects the operand pair)
 struct WgradMulti {
-    const float *gY[4], *X[4];
-    float *dW[4], *db[4];
+    const float *gY[6], *X[6];
+    float *dW[6], *db[6];
     int count;  // 0: the strided form (gY + z * sy, X + z * sx)
-    const float *xsc[4], *xsh[4];  // != NULL: the X operand of pair z is ReLU(x * xsc + xsh) (fused BatchNorm + ReLU)
+    const float *xsc[6], *xsh[6];  // != NULL: the X operand of pair z is ReLU(x * xsc + xsh) (fused BatchNorm + ReLU)
 };
 
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
@@ -871,13 +871,13 @@ struct MapWgradMulti {  // record = [count][cout*cin] weights, then [count][cout
     }
 };
 
-// count (<= 4) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
+// count (<= 6) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
 // shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))
 extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
                                                const float *const *X, float *const *dW, float *const *db,
                                                const float *const *xsc, const float *const *xsh, void *workspace,
                                                size_t workspace_bytes, void *stream) {
-    if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 4 || !gY || !X || !dW) return PTV2_ERR_ARG;
+    if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 6 || !gY || !X || !dW) return PTV2_ERR_ARG;
     const int chunk = wg_chunk(n);
     const int chunks = (n + chunk - 1) / chunk;
     const size_t rec = (size_t)count * ((size_t)cout * cin + cout);

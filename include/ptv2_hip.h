@@ -357,7 +357,7 @@ int bn_backward_residual_hip_launcher(int n, int c, const float *x, const float 
                                       void *stream);
 int linear_wgrad_hip_launcher(int n, int cout, int cin, const float *gY, const float *X, float *dW,
                               float *db, void *workspace, size_t workspace_bytes, void *stream);
-/* count (<= 4) weight gradients of one shape in one launch: dW[i] = gY[i]^T X[i], db[i] = column sums (db or db[i]
+/* count (<= 6) weight gradients of one shape in one launch: dW[i] = gY[i]^T X[i], db[i] = column sums (db or db[i]
  * may be NULL); workspace: dense_workspace_bytes(n, count * cout, cin) */
 int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
                                     const float *const *X, float *const *dW, float *const *db,
