@@ -272,10 +272,17 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     if (!G->inv_ptr) (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
     RUN(gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream));
     // linear_k / linear_q BatchNorm + ReLU
-    RUN(bn_backward_hip_launcher(n, c, S.hk, gk, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, batch[2], g_hk,
-                                 GP(PTV2_BLK_KN_G), GP(PTV2_BLK_KN_B), W.dense, W.dense_bytes, stream));
-    RUN(bn_backward_hip_launcher(n, c, S.hq, gq, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], g_hq,
-                                 GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
+    if (batch[1] == batch[2]) {  // one reduce / finalize / apply for both
+        const float *xs[2] = {S.hk, S.hq}, *gys[2] = {gk, gq}, *ms[2] = {S.mean[2], S.mean[1]}, *rs[2] = {S.rstd[2], S.rstd[1]};
+        const float *gs[2] = {P[PTV2_BLK_KN_G], P[PTV2_BLK_QN_G]}, *bs[2] = {P[PTV2_BLK_KN_B], P[PTV2_BLK_QN_B]};
+        float *gxs[2] = {g_hk, g_hq}, *dgs[2] = {GP(PTV2_BLK_KN_G), GP(PTV2_BLK_QN_G)}, *dbs[2] = {GP(PTV2_BLK_KN_B), GP(PTV2_BLK_QN_B)};
+        RUN(bn_backward_pair_hip_launcher(n, c, xs, gys, ms, rs, gs, bs, 1, batch[1], gxs, dgs, dbs, W.dense, W.dense_bytes, stream));
+    } else {
+        RUN(bn_backward_hip_launcher(n, c, S.hk, gk, S.mean[2], S.rstd[2], P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], 1, batch[2], g_hk,
+                                     GP(PTV2_BLK_KN_G), GP(PTV2_BLK_KN_B), W.dense, W.dense_bytes, stream));
+        RUN(bn_backward_hip_launcher(n, c, S.hq, gq, S.mean[1], S.rstd[1], P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], 1, batch[1], g_hq,
+                                     GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
+    }
     // g_f1 (tb) = g_hq Wq + g_hk Wk + gv Wv
     {
         const float *xs[3] = {g_hq, g_hk, gv}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};

@@ -274,16 +274,21 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_residual_kernel(
     }
 }
 
+// a second, independent BatchNorm of the same shape handled by blockIdx.y == 1 of the same launches (linear_q and
+// linear_k of a Block: their backward chains are independent, batching them saves three launches per Block)
+struct BnSecond {
+    const float *x, *gy, *mean, *rstd, *gamma, *beta;
+    float *gx, *dgamma, *dbeta;
+};
+
 // -------------------------------------------------------- BN: backward reduce --
 // partial columns [0,c): sum gy' ; [c,2c): sum gy' * xhat, with gy' = gy masked by the fused ReLU
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const float *__restrict__ x,
-                                                            const float *__restrict__ gy,
-                                                            const float *__restrict__ mean,
-                                                            const float *__restrict__ rstd,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, int relu,
-                                                            float *__restrict__ part) {
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const float *x, const float *gy,
+                                                            const float *mean, const float *rstd, const float *gamma,
+                                                            const float *beta, int relu, float *__restrict__ part,
+                                                            BnSecond second) {
     extern __shared__ float4 lds4[];
+    if (blockIdx.y) { x = second.x; gy = second.gy; mean = second.mean; rstd = second.rstd; gamma = second.gamma; beta = second.beta; }
     const int cq = c >> 2;
     const int rl = TPB / cq;
     const int q = threadIdx.x % cq, r = threadIdx.x / cq;
@@ -319,22 +324,22 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const 
             a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
             b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
         }
-        float *p = part + (size_t)blockIdx.x * 2 * c;
+        float *p = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * c;  // record of a block: [set 0 | set 1]
         ((float4 *)p)[threadIdx.x] = a;
         ((float4 *)(p + c))[threadIdx.x] = b2;
     }
 }
 
 // gx = gamma * rstd * (gy' - dbeta/n - xhat * dgamma/n)   (training);   gamma * rstd * gy' (eval)
-__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int cq, float inv_n,
-                                                           const float *__restrict__ x, const float *__restrict__ gy,
-                                                           const float *__restrict__ mean,
-                                                           const float *__restrict__ rstd,
-                                                           const float *__restrict__ gamma,
-                                                           const float *__restrict__ beta, int relu,
-                                                           const float *__restrict__ dbeta,
-                                                           const float *__restrict__ dgamma, int training,
-                                                           float *__restrict__ gx) {
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int cq, float inv_n, const float *x,
+                                                           const float *gy, const float *mean, const float *rstd,
+                                                           const float *gamma, const float *beta, int relu,
+                                                           const float *dbeta, const float *dgamma, int training, float *gx,
+                                                           BnSecond second) {
+    if (blockIdx.y) {
+        x = second.x; gy = second.gy; mean = second.mean; rstd = second.rstd; gamma = second.gamma; beta = second.beta;
+        dbeta = second.dbeta; dgamma = second.dgamma; gx = second.gx;
+    }
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
         const int q = (int)(e % cq);
         const float4 v = ((const float4 *)x)[e];
@@ -779,7 +784,7 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     {
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 8.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean,
-                           rstd, gamma, beta, relu, part);
+                           rstd, gamma, beta, relu, part, BnSecond{});
     }
     launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
@@ -787,7 +792,48 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     {
         PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean,
-                           rstd, gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx);
+                           rstd, gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx, BnSecond{});
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+struct MapBnPair {  // record [dbeta0 c | dgamma0 c | dbeta1 c | dgamma1 c]
+    float *db0, *dg0, *db1, *dg1;
+    int c;
+    __device__ void operator()(int j, double v) const {
+        const int s = j / c, k = j - s * c;
+        (s == 0 ? db0 : s == 1 ? dg0 : s == 2 ? db1 : dg1)[k] = (float)v;
+    }
+};
+
+// two BatchNorm backwards of one shape (x[i], gy[i], ... i = 0, 1) in the three launches of one
+// (workspace: dense_workspace_bytes(n, 2 * c, c))
+extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x, const float *const *gy,
+                                             const float *const *mean, const float *const *rstd, const float *const *gamma,
+                                             const float *const *beta, int relu, int training, float *const *gx,
+                                             float *const *dgamma, float *const *dbeta, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024 || !x || !gy || !mean || !rstd || !gamma || !beta || !gx || !dgamma || !dbeta)
+        return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < dense_workspace_bytes(n, 2 * c, c)) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = bn_grid(n, c);
+    float *part = (float *)workspace;
+    const BnSecond sec{x[1], gy[1], mean[1], rstd[1], gamma[1], beta[1], gx[1], dgamma[1], dbeta[1]};
+    {
+        PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 16.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, 2), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x[0], gy[0], mean[0],
+                           rstd[0], gamma[0], beta[0], relu, part, sec);
+    }
+    launch_finalize(st, (const float *)part, nblk, 4 * c, MapBnPair{dbeta[0], dgamma[0], dbeta[1], dgamma[1], c});
+    const long long total4 = (long long)n * (c >> 2);
+    const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 24.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2, 2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x[0], gy[0],
+                           mean[0], rstd[0], gamma[0], beta[0], relu, (const float *)dbeta[0], (const float *)dgamma[0], training,
+                           gx[0], sec);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

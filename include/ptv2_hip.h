@@ -344,6 +344,13 @@ int bn_backward_hip_launcher(int n, int c, const float *x, const float *gy, cons
                              const float *rstd, const float *gamma, const float *beta, int relu,
                              int training, float *gx, float *dgamma, float *dbeta, void *workspace,
                              size_t workspace_bytes, void *stream);
+/* two independent BatchNorm backwards of one shape (arrays of 2 pointers each) in the three launches of one;
+ * workspace: dense_workspace_bytes(n, 2 * c, c) */
+int bn_backward_pair_hip_launcher(int n, int c, const float *const *x, const float *const *gy,
+                                  const float *const *mean, const float *const *rstd, const float *const *gamma,
+                                  const float *const *beta, int relu, int training, float *const *gx,
+                                  float *const *dgamma, float *const *dbeta, void *workspace, size_t workspace_bytes,
+                                  void *stream);
 /* Block tail fused into the Block's last BatchNorm (point_transformer_v2m2_base.py:174-176):
  * y = ReLU(residual + rowscale[n] * BN(x)); rowscale (n) = per-point DropPath factor or NULL.  Backward returns
  * the BN input gradient gx, the residual gradient g_residual = gy * (y > 0), dgamma, dbeta. */
