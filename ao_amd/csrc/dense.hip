@@ -491,10 +491,12 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 // W in LDS, the x row is shared by the cout lanes of a point.
 // xsc / xsh != NULL: the input row passes through ReLU(x * xsc + xsh) first (BatchNorm + ReLU of linear_q / linear_k
 // fused into the projection that consumes them)
-__global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, int cout, const float *__restrict__ x,
-                                                         const float *__restrict__ W, const float *__restrict__ xsc,
-                                                         const float *__restrict__ xsh, float *__restrict__ y) {
+// blockIdx.y == 1 works on the second operand set (x2, xsc2, xsh2 -> y2; same W): the key and query projections
+__global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, int cout, const float *x, const float *__restrict__ W,
+                                                         const float *xsc, const float *xsh, float *y, const float *x2,
+                                                         const float *xsc2, const float *xsh2, float *y2) {
     extern __shared__ float4 lds4[];
+    if (blockIdx.y) { x = x2; xsc = xsc2; xsh = xsh2; y = y2; }
     float *sW = (float *)lds4;  // [cout][cin + 4], then [2][cin] scale / shift
     const int ldw = cin + 4, cq = cin >> 2;
     float *sSc = sW + (size_t)cout * ldw, *sSh = sSc + cin;
@@ -532,8 +534,9 @@ __global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, i
 }
 
 // gx[n,i] = sum_o gy[n,o] W[o,i]; one lane per float4 of gx
-__global__ __launch_bounds__(TPB) void skinny_bwd_kernel(long long n, int cin, int cout, const float *__restrict__ gy,
-                                                         const float *__restrict__ W, float *__restrict__ gx) {
+__global__ __launch_bounds__(TPB) void skinny_bwd_kernel(long long n, int cin, int cout, const float *gy,
+                                                         const float *__restrict__ W, float *gx, const float *gy2, float *gx2) {
+    if (blockIdx.y) { gy = gy2; gx = gx2; }
     const int cq = cin >> 2;
     const long long total = n * cq;
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
@@ -852,7 +855,28 @@ extern "C" int skinny_linear_forward_xf_hip_launcher(int n, int cin, int cout, c
     {
         PtvScopedTimer t(KID_SKINNY_FWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
         hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x, W, xsc,
-                           xsh, y);
+                           xsh, y, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// two projections through the same W in one launch (internal to the block runtime): y[i] = f(x[i]) W^T, i = 0, 1
+int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
+                               const float *const *xsh, float *const *y, void *stream) {
+    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1 || cout > 64) return PTV2_ERR_ARG;
+    if ((xsc[0] == nullptr) != (xsc[1] == nullptr)) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const size_t lds = sizeof(float) * ((size_t)cout * (cin + 4) + 2 * (size_t)cin);
+    if (lds > 160 * 1024) return PTV2_ERR_ARG;
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void *)skinny_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long long total = (long long)n * cout;
+    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 8);
+    {
+        PtvScopedTimer t(KID_SKINNY_FWD, (hipStream_t)stream, 8.0 * n * (cin + cout));
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(nblk, 2), dim3(TPB), lds, (hipStream_t)stream, (long long)n, cin, cout, x[0], W,
+                           xsc[0], xsh[0], y[0], x[1], xsc[1], xsh[1], y[1]);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -871,7 +895,23 @@ extern "C" int skinny_linear_backward_hip_launcher(int n, int cin, int cout, con
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
     {
         PtvScopedTimer t(KID_SKINNY_BWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
-        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx);
+        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx,
+                           (const float *)nullptr, (float *)nullptr);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// gx[i] = gy[i] W for two gradient tensors in one launch (internal to the block runtime)
+int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream) {
+    if (n < 0 || cin < 4 || cin % 4 != 0 || cout < 1) return PTV2_ERR_ARG;
+    if (n == 0) return PTV2_OK;
+    const long long total = (long long)n * (cin >> 2);
+    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
+    {
+        PtvScopedTimer t(KID_SKINNY_BWD, (hipStream_t)stream, 8.0 * n * (cin + cout));
+        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk, 2), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy[0], W,
+                           gx[0], gy[1], gx[1]);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

@@ -150,6 +150,9 @@ int gva_peb_forward_hip_launcher(int, int, int, const float *, const float *, co
 int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, const float *, float *, float *, void *);
 }
 
+int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
+                               const float *const *xsh, float *const *y, void *stream);
+int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_fold_p_backward2(int c, const float *Wp1, const float *bp1, const float *gamma, const double *mu, const double *cov,
                          const float *running_mean, const float *rstd, int training, const float *ga, const float *gb,
                          const float *ga2, const float *gb2, float *gWp1, float *gbp1, float *ggamma, float *gbeta,
@@ -232,8 +235,11 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
                                         B->rstd_p, stream));
     hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup(((long long)c * g + g) * WAVE, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
                        B->Ww1, B->bw1, B->M, B->cW);
-    RUN(skinny_linear_forward_xf_hip_launcher(n, c, g, B->key, B->Ww1, B->k_sc, B->k_sh, B->kW, stream));
-    RUN(skinny_linear_forward_xf_hip_launcher(n, c, g, B->q, B->Ww1, B->q_sc, B->q_sh, B->qW, stream));
+    {
+        const float *xs[2] = {B->key, B->q}, *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
+        float *ys[2] = {B->kW, B->qW};
+        RUN(skinny_linear_forward_pair(n, c, g, xs, B->Ww1, xsc, xsh, ys, stream));
+    }
     RUN(gva_logits_forward_hip_launcher(n, k, c, g, B->kW, B->qW, B->a, B->b, B->M, B->cW, B->coord, B->idx, B->W1, W.T1,
                                         W.T2, W.stage, W.stage_bytes, stream));
     RUN(gva_fold_w_forward_hip_launcher(g, W.T1, W.T2, B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w,
@@ -294,8 +300,11 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     RUN(gva_fold_p_backward2(c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1, W.gb1,
                              W.ga2, W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p, stream));
     // 6. projections kW = k Ww1^T, qW = q Ww1^T
-    RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gkW, B->Ww1, G->gk, stream));
-    RUN(skinny_linear_backward_hip_launcher(n, c, g, W.gqW, B->Ww1, G->gq, stream));
+    {
+        const float *gys[2] = {W.gkW, W.gqW};
+        float *gxs[2] = {G->gk, G->gq};
+        RUN(skinny_linear_backward_pair(n, c, g, gys, B->Ww1, gxs, stream));
+    }
     {
         const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
         float *dws[2] = {W.gWw1_k, W.gWw1_q};
