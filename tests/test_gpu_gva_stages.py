@@ -13,6 +13,18 @@ SHAPES = [(48, 6, 16, 3000), (96, 12, 16, 1500), (192, 24, 16, 700), (384, 48, 1
           (512, 64, 16, 130)]
 
 
+@pytest.fixture(params=["point", "flat"], autouse=True)
+def kernel_family(request, monkeypatch):
+    """Every stage test runs twice: with the MFMA point kernels where they are the default, and with the flat
+    one-lane-per-slot kernels (AO_AMD_BWD_STAGED=1) that remain the path for shapes the point kernels do not
+    cover (K > 16, channel / group counts outside the instantiated set)."""
+    if request.param == "flat":
+        monkeypatch.setenv("AO_AMD_BWD_STAGED", "1")
+    else:
+        monkeypatch.delenv("AO_AMD_BWD_STAGED", raising=False)
+    return request.param
+
+
 def make(c, g, k, n, seed=0):
     from ao_amd import pointops
 
