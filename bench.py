@@ -66,6 +66,23 @@ def algorithmic_step_bytes(levels, cfg):
     return total
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+    note of the microarchitecture guide, + WRITE_SIZE; tools/pmc_traffic.py).  Counters cannot be read from inside
+    this process, so the figure is the one measured with the same command and build under profiles/; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_per_launch.jsonl")
+    if not os.path.exists(path):
+        return None
+    base = kernel.split("<")[0]
+    for line in open(path):
+        rec = json.loads(line)
+        for name, v in rec.items():
+            short = name.split("::")[-1]
+            if short == kernel or (short.split("<")[0] == base and "<" not in kernel):
+                return 1e6 * (v["fetch_x2_MB_per_launch"] + v["write_MB_per_launch"])
+    return None
+
+
 def cpu_baseline(cfg, sample_points):
     """fwd+bwd+AdamW of the CPU oracle on a bounded crop of the same scene generator."""
     from ao_amd import synth
@@ -204,7 +221,9 @@ def main():
                 name, rec = dominant, summ[dominant]
                 achieved = rec["bytes_per_launch"] / (rec["avg_us"] * 1e-6) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name),
+                                   "traffic_source": "bytes/launch, profiles/r01_final_pmc_traffic_per_launch.jsonl "
+                                                     "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
                                    "avg_us": rec["avg_us"], "launches_timed": rec["launches"],
                                    "ms_per_step": 3 * rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
