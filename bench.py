@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--cpu-sample-points", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ops", action="store_true", help="skip the kNN / FPS us-per-query lines")
     return ap.parse_args()
 
 
@@ -81,6 +82,37 @@ def pmc_traffic(kernel):
             if short == kernel or (short.split("<")[0] == base and "<" not in kernel):
                 return 1e6 * (v["fetch_x2_MB_per_launch"] + v["write_MB_per_launch"])
     return None
+
+
+def op_microbench(data):
+    """BASELINE.json's second metric, "knn + FPS us/query", on the scene of this run (HIP-event time of the whole op
+    / queries): self kNN k=16, the 3-NN cross query of the interpolation, stride-4 farthest point sampling.  Runs
+    after the timed region (bench_ops.py is the stand-alone form with the CPU oracle beside it)."""
+    from ao_amd import pointops
+
+    xyz, off = data["coord"], data["offset"].int()
+    n = xyz.shape[0]
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / reps
+
+    out = {"knn_k16_self_us_per_query": timed(lambda: pointops.knn_query_dist2(16, xyz, off), 10) / n}
+    if off.numel() == 1:
+        coarse = xyz[::6].contiguous()
+        coff = torch.tensor([coarse.shape[0]], dtype=torch.int32, device=xyz.device)
+        out["knn_k3_cross_us_per_query"] = timed(lambda: pointops.knn_query_dist2(3, coarse, coff, xyz, off), 10) / n
+    noff = (off // 4).int()
+    out["fps_stride4_us_per_sample"] = timed(lambda: pointops.farthest_point_sampling(xyz, off, noff), 2) / int(noff[-1])
+    return out
 
 
 def cpu_baseline(cfg, sample_points):
@@ -232,6 +264,8 @@ def main():
                                                        "ms_per_step": round(v["total_us"] / 1e3 / max(survey_steps, 1), 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
                                                    for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])}}
+        if world == 1 and not args.no_ops:
+            out["ops"] = op_microbench(data)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_points)
         print(json.dumps(out))
