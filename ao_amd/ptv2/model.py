@@ -144,11 +144,12 @@ class Block(nn.Module):
         self.enable_checkpoint = enable_checkpoint
         self.drop_path = DropPath(drop_path_rate) if drop_path_rate > 0.0 else nn.Identity()
 
-    def forward(self, points, reference_index):
+    def forward(self, points, reference_index, rowscale=None):
+        """rowscale: optional precomputed per-point DropPath factor (BlockSequence draws the factors of all its
+        blocks in one go); drawn here when absent."""
         coord, feat, offset = points
         identity = feat
-        rowscale = None
-        if self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.0:
+        if rowscale is None and self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.0:
             keep = 1.0 - self.drop_path.drop_prob  # timm DropPath: per-point Bernoulli(keep) / keep
             rowscale = torch.empty(feat.shape[0], device=feat.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
         if os.environ.get("AO_AMD_BLOCK", "native") == "native" and os.environ.get("AO_AMD_GVA", "fused") == "fused":
@@ -186,8 +187,18 @@ class BlockSequence(nn.Module):
         coord, feat, offset = points
         if reference_index is None:  # stand-alone use: same call as the reference (:223)
             reference_index, _ = pointops.knn_query(self.neighbours, coord, offset)
-        for block in self.blocks:
-            points = block(points, reference_index)
+        # per-point DropPath factors of all blocks in two launches: Bernoulli(keep_i) / keep_i, row i for block i
+        scales = None
+        rates = [b.drop_path.drop_prob if isinstance(b.drop_path, DropPath) else 0.0 for b in self.blocks]
+        if self.training and any(r > 0.0 for r in rates):
+            keep = self.__dict__.get("_keep")
+            if keep is None or keep.device != feat.device:
+                keep = torch.tensor([1.0 - r for r in rates], dtype=torch.float32, device=feat.device).unsqueeze(1)
+                self.__dict__["_keep"] = keep  # plain attribute: not a buffer, so the state_dict stays the reference's
+            probs = keep.expand(len(rates), feat.shape[0])
+            scales = torch.bernoulli(probs).div_(probs)
+        for i, block in enumerate(self.blocks):
+            points = block(points, reference_index, scales[i] if scales is not None and rates[i] > 0.0 else None)
         return points
 
 
