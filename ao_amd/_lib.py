@@ -52,6 +52,9 @@ _SIGNATURES = {
     "pool_max_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6),
     "pool_max_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 4),
     "dense_workspace_bytes": (_c_size, [_c_int] * 3),
+    "cross_entropy_workspace_bytes": (_c_size, [_c_int]),
+    "cross_entropy_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 4 + [_c_size, _vp]),
+    "cross_entropy_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 5),
     "bn_stats_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [ctypes.c_float] * 2 + [_vp, _c_size, _vp]),
     "bn_apply_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 5 + [_c_int, _vp, _vp]),
     "bn_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 3 + [_c_int] + [_vp] * 5 + [ctypes.c_float] * 2 + [_vp] * 4

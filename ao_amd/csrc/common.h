@@ -36,7 +36,7 @@ struct PtvScopedTimer {
 
 // Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
 #define PTV2_NUM_COUNTERS 64
-enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS };
+enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE };
 unsigned *ptv2_stream_counters(hipStream_t st);
 
 // Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):

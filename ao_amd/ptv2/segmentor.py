@@ -21,6 +21,51 @@ SCANNET_BACKBONE = dict(  # configs/scannet/semseg-pt-v2m2-0-base.py:10-37
     enable_checkpoint=False, unpool_backend="map")
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """Mean softmax cross-entropy with ignore_index on ao_amd/csrc/loss.hip (fp32 CUDA logits (N,C), int64 labels)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, logits, label, ignore_index):
+        from .. import _lib
+
+        logits, label = logits.contiguous(), label.contiguous()
+        n, c = logits.shape
+        L = _lib.lib()
+        dev = logits.device
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)  # loss, labelled count
+        ws = _lib.workspace(L.cross_entropy_workspace_bytes(n), dev)
+        rc = L.cross_entropy_forward_hip_launcher(n, c, logits.data_ptr(), label.data_ptr(), int(ignore_index), lse.data_ptr(),
+                                                  out.data_ptr(), out.data_ptr() + 4, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "cross_entropy_forward_hip_launcher")
+        ctx.save_for_backward(logits, label, lse, out)
+        ctx.ignore_index = int(ignore_index)
+        return out[0]
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        from .. import _lib
+
+        logits, label, lse, out = ctx.saved_tensors
+        n, c = logits.shape
+        g = g.contiguous().float()
+        gl = torch.empty_like(logits)
+        rc = _lib.lib().cross_entropy_backward_hip_launcher(n, c, logits.data_ptr(), label.data_ptr(), ctx.ignore_index,
+                                                            lse.data_ptr(), g.data_ptr(), out.data_ptr() + 4, gl.data_ptr(),
+                                                            _lib.stream_ptr())
+        _lib.check(rc, "cross_entropy_backward_hip_launcher")
+        return gl, None, None
+
+
+def cross_entropy(logits, label, ignore_index=-1):
+    """F.cross_entropy(logits, label, ignore_index=...) (mean reduction) on the HIP kernel when it applies."""
+    if logits.is_cuda and logits.dim() == 2 and label.dtype == torch.int64 and logits.shape[0] > 0 and logits.shape[1] <= 1024:
+        return _CrossEntropy.apply(logits, label, ignore_index)
+    return torch.nn.functional.cross_entropy(logits, label, ignore_index=ignore_index)
+
+
 class DefaultSegmentor(nn.Module):
     """backbone + CrossEntropyLoss(ignore_index=-1); same return convention as the reference."""
 
@@ -28,12 +73,16 @@ class DefaultSegmentor(nn.Module):
         super().__init__()
         self.backbone = backbone if isinstance(backbone, nn.Module) else PointTransformerV2(
             **{k: v for k, v in dict(backbone).items() if k != "type"})
-        self.criteria = nn.CrossEntropyLoss(ignore_index=ignore_index)
+        self.criteria = nn.CrossEntropyLoss(ignore_index=ignore_index)  # kept for state / introspection parity
+        self.ignore_index = ignore_index
+
+    def loss(self, seg_logits, segment):
+        return cross_entropy(seg_logits, segment, self.ignore_index)
 
     def forward(self, input_dict):
         seg_logits = self.backbone(input_dict)
         if self.training:
-            return dict(loss=self.criteria(seg_logits, input_dict["segment"]))
+            return dict(loss=self.loss(seg_logits, input_dict["segment"]))
         if "segment" in input_dict:
-            return dict(loss=self.criteria(seg_logits, input_dict["segment"]), seg_logits=seg_logits)
+            return dict(loss=self.loss(seg_logits, input_dict["segment"]), seg_logits=seg_logits)
         return dict(seg_logits=seg_logits)
