@@ -57,6 +57,13 @@ class FlatGradSync:
         flat.div_(self.world)
         torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
 
+    def reduce_flat(self, flat):
+        """All-reduce (sum) an already flat gradient buffer in place (optim.FlatAdamW.flatten_grads()); the caller
+        folds the 1 / world into its update (FlatAdamW.step(flat_grad=..., grad_scale=1 / world))."""
+        if self.world > 1 or self.force:
+            dist.all_reduce(flat)
+        return 1.0 / self.world
+
 
 def fence(device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -176,7 +176,15 @@ def main():
             net = parallel.wrap_ddp(seg, device)
         else:
             sync = parallel.FlatGradSync(seg, force=force_sync)
-    opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+    # AdamW(lr 0.006, wd 0.05) as in the reference config; AO_AMD_OPTIM=torch selects torch.optim.AdamW(fused=True)
+    # instead of the one-kernel flat form (ao_amd/ptv2/optim.py)
+    flat_opt = os.environ.get("AO_AMD_OPTIM", "flat") == "flat" and not use_ddp
+    if flat_opt:
+        from ao_amd.ptv2.optim import FlatAdamW
+
+        opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+    else:
+        opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     data = make_batch(rank, args.scenes, args.points, device)
     n_points = int(data["coord"].shape[0])
     autocast = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" else None
@@ -197,6 +205,13 @@ def main():
             loss = net(batch)["loss"]
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if flat_opt:  # gradients -> one flat buffer -> (all-reduce) -> one update kernel
+            flat = opt.flatten_grads()
+            scale = sync.reduce_flat(flat) if sync is not None else 1.0
+            if prefetch is not None:
+                prefetch.start(data["coord"], data["offset"])
+            opt.step(flat_grad=flat, grad_scale=scale)
+            return loss
         if sync is not None:
             sync.sync()
         if prefetch is not None:
@@ -240,6 +255,7 @@ def main():
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
                        "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
+                       "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
                        "loss": float(loss.detach())},
         }
         step_bytes = algorithmic_step_bytes(levels, cfg)

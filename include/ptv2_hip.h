@@ -483,6 +483,13 @@ int cross_entropy_backward_hip_launcher(int n, int c, const float *logits, const
                                         const float *lse, const float *g_loss, const float *count, float *g_logits,
                                         void *stream);
 
+/* ------------------------------------------------------ optimizer step --
+ * torch.optim.AdamW (lr 0.006, weight_decay 0.05 in configs/s3dis/semseg-pt-v2m2-0-base.py:41) over one flat fp32
+ * buffer of all parameters: p, g, m (exp_avg), v (exp_avg_sq) of n floats, n % 4 == 0; step counts from 1;
+ * grad_scale multiplies g first (1 / world size when g is a sum over ranks). */
+int adamw_flat_hip_launcher(long long n, float *p, const float *g, float *m, float *v, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

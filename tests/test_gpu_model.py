@@ -132,7 +132,8 @@ def test_train_step_runs_and_reduces_loss(ptv2):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def test_optimizer_step_matches_reference(ptv2, golden):
+@pytest.mark.parametrize("which", ["torch", "flat"])
+def test_optimizer_step_matches_reference(ptv2, golden, which):
     """same init + batch + AdamW(lr 0.006, wd 0.05) -> same post-step weights and next loss as the
     reference module with torch.optim.AdamW (captured in tests/golden/ptv2_s3dis.npz)."""
     g = golden("ptv2_s3dis.npz")
@@ -143,7 +144,12 @@ def test_optimizer_step_matches_reference(ptv2, golden):
     seg = ptv2.DefaultSegmentor(ptv2.PointTransformerV2(**cfg)).cuda().train()
     seg.backbone.load_state_dict(st0, strict=True)
     data = dict(coord=dev(g["coord"]), feat=dev(g["feat"]), offset=dev(g["offset"]), segment=dev(g["label"]))
-    opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+    if which == "flat":
+        from ao_amd.ptv2.optim import FlatAdamW
+
+        opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+    else:
+        opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     loss = seg(data)["loss"]
     assert abs(float(loss.detach()) - float(g["loss_train"])) < 2e-5
     opt.zero_grad(set_to_none=True)
@@ -160,3 +166,28 @@ def test_optimizer_step_matches_reference(ptv2, golden):
             np.testing.assert_allclose(w, ref, rtol=0, atol=2 * 0.006 + 1e-6)
     loss2 = seg(data)["loss"]
     assert abs(float(loss2.detach()) - float(g["loss_step2"])) < 5e-3 * max(1.0, abs(float(g["loss_step2"])))
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """Five steps of FlatAdamW against torch.optim.AdamW on the same parameters and gradients (incl. tensors whose
+    sizes are not multiples of 4, gradients of very different scales and a learning-rate change between steps).
+    (A parameter WITHOUT a gradient is treated as a zero gradient under the global step count, where torch skips
+    it and its private step count: every PT-v2m2 parameter receives a gradient every step.)"""
+    from ao_amd.ptv2.optim import FlatAdamW
+
+    torch.manual_seed(0)
+    shapes = [(48, 48), (48,), (13, 48), (7,), (3, 5, 2), (1,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = torch.optim.AdamW(pa, lr=0.006, weight_decay=0.05)
+    ob = FlatAdamW(pb, lr=0.006, weight_decay=0.05)
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn_like(a) * (10.0 ** (i - 2))
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if step == 3:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 0.002
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
