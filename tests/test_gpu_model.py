@@ -191,3 +191,29 @@ def test_flat_adamw_matches_torch_adamw():
         ob.step()
         for a, b in zip(pa, pb):
             np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_prefetched_geometry_equals_inline_geometry(ptv2):
+    """bench.py builds the scene geometry of the next batch on a side stream (parallel.GeometryPrefetcher): the
+    tables and the logits must be exactly those of the inline build."""
+    from ao_amd import synth
+    from ao_amd.ptv2 import parallel
+
+    torch.manual_seed(0)
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    model = ptv2.PointTransformerV2(**cfg).cuda().eval()
+    b = synth.scene_batch([0, 1], point_max=4000, room=1)
+    data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    pre = parallel.GeometryPrefetcher(model, torch.device("cuda", 0))
+    with torch.no_grad():
+        ref = model(data)
+        for _ in range(2):  # twice: the second hand-over reuses side-stream memory of the first
+            pre.start(data["coord"], data["offset"])
+            geo = pre.take()
+            out = model(dict(data, geometry=geo))
+            inline = model.geometry(data["coord"], data["offset"])
+            for a, c in zip(geo.levels, inline.levels):
+                assert torch.equal(a.coord, c.coord) and torch.equal(a.offset, c.offset)
+                for k in c.knn:
+                    assert torch.equal(a.knn[k], c.knn[k])
+            assert torch.equal(out, ref)
