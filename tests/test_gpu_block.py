@@ -280,3 +280,28 @@ def test_native_block_with_short_clouds(monkeypatch, c, g):
         # the n*k rows, the fused path (closed-form BN fold) returns zero or its own noise
         floor = 5e-2 if nm in zero_grad else 1e-4
         assert rel(a, b) < 5e-3 or float((a - b).abs().max()) < floor, (nm, rel(a, b), float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("n,c,g", [(20000, 48, 6), (3000, 192, 24)])
+def test_native_block_is_bitwise_reproducible(monkeypatch, n, c, g):
+    """No float atomics on the Block path: scatter-adds are inverse-table gathers, every reduction is per-block
+    partials summed in a fixed order -- two runs give bit-identical outputs and gradients."""
+    from ao_amd import pointops, synth
+
+    monkeypatch.setenv("AO_AMD_BLOCK", "native")
+    coord = torch.from_numpy(synth.room_cloud(n, seed=3)).cuda()
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(16, coord, offset)
+    blk, _ = _block_pair(c, g, 0.0, seed=2)
+    blk.train()
+    torch.manual_seed(5)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    go = torch.randn(n, c, device="cuda")
+    runs = []
+    for _ in range(2):
+        x = x0.clone().requires_grad_(True)
+        y = blk([coord, x, offset], idx)[1]
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+        runs.append([y.detach()] + [t.clone() for t in grads])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
