@@ -35,6 +35,7 @@ _SIGNATURES = {
     "grouping_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
     "interpolation_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
     "interpolation_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
+    "interpolation_backward_gather_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),
     "subtraction_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
     "subtraction_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
     "aggregation_forward_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 6),

@@ -80,6 +80,39 @@ __global__ __launch_bounds__(TPB) void interpolation_bwd(long long total, int c,
     }
 }
 
+// the same gradient as a fixed-order gather through the inverse table of idx (inv_ptr (>= m+1), inv_rows: the slots
+// r = n*k + i with idx[r] == j, ascending): no float atomics, bitwise reproducible, no zero-fill of grad_input
+template <int VEC>
+__global__ __launch_bounds__(TPB) void interpolation_bwd_gather(long long total, int cv, int k,
+                                                                const float *__restrict__ grad_output,
+                                                                const int *__restrict__ inv_ptr,
+                                                                const int *__restrict__ inv_rows,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ grad_input) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long j = e / cv;
+        const int q = (int)(e - j * cv);
+        float acc[VEC];
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
+        for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) {
+            const int r = inv_rows[p];
+            const float w = weight[r];
+            const float *go = grad_output + ((long long)(r / k) * cv + q) * VEC;
+            if (VEC == 4) {
+                const float4 t4 = *(const float4 *)go;
+                acc[0] = __builtin_fmaf(w, t4.x, acc[0]); acc[1] = __builtin_fmaf(w, t4.y, acc[1]);
+                acc[2] = __builtin_fmaf(w, t4.z, acc[2]); acc[3] = __builtin_fmaf(w, t4.w, acc[3]);
+            } else {
+                acc[0] = __builtin_fmaf(w, go[0], acc[0]);
+            }
+        }
+        float *dst = grad_input + (j * cv + q) * VEC;
+        if (VEC == 4) *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dst[0] = acc[0];
+    }
+}
+
 // --------------------------------------------------------------- subtraction --
 // subtraction_cuda_kernel.cu:5-16
 template <int VEC>
@@ -295,6 +328,26 @@ extern "C" int interpolation_backward_hip_launcher(int n, int c, int k, const fl
     if (total == 0) return PTV2_OK;
     hipLaunchKernelGGL(interpolation_bwd, dim3(grid_for(total)), dim3(TPB), 0, ST, total, c, k, grad_output, idx,
                        weight, grad_input);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// grad_input (m,c) = scatter of grad_output (n,c) through idx (n,k), as a gather over the inverse table of idx
+// (inverse_table_hip_launcher); every row of grad_input is written (rows nobody points at get zeros)
+extern "C" int interpolation_backward_gather_hip_launcher(int m, int c, int k, const float *grad_output, const int *inv_ptr,
+                                                          const int *inv_rows, const float *weight, float *grad_input,
+                                                          void *stream) {
+    if (m < 0 || c < 0 || k < 1 || !inv_ptr || !inv_rows) return PTV2_ERR_ARG;
+    if ((long long)m * c == 0) return PTV2_OK;
+    if (c % 4 == 0 && aligned16(grad_output) && aligned16(grad_input)) {
+        const long long total = (long long)m * (c / 4);
+        hipLaunchKernelGGL(interpolation_bwd_gather<4>, dim3(grid_for(total)), dim3(TPB), 0, ST, total, c / 4, k, grad_output,
+                           inv_ptr, inv_rows, weight, grad_input);
+    } else {
+        const long long total = (long long)m * c;
+        hipLaunchKernelGGL(interpolation_bwd_gather<1>, dim3(grid_for(total)), dim3(TPB), 0, ST, total, c, k, grad_output, inv_ptr,
+                           inv_rows, weight, grad_input);
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

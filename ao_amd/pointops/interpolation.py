@@ -41,6 +41,14 @@ class _InterpolateRows(Function):
         idx, weight = ctx.saved_tensors
         grad_output = grad_output.contiguous()
         n, c = grad_output.shape
+        inv = getattr(idx, "_ao_inverse", None)  # built with the geometry (ao_amd/ptv2/geometry.py): gather, no atomics
+        if inv is not None and inv[0] == idx._version and ctx.m <= n:
+            grad_input = torch.empty((ctx.m, c), dtype=torch.float32, device=grad_output.device)
+            rc = _lib.lib().interpolation_backward_gather_hip_launcher(ctx.m, c, idx.shape[1], grad_output.data_ptr(),
+                                                                       inv[1].data_ptr(), inv[2].data_ptr(), weight.data_ptr(),
+                                                                       grad_input.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "interpolation_backward_gather_hip_launcher")
+            return grad_input, None, None
         grad_input = torch.zeros((ctx.m, c), dtype=torch.float32, device=grad_output.device)
         rc = _lib.lib().interpolation_backward_hip_launcher(n, c, idx.shape[1], grad_output.data_ptr(), idx.data_ptr(),
                                                             weight.data_ptr(), grad_input.data_ptr(),

@@ -142,5 +142,7 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
         cur.cluster, cur.order32, cur.idx_ptr32 = cluster, order, idx_ptr
         if interp:
             cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
+            from . import gva
+            gva.inverse_table(cur.up_idx)  # lets the unpool backward gather instead of scatter with float atomics
         cur = Level(coord=nc, offset=noff)
     return geo

@@ -95,6 +95,9 @@ def _geometry_tensors(geo):
         for v in vars(lv).values():
             if torch.is_tensor(v):
                 yield v
+                for t in getattr(v, "_ao_inverse", ()) or ():
+                    if torch.is_tensor(t):
+                        yield t
         for idx in lv.knn.values():
             yield idx
             for attr in ("_ao_inverse", "_ao_pos_moments"):

@@ -109,6 +109,11 @@ int interpolation_forward_hip_launcher(int n, int c, int k, const float *input, 
 int interpolation_backward_hip_launcher(int n, int c, int k, const float *grad_output,
                                         const int *idx, const float *weight, float *grad_input,
                                         void *stream);
+/* the same gradient as a fixed-order gather over the inverse table of idx (inverse_table_hip_launcher on the (n,k)
+ * table; requires m <= n): no float atomics, grad_input fully written (no zero fill needed) */
+int interpolation_backward_gather_hip_launcher(int m, int c, int k, const float *grad_output, const int *inv_ptr,
+                                               const int *inv_rows, const float *weight, float *grad_input,
+                                               void *stream);
 
 /* ---------------------------------------------------------- subtraction --
  * subtraction_{forward,backward}_cuda_launcher

@@ -217,3 +217,46 @@ def test_prefetched_geometry_equals_inline_geometry(ptv2):
                 for k in c.knn:
                     assert torch.equal(a.knn[k], c.knn[k])
             assert torch.equal(out, ref)
+
+
+def test_interp_unpool_backward_gathers_through_the_inverse_table():
+    """The "interp" unpool backward (a scatter-add with float atomics in the reference, interpolation.py:41-59) runs
+    as a fixed-order gather when the geometry has built the inverse table of the 3-NN table."""
+    from ao_amd import pointops, synth
+    from ao_amd.pointops.interpolation import _InterpolateRows, interpolation_index_weight
+    from ao_amd.ptv2.gva import inverse_table
+
+    fine = torch.from_numpy(synth.room_cloud(9000, seed=1)).cuda()
+    coarse = fine[::7].contiguous()
+    foff = torch.tensor([4000, 9000], dtype=torch.int32, device="cuda")
+    coff = torch.tensor([int((4000 + 6) // 7), coarse.shape[0]], dtype=torch.int32, device="cuda")
+    idx, w = interpolation_index_weight(coarse, fine, coff, foff, 3)
+    feat = torch.randn(coarse.shape[0], 96, device="cuda", requires_grad=True)
+    go = torch.randn(fine.shape[0], 96, device="cuda")
+    (g_atomic,) = torch.autograd.grad(_InterpolateRows.apply(feat, idx, w), [feat], go)
+    inverse_table(idx)
+    runs = [torch.autograd.grad(_InterpolateRows.apply(feat, idx, w), [feat], go)[0] for _ in range(2)]
+    assert torch.equal(runs[0], runs[1])
+    np.testing.assert_allclose(runs[0].cpu().numpy(), g_atomic.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_training_step_is_bitwise_reproducible(ptv2):
+    """S3DIS cfg: no float atomics anywhere on the step (attention scatter-adds, unpool, pooling, loss and
+    parameter-gradient reductions are fixed-order) -> two runs from the same state give identical gradients."""
+    from ao_amd import synth
+
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    b = synth.scene_batch([0, 1], point_max=6000, room=1)
+    data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    torch.manual_seed(0)
+    seg = ptv2.DefaultSegmentor(ptv2.PointTransformerV2(**cfg)).cuda().train()
+    state = {k: v.clone() for k, v in seg.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        seg.load_state_dict(state)
+        seg.zero_grad(set_to_none=True)
+        loss = seg(data)["loss"]
+        loss.backward()
+        runs.append([loss.detach().clone()] + [p.grad.clone() for p in seg.parameters()])
+    for a, b2 in zip(*runs):
+        assert torch.equal(a, b2)
