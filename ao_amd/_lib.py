@@ -52,6 +52,7 @@ _SIGNATURES = {
     "segment_minmax_hip_launcher": (_c_int, [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "pool_max_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6),
     "pool_max_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 4),
+    "segment_sum_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 5),
     "dense_workspace_bytes": (_c_size, [_c_int] * 3),
     "adamw_flat_hip_launcher": (_c_int, [ctypes.c_longlong] + [_vp] * 4 + [ctypes.c_float] * 5 + [_c_int, ctypes.c_float, _vp]),
     "cross_entropy_workspace_bytes": (_c_size, [_c_int]),

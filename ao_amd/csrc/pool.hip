@@ -145,3 +145,45 @@ extern "C" int pool_max_backward_hip_launcher(int n_out, int c, const float *gra
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
+
+// ------------------------------------------------------------- "map" unpool --
+// UnpoolWithSkip backend "map" (point_transformer_v2m2_base.py:305-310): out[i,:] = feat[cluster[i],:]; its gradient
+// is the sum over the fine points of each cluster, taken in the CSR order of the pooling (order, idx_ptr) -- a
+// fixed-order segment sum instead of the index_put atomics of the stock indexing backward.
+namespace {
+template <int VEC>
+__global__ __launch_bounds__(TPB) void segment_sum_rows(long long total, int cv, const float *__restrict__ grad_fine,
+                                                        const int *__restrict__ order, const int *__restrict__ idx_ptr,
+                                                        float *__restrict__ grad_coarse) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const int j = (int)(e / cv), q = (int)(e - (long long)j * cv);
+        if (VEC == 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = idx_ptr[j]; p < idx_ptr[j + 1]; ++p) {
+                const float4 v = ((const float4 *)grad_fine)[(size_t)order[p] * cv + q];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            ((float4 *)grad_coarse)[e] = acc;
+        } else {
+            float acc = 0.f;
+            for (int p = idx_ptr[j]; p < idx_ptr[j + 1]; ++p) acc += grad_fine[(size_t)order[p] * cv + q];
+            grad_coarse[e] = acc;
+        }
+    }
+}
+}  // namespace
+
+// grad_coarse (n_out,c) = sum over rows order[idx_ptr[j] .. idx_ptr[j+1]) of grad_fine (.,c)
+extern "C" int segment_sum_hip_launcher(int n_out, int c, const float *grad_fine, const int *order, const int *idx_ptr,
+                                        float *grad_coarse, void *stream) {
+    if (n_out < 0 || c < 1 || !grad_fine || !order || !idx_ptr || !grad_coarse) return PTV2_ERR_ARG;
+    if (n_out == 0) return PTV2_OK;
+    const bool vec = c % 4 == 0;
+    const int cv = vec ? c / 4 : c;
+    const long long total = (long long)n_out * cv;
+    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
+    if (vec) hipLaunchKernelGGL(segment_sum_rows<4>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total, cv, grad_fine, order, idx_ptr, grad_coarse);
+    else hipLaunchKernelGGL(segment_sum_rows<1>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, total, cv, grad_fine, order, idx_ptr, grad_coarse);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

@@ -234,6 +234,29 @@ class _SegmentMax(torch.autograd.Function):
         return gfeat, None, None
 
 
+class _MapUnpool(torch.autograd.Function):
+    """feat[cluster] (the "map" unpool, reference :305-310); backward = per-cluster sum of the fine gradients in the
+    pooling's CSR order (ao_amd/csrc/pool.hip: segment_sum) instead of index_put with float atomics."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feat, cluster, order, idx_ptr):
+        ctx.save_for_backward(order, idx_ptr)
+        ctx.n_coarse = feat.shape[0]
+        return feat[cluster]
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        order, idx_ptr = ctx.saved_tensors
+        grad = grad.contiguous()
+        out = torch.empty((ctx.n_coarse, grad.shape[1]), dtype=torch.float32, device=grad.device)
+        rc = _lib.lib().segment_sum_hip_launcher(ctx.n_coarse, grad.shape[1], grad.data_ptr(), order.data_ptr(),
+                                                 idx_ptr.data_ptr(), out.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "segment_sum_hip_launcher")
+        return out, None, None, None
+
+
 class GridPool(nn.Module):
     """Partition-based pooling (reference :229-269).  The clustering itself lives in geometry.py."""
 
@@ -263,7 +286,10 @@ class UnpoolWithSkip(nn.Module):
     def forward(self, feat, skip_feat, fine_level):
         feat = self.proj(feat)
         if self.backend == "map" and fine_level.cluster is not None:
-            feat = feat[fine_level.cluster]
+            if feat.is_cuda and feat.dtype == torch.float32 and fine_level.order32 is not None:
+                feat = _MapUnpool.apply(feat, fine_level.cluster, fine_level.order32, fine_level.idx_ptr32)
+            else:
+                feat = feat[fine_level.cluster]
         else:
             feat = _InterpolateRows.apply(feat, fine_level.up_idx, fine_level.up_weight)
         if self.skip:

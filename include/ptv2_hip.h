@@ -323,6 +323,11 @@ int pool_max_forward_hip_launcher(int n_out, int c, const float *feat, const int
 int pool_max_backward_hip_launcher(int n_out, int c, const float *grad_out, const int *arg,
                                    float *grad_feat, void *stream);
 
+/*   segment_sum:   grad_coarse[j,:] = sum over rows order[idx_ptr[j]..idx_ptr[j+1]) of grad_fine -- the backward of the
+ *                  "map" unpool feat[cluster] (:305-310) in the CSR order of the pooling (no index_put atomics) */
+int segment_sum_hip_launcher(int n_out, int c, const float *grad_fine, const int *order, const int *idx_ptr,
+                             float *grad_coarse, void *stream);
+
 /* ------------------------------------------------ per-point dense layers --
  * PointBatchNorm on (N,C) rows (point_transformer_v2m2_base.py:26-45: nn.BatchNorm1d) with an optional
  * fused ReLU, and the weight/bias gradient of nn.Linear as a split-K reduction.  c % 4 == 0, c <= 1024.

@@ -240,13 +240,18 @@ def test_interp_unpool_backward_gathers_through_the_inverse_table():
     np.testing.assert_allclose(runs[0].cpu().numpy(), g_atomic.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-def test_training_step_is_bitwise_reproducible(ptv2):
-    """S3DIS cfg: no float atomics anywhere on the step (attention scatter-adds, unpool, pooling, loss and
+@pytest.mark.parametrize("which", ["s3dis", "scannet"])
+def test_training_step_is_bitwise_reproducible(ptv2, which):
+    """No float atomics anywhere on the step (attention scatter-adds, "interp" and "map" unpool, pooling, loss and
     parameter-gradient reductions are fixed-order) -> two runs from the same state give identical gradients."""
     from ao_amd import synth
 
-    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
-    b = synth.scene_batch([0, 1], point_max=6000, room=1)
+    if which == "s3dis":
+        cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+        b = synth.scene_batch([0, 1], point_max=6000, room=1)
+    else:
+        cfg = dict(M.SCANNET_CFG, drop_path_rate=0.0)
+        b = synth.scene_batch([0, 1], point_max=6000, in_channels=9, num_classes=20, room=1)
     data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
     torch.manual_seed(0)
     seg = ptv2.DefaultSegmentor(ptv2.PointTransformerV2(**cfg)).cuda().train()
