@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--points", type=int, default=120000, help="points per scene (BASELINE.json configs[1]: ~120k)")
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--cfg", default="s3dis", choices=["s3dis", "scannet"],
+                    help="backbone config: the headline S3DIS one, or configs/scannet/semseg-pt-v2m2-0-base.py (BASELINE.json configs[4])")
     ap.add_argument("--cpu-sample-points", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -45,12 +47,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(rank, scenes, points, device):
+def make_batch(rank, scenes, points, device, in_channels=6, num_classes=13):
     from ao_amd import synth
 
     from ao_amd.ptv2.parallel import scene_seeds
 
-    b = synth.scene_batch(scene_seeds(rank, scenes), point_max=points, room=1)
+    b = synth.scene_batch(scene_seeds(rank, scenes), point_max=points, in_channels=in_channels, num_classes=num_classes, room=1)
     return {k: torch.from_numpy(v).to(device) for k, v in b.items()}
 
 
@@ -159,7 +161,7 @@ def main():
     from ao_amd import _lib
 
     torch.manual_seed(4242)
-    cfg = dict(ptv2.S3DIS_BACKBONE)
+    cfg = dict(ptv2.S3DIS_BACKBONE if args.cfg == "s3dis" else ptv2.SCANNET_BACKBONE)
     seg = ptv2.DefaultSegmentor(cfg).to(device).train()
     net = seg
     # gradient exchange: one flat all-reduce after backward (parallel.FlatGradSync, default) or torch DDP
@@ -185,7 +187,7 @@ def main():
         opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
     else:
         opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
-    data = make_batch(rank, args.scenes, args.points, device)
+    data = make_batch(rank, args.scenes, args.points, device, cfg["in_channels"], cfg["num_classes"])
     n_points = int(data["coord"].shape[0])
     autocast = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" else None
 
@@ -247,12 +249,12 @@ def main():
         levels = [int(lv.coord.shape[0]) for lv in geo.levels]
         ms = 1e3 * elapsed / args.steps
         out = {
-            "metric": "points/sec fwd+bwd PTv2m2 S3DIS", "value": points_per_step * args.steps / elapsed,
+            "metric": "points/sec fwd+bwd PTv2m2 S3DIS" if args.cfg == "s3dis" else "points/sec fwd+bwd PTv2m2 ScanNet cfg", "value": points_per_step * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "s3dis semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
-                                   "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.scenes, args.points),
+            "config": {"workload": "%s semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
+                                   "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.cfg, args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
                        "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
