@@ -136,9 +136,8 @@ def plan(blk):
 
 
 def supported(blk, feat, idx):
-    if not (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2 and feat.shape[0] >= 2):
-        return False
-    if torch.is_autocast_enabled():
+    if not (feat.is_cuda and feat.dtype in (torch.float32, torch.bfloat16, torch.float16) and feat.dim() == 2
+            and feat.shape[0] >= 2):
         return False
     p = plan(blk)
     if not p.static_ok or (blk.attn.attn_drop_rate != 0.0 and blk.training) or (not blk.training and not p.has_running):
@@ -211,4 +210,7 @@ def block_forward(blk, feat, coord, idx, rowscale):
     if training:
         mu, cov = _gva._pos_moments(_gva._HipImpl, coord, idx)
     inv = _gva.inverse_table(idx) if torch.is_grad_enabled() else None
-    return _NativeBlock.apply(feat, p, coord, idx, mu, cov, inv, rowscale, training, *p.params)
+    # under torch.autocast the Block still computes in fp32 (a superset of the reference's mixed precision: its
+    # BatchNorm / softmax are fp32 there too, only the Linear products would drop to bf16)
+    with torch.autocast("cuda", enabled=False):
+        return _NativeBlock.apply(feat.float(), p, coord, idx, mu, cov, inv, rowscale, training, *p.params)

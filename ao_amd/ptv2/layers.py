@@ -299,10 +299,11 @@ def lin_bn_relu(linear, bn, x):
     """ReLU(bn(linear(x))) for nn.Linear `linear` and RowBatchNorm1d `bn`; one fused autograd node when the row
     kernels cover the shape (fp32 CUDA rows, channel counts multiples of 4), the two-module path otherwise."""
     cout, cin = linear.weight.shape
-    if (isinstance(bn, RowBatchNorm1d) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and cin % 4 == 0
-            and cout % 4 == 0 and bn._fast(x.new_empty((2, cout))) and linear.weight.dtype == torch.float32
-            and not torch.is_autocast_enabled() and linear.weight.is_contiguous()):
+    if (isinstance(bn, RowBatchNorm1d) and x.is_cuda and x.dim() == 2 and cin % 4 == 0 and cout % 4 == 0
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and x.shape[0] > 1 and bn.affine
+            and bn.momentum is not None and 4 <= cout <= 1024 and linear.weight.dtype == torch.float32
+            and linear.weight.is_contiguous()):
         from . import block  # noqa: F401  (registers rows_gemm_hip_launcher)
 
-        return _LinBnRelu.apply(x, linear.weight, linear.bias, bn.weight, bn.bias, bn)
+        return _LinBnRelu.apply(x, linear.weight, linear.bias, bn.weight, bn.bias, bn)  # fp32 also under autocast
     return bn(linear(x), relu=True)

@@ -251,12 +251,15 @@ def main():
         out = {
             "metric": "points/sec fwd+bwd PTv2m2 S3DIS" if args.cfg == "s3dis" else "points/sec fwd+bwd PTv2m2 ScanNet cfg", "value": points_per_step * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the arithmetic type of the path: the Block runtime computes fp32 also under torch.autocast(bf16)
+            # (--dtype bf16 only exercises the autocast plumbing of the surrounding torch ops)
+            "dtype": "fp32",
             "data": "synthetic",
             "config": {"workload": "%s semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.cfg, args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
-                       "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
+                       "autocast": args.dtype if args.dtype != "fp32" else None, "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
                        "loss": float(loss.detach())},
         }

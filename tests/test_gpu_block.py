@@ -305,3 +305,32 @@ def test_native_block_is_bitwise_reproducible(monkeypatch, n, c, g):
         runs.append([y.detach()] + [t.clone() for t in grads])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+def test_native_block_under_autocast_computes_fp32(monkeypatch):
+    """The reference trainer wraps the step in torch.cuda.amp.autocast (reference pointcept/engines/train.py:178): the Block
+    runtime is still taken there and still computes fp32 -- same bits as without autocast."""
+    from ao_amd import pointops, synth
+    from ao_amd.ptv2 import block as native
+
+    monkeypatch.setenv("AO_AMD_BLOCK", "native")
+    n, c, g = 4000, 96, 12
+    coord = torch.from_numpy(synth.room_cloud(n, seed=8)).cuda()
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(16, coord, offset)
+    blk, _ = _block_pair(c, g, 0.0, seed=4)
+    blk.train()
+    torch.manual_seed(6)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    go = torch.randn(n, c, device="cuda")
+    runs = []
+    for amp in (False, True):
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            assert native.supported(blk, x, idx)
+            y = blk([coord, x, offset], idx)[1]
+        assert y.dtype == torch.float32
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+        runs.append([y.detach()] + [t.clone() for t in grads])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
