@@ -500,6 +500,23 @@ int cross_entropy_backward_hip_launcher(int n, int c, const float *logits, const
 int adamw_flat_hip_launcher(long long n, float *p, const float *g, float *m, float *v, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream);
 
+/* ------------------------------------------- data-side integer work (§8f) --
+ * GridSample (pointcept/datasets/transform.py:769-897): cell (n,3) = floor(coord / grid) computed in fp32,
+ * cell_range[0..2] / [3..5] = per-axis min / max of cell, key (n) = FNV64-1A (ravel == 0, transform.py:883-897) or
+ * the Fortran-style ravel (ravel != 0, transform.py:865-881) of (cell - min) as uint64.  The caller sorts the keys
+ * (unsigned order) and picks one point per run; see ao_amd/ptv2/transform.py. */
+int grid_sample_keys_hip_launcher(int n, const float *coord, float grid_x, float grid_y, float grid_z, int ravel,
+                                  int *cell, int *cell_range, unsigned long long *key, void *stream);
+/* SphereCrop (transform.py:970-981): dist2 (n) = sum((coord - center)^2, 1) with numpy's fp32 rounding sequence
+ * ((dx*dx + dy*dy) + dz*dz, products rounded separately); center: 3 floats in device memory. */
+int center_dist2_hip_launcher(int n, const float *coord, const float *center, float *dist2, void *stream);
+/* Validation counts (pointcept/utils/misc.py:58-70 intersection_and_union_gpu, called from
+ * engines/hooks/evaluator.py:136-141 after the k = 1 label transfer :124-134): hist (3,k) int64 = intersection,
+ * output and target areas (union = output + target - intersection).  pred (pred_n) int64 class ids; nn_idx (n) int32
+ * = nearest predicted point of every target point, or NULL for the identity; target (n) int64.  hist is zeroed here. */
+int seg_confusion_hip_launcher(long long n, int k, int ignore_index, const long long *pred, long long pred_n,
+                               const int *nn_idx, const long long *target, long long *hist, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

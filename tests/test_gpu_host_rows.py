@@ -1,0 +1,211 @@
+"""GPU: the data-side HIP kernels (ao_amd/csrc/dataops.hip) and their host mirrors (ao_amd/ptv2/transform.py,
+evaluate.py, schedule.py) against oracle/host_ref.py and the fixtures captured from the reference's own Python
+(tests/golden/host_*.npz).  Integer results (voxel keys, selections, crop indices, counts) are compared exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host_ref as H
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["fnv", "ravel"])
+def test_grid_sample_keys_and_selection(tag):
+    from ao_amd.ptv2.transform import GridSample
+
+    g = load("host_gridsample.npz")
+    coord, grid = g["coord"], float(g[tag + "_grid"])
+    gs = GridSample(grid_size=grid, hash_type=tag, mode="train", keys=("coord", "index"), return_discrete_coord=True,
+                    return_min_coord=True, return_displacement=True)
+    idx_sort, start, count, cell, lo, skey = gs.voxelise(cuda(coord))
+    o_sort, o_uniq, o_count, o_cell, o_lo = H.grid_sample_sorted(coord, grid, tag)
+    assert np.array_equal(cell.cpu().numpy(), o_cell) and np.array_equal(lo.cpu().numpy(), o_lo)
+    assert np.array_equal(idx_sort.cpu().numpy(), o_sort)  # stable order, bit-exact keys
+    assert np.array_equal(count.cpu().numpy(), o_count)
+    assert np.array_equal(np.unique(skey.cpu().numpy().view(np.uint64)), o_uniq)
+    # the reference's draw sequence -> the oracle's selection exactly, the reference's voxels / cells / min corner
+    np.random.seed(11)
+    draws = np.random.randint(0, o_count.max(), o_count.size)
+    d = gs(dict(coord=cuda(coord), index=torch.arange(coord.shape[0]).cuda()), draws=draws)
+    sel = d["index"].cpu().numpy()
+    assert np.array_equal(sel, H.grid_sample_train(coord, grid, draws, tag))
+    assert np.array_equal(d["discrete_coord"].cpu().numpy(), g[tag + "_train_cell"])
+    np.testing.assert_allclose(d["min_coord"].cpu().numpy(), g[tag + "_min_coord"], rtol=1e-6)
+    assert np.array_equal(d["coord"].cpu().numpy(), coord[sel])
+    single = o_count == 1
+    assert np.array_equal(sel[single], g[tag + "_train_index"][single])
+    # transform.py:820-822 subtracts the MIN-SHIFTED cell: the reference's displacement carries the min cell as an offset
+    disp = d["displacement"].cpu().numpy() - o_lo
+    assert disp.shape == (sel.shape[0], 3) and (disp > -0.5 - 1e-3).all() and (disp < 0.5 + 1e-3).all()
+
+
+def test_grid_sample_random_draws_and_test_mode():
+    from ao_amd.ptv2.transform import GridSample
+
+    g = load("host_gridsample.npz")
+    coord = g["coord"]
+    cell, _ = H.grid_cells(coord, 0.04)
+    key = H.fnv_hash_vec(cell)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    d = GridSample(grid_size=0.04, keys=("coord", "index"))(dict(coord=cuda(coord), index=torch.arange(coord.shape[0]).cuda()),
+                                                          generator=gen)
+    sel = d["index"].cpu().numpy()
+    assert np.array_equal(key[sel], np.unique(key))  # one point of every voxel, ascending key order
+    parts = GridSample(grid_size=0.04, mode="test", keys=("coord", "index"))(
+        dict(coord=cuda(coord), index=torch.arange(coord.shape[0]).cuda()))
+    ref = H.grid_sample_test(coord, 0.04)
+    assert [p["index"].shape[0] for p in parts] == list(g["fnv_test_sizes"])
+    for p, r in zip(parts, ref):
+        assert np.array_equal(p["index"].cpu().numpy(), r)
+        assert np.array_equal(p["coord"].cpu().numpy(), coord[r])
+
+
+def test_grid_sample_large_cloud_properties():
+    """1.2 M raw points (the size of an S3DIS room scan): every voxel represented once, idempotent."""
+    from ao_amd import synth
+    from ao_amd.ptv2.transform import GridSample
+
+    rng = np.random.default_rng(0)
+    base = synth.room_scene(seed=1, room=2, point_max=400000, density=8000.0, voxel=0.02)
+    assert base.shape[0] > 250000
+    pts = np.concatenate([base + rng.normal(0, 0.01, base.shape).astype(np.float32) for _ in range(4)])
+    gs = GridSample(grid_size=0.04, keys=("coord",))
+    d = gs(dict(coord=cuda(pts)), generator=torch.Generator(device="cuda").manual_seed(1))
+    out = d["coord"]
+    cells = np.unique(H.grid_cells(out.cpu().numpy(), 0.04)[0], axis=0)
+    assert cells.shape[0] == out.shape[0]  # no voxel twice
+    all_cells = np.unique(H.grid_cells(pts, 0.04)[0], axis=0)
+    assert all_cells.shape[0] == out.shape[0]  # no voxel missed
+    again = gs(dict(coord=out.clone()), generator=torch.Generator(device="cuda").manual_seed(2))["coord"]
+    assert again.shape == out.shape and torch.equal(torch.sort(again.sum(1))[0], torch.sort(out.sum(1))[0])
+
+
+def test_sphere_crop():
+    from ao_amd.ptv2.transform import SphereCrop
+
+    g = load("host_spherecrop.npz")
+    coord = g["coord"]
+    n = coord.shape[0]
+    d = SphereCrop(point_max=2500, mode="center")(dict(coord=cuda(coord), segment=torch.arange(n).cuda()))
+    assert np.array_equal(d["segment"].cpu().numpy(), H.sphere_crop(coord, 2500, n // 2))
+    d2 = H.center_dist2(coord, coord[n // 2])
+    assert np.array_equal(d2[d["segment"].cpu().numpy()], d2[g["center_index"]])  # the reference's distance sequence
+    c = int(g["random_center"])
+    d = SphereCrop(point_max=1000, mode="random")(dict(coord=cuda(coord), segment=torch.arange(n).cuda()), center_index=c)
+    assert np.array_equal(d["segment"].cpu().numpy(), H.sphere_crop(coord, 1000, c))
+    assert np.array_equal(np.sort(d["segment"].cpu().numpy()), np.sort(g["random_index"]))
+    assert np.array_equal(d["coord"].cpu().numpy(), coord[d["segment"].cpu().numpy()])
+    same = SphereCrop(point_max=10000)(dict(coord=cuda(coord), segment=torch.arange(n).cuda()))
+    assert np.array_equal(same["segment"].cpu().numpy(), g["nocrop_index"])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    r = SphereCrop(sample_rate=0.25)(dict(coord=cuda(coord), segment=torch.arange(n).cuda()), generator=gen)
+    assert r["coord"].shape[0] == n // 4
+
+
+def test_collect_and_collate():
+    from ao_amd.ptv2.transform import Collect, point_collate
+
+    clouds = []
+    for n in (100, 37, 250):
+        clouds.append(Collect(keys=("coord", "segment"), feat_keys=["coord", "color"])(
+            dict(coord=torch.randn(n, 3).cuda(), color=torch.rand(n, 3).cuda(), segment=torch.zeros(n, dtype=torch.long).cuda())))
+    b = point_collate(clouds)
+    assert b["coord"].shape == (387, 3) and b["feat"].shape == (387, 6)
+    assert b["offset"].dtype == torch.int32 and b["offset"].is_cuda and b["offset"].tolist() == [100, 137, 387]
+
+
+@pytest.mark.parametrize("tag", ["s3dis", "scannet"])
+def test_intersection_and_union(tag):
+    from ao_amd.ptv2.evaluate import intersection_and_union_gpu, summarize
+
+    g = load("host_iou.npz")
+    k = int(g[tag + "_k"])
+    pred = cuda(g[tag + "_pred"])
+    keep = pred.clone()
+    i, u, t = intersection_and_union_gpu(pred, cuda(g[tag + "_target"]), k, -1)
+    assert torch.equal(pred, keep)  # the caller's prediction is not masked in place
+    assert np.array_equal(i.cpu().numpy(), g[tag + "_intersection"])
+    assert np.array_equal(u.cpu().numpy(), g[tag + "_union"])
+    assert np.array_equal(t.cpu().numpy(), g[tag + "_target_area"])
+    s = summarize(i.cpu().numpy(), u.cpu().numpy(), t.cpu().numpy())
+    m = H.miou(g[tag + "_intersection"], g[tag + "_union"], g[tag + "_target_area"])
+    assert (s["mIoU"], s["mAcc"], s["allAcc"]) == pytest.approx(m, rel=1e-12)
+
+
+def test_evaluate_batch_with_label_transfer():
+    """evaluator.py:124-141: predictions on the grid-sampled cloud, scored on the original points through knn k = 1."""
+    from ao_amd import synth
+    from ao_amd.ptv2.evaluate import evaluate_batch
+    from oracle import pointops_ref as OP
+
+    k = 13
+    rng = np.random.default_rng(2)
+    origin = np.concatenate([synth.room_cloud(30000, seed=4), synth.room_cloud(20000, seed=6) + np.float32(20.0)])
+    origin_offset = np.array([30000, 50000], dtype=np.int32)
+    pick = np.sort(np.concatenate([rng.choice(30000, 4000, replace=False), 30000 + rng.choice(20000, 2500, replace=False)]))
+    coord, offset = origin[pick], np.array([4000, 6500], dtype=np.int32)
+    logits = rng.normal(size=(coord.shape[0], k)).astype(np.float32)
+    seg_o = rng.integers(-1, k, size=origin.shape[0])
+    out = evaluate_batch(dict(seg_logits=cuda(logits)),
+                         dict(coord=cuda(coord), offset=cuda(offset), origin_coord=cuda(origin), origin_offset=cuda(origin_offset),
+                              origin_segment=cuda(seg_o), segment=cuda(seg_o[pick])), k, -1)
+    idx, _ = OP.knn_query(1, torch.from_numpy(coord), torch.from_numpy(offset), torch.from_numpy(origin),
+                          torch.from_numpy(origin_offset))
+    pred = logits.argmax(1)[idx.numpy().reshape(-1)]
+    ref = H.intersection_and_union(pred, seg_o, k, -1)
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+    # a batch of 4 M labels: totals are conserved (checksum property at a size the oracle is not run at)
+    big_t = torch.randint(-1, k, (4_000_000,), device="cuda")
+    big_p = torch.randint(0, k, (4_000_000,), device="cuda")
+    from ao_amd.ptv2.evaluate import confusion_counts
+    h = confusion_counts(big_p, big_t, k)
+    assert int(h[2].sum()) == int((big_t >= 0).sum()) == int(h[1].sum())
+    assert int(h[0].sum()) == int((big_p == big_t).sum())
+
+
+def test_flat_adamw_follows_reference_schedules():
+    """engines/train.py:184-196 order (optimizer.step, scheduler.step) with the S3DIS and ScanNet schedules: FlatAdamW
+    driven by StepSchedule == torch.optim.AdamW driven by the reference's LR / beta1 curves (tests/golden)."""
+    from ao_amd.ptv2.schedule import build_optimizer, build_scheduler
+
+    g = load("host_schedules.npz")
+    for tag, ocfg, scfg in (("s3dis", dict(type="AdamW", lr=0.006, weight_decay=0.05),
+                             dict(type="MultiStepLR", milestones=[0.09, 0.2], gamma=0.1)),
+                            ("scannet", dict(type="AdamW", lr=0.005, weight_decay=0.02),
+                             dict(type="OneCycleLR", max_lr=0.005, pct_start=0.05, anneal_strategy="cos", div_factor=10.0,
+                                  final_div_factor=1000.0))):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4)).cuda()
+        ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4)).cuda()
+        ref.load_state_dict(net.state_dict())
+        opt = build_optimizer(ocfg, net)
+        assert type(opt).__name__ == "FlatAdamW"
+        sched = build_scheduler(scfg, opt, total_steps=200)
+        topt = torch.optim.AdamW(ref.parameters(), lr=ocfg["lr"], weight_decay=ocfg["weight_decay"])
+        for s in range(40):
+            x = torch.randn(32, 8, device="cuda")
+            for m, o in ((net, opt), (ref, topt)):
+                o.zero_grad()
+                m(x).square().mean().backward()
+            assert opt.param_groups[0]["lr"] == pytest.approx(float(g[tag + "_200_lr"][s]), rel=1e-9)
+            topt.param_groups[0]["lr"] = float(g[tag + "_200_lr"][s])
+            topt.param_groups[0]["betas"] = (float(g[tag + "_200_beta1"][s]), 0.999)
+            opt.step()
+            topt.step()
+            sched.step()
+        for a, b in zip(net.parameters(), ref.parameters()):
+            np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=1e-6)
