@@ -918,15 +918,23 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
     using K = BwdPointCfg<G, C, NW>;
     const bool local = NW == 1 && Wp2 != nullptr;
     const size_t lds = sizeof(float) * (K::lds_floats + (local ? (size_t)C * C + C + 4 * (size_t)K::G16 * C + 4 * K::G16 : 0));
-    // grid: enough workgroups to fill the chip, few enough that the partial records stay a small fraction of the
-    // traffic (<= 8 MB)
-    long long cap = (long long)(8u << 20) / (long long)(sizeof(float) * K::PF);
-    cap = std::max<long long>(256, std::min<long long>(cap / 256 * 256, 2048));
+    // grid: exactly the workgroups that are resident at once (occupancy x CUs, at most 512).  Every workgroup stages
+    // its weights once and then walks its points; any grid that is not co-resident runs a second, partly empty round
+    // (measured at 120 k points, (6,48): 340 us at 512 workgroups, 406 at 1280, 468 at 640; (24,192) at 4.5 k
+    // points: 92 / 116 / 111 us)
+    auto kern = attention_bwd_point_kernel<G, C, NW>;
+    static int resident[2] = {0, 0};
+    if (!resident[local]) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident[local] = std::max(64, std::min(occ * cus, 512));
+    }
+    const long long cap = resident[local];
     const long long groups = ((long long)n + K::PW - 1) / K::PW;
     const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
     if ((size_t)nblk * K::PF > part_floats_avail) return PTV2_ERR_WORKSPACE;
-    auto kern = attention_bwd_point_kernel<G, C, NW>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw,
                        gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr);
     launch_finalize(st, (const float *)part, nblk, K::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
@@ -1008,7 +1016,7 @@ int gva_bwd_point_supported(int k, int c, int g) {
 
 size_t gva_bwd_point_part_floats(int c, int g) {
     const size_t pf = 4 * (size_t)c + 3 * (size_t)g + (size_t)g * g;
-    return std::max<size_t>((8u << 20) / sizeof(float), 256 * pf) + 1024;
+    return std::max<size_t>((8u << 20) / sizeof(float), 512 * pf) + 1024;
 }
 
 int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,

@@ -8,7 +8,7 @@ from ao_amd import _lib, pointops, synth
 from ao_amd.ptv2.gva import _HipImpl, inverse_table
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-LEVELS = [(120000, 48, 6), (30000, 96, 12), (7500, 192, 24), (1900, 384, 48)]
+LEVELS = [(120000, 48, 6), (18900, 96, 12), (4500, 192, 24), (1074, 384, 48)]  # stage sizes of the 120 k-point bench scene
 for n, c, g in LEVELS:
     k = 16
     pts = synth.room_scene(seed=1, room=1, point_max=n, voxel=0.04 * (120000 / n) ** 0.5)  # coarser levels: coarser voxels
