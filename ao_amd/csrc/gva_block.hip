@@ -9,15 +9,23 @@
 #include <cstdlib>
 
 #include "gva_common.h"
+#include "gva_fold_p.h"
 
 namespace gva {
 
 // M[c',g] = sum_c Wp2[c,c'] Ww1[g,c];  cW[g] = sum_c Ww1[g,c] bp2[c] + bw1[g]
-// one wavefront per output, lanes over the reduction index (the outputs are few, the reduction is long)
+// one wavefront per output, lanes over the reduction index (the outputs are few, the reduction is long).
+// The workgroups from index mblocks on run the (independent, equally parameter-sized) BN_p fold of the same block:
+// one launch instead of two
 __global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
                                                          const float *__restrict__ bp2, const float *__restrict__ Ww1,
                                                          const float *__restrict__ bw1, float *__restrict__ M,
-                                                         float *__restrict__ cW) {
+                                                         float *__restrict__ cW, int mblocks, FoldPFwdArgs P) {
+    if ((int)blockIdx.x >= mblocks) {
+        const int ch = ((int)blockIdx.x - mblocks) * TPB + threadIdx.x;
+        if (ch < P.c) fold_p_fwd_channel(P, ch);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int e = (blockIdx.x * TPB + threadIdx.x) >> 6;  // wave index = output index
     if (e < c * g) {
@@ -42,7 +50,13 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
                                                          const float *__restrict__ gM, const float *__restrict__ gcW,
                                                          const float *__restrict__ gWw1_k,
                                                          const float *__restrict__ gWw1_q, float *__restrict__ gWw1,
-                                                         float *gWp2, float *gbp2, float *__restrict__ gbw1) {
+                                                         float *gWp2, float *gbp2, float *__restrict__ gbw1, int mblocks,
+                                                         FoldPBwdArgs P) {
+    if ((int)blockIdx.x >= mblocks) {  // the BN_p fold backward of the same block rides along (see fold_m_fwd_kernel)
+        const int ch = ((int)blockIdx.x - mblocks) * TPB + threadIdx.x;
+        if (ch < P.c) fold_p_bwd_channel(P, ch);
+        return;
+    }
     const long long n1 = (long long)g * c, n2 = (long long)c * c;
     const int wblocks = (int)((n1 + WPB - 1) / WPB);  // the first blocks: one wavefront per gWw1 output (a length-c dot
     if ((int)blockIdx.x < wblocks) {                  // product whose Wp2 row is read coalesced across the lanes)
@@ -153,10 +167,6 @@ int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, c
 int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
                                const float *const *xsh, float *const *y, void *stream);
 int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
-int gva_fold_p_backward2(int c, const float *Wp1, const float *bp1, const float *gamma, const double *mu, const double *cov,
-                         const float *running_mean, const float *rstd, int training, const float *ga, const float *gb,
-                         const float *ga2, const float *gb2, float *gWp1, float *gbp1, float *ggamma, float *gbeta,
-                         void *stream);
 int gva_bwd_point_local(int k, int c, int g);
 int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
                                      const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
@@ -230,11 +240,13 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
-    RUN(gva_fold_p_forward_hip_launcher(c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p,
-                                        B->run_var_p, B->batches_p, B->training, rows, B->eps_p, B->momentum_p, B->a, B->b,
-                                        B->rstd_p, stream));
-    hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(divup(((long long)c * g + g) * WAVE, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2,
-                       B->Ww1, B->bw1, B->M, B->cW);
+    {
+        const int mblocks = divup(((long long)c * g + g) * WAVE, TPB);
+        hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1, B->bw1,
+                           B->M, B->cW, mblocks,
+                           FoldPFwdArgs{c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p, B->run_var_p,
+                                        B->batches_p, B->training, rows, B->eps_p, B->momentum_p, B->a, B->b, B->rstd_p});
+    }
     {
         const float *xs[2] = {B->key, B->q}, *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
         float *ys[2] = {B->kW, B->qW};
@@ -296,9 +308,6 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     RUN(gva_logits_backward_hip_launcher(n, k, c, g, B->a, B->b, B->M, B->coord, B->idx, B->W1, W.gW1, W.gT1, W.gT2,
                                          G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage,
                                          W.stage_bytes, stream));
-    // 5. folded BN_p: both stages contribute to (a, b)
-    RUN(gva_fold_p_backward2(c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1, W.gb1,
-                             W.ga2, W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p, stream));
     // 6. projections kW = k Ww1^T, qW = q Ww1^T
     {
         const float *gys[2] = {W.gkW, W.gqW};
@@ -311,10 +320,16 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         const float *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
         RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.stage, W.stage_bytes, stream));
     }
-    // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1
-    hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(divup((long long)g * c, WPB) + divup((long long)c * c + c + g, TPB)), dim3(TPB), 0, st, c,
-                       g, B->Wp2, B->bp2, B->Ww1, (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k,
-                       (const float *)W.gWw1_q, G->gWw1, G->gWp2, G->gbp2, G->gbw1);
+    // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1; in the same launch the
+    //    folded BN_p backward (both stages contribute to the gradient of (a, b))
+    {
+        const int mblocks = divup((long long)g * c, WPB) + divup((long long)c * c + c + g, TPB);
+        hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1,
+                           (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k, (const float *)W.gWw1_q, G->gWw1,
+                           G->gWp2, G->gbp2, G->gbw1, mblocks,
+                           FoldPBwdArgs{c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1,
+                                        W.gb1, W.ga2, W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p});
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -12,82 +12,18 @@
 //  fold_w  (weight_encoding[1]: BatchNorm over the (N*K, G) logits, from their column sums T1, T2)
 //     mean = T1/R, var = T2/R - mean^2, sc = gamma / sqrt(var + eps), sh = beta - mean sc
 #include "gva_common.h"
+#include "gva_fold_p.h"
 
 namespace gva {
 
-__global__ void fold_p_fwd_kernel(int c, const float *__restrict__ Wp1, const float *__restrict__ bp1,
-                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                  const double *__restrict__ mu, const double *__restrict__ cov, float *run_mean,
-                                  float *run_var, long long *batches, int training, double rows, float eps,
-                                  float momentum, float *__restrict__ a, float *__restrict__ b,
-                                  float *__restrict__ rstd_out) {
+__global__ void fold_p_fwd_kernel(FoldPFwdArgs A) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    const double w0 = Wp1[3 * ch], w1 = Wp1[3 * ch + 1], w2 = Wp1[3 * ch + 2];
-    double mean, rstd;
-    if (training) {
-        mean = w0 * mu[0] + w1 * mu[1] + w2 * mu[2] + (double)bp1[ch];
-        const double t0 = cov[0] * w0 + cov[1] * w1 + cov[2] * w2;
-        const double t1 = cov[3] * w0 + cov[4] * w1 + cov[5] * w2;
-        const double t2 = cov[6] * w0 + cov[7] * w1 + cov[8] * w2;
-        double var = w0 * t0 + w1 * t1 + w2 * t2;
-        var = var > 0.0 ? var : 0.0;
-        rstd = 1.0 / sqrt(var + (double)eps);
-        if (run_mean) {
-            const double unb = rows > 1.0 ? var * (rows / (rows - 1.0)) : var;
-            run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * mean);
-            run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
-            if (ch == 0 && batches) *batches += 1;
-        }
-    } else {
-        mean = (double)run_mean[ch];
-        rstd = 1.0 / sqrt((double)run_var[ch] + (double)eps);
-    }
-    const double s = (double)gamma[ch] * rstd;
-    a[3 * ch] = (float)(w0 * s);
-    a[3 * ch + 1] = (float)(w1 * s);
-    a[3 * ch + 2] = (float)(w2 * s);
-    b[ch] = (float)(((double)bp1[ch] - mean) * s + (double)beta[ch]);
-    rstd_out[ch] = (float)rstd;
+    if (ch < A.c) fold_p_fwd_channel(A, ch);
 }
 
-__global__ void fold_p_bwd_kernel(int c, const float *__restrict__ Wp1, const float *__restrict__ bp1,
-                                  const float *__restrict__ gamma, const double *__restrict__ mu,
-                                  const double *__restrict__ cov, const float *__restrict__ run_mean,
-                                  const float *__restrict__ rstd_in, int training, const float *__restrict__ ga,
-                                  const float *__restrict__ gb, const float *__restrict__ ga2,
-                                  const float *__restrict__ gb2, float *__restrict__ gWp1, float *__restrict__ gbp1,
-                                  float *__restrict__ ggamma, float *__restrict__ gbeta) {
+__global__ void fold_p_bwd_kernel(FoldPBwdArgs A) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    const double w[3] = {Wp1[3 * ch], Wp1[3 * ch + 1], Wp1[3 * ch + 2]};
-    double g[3] = {ga[3 * ch], ga[3 * ch + 1], ga[3 * ch + 2]};
-    double gbv = gb[ch];
-    if (ga2) {  // (a, b) feed two stages (logits and aggregation): their gradients are summed here
-        g[0] += ga2[3 * ch]; g[1] += ga2[3 * ch + 1]; g[2] += ga2[3 * ch + 2];
-        gbv += gb2[ch];
-    }
-    const double rstd = rstd_in[ch], gam = gamma[ch];
-    const double s = gam * rstd;
-    gbeta[ch] = (float)gbv;
-    if (training) {
-        const double wmu = w[0] * mu[0] + w[1] * mu[1] + w[2] * mu[2];  // b = -wmu * s + beta
-        const double gs = g[0] * w[0] + g[1] * w[1] + g[2] * w[2] - gbv * wmu;
-        ggamma[ch] = (float)(gs * rstd);
-        const double gvar = gs * gam * (-0.5) * rstd * rstd * rstd;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double cw = cov[3 * d] * w[0] + cov[3 * d + 1] * w[1] + cov[3 * d + 2] * w[2];
-            gWp1[3 * ch + d] = (float)(g[d] * s - gbv * mu[d] * s + gvar * 2.0 * cw);
-        }
-        gbp1[ch] = 0.f;  // the batch mean removes the bias
-    } else {
-        const double dm = (double)bp1[ch] - (double)run_mean[ch];
-        ggamma[ch] = (float)((g[0] * w[0] + g[1] * w[1] + g[2] * w[2] + gbv * dm) * rstd);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) gWp1[3 * ch + d] = (float)(g[d] * s);
-        gbp1[ch] = (float)(gbv * s);
-    }
+    if (ch < A.c) fold_p_bwd_channel(A, ch);
 }
 
 __global__ void fold_w_fwd_kernel(int g, const double *__restrict__ T1, const double *__restrict__ T2,
@@ -152,8 +88,9 @@ extern "C" int gva_fold_p_forward_hip_launcher(int c, const float *Wp1, const fl
                                                long long *num_batches_tracked, int training, double rows, float eps,
                                                float momentum, float *a, float *b, float *rstd, void *stream) {
     if (c < 1) return PTV2_ERR_ARG;
-    hipLaunchKernelGGL(fold_p_fwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, beta,
-                       mu, cov, running_mean, running_var, num_batches_tracked, training, rows, eps, momentum, a, b, rstd);
+    hipLaunchKernelGGL(fold_p_fwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream,
+                       FoldPFwdArgs{c, Wp1, bp1, gamma, beta, mu, cov, running_mean, running_var, num_batches_tracked, training,
+                                    rows, eps, momentum, a, b, rstd});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -163,21 +100,9 @@ extern "C" int gva_fold_p_backward_hip_launcher(int c, const float *Wp1, const f
                                                 const float *rstd, int training, const float *ga, const float *gb,
                                                 float *gWp1, float *gbp1, float *ggamma, float *gbeta, void *stream) {
     if (c < 1) return PTV2_ERR_ARG;
-    hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, mu,
-                       cov, running_mean, rstd, training, ga, gb, (const float *)nullptr, (const float *)nullptr, gWp1, gbp1,
-                       ggamma, gbeta);
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-
-// the same with the gradient of (a, b) given as the sum of two contributions (internal to the block runtime)
-int gva_fold_p_backward2(int c, const float *Wp1, const float *bp1, const float *gamma, const double *mu, const double *cov,
-                         const float *running_mean, const float *rstd, int training, const float *ga, const float *gb,
-                         const float *ga2, const float *gb2, float *gWp1, float *gbp1, float *ggamma, float *gbeta,
-                         void *stream) {
-    if (c < 1) return PTV2_ERR_ARG;
-    hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream, c, Wp1, bp1, gamma, mu,
-                       cov, running_mean, rstd, training, ga, gb, ga2, gb2, gWp1, gbp1, ggamma, gbeta);
+    hipLaunchKernelGGL(fold_p_bwd_kernel, dim3(divup(c, 128)), dim3(128), 0, (hipStream_t)stream,
+                       FoldPBwdArgs{c, Wp1, bp1, gamma, mu, cov, running_mean, rstd, training, ga, gb, nullptr, nullptr, gWp1,
+                                    gbp1, ggamma, gbeta});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
