@@ -170,6 +170,11 @@ static bool use_batch(const ptv2_block *B, int i) { return B->training || !B->ru
 
 // statistics of BatchNorm `i` (input h, (n,c)) -> S.mean / S.rstd / S.sc / S.sh: from the producing GEMM's epilogue
 // records (`part` != NULL), from a pass over h (`part` == NULL, batch statistics), or from the running buffers (eval)
+int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
+                           float *const *mean, float *const *rstd, float *const *sc, float *const *sh, float *const *running_mean,
+                           float *const *running_var, long long *const *num_batches_tracked, float eps, float momentum,
+                           void *stream);
+
 static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, const float *gamma, const float *beta,
                       const Saved &S, const Work &W, void *stream) {
     if (use_batch(B, i)) {
@@ -212,8 +217,19 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
         float *ys[3] = {S.hq, S.hk, S.v}, *sts[3] = {st_hq, st_hk, nullptr};
         RUN(rows_gemm_fused_hip_launcher(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, S.bsc[0], S.bsh[0], sts, stream));
     }
-    RUN(bn_prepare(B, 1, S.hq, st_hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S, W, stream));
-    RUN(bn_prepare(B, 2, S.hk, st_hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S, W, stream));
+    if (st_hq && st_hk) {  // both from their GEMM records: one launch finishes the two BatchNorms
+        const bool tq = B->training && B->run_mean[1] && B->run_var[1], tk = B->training && B->run_mean[2] && B->run_var[2];
+        float *parts[2] = {st_hq, st_hk}, *means[2] = {S.mean[1], S.mean[2]}, *rstds[2] = {S.rstd[1], S.rstd[2]};
+        float *scs[2] = {S.bsc[1], S.bsc[2]}, *shs[2] = {S.bsh[1], S.bsh[2]};
+        const float *gs[2] = {P[PTV2_BLK_QN_G], P[PTV2_BLK_KN_G]}, *bs[2] = {P[PTV2_BLK_QN_B], P[PTV2_BLK_KN_B]};
+        float *rms[2] = {tq ? B->run_mean[1] : nullptr, tk ? B->run_mean[2] : nullptr};
+        float *rvs[2] = {tq ? B->run_var[1] : nullptr, tk ? B->run_var[2] : nullptr};
+        long long *nbs[2] = {tq ? B->batches[1] : nullptr, tk ? B->batches[2] : nullptr};
+        RUN(bn_tiles_finalize_pair(n, c, parts, gs, bs, means, rstds, scs, shs, rms, rvs, nbs, B->eps, B->momentum, stream));
+    } else {
+        RUN(bn_prepare(B, 1, S.hq, st_hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S, W, stream));
+        RUN(bn_prepare(B, 2, S.hk, st_hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S, W, stream));
+    }
     // grouped vector attention (q, k enter as hq, hk + folded affine)
     ptv2_gva_block V;
     fill_gva(B, S, &V);

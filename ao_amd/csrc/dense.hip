@@ -115,11 +115,40 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_ke
 
 // the same from the row GEMM's epilogue records part[nrb][2][c] (per 64-row block: column sums and sums of squares
 // about the block mean), merged with the parallel-variance identity  M2 = sum_b (M2_b + S_b^2 / n_b) - n mean^2
-__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_tiles_kernel(
-    const float *__restrict__ part, int nrb, int c, int n, float eps, float momentum, float *__restrict__ mean,
-    float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float *__restrict__ sc, float *__restrict__ sh) {
+// one or two tensors per launch (blockIdx.z selects the set: the q / k BatchNorms of a Block are finished together)
+struct BnTileSet {
+    const float *part;
+    float *mean, *rstd, *run_mean, *run_var;
+    long long *batches;
+    const float *gamma, *beta;
+    float *sc, *sh;
+    double *fold;  // two-level scratch (bn_fold_tiles_kernel)
+};
+
+__device__ __forceinline__ void bn_tiles_emit(const BnTileSet &S, int ch, double t1, double t2, int n, float eps, float momentum) {
+    const double m = t1 / n;
+    double var = t2 / n - m * m;
+    var = var > 0.0 ? var : 0.0;
+    S.mean[ch] = (float)m;
+    S.rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (S.sc) {
+        const float scale = S.rstd[ch] * S.gamma[ch];
+        S.sc[ch] = scale;
+        S.sh[ch] = S.beta[ch] - S.mean[ch] * scale;
+    }
+    if (S.run_mean) {
+        const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+        S.run_mean[ch] = (float)((1.0 - momentum) * (double)S.run_mean[ch] + momentum * m);
+        S.run_var[ch] = (float)((1.0 - momentum) * (double)S.run_var[ch] + momentum * unb);
+        if (ch == 0 && S.batches) *S.batches += 1;
+    }
+}
+
+__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_tiles_kernel(BnTileSet A, BnTileSet B, int nrb, int c,
+                                                                                           int n, float eps, float momentum) {
     __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+    const BnTileSet &S = blockIdx.z ? B : A;
+    const float *__restrict__ part = S.part;
     const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
     const int ch = blockIdx.x * gva::FIN_COLS + col;
     double a = 0.0, b = 0.0;
@@ -138,22 +167,7 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_ti
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
         for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
-        const double m = t1 / n;
-        double var = t2 / n - m * m;
-        var = var > 0.0 ? var : 0.0;
-        mean[ch] = (float)m;
-        rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-        if (sc) {
-            const float scale = rstd[ch] * gamma[ch];
-            sc[ch] = scale;
-            sh[ch] = beta[ch] - mean[ch] * scale;
-        }
-        if (run_mean) {
-            const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
-            run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
-            run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
-            if (ch == 0 && batches) *batches += 1;
-        }
+        bn_tiles_emit(S, ch, t1, t2, n, eps, momentum);
     }
 }
 
@@ -620,9 +634,12 @@ extern "C" int bn_stats_affine_hip_launcher(int n, int c, const float *x, const 
 
 // first level for many records: block (x, y) folds records y, y + gridDim.y, ... of 64 columns into ONE record of
 // the same form (sum; centred sum of squares; its row count is implied by the records it covers)
-__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_fold_tiles_kernel(const float *__restrict__ part, int nrb,
-                                                                                       int c, int n, double *__restrict__ out) {
+__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_fold_tiles_kernel(BnTileSet A, BnTileSet B, int nrb, int c,
+                                                                                       int n) {
     __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+    const BnTileSet &S = blockIdx.z ? B : A;
+    const float *__restrict__ part = S.part;
+    double *__restrict__ out = S.fold;
     const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
     const int ch = blockIdx.x * gva::FIN_COLS + col;
     double a = 0.0, b = 0.0;
@@ -647,30 +664,14 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_fold_tiles_
 }
 
 // second level: nrec folded records (float64) -> mean, rstd, folded affine, running buffers
-__global__ void bn_finalize_folded_kernel(const double *__restrict__ rec, int nrec, int c, int n, float eps, float momentum,
-                                          float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var,
-                                          long long *batches, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                          float *__restrict__ sc, float *__restrict__ sh) {
+__global__ void bn_finalize_folded_kernel(BnTileSet A, BnTileSet B, int nrec, int c, int n, float eps, float momentum) {
+    const BnTileSet &S = blockIdx.z ? B : A;
+    const double *__restrict__ rec = S.fold;
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= c) return;
     double t1 = 0.0, t2 = 0.0;
     for (int k = 0; k < nrec; ++k) { t1 += rec[(size_t)k * 2 * c + ch]; t2 += rec[(size_t)k * 2 * c + c + ch]; }
-    const double m = t1 / n;
-    double var = t2 / n - m * m;
-    var = var > 0.0 ? var : 0.0;
-    mean[ch] = (float)m;
-    rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
-    if (sc) {
-        const float scale = rstd[ch] * gamma[ch];
-        sc[ch] = scale;
-        sh[ch] = beta[ch] - mean[ch] * scale;
-    }
-    if (run_mean) {
-        const double unb = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
-        run_mean[ch] = (float)((1.0 - momentum) * (double)run_mean[ch] + momentum * m);
-        run_var[ch] = (float)((1.0 - momentum) * (double)run_var[ch] + momentum * unb);
-        if (ch == 0 && batches) *batches += 1;
-    }
+    bn_tiles_emit(S, ch, t1, t2, n, eps, momentum);
 }
 
 // statistics of a (n,c) tensor from the records its producing rows_gemm_fused launch left in `part`
@@ -678,29 +679,52 @@ extern "C" size_t bn_tiles_floats(int n, int c) {  // floats of a statistics rec
     return (size_t)((n + 63) / 64) * 2 * c + 2 + 2 * (size_t)16 * 2 * c;
 }
 
+// count (1 or 2) tensors of one shape in one launch (two for > 512 records: fold, then finish)
+static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, float eps, float momentum, void *stream) {
+    const int nrb_all = (n + 63) / 64;
+    for (int i = 0; i < count; ++i) {
+        BnTileSet &S = sets[i];
+        if (!S.part || !S.mean || !S.rstd || ((S.sc != nullptr) && (!S.gamma || !S.beta || !S.sh))) return PTV2_ERR_ARG;
+        // the folded records live behind the tile records (the GEMM wrote nrb * 2c floats; 16 * 2c doubles more are reserved)
+        S.fold = (double *)(const_cast<float *>(S.part) + (((size_t)nrb_all * 2 * c + 1) & ~(size_t)1));
+    }
+    const BnTileSet A = sets[0], B = sets[count - 1];
+    const unsigned cb = (unsigned)((c + gva::FIN_COLS - 1) / gva::FIN_COLS);
+    if (nrb_all > 512) {  // two levels: 16 folding blocks per 64 columns, then a one-thread-per-column finish
+        const int ny = 16;
+        hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(cb, ny, count), dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream,
+                           A, B, nrb_all, c, n);
+        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((c + 63) / 64, 1, count), dim3(64), 0, (hipStream_t)stream, A, B, ny, c, n,
+                           eps, momentum);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
+    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cb, 1, count), dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, A, B,
+                       nrb_all, c, n, eps, momentum);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 extern "C" int bn_tiles_finalize_hip_launcher(int n, int c, float *part, const float *gamma, const float *beta,
                                               float *mean, float *rstd, float *sc, float *sh, float *running_mean,
                                               float *running_var, long long *num_batches_tracked, float eps, float momentum,
                                               void *stream) {
-    if (n < 1 || c < 4 || !part || !mean || !rstd || ((sc != nullptr) && (!gamma || !beta || !sh))) return PTV2_ERR_ARG;
-    const int nrb_all = (n + 63) / 64;
-    if (nrb_all > 512) {  // two levels: 16 folding blocks per 64 columns, then a one-thread-per-column finish.  The folded
-        // records live behind the tile records (the GEMM wrote nrb * 2c floats; 16 * 2c doubles more are reserved)
-        double *fold = (double *)(part + (((size_t)nrb_all * 2 * c + 1) & ~(size_t)1));
-        const int ny = 16;
-        hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS, ny),
-                           dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, part, nrb_all, c, n, fold);
-        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                           (const double *)fold, ny, c, n, eps, momentum, mean, rstd, running_mean, running_var,
-                           num_batches_tracked, gamma, beta, sc, sh);
-        PTV2_CHECK_LAUNCH();
-        return PTV2_OK;
-    }
-    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
-                       dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, part, (n + 63) / 64, c, n, eps, momentum,
-                       mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
+    if (n < 1 || c < 4) return PTV2_ERR_ARG;
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr};
+    return bn_tiles_finalize_sets(n, c, 1, &S, eps, momentum, stream);
+}
+
+// two tensors of one shape (internal to the block runtime: the q / k BatchNorms); arrays of 2
+int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
+                           float *const *mean, float *const *rstd, float *const *sc, float *const *sh, float *const *running_mean,
+                           float *const *running_var, long long *const *num_batches_tracked, float eps, float momentum,
+                           void *stream) {
+    if (n < 1 || c < 4) return PTV2_ERR_ARG;
+    BnTileSet S[2];
+    for (int i = 0; i < 2; ++i)
+        S[i] = BnTileSet{part[i], mean[i], rstd[i], running_mean[i], running_var[i], num_batches_tracked[i], gamma[i], beta[i], sc[i],
+                         sh[i], nullptr};
+    return bn_tiles_finalize_sets(n, c, 2, S, eps, momentum, stream);
 }
 
 extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
