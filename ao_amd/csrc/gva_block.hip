@@ -164,6 +164,9 @@ int gva_peb_forward_hip_launcher(int, int, int, const float *, const float *, co
 int gva_peb_backward_hip_launcher(int, int, int, const float *, const float *, const float *, float *, float *, void *);
 }
 
+int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                            const float *M, const float *cW, const float *coord, const int *idx, float *W1, double *T1, double *T2,
+                            const gva::FoldWFwdArgs &F, void *workspace, size_t workspace_bytes, void *stream);
 int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
                                const float *const *xsh, float *const *y, void *stream);
 int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
@@ -252,11 +255,11 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
         float *ys[2] = {B->kW, B->qW};
         RUN(skinny_linear_forward_pair(n, c, g, xs, B->Ww1, xsc, xsh, ys, stream));
     }
-    RUN(gva_logits_forward_hip_launcher(n, k, c, g, B->kW, B->qW, B->a, B->b, B->M, B->cW, B->coord, B->idx, B->W1, W.T1,
-                                        W.T2, W.stage, W.stage_bytes, stream));
-    RUN(gva_fold_w_forward_hip_launcher(g, W.T1, W.T2, B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w,
-                                        B->training, rows, B->eps_w, B->momentum_w, B->sc, B->sh, B->mean_w, B->rstd_w,
-                                        stream));
+    // logits + their BatchNorm statistics; the final reduction of the sums also folds BN_w into (sc, sh)
+    RUN(gva_logits_forward_fold(n, k, c, g, B->kW, B->qW, B->a, B->b, B->M, B->cW, B->coord, B->idx, B->W1, W.T1, W.T2,
+                                FoldWFwdArgs{B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w, B->training, rows,
+                                             B->eps_w, B->momentum_w, B->sc, B->sh, B->mean_w, B->rstd_w},
+                                W.stage, W.stage_bytes, stream));
     RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
                                            B->idx, W.out_v, B->A, B->sw, B->w, stream));
     RUN(gva_peb_forward_hip_launcher(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, stream));

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void attention_logits_point_kernel(int n, int 
                                                                      const float *__restrict__ coord,
                                                                      const int *__restrict__ idx, float *__restrict__ W1,
                                                                      float *part, unsigned *counter, double *__restrict__ T1,
-                                                                     double *__restrict__ T2) {
+                                                                     double *__restrict__ T2, FoldWFwdArgs F) {
     constexpr int GT = (G + 15) / 16;
     extern __shared__ float4 lds4[];
     float4 *sAB = lds4;  // [c]
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void attention_logits_point_kernel(int n, int 
         for (int wv = 0; wv < 4; ++wv) v += s_w[wv][col];
         part_store(part + (size_t)blockIdx.x * 2 * G + tid, v);
     }
-    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, 2 * G, MapSplit2<double>{T1, T2, G});
+    if (counter && last_block_arrives(counter)) finalize_logit_sums(part, gridDim.x, G, T1, T2, F);
 }
 
 // Parameter gradients of the logits stage per point on the matrix cores:
@@ -961,7 +961,7 @@ int gva_logits_params_point_launch(int n, int k, int c, int g, const float *a, c
 // logits stage on the matrix cores; part: >= nblk * 2g floats; returns the grid size through *nblk_out
 int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
                             const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
-                            double *T1, double *T2, hipStream_t st) {
+                            double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st) {
     using namespace gva;
     if (k < 1 || k > 16 || c % 4 != 0 || c > 2048) return PTV2_ERR_ARG;
     const int nblk = (int)std::max<long long>(1, std::min<long long>(((long long)n + 3) / 4, MAX_BLOCKS));
@@ -973,13 +973,13 @@ int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const f
 #define CASE(GG)                                                                                                        \
     case GG:                                                                                                            \
         hipLaunchKernelGGL(attention_logits_point_kernel<GG>, dim3(nblk), dim3(256), lds, st, n, k, c, kW, qW, a, b, M, cW, \
-                           coord, idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                        \
+                           coord, idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2, F);                     \
         break;
         CASE(6) CASE(12) CASE(24) CASE(48) CASE(64)
 #undef CASE
         default: return PTV2_ERR_ARG;
     }
-    if (!own_final) launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
+    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3(1), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
     return PTV2_OK;
 }
 

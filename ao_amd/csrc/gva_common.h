@@ -169,4 +169,84 @@ struct MapSplit2 {  // columns [0,len1) -> out1, rest -> out2
     }
 };
 
+// BatchNorm over the (N*K, G) logits from their column sums T1, T2 (gva_fold.hip: fold_w).  sc == NULL: absent.
+// The block runtime passes it to the logits stage, whose final reduction then also emits the folded affine
+// (one launch less per attention block than a separate fold kernel).
+struct FoldWFwdArgs {
+    const float *gamma, *beta;
+    float *run_mean, *run_var;
+    long long *batches;
+    int training;
+    double rows;
+    float eps, momentum;
+    float *sc, *sh;
+    double *mean_out, *rstd_out;
+};
+
+__device__ inline void fold_w_fwd_channel(const FoldWFwdArgs &A, int j, double t1, double t2) {
+    double mean, rstd;
+    if (A.training) {
+        mean = t1 / A.rows;
+        double var = t2 / A.rows - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        rstd = 1.0 / sqrt(var + (double)A.eps);
+        if (A.run_mean) {
+            const double unb = A.rows > 1.0 ? var * (A.rows / (A.rows - 1.0)) : var;
+            A.run_mean[j] = (float)((1.0 - A.momentum) * (double)A.run_mean[j] + A.momentum * mean);
+            A.run_var[j] = (float)((1.0 - A.momentum) * (double)A.run_var[j] + A.momentum * unb);
+            if (j == 0 && A.batches) *A.batches += 1;
+        }
+    } else {
+        mean = (double)A.run_mean[j];
+        rstd = 1.0 / sqrt((double)A.run_var[j] + (double)A.eps);
+    }
+    const double s = (double)A.gamma[j] * rstd;
+    A.sc[j] = (float)s;
+    A.sh[j] = (float)((double)A.beta[j] - mean * s);
+    A.mean_out[j] = mean;
+    A.rstd_out[j] = rstd;
+}
+
+// "last block" tail of the logits kernels: column sums -> T1, T2 (-> folded affine)
+__device__ __forceinline__ void finalize_logit_sums(const float *part, int nblk, int g, double *T1, double *T2,
+                                                    const FoldWFwdArgs &F) {
+    finalize_columns(part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
+    if (F.sc) {
+        __threadfence_block();
+        __syncthreads();
+        if ((int)threadIdx.x < g) fold_w_fwd_channel(F, threadIdx.x, T1[threadIdx.x], T2[threadIdx.x]);
+    }
+}
+
+// the same as a launch of its own (large grids): one workgroup; its 1024 threads are split into S = 1024 / (2g) record
+// slices per column (2g <= 128), four independent chains per thread, slice sums combined in slice order
+static __global__ __launch_bounds__(1024) void finalize_logit_sums_kernel(const float *__restrict__ part, int nblk, int g, double *T1,
+                                                                          double *T2, FoldWFwdArgs F) {
+    __shared__ double s_acc[1024];
+    __shared__ double s_sum[128];
+    const int len = 2 * g, S = 1024 / len;
+    const int col = threadIdx.x % len, sl = threadIdx.x / len;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (sl < S) {
+        int b = sl;
+        for (; b + 3 * S < nblk; b += 4 * S) {
+            a0 += (double)part[(size_t)b * len + col];
+            a1 += (double)part[(size_t)(b + S) * len + col];
+            a2 += (double)part[(size_t)(b + 2 * S) * len + col];
+            a3 += (double)part[(size_t)(b + 3 * S) * len + col];
+        }
+        for (; b < nblk; b += S) a0 += (double)part[(size_t)b * len + col];
+    }
+    s_acc[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if ((int)threadIdx.x < len) {
+        double v = 0.0;
+        for (int t = 0; t < S; ++t) v += s_acc[t * len + threadIdx.x];
+        s_sum[threadIdx.x] = v;
+        if ((int)threadIdx.x < g) T1[threadIdx.x] = v; else T2[threadIdx.x - g] = v;
+    }
+    __syncthreads();
+    if (F.sc && (int)threadIdx.x < g) fold_w_fwd_channel(F, threadIdx.x, s_sum[threadIdx.x], s_sum[g + threadIdx.x]);
+}
+
 }  // namespace gva

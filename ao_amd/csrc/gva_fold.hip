@@ -26,34 +26,9 @@ __global__ void fold_p_bwd_kernel(FoldPBwdArgs A) {
     if (ch < A.c) fold_p_bwd_channel(A, ch);
 }
 
-__global__ void fold_w_fwd_kernel(int g, const double *__restrict__ T1, const double *__restrict__ T2,
-                                  const float *__restrict__ gamma, const float *__restrict__ beta, float *run_mean,
-                                  float *run_var, long long *batches, int training, double rows, float eps,
-                                  float momentum, float *__restrict__ sc, float *__restrict__ sh,
-                                  double *__restrict__ mean_out, double *__restrict__ rstd_out) {
+__global__ void fold_w_fwd_kernel(int g, const double *__restrict__ T1, const double *__restrict__ T2, FoldWFwdArgs A) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= g) return;
-    double mean, rstd;
-    if (training) {
-        mean = T1[j] / rows;
-        double var = T2[j] / rows - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        rstd = 1.0 / sqrt(var + (double)eps);
-        if (run_mean) {
-            const double unb = rows > 1.0 ? var * (rows / (rows - 1.0)) : var;
-            run_mean[j] = (float)((1.0 - momentum) * (double)run_mean[j] + momentum * mean);
-            run_var[j] = (float)((1.0 - momentum) * (double)run_var[j] + momentum * unb);
-            if (j == 0 && batches) *batches += 1;
-        }
-    } else {
-        mean = (double)run_mean[j];
-        rstd = 1.0 / sqrt((double)run_var[j] + (double)eps);
-    }
-    const double s = (double)gamma[j] * rstd;
-    sc[j] = (float)s;
-    sh[j] = (float)((double)beta[j] - mean * s);
-    mean_out[j] = mean;
-    rstd_out[j] = rstd;
+    if (j < g) fold_w_fwd_channel(A, j, T1[j], T2[j]);
 }
 
 __global__ void fold_w_bwd_kernel(int g, const float *__restrict__ gamma, const double *__restrict__ mean_in,
@@ -113,8 +88,9 @@ extern "C" int gva_fold_w_forward_hip_launcher(int g, const double *T1, const do
                                                float momentum, float *sc, float *sh, double *mean, double *rstd,
                                                void *stream) {
     if (g < 1) return PTV2_ERR_ARG;
-    hipLaunchKernelGGL(fold_w_fwd_kernel, dim3(divup(g, 64)), dim3(64), 0, (hipStream_t)stream, g, T1, T2, gamma, beta,
-                       running_mean, running_var, num_batches_tracked, training, rows, eps, momentum, sc, sh, mean, rstd);
+    hipLaunchKernelGGL(fold_w_fwd_kernel, dim3(divup(g, 64)), dim3(64), 0, (hipStream_t)stream, g, T1, T2,
+                       FoldWFwdArgs{gamma, beta, running_mean, running_var, num_batches_tracked, training, rows, eps, momentum, sc,
+                                    sh, mean, rstd});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
                                                          const float *__restrict__ cW, const float *__restrict__ coord,
                                                          const int *__restrict__ idx, float *__restrict__ W1, float *part,
                                                          unsigned *counter, double *__restrict__ T1,
-                                                         double *__restrict__ T2) {
+                                                         double *__restrict__ T2, FoldWFwdArgs F) {
     extern __shared__ float4 lds4[];
     constexpr int G4 = (G + 3) & ~3;
     constexpr int RPB = TPB / SPLIT;  // rows per workgroup iteration
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
         part_store(part + (size_t)blockIdx.x * 2 * G + threadIdx.x, v);
     }
     // small grids finish their own column sums (counter != NULL); large ones leave them to finalize_kernel
-    if (counter && last_block_arrives(counter)) finalize_columns(part, gridDim.x, 2 * G, MapSplit2<double>{T1, T2, G});
+    if (counter && last_block_arrives(counter)) finalize_logit_sums(part, gridDim.x, G, T1, T2, F);
 }
 
 inline int stage_grid(long long work_items, int per_block) {
@@ -204,12 +204,12 @@ extern "C" int gva_pos_stats_hip_launcher(int n, int k, const float *coord, cons
 
 int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
                             const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
-                            double *T1, double *T2, hipStream_t st);
+                            double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st);
 
-extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
-                                               const float *a, const float *b, const float *M, const float *cW,
-                                               const float *coord, const int *idx, float *W1, double *T1, double *T2,
-                                               void *workspace, size_t workspace_bytes, void *stream) {
+// F.sc != NULL: the final reduction also folds BN_w (block runtime); the C entry point below passes none
+int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                            const float *M, const float *cW, const float *coord, const int *idx, float *W1, double *T1, double *T2,
+                            const gva::FoldWFwdArgs &F, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 0 || k < 1 || c < 1 || g < 1) return PTV2_ERR_ARG;
     if (!workspace || workspace_bytes < gva_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -217,7 +217,7 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
     const long long rows = (long long)n * k;
     if (k <= 16 && c % 4 == 0 && (g == 48 || g == 64) && !getenv("AO_AMD_BWD_STAGED")) {  // pays for wide G only
         PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
-        const int rc = gva_logits_point_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, st);
+        const int rc = gva_logits_point_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st);
         if (rc != PTV2_OK) return rc;
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
@@ -239,13 +239,13 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
             (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                   \
         hipLaunchKernelGGL((logits_fwd_kernel<GG, 4>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
-                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                                                                         \
+                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2, F);                                                                         \
     } else {                                                                                                       \
         if (lds > 32 * 1024)                                                                                       \
             (void)hipFuncSetAttribute((const void *)logits_fwd_kernel<GG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                   \
         hipLaunchKernelGGL((logits_fwd_kernel<GG, 1>), dim3(nblk), dim3(TPB), lds, st, n, k, c, kW, qW, a, b, M, cW, coord, \
-                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2);                                                                         \
+                           idx, W1, part, cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2, F);                                                                         \
     }
     {
         // idx, coord, kW (unique rows once), qW in; W1 out
@@ -253,7 +253,15 @@ extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const
         GVA_DISPATCH_G(g, CALL)
     }
 #undef CALL
-    if (!own_final) launch_finalize(st, (const float *)part, nblk, 2 * g, MapSplit2<double>{T1, T2, g});
+    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3(1), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
+}
+
+extern "C" int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
+                                               const float *a, const float *b, const float *M, const float *cW,
+                                               const float *coord, const int *idx, float *W1, double *T1, double *T2,
+                                               void *workspace, size_t workspace_bytes, void *stream) {
+    return gva_logits_forward_fold(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, T1, T2, gva::FoldWFwdArgs{}, workspace,
+                                   workspace_bytes, stream);
 }
