@@ -152,12 +152,11 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
 #pragma unroll
         for (int g = 0; g < G; ++g) accA[g] = 0.f;
         float ov = 0.f;
-        for (int s = 0; s < k; ++s) {
+        auto slot = [&](int s, float vv) {
             const float4 ps = sPos[p * k + s];
-            const int src = sSrc[p * k + s];
             const float P = pe_act(ax, ay, az, bb, ps.x, ps.y, ps.z);
             const float *wrow = sW + (size_t)(p * k + s) * G4;
-            if (src >= 0) ov = __builtin_fmaf(wrow[gl], v[(long long)src * c + ch], ov);
+            ov = __builtin_fmaf(wrow[gl], vv, ov);
             if (G % 4 == 0) {
 #pragma unroll
                 for (int g = 0; g < G; g += 4) {
@@ -170,6 +169,21 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
             } else {
 #pragma unroll
                 for (int g = 0; g < G; ++g) accA[g] = __builtin_fmaf(wrow[g], P, accA[g]);
+            }
+        };
+        if (k == 16) {  // the config's K: all 16 neighbour rows are requested before the first one is consumed
+            float vv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int src = sSrc[p * 16 + s];
+                vv[s] = src >= 0 ? v[(long long)src * c + ch] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) slot(s, vv[s]);
+        } else {
+            for (int s = 0; s < k; ++s) {
+                const int src = sSrc[p * k + s];
+                slot(s, src >= 0 ? v[(long long)src * c + ch] : 0.f);
             }
         }
         const long long pt = n0 + p;
@@ -400,18 +414,34 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = 0.f;
         const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
-        for (int p = p0; p < p1; ++p) {
-            const int r = inv_rows[p];
-            const float wv = w[(long long)r * g + gl];
-            const float *go = g_out + (long long)(r / k) * c + ch;
-            if (V == 4) {
-                const float4 t = *(const float4 *)go;
-                acc[0] = __builtin_fmaf(wv, t.x, acc[0]); acc[1] = __builtin_fmaf(wv, t.y, acc[1]);
-                acc[2] = __builtin_fmaf(wv, t.z, acc[2]); acc[3] = __builtin_fmaf(wv, t.w, acc[3]);
-            } else {
+        // the list is walked 8 entries at a time: slot ids first, then all weights and gradient rows, then the sums in
+        // list order (an entry-by-entry loop pays three dependent memory latencies per entry)
+        constexpr int UB = 8;
+        for (int p = p0; p < p1; p += UB) {
+            int r[UB];
+            float wv[UB], t[UB][V];
 #pragma unroll
-                for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv, go[i], acc[i]);
+            for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? inv_rows[p + u] : -1;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (r[u] >= 0) {
+                    wv[u] = w[(long long)r[u] * g + gl];
+                    const float *go = g_out + (long long)(r[u] / k) * c + ch;
+                    if (V == 4) {
+                        const float4 q = *(const float4 *)go;
+                        t[u][0] = q.x; t[u][1 % V] = q.y; t[u][2 % V] = q.z; t[u][3 % V] = q.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) t[u][i] = go[i];
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (r[u] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv[u], t[u][i], acc[i]);
+                }
         }
         if (V == 4) *(float4 *)(gv + (long long)j * c + ch) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else

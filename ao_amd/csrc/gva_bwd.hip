@@ -99,11 +99,31 @@ __global__ __launch_bounds__(TPB) void logits_bwd_gather_kernel(int n, int k, in
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
         const int j = (int)(e / g), gi = (int)(e - (long long)j * g);
         float q = 0.f;
-        for (int s = 0; s < k; ++s) q += gWt[((long long)j * k + s) * g + gi];
+        if (k == 16) {  // all 16 slot loads in flight before the first add
+            float t[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) t[s] = gWt[((long long)j * 16 + s) * g + gi];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) q += t[s];
+        } else {
+            for (int s = 0; s < k; ++s) q += gWt[((long long)j * k + s) * g + gi];
+        }
         gqW[e] = -q;
         if (inv_ptr) {
             float acc = 0.f;
-            for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) acc += gWt[(long long)inv_rows[p] * g + gi];
+            const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
+            constexpr int UB = 8;  // 8 list entries at a time: ids, then values, then the sums in list order
+            for (int p = p0; p < p1; p += UB) {
+                int r[UB];
+                float t[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? inv_rows[p + u] : -1;
+#pragma unroll
+                for (int u = 0; u < UB; ++u) t[u] = r[u] >= 0 ? gWt[(long long)r[u] * g + gi] : 0.f;
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (r[u] >= 0) acc += t[u];
+            }
             gkW[e] = acc;
         }
     }
