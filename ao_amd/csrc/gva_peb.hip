@@ -61,32 +61,51 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, int c
 }
 
 // gA[n,g,c'] = sum_i gO[n, g*I+i] * Wp2[g*I+i, c'] ;  g_sw[n,g] = sum_i gO[n, g*I+i] * bp2[g*I+i]
+// A thread owns one (group, float4 of c') for all of its points -- the launcher makes the thread count a multiple of
+// g * c / 4 -- so its I rows of Wp2 stay in registers; re-reading them per output (8 x the bytes written, from L2) held
+// the kernel at 2 TB/s of writes.
 template <int I>
 __global__ __launch_bounds__(TPB) void peb_bwd_kernel(int n, int c, int g, const float *__restrict__ gO,
                                                       const float *__restrict__ Wp2, const float *__restrict__ bp2,
                                                       float *__restrict__ gA, float *__restrict__ g_sw) {
-    const long long total = (long long)g * n * (c / 4);
-    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
-        const int q = (int)(e % (c / 4));
-        const long long ng = e / (c / 4);
-        const int gi = (int)(ng % g), nn = (int)(ng / g);
-        const float *go = gO + (size_t)nn * c + gi * I;
+    const int cq = c / 4, per = g * cq;  // float4 outputs per point
+    const long long threads = (long long)gridDim.x * TPB, t = (long long)blockIdx.x * TPB + threadIdx.x;
+    const int gq = (int)(t % per), gi = gq / cq, q = gq - gi * cq;
+    float4 w[I];
+    float bp[I];
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+        w[i] = *(const float4 *)(Wp2 + (size_t)(gi * I + i) * c + 4 * q);
+        bp[i] = bp2[gi * I + i];
+    }
+    const long long step = threads / per;
+    for (long long pt = t / per; pt < n; pt += step) {
+        const float *go = gO + (size_t)pt * c + gi * I;
+        float s[I];
+        if (I % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < I; i += 4) {
+                const float4 v = *(const float4 *)(go + i);
+                s[i] = v.x; s[i + 1] = v.y; s[i + 2] = v.z; s[i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < I; ++i) s[i] = go[i];
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < I; ++i) {
-            const float s = go[i];
-            const float4 w = *(const float4 *)(Wp2 + (size_t)(gi * I + i) * c + 4 * q);
-            acc.x = __builtin_fmaf(s, w.x, acc.x);
-            acc.y = __builtin_fmaf(s, w.y, acc.y);
-            acc.z = __builtin_fmaf(s, w.z, acc.z);
-            acc.w = __builtin_fmaf(s, w.w, acc.w);
+            acc.x = __builtin_fmaf(s[i], w[i].x, acc.x);
+            acc.y = __builtin_fmaf(s[i], w[i].y, acc.y);
+            acc.z = __builtin_fmaf(s[i], w[i].z, acc.z);
+            acc.w = __builtin_fmaf(s[i], w[i].w, acc.w);
         }
-        ((float4 *)gA)[e] = acc;
+        ((float4 *)gA)[(size_t)pt * per + gq] = acc;
         if (q == 0) {
-            float t = 0.f;
+            float tt = 0.f;
 #pragma unroll
-            for (int i = 0; i < I; ++i) t = __builtin_fmaf(go[i], bp2[gi * I + i], t);
-            g_sw[(size_t)nn * g + gi] = t;
+            for (int i = 0; i < I; ++i) tt = __builtin_fmaf(s[i], bp[i], tt);
+            g_sw[(size_t)pt * g + gi] = tt;
         }
     }
 }
@@ -131,7 +150,14 @@ extern "C" int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g
     if (n == 0) return PTV2_OK;
     const int I = c / g;
     const long long total = (long long)g * n * (c / 4);
-    const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
+    // thread count = a multiple of the float4 outputs per point (so that a thread keeps its (group, c') for every point)
+    const long long per = (long long)g * (c / 4);
+    long long a = per, b = TPB;
+    while (b) { const long long r = a % b; a = b; b = r; }
+    const long long unit = per / a;  // workgroups per whole number of points
+    if (unit > 256 * 16) return PTV2_ERR_ARG;
+    const long long want = std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
+    const int nblk = (int)std::max<long long>(unit, want / unit * unit);
 #define CALL(II) \
     hipLaunchKernelGGL(peb_bwd_kernel<II>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, n, c, g, g_out, Wp2, bp2, g_A, g_sw)
     {
