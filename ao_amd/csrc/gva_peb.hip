@@ -132,12 +132,18 @@ extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A,
     const size_t lds = sizeof(float) * (size_t)ct * (c + 4);
     if (lds > 160 * 1024) return PTV2_ERR_ARG;
     const int tp = TPB / ct;
-    const int gx = (int)std::min<long long>(((long long)n + tp - 1) / tp, lds > 40 * 1024 ? 256 : 1024);
+    // every workgroup first stages its ct rows of Wp2 (up to 99 KB) in LDS: keep the whole grid co-resident, so that this
+    // is paid once per CU slot and not once per round (C = 384: 6 column blocks x 256 workgroups at one per CU was six
+    // rounds of staging, 106 us for 80 MB)
+    const int ny = (c + ct - 1) / ct;
+    const long long slots = 256LL * std::max<size_t>(1, (160 * 1024) / std::max<size_t>(lds, 1));
+    const long long cap = std::min<long long>(lds > 40 * 1024 ? 256 : 1024, std::max<long long>(1, slots / ny));
+    const int gx = (int)std::min<long long>(((long long)n + tp - 1) / tp, cap);
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void *)peb_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     {
         PtvScopedTimer t(KID_PEB_FWD, (hipStream_t)stream, 4.0 * ((double)n * g * c + 2.0 * n * c + (double)n * g + (double)c * c));
-        hipLaunchKernelGGL(peb_fwd_kernel, dim3(gx, (c + ct - 1) / ct), dim3(TPB), lds, (hipStream_t)stream, n, c, g, ct, A, Wp2,
+        hipLaunchKernelGGL(peb_fwd_kernel, dim3(gx, ny), dim3(TPB), lds, (hipStream_t)stream, n, c, g, ct, A, Wp2,
                            bp2, sw, out_v, out);
     }
     PTV2_CHECK_LAUNCH();
