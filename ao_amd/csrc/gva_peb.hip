@@ -110,6 +110,34 @@ __global__ __launch_bounds__(TPB) void peb_bwd_kernel(int n, int c, int g, const
     }
 }
 
+// the same for shapes whose g * c / 4 shares too few factors with the workgroup size for the fixed assignment above
+template <int I>
+__global__ __launch_bounds__(TPB) void peb_bwd_any_kernel(int n, int c, int g, const float *__restrict__ gO,
+                                                          const float *__restrict__ Wp2, const float *__restrict__ bp2,
+                                                          float *__restrict__ gA, float *__restrict__ g_sw) {
+    const int cq = c / 4;
+    const long long total = (long long)g * n * cq;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const int q = (int)(e % cq);
+        const long long ng = e / cq;
+        const int gi = (int)(ng % g);
+        const long long pt = ng / g;
+        const float *go = gO + (size_t)pt * c + gi * I;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float tt = 0.f;
+#pragma unroll
+        for (int i = 0; i < I; ++i) {
+            const float sv = go[i];
+            const float4 w = *(const float4 *)(Wp2 + (size_t)(gi * I + i) * c + 4 * q);
+            acc.x = __builtin_fmaf(sv, w.x, acc.x); acc.y = __builtin_fmaf(sv, w.y, acc.y);
+            acc.z = __builtin_fmaf(sv, w.z, acc.z); acc.w = __builtin_fmaf(sv, w.w, acc.w);
+            tt = __builtin_fmaf(sv, bp2[gi * I + i], tt);
+        }
+        ((float4 *)gA)[e] = acc;
+        if (q == 0) g_sw[(size_t)pt * g + gi] = tt;
+    }
+}
+
 }  // namespace gva
 
 using namespace gva;
@@ -161,11 +189,14 @@ extern "C" int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g
     long long a = per, b = TPB;
     while (b) { const long long r = a % b; a = b; b = r; }
     const long long unit = per / a;  // workgroups per whole number of points
-    if (unit > 256 * 16) return PTV2_ERR_ARG;
     const long long want = std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
-    const int nblk = (int)std::max<long long>(unit, want / unit * unit);
-#define CALL(II) \
-    hipLaunchKernelGGL(peb_bwd_kernel<II>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, n, c, g, g_out, Wp2, bp2, g_A, g_sw)
+    const bool fixed = unit <= 256 * 4;
+    const int nblk = fixed ? (int)std::max<long long>(unit, want / unit * unit) : (int)want;
+#define CALL(II)                                                                                                          \
+    if (fixed)                                                                                                            \
+        hipLaunchKernelGGL(peb_bwd_kernel<II>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, n, c, g, g_out, Wp2, bp2, g_A, g_sw); \
+    else                                                                                                                  \
+        hipLaunchKernelGGL(peb_bwd_any_kernel<II>, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, n, c, g, g_out, Wp2, bp2, g_A, g_sw)
     {
         PtvScopedTimer t(KID_PEB_BWD, (hipStream_t)stream, 4.0 * ((double)n * g * c + (double)n * c + (double)n * g + (double)c * c));
         PEB_DISPATCH_I(I, CALL)

@@ -128,3 +128,35 @@ def test_inverse_table_matches_host_statement():
     ptr, rows = inverse_table(idx)
     hptr, hrows = inverse_table(idx.cpu())
     assert torch.equal(ptr.cpu(), hptr) and torch.equal(rows.cpu(), hrows)
+
+
+@pytest.mark.parametrize("n,c,g", [(3000, 48, 6), (500, 192, 24), (129, 384, 48), (40, 520, 65), (33, 40, 5), (1, 96, 12)])
+def test_grouped_projection_kernels(n, c, g):
+    """out = out_v + A Wp2_g^T + bp2 * sw and its backward (g_A, g_sw) against torch, incl. shapes whose g * c / 4 does not
+    divide into workgroups (generic backward kernel) and C > 256 (column blocks, co-resident grid)."""
+    from ao_amd import _lib
+    import ao_amd.ptv2.gva  # noqa: F401
+
+    L = _lib.lib()
+    torch.manual_seed(n + c)
+    I = c // g
+    A = torch.randn(n, g, c, device="cuda")
+    Wp2 = torch.randn(c, c, device="cuda") / c ** 0.5
+    bp2 = torch.randn(c, device="cuda")
+    sw = torch.rand(n, g, device="cuda")
+    out_v = torch.randn(n, c, device="cuda")
+    out = torch.empty(n, c, device="cuda")
+    _lib.check(L.gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), sw.data_ptr(), out_v.data_ptr(),
+                                              out.data_ptr(), _lib.stream_ptr()), "peb fwd")
+    Wg = Wp2.view(g, I, c).double()
+    ref = out_v.double() + torch.einsum("ngc,gic->ngi", A.double(), Wg).reshape(n, c) + bp2.double() * sw.double().repeat_interleave(I, 1)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    go = torch.randn(n, c, device="cuda")
+    gA = torch.empty(n, g, c, device="cuda")
+    gsw = torch.empty(n, g, device="cuda")
+    _lib.check(L.gva_peb_backward_hip_launcher(n, c, g, go.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), gA.data_ptr(), gsw.data_ptr(),
+                                               _lib.stream_ptr()), "peb bwd")
+    gA_ref = torch.einsum("ngi,gic->ngc", go.double().view(n, g, I), Wg)
+    gsw_ref = (go.double() * bp2.double()).view(n, g, I).sum(-1)
+    np.testing.assert_allclose(gA.cpu().numpy(), gA_ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gsw.cpu().numpy(), gsw_ref.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
