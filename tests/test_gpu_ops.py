@@ -251,3 +251,23 @@ def test_fps_cooperative_multi_workgroup(hp):
     idx = hp.farthest_point_sampling(dev(b["coord"]), dev(b["offset"]), dev(np.array([2300], np.int32)))
     ref = P.farthest_point_sampling(cpu(b["coord"]), cpu(b["offset"]), torch.tensor([2300], dtype=torch.int32))
     assert torch.equal(idx.cpu(), ref) and len(set(idx.cpu().tolist())) == 2300
+
+
+def test_empty_inputs(hp):
+    """Zero queries / zero rows: every op returns an empty result of the right shape and dtype (the reference launches
+    zero-size grids; here the launchers return before launching)."""
+    xyz = dev(synth.random_cloud(100, seed=1))
+    off = dev(np.array([100], np.int32))
+    none = torch.zeros((0, 3), device="cuda")
+    noff = dev(np.array([0], np.int32))
+    idx, dist = hp.knn_query(4, xyz, off, none, noff)
+    assert idx.shape == (0, 4) and idx.dtype == torch.int32 and dist.shape == (0, 4)
+    feat = torch.randn(100, 8, device="cuda", requires_grad=True)
+    g = hp.grouping(idx, feat, xyz, none, with_xyz=True)
+    assert g.shape == (0, 4, 11)
+    g.sum().backward()
+    assert feat.grad is not None and float(feat.grad.abs().sum()) == 0.0
+    out = hp.interpolation(xyz, none, feat.detach(), off, noff)
+    assert out.shape == (0, 8)
+    sub = hp.subtraction(torch.zeros((0, 8), device="cuda"), torch.zeros((0, 8), device="cuda"), torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
+    assert sub.shape == (0, 4, 8)
