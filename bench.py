@@ -144,6 +144,12 @@ def cpu_baseline(cfg, sample_points):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result of rank 0: everything else that writes to file descriptor 1 in any
+    # rank (RCCL prints a "ROCm version / Hostname / Librccl path" banner there when a communicator is created) is sent
+    # to stderr for the lifetime of the process; the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     from ao_amd.ptv2 import parallel
 
     rank, local_rank, world = parallel.rank_world()
@@ -289,7 +295,7 @@ def main():
             out["ops"] = op_microbench(data)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_points)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
