@@ -20,9 +20,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# the pool's host driver only supports dmabuf IPC: without this RCCL / cross-process tensor sharing fails with
+# `hipIpcGetMemHandle: invalid argument` (already exported on the GPU boxes; kept here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
