@@ -6,6 +6,11 @@ with one streaming kernel per step instead of torch's 24 multi-tensor launches o
 `torch.optim.Optimizer` (one param group; `param_groups[0]["lr"]` is read every step, so LR schedulers work);
 the arithmetic is torch.optim.AdamW's.  Build it AFTER the model is on its device; `.to()` afterwards would
 detach the parameters from the buffer.
+
+Checkpoints: `state_dict()` / `load_state_dict()` speak torch.optim.AdamW's layout (state[i] = {step, exp_avg,
+exp_avg_sq} per parameter in group order, pointcept/engines/hooks/misc.py:180-183 saves it, :247 restores it), so a
+run resumes with its moments and bias-correction step, and an optimizer state written by the reference's
+torch.optim.AdamW loads into this class (and the other way round).
 """
 import torch
 
@@ -19,7 +24,7 @@ class FlatAdamW(torch.optim.Optimizer):
         assert len(self.param_groups) == 1, "FlatAdamW takes one parameter group"
         self._params = self.param_groups[0]["params"]
         dev = self._params[0].device
-        assert all(p.is_cuda and p.device == dev and p.dtype == torch.float32 for p in self._params)
+        assert all(p.device == dev and p.dtype == torch.float32 for p in self._params)
         self._sizes = [p.numel() for p in self._params]
         total = sum(self._sizes)
         self._n = (total + 3) // 4 * 4
@@ -48,17 +53,74 @@ class FlatAdamW(torch.optim.Optimizer):
         torch._foreach_copy_(dst, src)
         return self.flat_grad
 
+    # -- checkpoint format: torch.optim.AdamW's --
+    def state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly as torch.optim.AdamW lays
+        it out (tensors are copies shaped like their parameter; "step" is a float scalar tensor as in torch >= 1.12)."""
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self._params)))
+        state = {}
+        if self._step > 0:
+            m = self.exp_avg[:self._total].split(self._sizes)
+            v = self.exp_avg_sq[:self._total].split(self._sizes)
+            for i, p in enumerate(self._params):
+                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": m[i].view_as(p).clone(),
+                            "exp_avg_sq": v[i].view_as(p).clone()}
+        return {"state": state, "param_groups": [group]}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self._params):
+            raise ValueError("FlatAdamW.load_state_dict: expected one parameter group of %d parameters, got %s"
+                             % (len(self._params), [len(g["params"]) for g in groups]))
+        for k, v in groups[0].items():
+            if k != "params" and k in self.param_groups[0]:  # torch-only keys (amsgrad, foreach, fused, ...) are dropped
+                self.param_groups[0][k] = v
+        if groups[0].get("amsgrad") or groups[0].get("maximize"):
+            raise ValueError("FlatAdamW does not implement amsgrad / maximize")
+        ids = groups[0]["params"]
+        state = state_dict["state"]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        m = self.exp_avg[:self._total].split(self._sizes)
+        v = self.exp_avg_sq[:self._total].split(self._sizes)
+        for i, (pid, p) in enumerate(zip(ids, self._params)):
+            st = state.get(pid, state.get(str(pid)))
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("FlatAdamW.load_state_dict: parameter %d has shape %s, state has %s"
+                                 % (i, tuple(p.shape), tuple(st["exp_avg"].shape)))
+            m[i].copy_(st["exp_avg"].reshape(-1))
+            v[i].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW.load_state_dict: parameters carry different step counts %s (one kernel applies "
+                             "one bias correction)" % sorted(steps))
+        if steps and len(state) != len(self._params):
+            raise ValueError("FlatAdamW.load_state_dict: state for %d of %d parameters" % (len(state), len(self._params)))
+        self._step = steps.pop() if steps else 0
+
+    def _launch(self, g, grp, grad_scale):
+        """The update itself: ao_amd/csrc/optim.hip on the flat buffers.  GPU only -- there is no CPU arithmetic in this
+        package (tests/test_ddp_cpu.py substitutes a torch statement of the same update to drive the host logic)."""
+        if not self.flat_param.is_cuda:
+            raise RuntimeError("FlatAdamW updates on the GPU only (parameters are on %s); there is no CPU fallback"
+                               % self.flat_param.device)
+        rc = _lib.lib().adamw_flat_hip_launcher(self._n, self.flat_param.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), float(grp["lr"]), float(grp["betas"][0]),
+                                                float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
+                                                self._step, float(grad_scale), _lib.stream_ptr())
+        _lib.check(rc, "adamw_flat_hip_launcher")
+
     @torch.no_grad()
     def step(self, closure=None, flat_grad=None, grad_scale=1.0):
         """flat_grad: an already flattened (e.g. all-reduced) gradient in this optimizer's parameter order; default:
         gather the `.grad`s.  grad_scale multiplies it inside the kernel (1 / world for a summed gradient)."""
         loss = closure() if closure is not None else None
         g = self.flatten_grads() if flat_grad is None else flat_grad
-        grp = self.param_groups[0]
         self._step += 1
-        rc = _lib.lib().adamw_flat_hip_launcher(self._n, self.flat_param.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), float(grp["lr"]), float(grp["betas"][0]),
-                                                float(grp["betas"][1]), float(grp["eps"]), float(grp["weight_decay"]),
-                                                self._step, float(grad_scale), _lib.stream_ptr())
-        _lib.check(rc, "adamw_flat_hip_launcher")
+        self._launch(g, self.param_groups[0], grad_scale)
         return loss

@@ -126,10 +126,18 @@ class StepSchedule:
         return [g["lr"] for g in self.optimizer.param_groups]
 
     def state_dict(self):
-        return {"last_step": self.last_step}
+        # "last_epoch" is what torch's schedulers call the same counter (number of step() calls so far)
+        return {"last_step": self.last_step, "last_epoch": self.last_step}
 
     def load_state_dict(self, state):
-        self.last_step = int(state["last_step"])
+        """Accepts this class's own state or a torch.optim.lr_scheduler state_dict (the reference checkpoints the
+        latter, pointcept/engines/hooks/misc.py:184,248): there the counter is `last_epoch`."""
+        if "last_step" in state:
+            self.last_step = int(state["last_step"])
+        elif "last_epoch" in state:
+            self.last_step = int(state["last_epoch"])
+        else:
+            raise KeyError("scheduler state has neither 'last_step' nor 'last_epoch': %s" % sorted(state))
         self._apply()
 
 

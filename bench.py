@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- points/sec, forward+backward+optimizer step, PT-v2m2 S3DIS config, synthetic scenes.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher: this process becomes a PARENT that never touches the GPU (it imports neither torch nor
+the HIP library); it starts N children, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+set (the reference's own launcher does the same with mp.spawn, pointcept/engines/launch.py:74-135), relays rank 0's
+JSON line and exits non-zero if any child does.  Under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` the ranks already exist and each process is a child.
 
 One "step" = one full training step of the hot path on one batch that is already resident in HBM:
 geometry (kNN tables, grid pooling, interpolation tables) + PT-v2m2 forward + cross-entropy +
@@ -13,10 +19,16 @@ Extra objects on that line (task section 4):
   roofline      the dominant hand-written kernel, timed live with HIP events on the launch stream
   cpu_baseline  the CPU oracle (oracle/ptv2_ref.py + C kNN) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N=1 only)
+
+Environment switches for boxes with fewer GPUs than ranks (tests/test_gpu_bench_spawn.py):
+  AO_AMD_BENCH_BACKEND=gloo      exchange gradients over gloo instead of RCCL (RCCL refuses two ranks on one device)
+  AO_AMD_BENCH_ONE_DEVICE=1      every rank uses cuda:0
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,12 +36,19 @@ import time
 # `hipIpcGetMemHandle: invalid argument` (already exported on the GPU boxes; kept here for any other launcher)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+np = torch = dist = None  # imported by the rank processes only (child_main): the spawning parent stays GPU-free
+
+
+def _imports():
+    global np, torch, dist
+    import numpy
+    import torch as _torch
+    import torch.distributed as _dist
+
+    np, torch, dist = numpy, _torch, _dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
@@ -146,8 +165,82 @@ def cpu_baseline(cfg, sample_points):
                        "torch-CPU restatement + C kNN (oracle/), drop_path 0" % (sample_points, t))
 
 
+def spawn_ranks(args):
+    """Parent of an N-rank run: start one child per GPU and relay rank 0's JSON line.  This process makes no HIP call
+    (no torch import at all), so nothing that has initialised the GPU is ever forked or re-executed; every child is a
+    fresh interpreter.  A child that fails takes the job down: the others are terminated by PID and the parent exits
+    with the failing status (reference: pointcept/engines/launch.py:74-87 mp.spawn(..., join) semantics)."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AO_AMD_BENCH_CHILD="1")
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                         stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    out0 = b""
+    failed = None
+    pending = set(range(n))
+    # rank 0's stdout carries only the result line (child_main redirects everything else to stderr), so reading it to
+    # EOF cannot block on a full pipe of chatter; poll the others meanwhile so that a dead rank is noticed
+    import selectors
+
+    sel = selectors.DefaultSelector()
+    sel.register(children[0].stdout, selectors.EVENT_READ)
+    eof = False
+    while pending:
+        if not eof:
+            for key, _ in sel.select(timeout=0.2):
+                chunk = os.read(key.fileobj.fileno(), 65536)
+                if chunk:
+                    out0 += chunk
+                else:
+                    eof = True
+                    sel.unregister(key.fileobj)
+        else:
+            time.sleep(0.2)
+        for r in list(pending):
+            rc = children[r].poll()
+            if rc is not None:
+                pending.discard(r)
+                if rc != 0 and failed is None:
+                    failed = (r, rc)
+        if failed is not None:
+            for r in pending:
+                children[r].terminate()
+            for r in pending:
+                try:
+                    children[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    children[r].kill()
+            break
+    if failed is not None:
+        sys.stderr.write("bench.py: rank %d exited with status %d; job aborted\n" % failed)
+        raise SystemExit(failed[1] if failed[1] > 0 else 1)
+    if not eof:
+        out0 += children[0].stdout.read()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+
+
+def _launcher_name():
+    if "TORCHELASTIC_RUN_ID" in os.environ:
+        return "torch.distributed.run"
+    return "bench.py spawn" if os.environ.get("AO_AMD_BENCH_CHILD") == "1" else "single"
+
+
 def main():
     args = parse()
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        return spawn_ranks(args)
+    return child_main(args)
+
+
+def child_main(args):
+    _imports()
     # stdout carries exactly ONE line, the JSON result of rank 0: everything else that writes to file descriptor 1 in any
     # rank (RCCL prints a "ROCm version / Hostname / Librccl path" banner there when a communicator is created) is sent
     # to stderr for the lifetime of the process; the result is written to the saved descriptor at the end
@@ -157,15 +250,40 @@ def main():
     from ao_amd.ptv2 import parallel
 
     rank, local_rank, world = parallel.rank_world()
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                         % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("AO_AMD_BENCH_DRYRUN") == "1":
+        # launcher check only (tests/test_bench_spawn.py, no GPU): rendezvous + the barrier / max-over-ranks timing
+        # protocol around an empty step; reports no throughput
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        cpu = torch.device("cpu")
+        elapsed, pts, _ = parallel.timed_steps(lambda: None, args.steps, cpu, args.points)
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"dry_run": True, "value": None, "n_gpus": world, "steps": args.steps,
+                                             "points_per_step": pts, "launcher": _launcher_name(),
+                                             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1}) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    if os.environ.get("AO_AMD_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("AO_AMD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+
+    def init_group():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if world > 1:
+        init_group()
 
     import ao_amd.ptv2 as ptv2
     from ao_amd import _lib
@@ -181,9 +299,7 @@ def main():
     force_sync = os.environ.get("AO_AMD_FORCE_SYNC") == "1"  # 1-GPU box: run the flat exchange in a 1-rank group
     if world > 1 or os.environ.get("AO_AMD_FORCE_DDP") == "1" or force_sync:
         if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            init_group()
         if use_ddp:
             net = parallel.wrap_ddp(seg, device)
         else:
@@ -269,7 +385,11 @@ def main():
             "config": {"workload": "%s semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.cfg, args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
-                       "autocast": args.dtype if args.dtype != "fp32" else None, "parallelism": "dp%d" % world, "grad_sync": "ddp" if use_ddp else "flat all-reduce",
+                       "autocast": args.dtype if args.dtype != "fp32" else None, "parallelism": "dp%d" % world,
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                       "comm_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "launcher": _launcher_name(),
+                       "grad_sync": "ddp" if use_ddp else "flat all-reduce",
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
                        "loss": float(loss.detach())},
         }

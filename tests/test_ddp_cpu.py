@@ -66,6 +66,32 @@ def _worker(rank, world, port, out_dir):
     sync.sync()
     flat_grads = {k: p.grad.clone() for k, p in twin.named_parameters()}
 
+    # bench.py's default exchange, step by step: FlatAdamW.flatten_grads -> FlatGradSync.reduce_flat (SUM) ->
+    # FlatAdamW.step(flat_grad, grad_scale = 1 / world); the HIP update kernel is replaced by its torch statement
+    # (tests/_cpu_adamw.py) -- against DDP + torch.optim.AdamW on a third copy
+    from tests._cpu_adamw import TorchStatementAdamW
+
+    flat_model, ddp_model = copy.deepcopy(model), copy.deepcopy(model)
+    fsync = parallel.FlatGradSync(flat_model)
+    fopt = TorchStatementAdamW(flat_model.parameters(), lr=0.006, weight_decay=0.05)
+    dnet = parallel.wrap_ddp(ddp_model, device)
+    dopt = torch.optim.AdamW(ddp_model.parameters(), lr=0.006, weight_decay=0.05)
+    scales = []
+    for _ in range(3):
+        loss = _loss(flat_model, data)
+        fopt.zero_grad(set_to_none=True)
+        loss.backward()
+        flat = fopt.flatten_grads()
+        scale = fsync.reduce_flat(flat)
+        scales.append(scale)
+        fopt.step(flat_grad=flat, grad_scale=scale)
+        dloss = _loss(dnet, data)
+        dopt.zero_grad(set_to_none=True)
+        dloss.backward()
+        dopt.step()
+    flat_exchange = dict(scales=scales, flat={k: p.detach().clone() for k, p in flat_model.named_parameters()},
+                         ddp={k: p.detach().clone() for k, p in ddp_model.named_parameters()})
+
     def step():
         loss = _loss(net, data)
         opt.zero_grad(set_to_none=True)
@@ -74,11 +100,18 @@ def _worker(rank, world, port, out_dir):
         return loss
 
     elapsed, pts, loss = parallel.timed_steps(step, 2, device, data["coord"].shape[0])
-    torch.save(dict(seeds=seeds, grads=grads, flat_grads=flat_grads, params={k: p.detach().clone() for k, p in model.named_parameters()},
+    torch.save(dict(seeds=seeds, grads=grads, flat_grads=flat_grads, flat_exchange=flat_exchange, params={k: p.detach().clone() for k, p in model.named_parameters()},
                     elapsed=elapsed, pts=pts, n=data["coord"].shape[0], loss=float(loss.detach())),
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _pre_bn_bias(name):
+    """Linear biases with an exactly-zero true gradient: every one that feeds a training-mode BatchNorm (directly, or
+    as a per-channel constant through the attention sum) or a softmax over the neighbour slots -- i.e. every Linear
+    bias of PT-v2m2 except the last head layer's."""
+    return name.endswith("bias") and not name.endswith("norm/bias") and not name.startswith("seg_head/3")
 
 
 def test_two_rank_data_parallel_step(tmp_path):
@@ -94,6 +127,15 @@ def test_two_rank_data_parallel_step(tmp_path):
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k  # replicas stay identical
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k
+
+    # flat all-reduce + FlatAdamW(grad_scale) == DDP + torch.optim.AdamW after 3 steps, and identical on both ranks
+    fx0, fx1 = r0["flat_exchange"], r1["flat_exchange"]
+    assert fx0["scales"] == [0.5, 0.5, 0.5]
+    for k in fx0["flat"]:
+        assert torch.equal(fx0["flat"][k], fx1["flat"][k]), k
+        # Adam turns a zero-mean-noise gradient (biases in front of a training-mode BatchNorm) into +-lr steps
+        if not _pre_bn_bias(k):
+            np.testing.assert_allclose(fx0["flat"][k].numpy(), fx0["ddp"][k].numpy(), rtol=0, atol=2e-5, err_msg=k)
 
     # single-process reference: mean of the two per-scene gradients (BatchNorm statistics are per scene,
     # exactly as in the two-process run with broadcast_buffers=False)
