@@ -12,4 +12,5 @@ from .model import (  # noqa: F401
     UnpoolWithSkip,
     build_from_cfg,
 )
-from .segmentor import DefaultSegmentor, S3DIS_BACKBONE, SCANNET_BACKBONE  # noqa: F401
+from .basket import LogitBasket  # noqa: F401
+from .segmentor import DefaultSegmentor, DefaultSegmentorSAM_Image, S3DIS_BACKBONE, SCANNET_BACKBONE  # noqa: F401

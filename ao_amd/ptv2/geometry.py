@@ -71,11 +71,13 @@ def segment_minmax(coord, offset):
     return lo, hi
 
 
-def voxel_cluster_ids(coord, offset, grid_size):
-    """Cluster id of GridPool (:246-259): per-cloud min-shifted coords, torch_cluster.grid_cluster
-    formula with the batch index as the most significant digit (oracle/ptv2_ref.py:voxel_grid)."""
+def voxel_cluster_ids(coord, offset, grid_size, start=None):
+    """Cluster id of GridPool (:246-259): per-cloud min-shifted coords (or the caller's `start`, (B,3)),
+    torch_cluster.grid_cluster formula with the batch index as the most significant digit
+    (oracle/ptv2_ref.py:voxel_grid)."""
     batch = offset2batch(offset)
-    start, _ = segment_minmax(coord, offset)
+    if start is None:
+        start, _ = segment_minmax(coord, offset)
     pos = coord - start[batch]
     size = coord.new_tensor([grid_size, grid_size, grid_size])
     num = (pos.max(0)[0] / size).long() + 1          # voxels per axis over the whole batch
@@ -84,10 +86,10 @@ def voxel_cluster_ids(coord, offset, grid_size):
     return cell[:, 0] + cell[:, 1] * stride_y + cell[:, 2] * stride_z + batch * stride_b, batch
 
 
-def grid_pool_geometry_torch(coord, offset, grid_size):
+def grid_pool_geometry_torch(coord, offset, grid_size, start=None):
     """Coordinates-only half of GridPool.forward (:257-268) as torch ops (kept as the in-framework statement
     of what the device kernel computes; AO_AMD_GRIDPOOL=torch selects it)."""
-    key, batch = voxel_cluster_ids(coord, offset, grid_size)
+    key, batch = voxel_cluster_ids(coord, offset, grid_size, start)
     _, cluster, counts = torch.unique(key, sorted=True, return_inverse=True, return_counts=True)
     order = torch.sort(cluster, stable=True)[1]
     idx_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, dim=0)])

@@ -11,7 +11,14 @@ the execution plan:
   * grouped vector attention runs through `ao_amd.ptv2.gva` (fused HIP kernels) -- the unfused
     composition of gather ops below (`gva_unfused`) is kept as the in-framework statement of
     the same math for debugging (AO_AMD_GVA=unfused);
-  * dense Linear layers stay on rocBLAS/hipBLASLt (MFMA) through torch.
+  * dense per-point Linear layers run on the fp32-MFMA row GEMM of ao_amd/csrc/gemm.hip (`RowLinear`), with the
+    BatchNorm around them fused into its epilogue / operand load (ao_amd/csrc/dense.hip).
+
+Every stage module also answers the reference's own `forward` signature -- `GridPool(points, start=None) ->
+(points, cluster)`, `UnpoolWithSkip(points, skip_points, cluster=None)`, `Encoder(points) -> (points, cluster)`,
+`Decoder(points, skip_points, cluster)`, `GVAPatchEmbed(points)` (reference :244,305,356,400,441) -- as adapters over
+the same kernels, so code that drives a stage directly keeps working; `PointTransformerV2.forward` itself goes
+through the geometry plan (`pool` / `unpool` methods) so that nothing geometric is recomputed.
 """
 import os
 
@@ -20,8 +27,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib, pointops
-from ..pointops.interpolation import _InterpolateRows
-from .geometry import build_geometry
+from ..pointops.interpolation import _InterpolateRows, interpolation_index_weight
+from .geometry import Level, build_geometry, grid_pool_geometry, grid_pool_geometry_torch
 from .layers import RowBatchNorm1d, RowLinear, bn_residual_relu, lin_bn_relu
 
 
@@ -267,9 +274,21 @@ class GridPool(nn.Module):
         self.norm = PointBatchNorm(out_channels)
         self.act = nn.ReLU(inplace=True)
 
-    def forward(self, feat, fine_level, coarse_level):
+    def pool(self, feat, fine_level):
+        """Plan path: the clustering of `fine_level` (geometry.py) is already known."""
         feat = lin_bn_relu(self.fc, self.norm.norm, feat)
         return _SegmentMax.apply(feat, fine_level.order32, fine_level.idx_ptr32)
+
+    def forward(self, points, start=None):
+        """Reference signature (:244-269): points = [coord, feat, offset] -> ([coord', feat', offset'], cluster).
+        `start` (per-cloud origin of the voxel grid, (B,3)) defaults to the per-cloud minimum, as there."""
+        coord, feat, offset = points
+        if start is None:
+            new_coord, new_offset, cluster, order, idx_ptr = grid_pool_geometry(coord.contiguous(), offset, self.grid_size)
+        else:
+            new_coord, new_offset, cluster, order, idx_ptr = grid_pool_geometry_torch(coord, offset, self.grid_size, start)
+        level = Level(coord=coord, offset=offset, cluster=cluster, order32=order, idx_ptr32=idx_ptr)
+        return [new_coord, self.pool(feat, level), new_offset], cluster
 
 
 class UnpoolWithSkip(nn.Module):
@@ -283,7 +302,27 @@ class UnpoolWithSkip(nn.Module):
         self.proj = _lin_bn_relu(in_channels, out_channels, bias)
         self.proj_skip = _lin_bn_relu(skip_channels, out_channels, bias)
 
-    def forward(self, feat, skip_feat, fine_level):
+    def forward(self, points, skip_points, cluster=None):
+        """Reference signature (:305-316): returns [skip_coord, feat, skip_offset]."""
+        coord, feat, offset = points
+        skip_coord, skip_feat, skip_offset = skip_points
+        level = Level(coord=skip_coord, offset=skip_offset)
+        if self.backend == "map" and cluster is not None:
+            # CSR of the cluster map, so that the backward is the ordered per-cluster sum of the plan path
+            level.cluster = cluster
+            level.order32 = torch.sort(cluster, stable=True)[1].int()
+            counts = torch.bincount(cluster, minlength=feat.shape[0])
+            level.idx_ptr32 = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).int()
+        else:
+            with torch.no_grad():
+                level.up_idx, level.up_weight = interpolation_index_weight(coord, skip_coord, offset.int(), skip_offset.int(), 3)
+                from . import gva
+
+                gva.inverse_table(level.up_idx)  # backward gathers in a fixed order (no float atomics)
+        return [skip_coord, self.unpool(feat, skip_feat, level), skip_offset]
+
+    def unpool(self, feat, skip_feat, fine_level):
+        """Plan path: cluster map / 3-NN table of `fine_level` (geometry.py) already known."""
         feat = self.proj(feat)
         if self.backend == "map" and fine_level.cluster is not None:
             if feat.is_cuda and feat.dtype == torch.float32 and fine_level.order32 is not None:
@@ -306,6 +345,11 @@ class Encoder(nn.Module):
                                     attn_drop_rate if attn_drop_rate is not None else 0.0,
                                     drop_path_rate if drop_path_rate is not None else 0.0, enable_checkpoint)
 
+    def forward(self, points):
+        """Reference signature (:356-358)."""
+        points, cluster = self.down(points)
+        return self.blocks(points), cluster
+
 
 class Decoder(nn.Module):
     def __init__(self, in_channels, skip_channels, embed_channels, groups, depth, neighbours=16, qkv_bias=True,
@@ -317,6 +361,10 @@ class Decoder(nn.Module):
                                     attn_drop_rate if attn_drop_rate is not None else 0.0,
                                     drop_path_rate if drop_path_rate is not None else 0.0, enable_checkpoint)
 
+    def forward(self, points, skip_points, cluster):
+        """Reference signature (:400-402)."""
+        return self.blocks(self.up(points, skip_points, cluster))
+
 
 class GVAPatchEmbed(nn.Module):
     def __init__(self, depth, in_channels, embed_channels, groups, neighbours=16, qkv_bias=True, pe_multiplier=False,
@@ -326,6 +374,11 @@ class GVAPatchEmbed(nn.Module):
         self.proj = _lin_bn_relu(in_channels, embed_channels, False)
         self.blocks = BlockSequence(depth, embed_channels, groups, neighbours, qkv_bias, pe_multiplier, pe_bias,
                                     attn_drop_rate, drop_path_rate, enable_checkpoint)
+
+    def forward(self, points):
+        """Reference signature (:441-444)."""
+        coord, feat, offset = points
+        return self.blocks([coord, self.proj(feat), offset])
 
 
 class PointTransformerV2(nn.Module):
@@ -385,13 +438,13 @@ class PointTransformerV2(nn.Module):
         feat = pe.blocks([lv[0].coord, pe.proj(feat), lv[0].offset], lv[0].neighbours(pe.blocks.neighbours))[1]
         skips = [feat]
         for i, enc in enumerate(self.enc_stages):
-            feat = enc.down(feat, lv[i], lv[i + 1])
+            feat = enc.down.pool(feat, lv[i])
             feat = enc.blocks([lv[i + 1].coord, feat, lv[i + 1].offset], lv[i + 1].neighbours(enc.blocks.neighbours))[1]
             skips.append(feat)
         feat = skips.pop()
         for i in reversed(range(self.num_stages)):
             dec = self.dec_stages[i]
-            feat = dec.up(feat, skips.pop(), lv[i])
+            feat = dec.up.unpool(feat, skips.pop(), lv[i])
             feat = dec.blocks([lv[i].coord, feat, lv[i].offset], lv[i].neighbours(dec.blocks.neighbours))[1]
         if isinstance(self.seg_head, nn.Sequential):
             return self.seg_head[3](lin_bn_relu(self.seg_head[0], self.seg_head[1].norm, feat))

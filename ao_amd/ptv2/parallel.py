@@ -72,14 +72,17 @@ def fence(device):
         torch.cuda.synchronize(device)
 
 
-def timed_steps(step_fn, steps, device, points_this_rank):
+def timed_steps(step_fn, steps, device, points_this_rank, finish=None):
     """Run exactly `steps` steps bracketed by barrier+synchronize; returns (max elapsed over ranks,
-    total points per step over all ranks, last loss)."""
+    total points per step over all ranks, last loss).  `finish` (e.g. LogitBasket.flush) runs inside the timed
+    region after the last step: work the steps left in flight counts."""
     fence(device)
     t0 = time.perf_counter()
     loss = None
     for _ in range(steps):
         loss = step_fn()
+    if finish is not None:
+        finish()
     fence(device)
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)

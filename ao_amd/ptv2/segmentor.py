@@ -66,23 +66,89 @@ def cross_entropy(logits, label, ignore_index=-1):
     return torch.nn.functional.cross_entropy(logits, label, ignore_index=ignore_index)
 
 
-class DefaultSegmentor(nn.Module):
-    """backbone + CrossEntropyLoss(ignore_index=-1); same return convention as the reference."""
+def _parse_criteria(criteria, ignore_index):
+    """The reference builds `criteria` from a list of loss configs and sums them (pointcept/models/losses/builder.py:
+    13-29).  On this path every config uses ONE CrossEntropyLoss (configs/s3dis/semseg-pt-v2m2-0-base.py:37,
+    semseg-pt-v2m2-0-sam-final.py:37); that is what is implemented: a list of CrossEntropyLoss entries, each with its
+    loss_weight / ignore_index (losses/misc.py:14-39)."""
+    if criteria is None:
+        return [(1.0, ignore_index)]
+    out = []
+    for c in criteria:
+        c = dict(c)
+        kind = c.pop("type", "CrossEntropyLoss")
+        extra = set(c) - {"loss_weight", "ignore_index"}
+        if kind != "CrossEntropyLoss" or extra:
+            raise NotImplementedError("criteria %r with %s: only CrossEntropyLoss(loss_weight, ignore_index) is on the "
+                                      "PT-v2m2 path" % (kind, sorted(extra)))
+        out.append((float(c.get("loss_weight", 1.0)), int(c.get("ignore_index", -1))))
+    return out
 
-    def __init__(self, backbone=None, ignore_index=-1):
+
+class DefaultSegmentor(nn.Module):
+    """backbone + CrossEntropyLoss(ignore_index=-1); constructor and return convention of the reference
+    (pointcept/models/default.py:232-251): `DefaultSegmentor(backbone=dict(type="PT-v2m2", ...), criteria=[dict(
+    type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)])`."""
+
+    def __init__(self, backbone=None, criteria=None, ignore_index=-1):
         super().__init__()
         self.backbone = backbone if isinstance(backbone, nn.Module) else PointTransformerV2(
             **{k: v for k, v in dict(backbone).items() if k != "type"})
-        self.criteria = nn.CrossEntropyLoss(ignore_index=ignore_index)  # kept for state / introspection parity
-        self.ignore_index = ignore_index
+        self._criteria = _parse_criteria(criteria, ignore_index)
+        self.ignore_index = self._criteria[0][1]
+        self.criteria = nn.CrossEntropyLoss(ignore_index=self.ignore_index)  # kept for state / introspection parity
 
     def loss(self, seg_logits, segment):
-        return cross_entropy(seg_logits, segment, self.ignore_index)
+        total = None
+        for weight, ignore in self._criteria:
+            term = cross_entropy(seg_logits, segment, ignore)
+            term = term if weight == 1.0 else term * weight
+            total = term if total is None else total + term
+        return total
 
     def forward(self, input_dict):
         seg_logits = self.backbone(input_dict)
         if self.training:
             return dict(loss=self.loss(seg_logits, input_dict["segment"]))
+        if "segment" in input_dict:
+            return dict(loss=self.loss(seg_logits, input_dict["segment"]), seg_logits=seg_logits)
+        return dict(seg_logits=seg_logits)
+
+
+class DefaultSegmentorSAM_Image(DefaultSegmentor):
+    """REAL's segmentor (pointcept/models/default.py:15-76): in training it returns `(dict(loss=loss), seg_dict)` with
+    `seg_dict[scene_key] = (seg_logits of that scene (n, C), original point ids of those rows (n,))`, where
+    `scene_key = scene_id.replace("/", "_")[:-4]` (:53) and the ids come from `input_dict["instance"]` (:31); eval /
+    test returns are DefaultSegmentor's.  The trainer copies seg_dict into its basket every step
+    (engines/train_sam_real.py:229-234; here: ao_amd/ptv2/basket.LogitBasket.put, asynchronous).
+
+    The reference slices with device-tensor bounds (:39-40) and calls `.unique()` per scene (:46-48, result unused):
+    at least three host synchronisations per scene before the backward is issued.  Here the bounds come from
+    `input_dict["offset_host"]` (a python list the collate function already has, ao_amd/ptv2/transform.collate) when
+    present -- no synchronisation at all -- else from ONE `offset.tolist()`."""
+
+    def __init__(self, backbone=None, criteria=None, ignore_index=-1):
+        super().__init__(backbone, criteria, ignore_index)
+        self.count = 0  # the reference trainer resets this attribute every epoch (train_sam_real.py:259)
+
+    @staticmethod
+    def scene_key(scene_id):
+        return scene_id.replace("/", "_")[:-4]
+
+    def forward(self, input_dict):
+        seg_logits = self.backbone(input_dict)
+        if self.training:
+            seg_dict = {}
+            with torch.no_grad():
+                bounds = input_dict.get("offset_host")
+                if bounds is None:
+                    bounds = input_dict["offset"].tolist()
+                original_idx, detached, start = input_dict["instance"], seg_logits.detach(), 0
+                for scene_id, end in zip(input_dict["scene_id"], bounds):
+                    end = int(end)
+                    seg_dict[self.scene_key(scene_id)] = (detached[start:end], original_idx[start:end])
+                    start = end
+            return dict(loss=self.loss(seg_logits, input_dict["segment"])), seg_dict
         if "segment" in input_dict:
             return dict(loss=self.loss(seg_logits, input_dict["segment"]), seg_logits=seg_logits)
         return dict(seg_logits=seg_logits)

@@ -170,7 +170,12 @@ def point_collate(batch):
         else:
             out[key] = list(vals)
     dev = out["coord"].device if "coord" in out else None
+    host = {}
     for key in out:
         if "offset" in key and torch.is_tensor(out[key]):
-            out[key] = torch.cumsum(out[key], dim=0).int().to(dev)
+            ends = torch.cumsum(out[key], dim=0).int()
+            if not ends.is_cuda:  # Collect() makes the counts on the host: keep the bounds there too, so that callers
+                host[key + "_host"] = ends.tolist()  # that slice per scene (DefaultSegmentorSAM_Image) need no read-back
+            out[key] = ends.to(dev)
+    out.update(host)
     return out

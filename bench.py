@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--cfg", default="s3dis", choices=["s3dis", "scannet"],
                     help="backbone config: the headline S3DIS one, or configs/scannet/semseg-pt-v2m2-0-base.py (BASELINE.json configs[4])")
+    ap.add_argument("--segmentor", default="default", choices=["default", "sam_image"],
+                    help="sam_image: DefaultSegmentorSAM_Image + the per-step logit basket of train_real (BASELINE.json configs[3])")
     ap.add_argument("--cpu-sample-points", type=int, default=12000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -290,7 +292,7 @@ def child_main(args):
 
     torch.manual_seed(4242)
     cfg = dict(ptv2.S3DIS_BACKBONE if args.cfg == "s3dis" else ptv2.SCANNET_BACKBONE)
-    seg = ptv2.DefaultSegmentor(cfg).to(device).train()
+    seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(cfg).to(device).train()
     net = seg
     # gradient exchange: one flat all-reduce after backward (parallel.FlatGradSync, default) or torch DDP
     # (AO_AMD_GRAD_SYNC=ddp; AO_AMD_FORCE_DDP=1 also wraps a 1-rank run so that a 1-GPU box exercises that path)
@@ -316,6 +318,15 @@ def child_main(args):
     data = make_batch(rank, args.scenes, args.points, device, cfg["in_channels"], cfg["num_classes"])
     n_points = int(data["coord"].shape[0])
     autocast = torch.autocast("cuda", dtype=torch.bfloat16) if args.dtype == "bf16" else None
+    basket = None
+    if args.segmentor == "sam_image":
+        # REAL's extra batch keys: scene names and the original index of every point; the basket holds whole scenes
+        bounds = [0] + data["offset"].tolist()
+        data["scene_id"] = ["Area_%d/room_%d.pth" % (rank + 1, i) for i in range(args.scenes)]
+        data["instance"] = torch.cat([torch.randperm(2 * (b - a), device=device)[: b - a] for a, b in zip(bounds, bounds[1:])])
+        data["offset_host"] = bounds[1:]
+        basket = ptv2.LogitBasket({seg.scene_key(s): 2 * (b - a) for s, a, b in zip(data["scene_id"], bounds, bounds[1:])},
+                                  cfg["num_classes"], device=device, max_rows=n_points)
 
     # geometry of batch i+1 (coordinates only) is built on a side stream during the backward of batch i, as a
     # loader would; every step still builds exactly one geometry (AO_AMD_PREFETCH=0: build it inline instead)
@@ -328,9 +339,13 @@ def child_main(args):
         batch = data if prefetch is None else dict(data, geometry=prefetch.take())
         if autocast is not None:
             with autocast:
-                loss = net(batch)["loss"]
+                out = net(batch)
         else:
-            loss = net(batch)["loss"]
+            out = net(batch)
+        if basket is not None:  # engines/train_sam_real.py:229-234, without its two blocking copies per scene
+            out, seg_dict = out
+            basket.put(seg_dict)
+        loss = out["loss"]
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if flat_opt:  # gradients -> one flat buffer -> (all-reduce) -> one update kernel
@@ -365,7 +380,8 @@ def child_main(args):
         if survey:
             dominant = max(survey.items(), key=lambda kv: kv[1]["total_us"])[0]
             _lib.kernel_timer(True, only=dominant, stride=3)  # every 3rd launch: a uniform sample, a third of the events
-    elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points)
+    elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points,
+                                                          finish=basket.flush if basket is not None else None)
     if not args.no_roofline:
         _lib.lib().ptv2_profile_enable(0)
 
@@ -391,6 +407,8 @@ def child_main(args):
                        "launcher": _launcher_name(),
                        "grad_sync": "ddp" if use_ddp else "flat all-reduce",
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
+                       "segmentor": "DefaultSegmentorSAM_Image + LogitBasket (%d puts, %d waits for a staging slot)"
+                                    % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",
                        "loss": float(loss.detach())},
         }
         step_bytes = algorithmic_step_bytes(levels, cfg)

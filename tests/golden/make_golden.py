@@ -368,6 +368,82 @@ def gen_model(ref):
     print("manifest keys:", {k: (len(v) if isinstance(v, dict) else v) for k, v in manifest.items()})
 
 
+def load_reference_segmentors():
+    """pointcept/models/default.py with the reference's REAL registry / builders (pointcept/utils/registry.py,
+    models/builder.py, models/losses/builder.py, models/losses/misc.py), loaded file by file because
+    `import pointcept.models` pulls spconv.  Replaces the no-op registry stub, then re-imports the PT-v2m2 module so
+    that it registers itself as "PT-v2m2"."""
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    utils = types.ModuleType("pointcept.utils")
+    utils.__path__ = [os.path.join(REF, "pointcept/utils")]
+    sys.modules["pointcept.utils"] = utils
+    load("pointcept.utils.misc", "pointcept/utils/misc.py")
+    load("pointcept.utils.registry", "pointcept/utils/registry.py")
+    load("pointcept.utils.ply", "pointcept/utils/ply.py")
+    load("pointcept.models.builder", "pointcept/models/builder.py")
+    sys.modules["pointcept.models.losses"] = types.ModuleType("pointcept.models.losses")
+    lb = load("pointcept.models.losses.builder", "pointcept/models/losses/builder.py")
+    load("pointcept.models.losses.misc", "pointcept/models/losses/misc.py")
+    sys.modules["pointcept.models.losses"].build_criteria = lb.build_criteria
+    load_reference_model_module()
+    return load("pointcept.models.default", "pointcept/models/default.py")
+
+
+def gen_segmentor():
+    """DefaultSegmentorSAM_Image (pointcept/models/default.py:15-76), built through the reference's registry from the
+    model dict of configs/s3dis/semseg-pt-v2m2-0-sam-final.py:10-38, on the inputs of ptv2_s3dis.npz plus the REAL
+    batch keys (scene_id, instance); then the trainer's basket statement (engines/train_sam_real.py:229-234) on a
+    -100-filled basket.  Also DefaultSegmentor's three return forms."""
+    default = load_reference_segmentors()
+    g = np.load(os.path.join(HERE, "ptv2_s3dis.npz"))
+    cfg = dict(OM.S3DIS_CFG, drop_path_rate=0.0)
+    criteria = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+    seg = default.MODELS.build(dict(type="DefaultSegmentorSAM_Image", backbone=dict(type="PT-v2m2", **cfg), criteria=criteria))
+    st = OM.init_state(cfg, seed=int(g["state_seed"]))
+    seg.backbone.load_state_dict(st, strict=True)
+    assert all(k.startswith("backbone.") for k in seg.state_dict())
+    coord, feat, offset, label = (torch.from_numpy(g[k]) for k in ("coord", "feat", "offset", "label"))
+    n = coord.shape[0]
+    gen = torch.Generator().manual_seed(77)
+    scene_id = ["Area_1/office_3.pth", "Area_4/hallway_11.pth"]
+    scene_points = [9000, 7000]  # points of the un-cropped scenes
+    bounds = [0] + offset.tolist()
+    instance = torch.cat([torch.randperm(scene_points[i], generator=gen)[: bounds[i + 1] - bounds[i]] for i in range(2)])
+    batch = dict(coord=coord, feat=feat, offset=offset, segment=label, scene_id=scene_id, instance=instance)
+    seg.train()
+    out, seg_dict = seg(batch)
+    keys = list(seg_dict)
+    basket = {k: np.full((m, cfg["num_classes"]), -100.0, np.float32) for k, m in zip(keys, scene_points)}
+    for k, v in seg_dict.items():  # train_sam_real.py:231-234
+        s_, ori_idx = v[0], v[1]
+        basket[k][ori_idx.cpu().detach().numpy()] = s_.cpu().detach().numpy()
+    fix = dict(scene_id=np.array(scene_id), scene_points=np.array(scene_points), instance=instance, keys=np.array(keys),
+               loss_train=out["loss"], state_seed=int(g["state_seed"]))
+    for i, k in enumerate(keys):
+        fix["seg_logits_%d" % i], fix["seg_ids_%d" % i], fix["basket_%d" % i] = seg_dict[k][0], seg_dict[k][1], basket[k]
+    seg.backbone.load_state_dict(st, strict=True)
+    seg.eval()
+    with torch.no_grad():
+        ev = seg(batch)
+        te = seg(dict(coord=coord, feat=feat, offset=offset))
+    assert sorted(ev) == ["loss", "seg_logits"] and sorted(te) == ["seg_logits"]
+    fix.update(loss_eval=ev["loss"], eval_keys=np.array(sorted(ev)), test_keys=np.array(sorted(te)))
+    # loss_weight is honoured (losses/misc.py:38)
+    seg2 = default.MODELS.build(dict(type="DefaultSegmentor", backbone=dict(type="PT-v2m2", **cfg),
+                                     criteria=[dict(type="CrossEntropyLoss", loss_weight=0.5, ignore_index=-1)]))
+    seg2.backbone.load_state_dict(st, strict=True)
+    seg2.eval()
+    with torch.no_grad():
+        fix["loss_eval_half_weight"] = seg2(batch)["loss"]
+    save("segmentor_sam.npz", **fix)
+
+
 def main():
     assert os.path.isdir(REF), "run in the build container: needs /root/reference"
     OP.build()
@@ -378,6 +454,7 @@ def main():
     ref = load_reference_model_module()
     gen_gva(ref)
     gen_model(ref)
+    gen_segmentor()
 
 
 if __name__ == "__main__":

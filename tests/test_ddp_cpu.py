@@ -84,12 +84,15 @@ def _worker(rank, world, port, out_dir):
         flat = fopt.flatten_grads()
         scale = fsync.reduce_flat(flat)
         scales.append(scale)
-        fopt.step(flat_grad=flat, grad_scale=scale)
         dloss = _loss(dnet, data)
         dopt.zero_grad(set_to_none=True)
         dloss.backward()
+        if _ == 0:  # the averaged gradient itself: summed flat buffer x grad_scale == DDP's mean (Adam hides a scale)
+            mean0 = [(v * scale).view_as(p).clone() for v, p in zip(flat[:fopt._total].split(fopt._sizes), fopt._params)]
+            ddp0 = [p.grad.clone() for p in ddp_model.parameters()]
+        fopt.step(flat_grad=flat, grad_scale=scale)
         dopt.step()
-    flat_exchange = dict(scales=scales, flat={k: p.detach().clone() for k, p in flat_model.named_parameters()},
+    flat_exchange = dict(scales=scales, mean0=mean0, ddp0=ddp0, flat={k: p.detach().clone() for k, p in flat_model.named_parameters()},
                          ddp={k: p.detach().clone() for k, p in ddp_model.named_parameters()})
 
     def step():
@@ -134,8 +137,13 @@ def test_two_rank_data_parallel_step(tmp_path):
     for k in fx0["flat"]:
         assert torch.equal(fx0["flat"][k], fx1["flat"][k]), k
         # Adam turns a zero-mean-noise gradient (biases in front of a training-mode BatchNorm) into +-lr steps
+        # three Adam steps move a weight by up to 3 lr = 1.8e-2; thread-order noise in a near-zero gradient is turned
+        # into a fraction of a step by Adam's normalisation (single elements by up to one step): RMS / max criteria
         if not _pre_bn_bias(k):
-            np.testing.assert_allclose(fx0["flat"][k].numpy(), fx0["ddp"][k].numpy(), rtol=0, atol=2e-5, err_msg=k)
+            d = (fx0["flat"][k] - fx0["ddp"][k]).double()
+            assert float(d.pow(2).mean().sqrt()) <= 5e-4 and float(d.abs().max()) <= 6e-3, (k, float(d.abs().max()))
+    for a, b in zip(fx0["mean0"], fx0["ddp0"]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=2e-6)
 
     # single-process reference: mean of the two per-scene gradients (BatchNorm statistics are per scene,
     # exactly as in the two-process run with broadcast_buffers=False)
