@@ -59,7 +59,7 @@ _SIGNATURES = {
     "center_dist2_hip_launcher": (_c_int, [_c_int] + [_vp] * 4),
     "seg_confusion_hip_launcher": (_c_int, [ctypes.c_longlong, _c_int, _c_int, _vp, ctypes.c_longlong] + [_vp] * 4),
     "cross_entropy_workspace_bytes": (_c_size, [_c_int]),
-    "cross_entropy_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 4 + [_c_size, _vp]),
+    "cross_entropy_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "cross_entropy_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 5),
     "bn_stats_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [ctypes.c_float] * 2 + [_vp, _c_size, _vp]),
     "bn_apply_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 5 + [_c_int, _vp, _vp]),
@@ -85,6 +85,9 @@ _SIGNATURES = {
 _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace too small)",
         3: "PTV2_ERR_LAUNCH (HIP launch failed)"}
 _lib = None
+# bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
+# mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
+EXPECTED_ABI = 2
 
 
 def build(verbose=False):
@@ -117,6 +120,10 @@ def lib():
                 "or `make -C ao_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
         _bind(handle, _SIGNATURES)
+        have = handle.ptv2_abi_version()
+        if have != EXPECTED_ABI:
+            raise RuntimeError("ao_amd: %s has ABI version %d, the python side expects %d -- stale build; rebuild with "
+                               "`make -C ao_amd/csrc`" % (LIB_PATH, have, EXPECTED_ABI))
         _lib = handle
     return _lib
 

@@ -5,7 +5,7 @@
 
 #include "common.h"
 
-extern "C" int ptv2_abi_version(void) { return 1; }
+extern "C" int ptv2_abi_version(void) { return 2; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 extern "C" const char *ptv2_build_info(void) {
     return "libptv2_hip gfx950 (MI355X) hipcc " __VERSION__ " built " __DATE__;
@@ -14,20 +14,32 @@ extern "C" const char *ptv2_build_info(void) {
 // ------------------------------------------------------- per-stream arrival counters --
 // Kernels that finish their own per-block partial sums ("last block done", gva_common.h) need a zeroed device
 // counter; the last block resets it, so one small array per stream lives for the life of the library (kernels
-// on one stream are serialised, each launcher uses its own slot).
+// on one stream are serialised, each launcher uses its own slot).  Keyed by (device, stream): the default stream
+// has the same handle (0) on every device, and the array must live on the device the kernel runs on.
 namespace {
 std::mutex g_cnt_mu;
-std::unordered_map<hipStream_t, unsigned *> g_counters;
+struct CounterKey {
+    int device;
+    hipStream_t stream;
+    bool operator==(const CounterKey &o) const { return device == o.device && stream == o.stream; }
+};
+struct CounterKeyHash {
+    size_t operator()(const CounterKey &k) const { return std::hash<void *>()((void *)k.stream) * 31u + (size_t)k.device; }
+};
+std::unordered_map<CounterKey, unsigned *, CounterKeyHash> g_counters;
 }  // namespace
 
 unsigned *ptv2_stream_counters(hipStream_t st) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_cnt_mu);
-    auto it = g_counters.find(st);
+    const CounterKey key{device, st};
+    auto it = g_counters.find(key);
     if (it != g_counters.end()) return it->second;
     unsigned *p = nullptr;
     if (hipMalloc((void **)&p, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
-    g_counters[st] = p;
+    g_counters[key] = p;
     return p;
 }
 

@@ -1,5 +1,7 @@
 """Thin caller-side pieces the bench/tests need around the backbone:
 the segmentor wrapper (pointcept/models/default.py:232-251) and the two reference configs."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -34,11 +36,15 @@ class _CrossEntropy(torch.autograd.Function):
         L = _lib.lib()
         dev = logits.device
         lse = torch.empty(n, dtype=torch.float32, device=dev)
-        out = torch.empty(2, dtype=torch.float32, device=dev)  # loss, labelled count
+        out = torch.empty(3, dtype=torch.float32, device=dev)  # loss, labelled count, out-of-range labels
         ws = _lib.workspace(L.cross_entropy_workspace_bytes(n), dev)
         rc = L.cross_entropy_forward_hip_launcher(n, c, logits.data_ptr(), label.data_ptr(), int(ignore_index), lse.data_ptr(),
-                                                  out.data_ptr(), out.data_ptr() + 4, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                                  out.data_ptr(), out.data_ptr() + 4, out.data_ptr() + 8, ws.data_ptr(),
+                                                  ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "cross_entropy_forward_hip_launcher")
+        if os.environ.get("AO_AMD_CHECK_LABELS") == "1" and float(out[2]) > 0:  # costs a synchronisation: debugging aid
+            raise ValueError("cross_entropy: %d labels are neither ignore_index=%d nor in [0, %d)"
+                             % (int(out[2]), int(ignore_index), c))
         ctx.save_for_backward(logits, label, lse, out)
         ctx.ignore_index = int(ignore_index)
         return out[0]
@@ -60,7 +66,13 @@ class _CrossEntropy(torch.autograd.Function):
 
 
 def cross_entropy(logits, label, ignore_index=-1):
-    """F.cross_entropy(logits, label, ignore_index=...) (mean reduction) on the HIP kernel when it applies."""
+    """F.cross_entropy(logits, label, ignore_index=...) (mean reduction) on the HIP kernel when it applies.
+
+    A label that is neither `ignore_index` nor in [0, C) -- torch raises a device-side assert for it (e.g. a dataset
+    that marks "unlabelled" with 255 while the loss ignores -1) -- makes the loss NaN here: no synchronisation is
+    spent on the check, and the run fails at the first place the loss is looked at instead of silently training on
+    fewer points.  AO_AMD_CHECK_LABELS=1 raises a ValueError at the call instead (one host synchronisation per step).
+    With no labelled point at all the loss is NaN and the gradient zero, as torch."""
     if logits.is_cuda and logits.dim() == 2 and label.dtype == torch.int64 and logits.shape[0] > 0 and logits.shape[1] <= 1024:
         return _CrossEntropy.apply(logits, label, ignore_index)
     return torch.nn.functional.cross_entropy(logits, label, ignore_index=ignore_index)

@@ -484,11 +484,13 @@ int ptv2_block_backward_hip_launcher(const ptv2_block *blk, const ptv2_block_gra
 /* ------------------------------------------------ segmentation loss --
  * nn.CrossEntropyLoss(ignore_index) of DefaultSegmentor (pointcept/models/default.py:239-251): mean over the labelled
  * rows of -log softmax(logits)[label]; logits (n,c) fp32, label (n) int64.  loss, count: device scalars; lse (n) is
- * kept for the backward, which writes g_logits = (softmax - onehot) * g_loss / count (0 for ignored rows). */
+ * kept for the backward, which writes g_logits = (softmax - onehot) * g_loss / count (0 for ignored rows; all zero
+ * when no row is labelled, as torch's CPU kernel).  bad_labels: device scalar, number of labels that are neither
+ * ignore_index nor in [0,c) -- torch raises a device assert for those; here the loss becomes nan. */
 size_t cross_entropy_workspace_bytes(int n);
 int cross_entropy_forward_hip_launcher(int n, int c, const float *logits, const long long *label, int ignore_index,
-                                       float *lse, float *loss, float *count, void *workspace, size_t workspace_bytes,
-                                       void *stream);
+                                       float *lse, float *loss, float *count, float *bad_labels, void *workspace,
+                                       size_t workspace_bytes, void *stream);
 int cross_entropy_backward_hip_launcher(int n, int c, const float *logits, const long long *label, int ignore_index,
                                         const float *lse, const float *g_loss, const float *count, float *g_logits,
                                         void *stream);

@@ -334,3 +334,43 @@ def test_native_block_under_autocast_computes_fp32(monkeypatch):
         runs.append([y.detach()] + [t.clone() for t in grads])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+def test_plan_follows_rehomed_parameters_and_buffers():
+    """the cached native plan holds raw device pointers of all 30 parameters and 21 BatchNorm buffers; it
+    must be rebuilt when ANY of them moves -- FlatAdamW re-homing every trainable `p.data` while fc1 is frozen,
+    load_state_dict(assign=True), a replaced running buffer."""
+    import ao_amd.ptv2 as ptv2
+    from ao_amd import pointops
+    from ao_amd.ptv2.optim import FlatAdamW
+
+    torch.manual_seed(3)
+    blk = ptv2.Block(48, 6).cuda().eval()
+    n = 1500
+    coord = torch.rand(n, 3, device="cuda")
+    off = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx = pointops.knn_query(16, coord, off)[0]
+    feat = torch.randn(n, 48, device="cuda")
+    with torch.no_grad():
+        y0 = blk([coord, feat, off], idx)[1].clone()
+        # 1) fc1 frozen, everything else re-homed into a flat buffer by the optimizer
+        blk.fc1.weight.requires_grad_(False)
+        opt = FlatAdamW(blk.parameters(), lr=0.1)
+        assert torch.equal(blk([coord, feat, off], idx)[1], y0)
+        opt.flat_param.mul_(1.5)  # the parameters now live here: the output must follow
+        y1 = blk([coord, feat, off], idx)[1].clone()
+        assert not torch.allclose(y1, y0)
+        twin = ptv2.Block(48, 6).cuda().eval()
+        twin.load_state_dict(copy.deepcopy(blk.state_dict()))
+        assert torch.allclose(twin([coord, feat, off], idx)[1], y1, atol=1e-6)
+        # 2) a replaced BatchNorm buffer
+        blk.norm2.norm.running_var = blk.norm2.norm.running_var * 4.0
+        y2 = blk([coord, feat, off], idx)[1].clone()
+        twin.load_state_dict(copy.deepcopy(blk.state_dict()))
+        assert not torch.allclose(y2, y1) and torch.allclose(twin([coord, feat, off], idx)[1], y2, atol=1e-6)
+        # 3) load_state_dict(assign=True) swaps the Parameter objects themselves
+        sd = {k: v.clone() * (0.5 if k == "attn.linear_v.weight" else 1.0) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(sd, assign=True)
+        y3 = blk([coord, feat, off], idx)[1].clone()
+        twin.load_state_dict(copy.deepcopy(blk.state_dict()))
+        assert not torch.allclose(y3, y2) and torch.allclose(twin([coord, feat, off], idx)[1], y3, atol=1e-6)

@@ -40,3 +40,33 @@ def test_segmentor_loss_uses_the_kernel_and_matches():
     logits = seg.backbone(data)
     np.testing.assert_allclose(float(seg.loss(logits, data["segment"]).detach()),
                                float(F.cross_entropy(logits, data["segment"], ignore_index=-1).detach()), rtol=2e-6)
+
+
+def test_out_of_range_label_poisons_the_loss(monkeypatch):
+    """torch device-asserts on a label outside [0, C) that is not ignore_index; the HIP kernel must not
+    silently treat it as ignored: the loss becomes NaN (no synchronisation), AO_AMD_CHECK_LABELS=1 raises."""
+    from ao_amd.ptv2.segmentor import cross_entropy
+
+    torch.manual_seed(1)
+    logits = torch.randn(5000, 13, device="cuda", requires_grad=True)
+    label = torch.randint(0, 13, (5000,), device="cuda")
+    label[::7] = -1
+    assert torch.isfinite(cross_entropy(logits, label, -1))
+    label[1234] = 255  # e.g. a dataset whose "unlabelled" value is not the configured ignore_index
+    assert torch.isnan(cross_entropy(logits, label, -1))
+    clean = torch.where(label == -1, torch.zeros_like(label), label)  # only 255 left as a non-class value
+    assert torch.isfinite(cross_entropy(logits, clean, 255))  # fine when that IS the ignore_index
+    monkeypatch.setenv("AO_AMD_CHECK_LABELS", "1")
+    with pytest.raises(ValueError, match="1 labels are neither"):
+        cross_entropy(logits, clean, -1)
+
+
+def test_no_labelled_point_gives_nan_loss_and_zero_gradient():
+    from ao_amd.ptv2.segmentor import cross_entropy
+
+    logits = torch.randn(300, 13, device="cuda", requires_grad=True)
+    label = torch.full((300,), -1, device="cuda")
+    out = cross_entropy(logits, label, -1)
+    assert torch.isnan(out)  # 0 / 0, as torch
+    (g,) = torch.autograd.grad(out, [logits])
+    assert torch.equal(g, torch.zeros_like(g))  # torch's CPU kernel: zeros
