@@ -7,8 +7,12 @@
 
 extern "C" int ptv2_abi_version(void) { return 2; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
+#ifndef PTV2_SRC_HASH
+#define PTV2_SRC_HASH "unknown"
+#endif
+
 extern "C" const char *ptv2_build_info(void) {
-    return "libptv2_hip gfx950 (MI355X) hipcc " __VERSION__ " built " __DATE__;
+    return "libptv2_hip gfx950 (MI355X) src " PTV2_SRC_HASH " hipcc " __VERSION__ " built " __DATE__;
 }
 
 // ------------------------------------------------------- per-stream arrival counters --

@@ -955,7 +955,9 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     dim3 grid(chunks, tiles_o * tiles_i, batch);
     {
-        PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)chunks * cout * cin));
+        // algorithmic bytes, strict: every operand read once, every result written once (the split-K partial
+        // records of this implementation are its own overhead, not the op's)
+        PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0)));
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                            db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
     }
@@ -1006,7 +1008,15 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     dim3 grid(chunks, tiles_o * tiles_i, count);
     {
-        PtvScopedTimer t(KID_WGRAD, st, 4.0 * count * ((double)n * (cout + cin) + (double)chunks * cout * cin));
+        // algorithmic bytes, strict: gY[i] once each, every DISTINCT X once (q, k, v share theirs), dW / db once each
+        int distinct_x = 0;
+        for (int i = 0; i < count; ++i) {
+            bool seen = false;
+            for (int j = 0; j < i; ++j) seen |= m.X[j] == m.X[i] && m.xsc[j] == m.xsc[i];
+            distinct_x += !seen;
+        }
+        PtvScopedTimer t(KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
+                                               (double)count * cout * (cin + 1)));
         hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                            (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
     }

@@ -41,6 +41,7 @@ class LogitBasket:
                 self._arrays[k] = t.numpy()
             else:
                 self._arrays[k] = np.full((int(n), self.num_classes), self.fill, np.float32)
+        self._tensors = {k: torch.from_numpy(v) for k, v in self._arrays.items()}  # same memory
         self._max_rows = int(max_rows)
         self._slots = [self._new_slot() for _ in range(int(slots))]
         self._free = queue.Queue()
@@ -128,9 +129,12 @@ class LogitBasket:
             try:
                 if slot["done"] is not None:
                     slot["done"].synchronize()  # blocks this thread only
-                lg, ids = slot["logits"].numpy(), slot["ids"].numpy()
+                # the reference's statement `basket[k][ori_idx] = seg` (train_sam_real.py:234) as torch's index_copy_ on
+                # views of the same host arrays: unlike numpy's fancy assignment it runs WITHOUT the interpreter lock,
+                # so this thread does not stall the training thread's kernel launches (measured: 0.7 ms of a 15 ms
+                # step with the numpy form).  The ids of one crop are distinct, so the two forms agree.
                 for k, a, b in plan:
-                    self._arrays[k][ids[a:b]] = lg[a:b]  # the reference's statement (train_sam_real.py:234)
+                    self._tensors[k].index_copy_(0, slot["ids"][a:b], slot["logits"][a:b])
             except BaseException as e:  # surfaced by the next put() / flush()
                 self._error = e
             finally:

@@ -94,21 +94,40 @@ def algorithmic_step_bytes(levels, cfg):
     return total
 
 
-def pmc_traffic(kernel):
+def src_hash(build_info):
+    """The source digest inside ptv2_build_info() ("... src <12 hex> hipcc ...")."""
+    parts = build_info.split()
+    return parts[parts.index("src") + 1] if "src" in parts else None
+
+
+def pmc_traffic(kernel, build_info):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
     note of the microarchitecture guide, + WRITE_SIZE; tools/pmc_traffic.py).  Counters cannot be read from inside
-    this process, so the figure is the one measured with the same command and build under profiles/; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_per_launch.jsonl")
-    if not os.path.exists(path):
-        return None
-    base = kernel.split("<")[0]
-    for line in open(path):
-        rec = json.loads(line)
-        for name, v in rec.items():
-            short = name.split("::")[-1]
-            if short == kernel or (short.split("<")[0] == base and "<" not in kernel):
-                return 1e6 * (v["fetch_x2_MB_per_launch"] + v["write_MB_per_launch"])
-    return None
+    this process, so the figure is the one measured with the same command under profiles/ -- accepted only when the
+    profile's first line carries the source digest of THIS build of the library; (None, why) otherwise."""
+    import glob
+
+    want = src_hash(build_info)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_per_launch.jsonl")), reverse=True)
+    stale = []
+    for path in files:
+        recs = [json.loads(line) for line in open(path) if line.strip()]
+        stamp = next((r["_build"] for r in recs if "_build" in r), None)
+        if stamp is None or src_hash(stamp) != want:
+            stale.append(os.path.basename(path))
+            continue
+        base = kernel.split("<")[0]
+        for rec in recs:
+            for name, v in rec.items():
+                if name == "_build":
+                    continue
+                short = name.split("::")[-1]
+                if short == kernel or (short.split("<")[0] == base and "<" not in kernel):
+                    return (1e6 * (v["fetch_x2_MB_per_launch"] + v["write_MB_per_launch"]),
+                            "bytes/launch, profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                            "same library build %s)" % (os.path.basename(path), want))
+        return None, "profiles/%s is of this build but does not list %s" % (os.path.basename(path), kernel)
+    return None, "no PMC profile of this build (src %s) under profiles/ (other builds: %s)" % (want, ", ".join(stale) or "none")
 
 
 def op_microbench(data):
@@ -133,6 +152,13 @@ def op_microbench(data):
         return a.elapsed_time(b) * 1e3 / reps
 
     out = {"knn_k16_self_us_per_query": timed(lambda: pointops.knn_query_dist2(16, xyz, off), 10) / n}
+    # against the fp32 VALU peak.  The reference kernel evaluates every (query, point-of-its-cloud) pair
+    # (knn_query_cuda_kernel.cu:88-97), ~8 flop each; the grid method returns the same table while visiting a small
+    # fraction of them, so this is the brute-force-EQUIVALENT pair rate (it may exceed what the VALU could evaluate)
+    sizes = torch.diff(off.long(), prepend=off.new_zeros(1).long()).double()
+    pairs = float((sizes * sizes).sum())
+    out["knn_k16_self_bruteforce_equiv_pairs_per_s"] = pairs / (out["knn_k16_self_us_per_query"] * n * 1e-6)
+    out["knn_k16_self_equiv_frac_of_fp32_valu_peak"] = out["knn_k16_self_bruteforce_equiv_pairs_per_s"] * 8 / 157.3e12
     if off.numel() == 1:
         coarse = xyz[::6].contiguous()
         coff = torch.tensor([coarse.shape[0]], dtype=torch.int32, device=xyz.device)
@@ -390,6 +416,7 @@ def child_main(args):
             geo = seg.backbone.geometry(data["coord"], data["offset"])
         levels = [int(lv.coord.shape[0]) for lv in geo.levels]
         ms = 1e3 * elapsed / args.steps
+        build_info = _lib.lib().ptv2_build_info().decode()
         out = {
             "metric": "points/sec fwd+bwd PTv2m2 S3DIS" if args.cfg == "s3dis" else "points/sec fwd+bwd PTv2m2 ScanNet cfg", "value": points_per_step * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -409,7 +436,7 @@ def child_main(args):
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
                        "segmentor": "DefaultSegmentorSAM_Image + LogitBasket (%d puts, %d waits for a staging slot)"
                                     % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",
-                       "loss": float(loss.detach())},
+                       "loss": float(loss.detach()), "library_build": "src " + str(src_hash(build_info))},
         }
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
@@ -421,10 +448,10 @@ def child_main(args):
                 # over the timed region
                 name, rec = dominant, summ[dominant]
                 achieved = rec["bytes_per_launch"] / (rec["avg_us"] * 1e-6) / 1e9
+                traffic, traffic_source = pmc_traffic(name, build_info)
                 out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name),
-                                   "traffic_source": "bytes/launch, profiles/r01_final_pmc_traffic_per_launch.jsonl "
-                                                     "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                   "traffic_source": traffic_source,
                                    "avg_us": rec["avg_us"], "launches_timed": rec["launches"],
                                    "ms_per_step": 3 * rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],

@@ -1,0 +1,156 @@
+"""Full-size TRAIN-mode parity: the kernels bench.py times at BASELINE.json configs[1] take
+size-dependent branches -- attention_bwd_point_kernel<6,48,1> on its co-resident 512-workgroup grid, the
+2 048-workgroup-capped row kernels, the 24 000-workgroup aggregate_tile_kernel<6> -- that the fixture-sized parity
+tests (N <= 6 000) never reach.  Here, at N = 120 000 and 2 x 80 000 points, train mode, drop_path 0:
+
+  * one S0 Block (C 48, G 6) and the whole S3DIS model, fused native runtime (what the bench runs) against
+    AO_AMD_GVA=unfused -- the literal `pointops.grouping`-based op sequence of the reference
+    (point_transformer_v2m2_base.py:103-129), itself pinned to the reference nn.Module fixtures at small N
+    (tests/test_gpu_model.py, gva_mode "unfused"): output 1e-4 (north_star), input gradient and EVERY parameter
+    gradient in relative L2;
+  * the whole model against the CPU oracle (oracle/ptv2_ref.py) on a 24 000-point scene, whose deeper levels have the
+    row counts of the bench's deep stages (3 700 / 900 / 220 points).
+
+Tolerances: forward 1e-4 absolute on O(1) features (logits: 2e-4 + 1e-3 relative through 15 blocks, the bound the
+fixture tests use); gradients: relative L2 5e-3 per Block, 3e-2 through the whole model (a 1e-6 difference flips ReLU
+masks and moves whole terms); biases with an exactly-zero true gradient (in front of a training-mode BatchNorm / softmax)
+only have to be negligible next to their weight's gradient."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ptv2_ref as M
+
+pytestmark = pytest.mark.gpu
+
+ZERO_GRAD_BIAS = ("linear_q.0.bias", "linear_k.0.bias", "linear_v.bias", "linear_p_bias.0.bias", "linear_p_bias.3.bias",
+                  "weight_encoding.0.bias", "weight_encoding.3.bias", "proj.0.bias", "proj_skip.0.bias", "seg_head.0.bias")
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _scene(seeds, points):
+    from ao_amd import synth
+
+    b = synth.scene_batch(seeds, point_max=points, room=1)
+    return {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+
+
+def _compare_grads(names, got, ref, rel_l2, weights=None):
+    worst = ("", 0.0)
+    for nm, a, b in zip(names, got, ref):
+        if nm.endswith(ZERO_GRAD_BIAS):
+            scale = float(weights[nm].double().norm()) if weights and nm in weights else float(b.double().norm()) + 1.0
+            assert float(a.double().norm()) <= 2e-2 * scale + 1e-3, (nm, float(a.norm()), scale)
+            continue
+        r = rel(a, b)
+        if r > worst[1]:
+            worst = (nm, r)
+        assert r < rel_l2 or float((a - b).abs().max()) < 1e-5, (nm, r, float((a - b).abs().max()))
+    return worst
+
+
+@pytest.mark.parametrize("seeds,points", [((0,), 120000), ((4, 5), 80000)])
+def test_full_size_block_forward_backward_matches_unfused(monkeypatch, seeds, points):
+    import ao_amd.ptv2 as ptv2
+    from ao_amd import pointops
+    from ao_amd.ptv2 import block as native
+    from tests.test_gpu_block import _block_pair
+
+    data = _scene(seeds, points)
+    coord, offset = data["coord"], data["offset"].int()
+    n = coord.shape[0]
+    assert n >= 0.9 * points * len(seeds)
+    idx, _ = pointops.knn_query(16, coord, offset)
+    torch.manual_seed(11)
+    x0 = torch.randn(n, 48, device="cuda").relu_()
+    go = torch.randn(n, 48, device="cuda")
+    blk_f, blk_u = _block_pair(48, 6, 0.0, seed=4)
+    res = {}
+    for tag, blk in (("fused", blk_f), ("unfused", blk_u)):
+        monkeypatch.setenv("AO_AMD_GVA", tag)
+        monkeypatch.setenv("AO_AMD_BLOCK", "native")
+        blk.train()
+        x = x0.clone().requires_grad_(True)
+        if tag == "fused":
+            assert native.supported(blk, x, idx)  # the one-call runtime the bench times
+        y = blk([coord, x, offset], idx)[1]
+        grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+        res[tag] = (y.detach(), grads, {k: v.clone() for k, v in blk.state_dict().items()})
+        del y, x
+    y_f, g_f, sd_f = res["fused"]
+    y_u, g_u, sd_u = res["unfused"]
+    np.testing.assert_allclose(y_f.cpu().numpy(), y_u.cpu().numpy(), rtol=0, atol=1e-4)
+    names = ["x"] + [nm for nm, _ in blk_f.named_parameters()]
+    weights = {nm: g for nm, g in zip(names, g_u)}
+    weights = {nm: weights.get(nm[:-4] + "weight", weights[nm]) for nm in names}
+    worst = _compare_grads(names, g_f, g_u, 5e-3, weights)
+    print("block %s x %d: max |dy| %.2e, worst gradient %s rel L2 %.2e" % (seeds, points, float((y_f - y_u).abs().max()), *worst))
+    for key in sd_u:  # BatchNorm running statistics after the training forward
+        np.testing.assert_allclose(sd_f[key].cpu().numpy(), sd_u[key].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
+
+
+@pytest.mark.parametrize("seeds,points", [((0,), 120000), ((4, 5), 80000)])
+def test_full_size_model_train_step_matches_unfused(monkeypatch, seeds, points):
+    import ao_amd.ptv2 as ptv2
+
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    data = _scene(seeds, points)
+    state = M.init_state(cfg, seed=13)
+    res = {}
+    for tag in ("fused", "unfused"):
+        monkeypatch.setenv("AO_AMD_GVA", tag)
+        model = ptv2.PointTransformerV2(**cfg).cuda().train()
+        model.load_state_dict(state, strict=True)
+        logits = model(data)
+        loss = F.cross_entropy(logits, data["segment"], ignore_index=-1)
+        names = [nm for nm, _ in model.named_parameters()]
+        grads = torch.autograd.grad(loss, list(model.parameters()))
+        res[tag] = (logits.detach(), float(loss.detach()), names, grads)
+        del model, logits, loss
+        torch.cuda.empty_cache()
+    lf, loss_f, names, gf = res["fused"]
+    lu, loss_u, _, gu = res["unfused"]
+    assert abs(loss_f - loss_u) < 2e-5
+    np.testing.assert_allclose(lf.cpu().numpy(), lu.cpu().numpy(), rtol=1e-3, atol=2e-4)
+    weights = {nm: g for nm, g in zip(names, gu)}
+    weights = {nm: weights.get(nm[:-4] + "weight", weights[nm]) for nm in names}
+    worst = _compare_grads(names, gf, gu, 3e-2, weights)
+    print("model %s x %d: max |dlogit| %.2e, loss %.6f / %.6f, worst gradient %s rel L2 %.2e"
+          % (seeds, points, float((lf - lu).abs().max()), loss_f, loss_u, *worst))
+
+
+def test_model_train_step_matches_the_oracle_at_24k_points():
+    """Whole model, train mode, against the CPU oracle: 24 000 points give level sizes ~(24 000, 3 700, 900, 220), the
+    row counts of the bench's deep stages -- logits, loss and every parameter gradient."""
+    import ao_amd.ptv2 as ptv2
+    from ao_amd import synth
+
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    b = synth.scene_batch([6], point_max=24000, room=1)
+    cpu = {k: torch.from_numpy(v) for k, v in b.items()}
+    gpu = {k: v.cuda() for k, v in cpu.items()}
+    state = M.init_state(cfg, seed=21)
+    model = ptv2.PointTransformerV2(**cfg).cuda().train()
+    model.load_state_dict(state, strict=True)
+    logits = model(gpu)
+    loss = F.cross_entropy(logits, gpu["segment"], ignore_index=-1)
+    names = [nm for nm, _ in model.named_parameters()]
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    ref = M.RefModule(cfg, seed=21, randomize_bn=True).train()
+    ref_logits = ref(cpu)
+    ref_loss = F.cross_entropy(ref_logits, cpu["segment"], ignore_index=-1)
+    ref_params = dict(ref.named_parameters())
+    ref_grads = torch.autograd.grad(ref_loss, [ref_params[nm.replace(".", "/")] for nm in names])
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref_logits.detach().numpy(), rtol=1e-3, atol=2e-4)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-5
+    got = [g.cpu() for g in grads]
+    weights = {nm: g for nm, g in zip(names, ref_grads)}
+    weights = {nm: weights.get(nm[:-4] + "weight", weights[nm]) for nm in names}
+    worst = _compare_grads(names, got, list(ref_grads), 3e-2, weights)
+    print("oracle 24k: max |dlogit| %.2e, worst gradient %s rel L2 %.2e"
+          % (float((logits.detach().cpu() - ref_logits.detach()).abs().max()), *worst))

@@ -49,7 +49,8 @@ def test_sam_image_segmentor_and_async_basket_match_the_reference(golden):
         np.testing.assert_allclose(basket[k], ref, rtol=1e-3, atol=2e-4)
         assert np.array_equal(basket[k][ids.cpu().numpy()], lg.cpu().numpy())  # bit-for-bit what the model produced
     basket.close()
-    seg.eval()
+    seg.backbone.load_state_dict(M.init_state(dict(M.S3DIS_CFG, drop_path_rate=0.0), seed=int(g["state_seed"])), strict=True)
+    seg.eval()  # (running statistics reset, as the fixture's generator does before its eval pass)
     with torch.no_grad():
         ev = seg(batch)
         te = seg({k: v for k, v in batch.items() if k != "segment"})

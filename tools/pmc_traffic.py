@@ -2,8 +2,13 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), per launch.
 Units and corrections as guides/MI355X_MICROARCH.md (HBM section): counters are in KiB; on gfx950 FETCH_SIZE
 reports half of the bytes of wide coalesced reads, so the read side is doubled (upper bound for narrow reads).
+The first output line is {"_build": ptv2_build_info()} of the library in this tree: bench.py accepts the profile for
+its roofline.traffic only when that source digest equals the running build's.
 usage: tools/pmc_traffic.py <dir_fetch> <dir_write> [name substrings...]"""
-import csv, glob, sys, collections, json
+import csv, glob, sys, collections, json, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ao_amd import _lib
+print(json.dumps({"_build": _lib.lib().ptv2_build_info().decode()}))
 
 def load(d, counter):
     f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
