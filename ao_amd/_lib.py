@@ -58,6 +58,7 @@ _SIGNATURES = {
     "grid_sample_keys_hip_launcher": (_c_int, [_c_int, _vp] + [ctypes.c_float] * 3 + [_c_int] + [_vp] * 4),
     "center_dist2_hip_launcher": (_c_int, [_c_int] + [_vp] * 4),
     "seg_confusion_hip_launcher": (_c_int, [ctypes.c_longlong, _c_int, _c_int, _vp, ctypes.c_longlong] + [_vp] * 4),
+    "basket_scatter_rows_host": (_c_int, [_vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _c_int]),
     "cross_entropy_workspace_bytes": (_c_size, [_c_int]),
     "cross_entropy_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "cross_entropy_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [_c_int] + [_vp] * 5),

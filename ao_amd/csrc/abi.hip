@@ -1,4 +1,5 @@
 // ao_amd/csrc/abi.hip -- library identification and the optional per-kernel timer (host only).
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -13,6 +14,21 @@ extern "C" int ptv2_abi_version(void) { return 2; }  // == EXPECTED_ABI in ao_am
 
 extern "C" const char *ptv2_build_info(void) {
     return "libptv2_hip gfx950 (MI355X) src " PTV2_SRC_HASH " hipcc " __VERSION__ " built " __DATE__;
+}
+
+// ------------------------------------------------------------ logit basket (host) --
+// dst[ids[r], :] = src[r, :] for r in [0, rows): the trainer statement `basket[k][ori_idx] = seg`
+// (pointcept/engines/train_sam_real.py:234) on host memory, called by ao_amd/ptv2/basket.py's worker thread through
+// ctypes (which drops the interpreter lock for the call, so the training thread keeps launching kernels).  Rows are
+// written in ascending r (a repeated id keeps its LAST row, as numpy's assignment does).  Returns PTV2_ERR_ARG, writing
+// nothing, if an id is outside [0, dst_rows).
+extern "C" int basket_scatter_rows_host(float *dst, long long dst_rows, const long long *ids, const float *src, long long rows,
+                                        int c) {
+    if (!dst || !ids || !src || rows < 0 || c < 1 || dst_rows < 0) return PTV2_ERR_ARG;
+    for (long long r = 0; r < rows; ++r)
+        if (ids[r] < 0 || ids[r] >= dst_rows) return PTV2_ERR_ARG;
+    for (long long r = 0; r < rows; ++r) memcpy(dst + ids[r] * c, src + r * c, sizeof(float) * (size_t)c);
+    return PTV2_OK;
 }
 
 // ------------------------------------------------------- per-stream arrival counters --

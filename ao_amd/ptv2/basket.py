@@ -41,7 +41,9 @@ class LogitBasket:
                 self._arrays[k] = t.numpy()
             else:
                 self._arrays[k] = np.full((int(n), self.num_classes), self.fill, np.float32)
-        self._tensors = {k: torch.from_numpy(v) for k, v in self._arrays.items()}  # same memory
+        from .. import _lib
+
+        self._scatter = _lib.lib().basket_scatter_rows_host
         self._max_rows = int(max_rows)
         self._slots = [self._new_slot() for _ in range(int(slots))]
         self._free = queue.Queue()
@@ -129,12 +131,18 @@ class LogitBasket:
             try:
                 if slot["done"] is not None:
                     slot["done"].synchronize()  # blocks this thread only
-                # the reference's statement `basket[k][ori_idx] = seg` (train_sam_real.py:234) as torch's index_copy_ on
-                # views of the same host arrays: unlike numpy's fancy assignment it runs WITHOUT the interpreter lock,
-                # so this thread does not stall the training thread's kernel launches (measured: 0.7 ms of a 15 ms
-                # step with the numpy form).  The ids of one crop are distinct, so the two forms agree.
+                # the reference's statement `basket[k][ori_idx] = seg` (train_sam_real.py:234) as one native call per
+                # scene (ao_amd/csrc/abi.hip: basket_scatter_rows_host).  ctypes drops the interpreter lock for the
+                # call, so this thread does not stall the training thread's kernel launches: numpy's fancy assignment
+                # holds the lock (measured +0.7 ms on a 15 ms step), torch's index_copy_ from a second thread starts a
+                # second OpenMP team (measured 53 ms per step on a 128-core host).
+                lg_ptr, id_ptr = slot["logits"].data_ptr(), slot["ids"].data_ptr()
                 for k, a, b in plan:
-                    self._tensors[k].index_copy_(0, slot["ids"][a:b], slot["logits"][a:b])
+                    arr = self._arrays[k]
+                    rc = self._scatter(arr.ctypes.data, arr.shape[0], id_ptr + 8 * a, lg_ptr + 4 * self.num_classes * a,
+                                       b - a, self.num_classes)
+                    if rc != 0:
+                        raise IndexError("scene %r: an original point id is outside [0, %d)" % (k, arr.shape[0]))
             except BaseException as e:  # surfaced by the next put() / flush()
                 self._error = e
             finally:

@@ -495,6 +495,13 @@ int cross_entropy_backward_hip_launcher(int n, int c, const float *logits, const
                                         const float *lse, const float *g_loss, const float *count, float *g_logits,
                                         void *stream);
 
+/* ------------------------------------------------- REAL's logit basket (host memory) --
+ * dst (dst_rows, c) fp32 HOST array of one whole scene; dst[ids[r], :] = src[r, :] for r = 0 .. rows-1 in that order:
+ * the trainer statement `self.basket[k][ori_idx] = seg` (pointcept/engines/train_sam_real.py:234).  ids int64, src
+ * (rows, c) fp32, both host (pinned staging of ao_amd/ptv2/basket.py).  No GPU work, no stream; PTV2_ERR_ARG and nothing
+ * written when an id is outside [0, dst_rows). */
+int basket_scatter_rows_host(float *dst, long long dst_rows, const long long *ids, const float *src, long long rows, int c);
+
 /* ------------------------------------------------------ optimizer step --
  * torch.optim.AdamW (lr 0.006, weight_decay 0.05 in configs/s3dis/semseg-pt-v2m2-0-base.py:41) over one flat fp32
  * buffer of all parameters: p, g, m (exp_avg), v (exp_avg_sq) of n floats, n % 4 == 0; step counts from 1;
