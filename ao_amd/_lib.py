@@ -20,6 +20,7 @@ _c_int, _c_size, _vp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p
 _SIGNATURES = {
     "ptv2_abi_version": (_c_int, []),
     "ptv2_build_info": (ctypes.c_char_p, []),
+    "ptv2_struct_bytes": (ctypes.c_longlong, [_c_int]),
     "ptv2_profile_enable": (_c_int, [_c_int]),
     "ptv2_profile_select": (_c_int, [_c_int]),
     "ptv2_profile_stride": (_c_int, [_c_int]),
@@ -88,7 +89,7 @@ _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace 
 _lib = None
 # bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
 # mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
-EXPECTED_ABI = 2
+EXPECTED_ABI = 3
 
 
 def build(verbose=False):
@@ -127,6 +128,14 @@ def lib():
                                "`make -C ao_amd/csrc`" % (LIB_PATH, have, EXPECTED_ABI))
         _lib = handle
     return _lib
+
+
+def check_struct(which, mirror):
+    """A ctypes mirror of a C struct must have the size the library was compiled with."""
+    have, want = lib().ptv2_struct_bytes(which), ctypes.sizeof(mirror)
+    if have != want:
+        raise RuntimeError("ao_amd: %s is %d bytes in python, %d in %s (stale build or a drifted mirror)"
+                           % (mirror.__name__, want, have, LIB_PATH))
 
 
 def check(status, what):

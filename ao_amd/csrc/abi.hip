@@ -6,7 +6,18 @@
 
 #include "common.h"
 
-extern "C" int ptv2_abi_version(void) { return 2; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 3; }  // == EXPECTED_ABI in ao_amd/_lib.py
+
+// sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
+// layout drift between the header and a python mirror is an import error, not a misread pointer
+extern "C" long long ptv2_struct_bytes(int which) {
+    switch (which) {
+        case 0: return (long long)sizeof(ptv2_block);
+        case 1: return (long long)sizeof(ptv2_block_grads);
+        case 2: return (long long)sizeof(ptv2_model);
+        default: return -1;
+    }
+}
 
 #ifndef PTV2_SRC_HASH
 #define PTV2_SRC_HASH "unknown"

@@ -250,7 +250,7 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
 
 extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_block_grads *G, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
-    if (!args_ok(B) || !G || !G->gy || !G->gx || !G->gparam) return PTV2_ERR_ARG;
+    if (!args_ok(B) || !G || !G->gy || !G->gx) return PTV2_ERR_ARG;
     const int n = B->n, k = B->k, c = B->c, g = B->g;
     const Saved S = carve_saved(B->saved, n, k, c, g);
     if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;
@@ -259,8 +259,11 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     const float *const *P = B->param;
     long long off[PTV2_BLK_NPARAM + 1];
     (void)ptv2_block_param_layout(c, g, off);
-    auto GP = [&](int i) { return G->gparam + off[i]; };
-    auto GPB = [&](int i) { return P[i] ? G->gparam + off[i] : (float *)nullptr; };  // optional biases
+    // gradient destinations: slots of one flat buffer (ptv2_block_param_layout), or one pointer per parameter
+    auto GP = [&](int i) { return G->gparam ? G->gparam + off[i] : G->gp[i]; };
+    auto GPB = [&](int i) { return P[i] ? GP(i) : (float *)nullptr; };  // optional biases
+    for (int i = 0; i < PTV2_BLK_NPARAM; ++i)
+        if (P[i] && !GP(i)) return PTV2_ERR_ARG;
     int batch[PTV2_BLK_NBN];
     for (int i = 0; i < PTV2_BLK_NBN; ++i) batch[i] = (B->training || !B->run_mean[i] || !B->run_var[i]) ? 1 : 0;
     // gradient tensors; g_h3, g_hq, g_hk, gv, g_h1 are also the gY operands of the five (c,c) weight gradients, which run

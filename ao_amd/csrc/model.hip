@@ -1,0 +1,449 @@
+// ao_amd/csrc/model.hip -- PointTransformerV2.forward / backward (point_transformer_v2m2_base.py:556-576) as ONE native
+// call per direction.
+//
+//   forward:   x = ReLU(BN(feat We^T))                               GVAPatchEmbed.proj (:424-428, :441-444)
+//              x = blocks(seq 0)                                     patch_embed.blocks
+//              for i in 0..S-1:  d = ReLU(BN(x Wd^T)); x = segment-max of d over the voxels of level i (GridPool :244-269)
+//                                x = blocks(seq 1+i);  skip[i+1] = x
+//              for i in S-1..0:  u = ReLU(BN(x Wu^T + bu)); s = ReLU(BN(skip[i] Ws^T + bs))
+//                                x = interp(u) + s   or   u[cluster] + s      (UnpoolWithSkip :305-316)
+//                                x = blocks(seq 1+S+i)
+//              logits = ReLU(BN(x Wh^T + bh)) Wc^T + bc                       (seg_head :545-554)
+//   backward:  the same chain reversed.  The gradient of a skip tensor has two contributions (the decoder's proj_skip and
+//              the encoder's GridPool.fc); the second is added by the row GEMM's accumulate epilogue.
+//
+// Every kernel is enqueued on the caller's stream from here (block.hip runs the Blocks); nothing synchronises, nothing is
+// allocated: activations live in the caller-owned `saved` arena (288 GB of HBM: nothing is recomputed), temporaries in
+// the caller's workspace.  Parameter gradients go straight to the destinations named in the ptv2_model (slots of the
+// optimizer's flat gradient buffer in ao_amd/ptv2/native_model.py): no per-parameter tensors, no flatten copy.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// y[r, o] = sum_i x[r, i] W[o, i] + b[o] for a narrow side (cin or cout not a multiple of 4, or tiny): the patch embedding's
+// Linear(in_channels = 6 or 9, c0) and the classifier Linear(c0, num_classes = 13 or 20).  One thread per output element,
+// W and b in LDS; the x row of a thread is shared with its cout neighbours through L1.
+__global__ __launch_bounds__(TPB) void small_linear_fwd_kernel(long long n, int cin, int cout, const float *__restrict__ x,
+                                                               const float *__restrict__ W, const float *__restrict__ b,
+                                                               float *__restrict__ y) {
+    extern __shared__ float lds[];
+    float *w = lds, *bias = lds + (size_t)cout * cin;
+    for (int e = threadIdx.x; e < cout * cin; e += TPB) w[e] = W[e];
+    for (int e = threadIdx.x; e < cout; e += TPB) bias[e] = b ? b[e] : 0.f;
+    __syncthreads();
+    const long long total = n * cout;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long r = e / cout;
+        const int o = (int)(e - r * cout);
+        const float *xr = x + r * cin, *wr = w + (size_t)o * cin;
+        float acc = bias[o];
+        for (int i = 0; i < cin; ++i) acc = __builtin_fmaf(xr[i], wr[i], acc);
+        y[e] = acc;
+    }
+}
+
+// gx[r, i] = sum_o gy[r, o] W[o, i]: the input gradient of the classifier
+__global__ __launch_bounds__(TPB) void small_linear_bwd_kernel(long long n, int cin, int cout, const float *__restrict__ gy,
+                                                               const float *__restrict__ W, float *__restrict__ gx) {
+    extern __shared__ float lds[];
+    for (int e = threadIdx.x; e < cout * cin; e += TPB) lds[e] = W[e];
+    __syncthreads();
+    const long long total = n * cin;
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+        const long long r = e / cin;
+        const int i = (int)(e - r * cin);
+        const float *g = gy + r * cout;
+        float acc = 0.f;
+        for (int o = 0; o < cout; ++o) acc = __builtin_fmaf(g[o], lds[(size_t)o * cin + i], acc);
+        gx[e] = acc;
+    }
+}
+
+// out[i, :] += u[cluster[i], :]: the "map" unpool onto the skip branch (:309-310, :315)
+__global__ __launch_bounds__(TPB) void gather_add_rows_kernel(long long total4, int c4, const float4 *__restrict__ u,
+                                                              const long long *__restrict__ cluster, float4 *out) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total4; e += (long long)gridDim.x * TPB) {
+        const long long r = e / c4;
+        const int q = (int)(e - r * c4);
+        const float4 a = u[cluster[r] * c4 + q];
+        float4 o = out[e];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        out[e] = o;
+    }
+}
+
+__global__ void bn_eval_moments_kernel(int c, const float *__restrict__ rm, const float *__restrict__ rv, float eps,
+                                       float *__restrict__ mean, float *__restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        mean[i] = rm[i];
+        rstd[i] = 1.0f / sqrtf(rv[i] + eps);
+    }
+}
+
+int grid_for(long long total) { return (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 8); }
+
+struct LinBnSaved {
+    float *h, *y, *mean, *rstd;  // pre-BatchNorm rows, ReLU(BN(h)), batch (or running) moments
+};
+
+struct Arena {  // the `saved` buffer of one forward
+    LinBnSaved embed, down[PTV2_MAX_STAGES], up[PTV2_MAX_STAGES], up_skip[PTV2_MAX_STAGES], head;
+    float *pooled[PTV2_MAX_STAGES];  // (n_{i+1}, c_{i+1})
+    int *arg[PTV2_MAX_STAGES];       // arg-max rows of the pooling
+    float *block_y[PTV2_MAX_BLOCKS];
+    char *block_saved[PTV2_MAX_BLOCKS];
+    size_t block_saved_bytes[PTV2_MAX_BLOCKS];
+    size_t bytes;
+};
+
+bool model_ok(const ptv2_model *M) {
+    if (!M || M->num_stages < 1 || M->num_stages > PTV2_MAX_STAGES || M->num_blocks < 1 || M->num_blocks > PTV2_MAX_BLOCKS)
+        return false;
+    if (M->in_channels < 1 || M->num_classes < 1 || M->in_channels > 64 || M->num_classes > 256) return false;
+    const int S = M->num_stages;
+    for (int i = 0; i <= S; ++i)
+        if (M->level[i].n < 2 || !M->level[i].coord) return false;
+    for (int q = 0; q <= 2 * S; ++q) {
+        const ptv2_seq &s = M->seq[q];
+        if (s.depth < 0 || s.first_block < 0 || s.first_block + s.depth > M->num_blocks || s.level < 0 || s.level > S) return false;
+        if (s.depth > 0 && (!s.idx || s.c < 4 || s.g < 1 || s.k < 1)) return false;
+    }
+    if (M->embed.cin != M->in_channels || (M->seq[0].depth > 0 && M->embed.cout != M->seq[0].c)) return false;
+    return M->feat && M->logits && M->head_w;
+}
+
+Arena carve(const ptv2_model *M, void *base) {
+    Arena A;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    auto linbn = [&](const ptv2_linbn &L, int n, bool keep_y) {
+        LinBnSaved s;
+        s.h = (float *)take(sizeof(float) * (size_t)n * L.cout);
+        s.y = keep_y ? (float *)take(sizeof(float) * (size_t)n * L.cout) : nullptr;
+        s.mean = (float *)take(sizeof(float) * L.cout);
+        s.rstd = (float *)take(sizeof(float) * L.cout);
+        return s;
+    };
+    const int S = M->num_stages;
+    A.embed = linbn(M->embed, M->level[0].n, true);
+    for (int i = 0; i < S; ++i) {
+        A.down[i] = linbn(M->down[i], M->level[i].n, true);
+        A.pooled[i] = (float *)take(sizeof(float) * (size_t)M->level[i + 1].n * M->down[i].cout);
+        A.arg[i] = (int *)take(sizeof(int) * (size_t)M->level[i + 1].n * M->down[i].cout);
+        A.up[i] = linbn(M->up[i], M->level[i + 1].n, true);
+        A.up_skip[i] = linbn(M->up_skip[i], M->level[i].n, true);  // y = the unpool output (skip branch + unpooled rows)
+    }
+    A.head = linbn(M->head, M->level[0].n, true);
+    for (int q = 0; q <= 2 * S; ++q) {
+        const ptv2_seq &s = M->seq[q];
+        const int n = M->level[s.level].n;
+        for (int j = 0; j < s.depth; ++j) {
+            const int b = s.first_block + j;
+            A.block_y[b] = (float *)take(sizeof(float) * (size_t)n * s.c);
+            A.block_saved_bytes[b] = ptv2_block_saved_bytes(n, s.k, s.c, s.g);
+            A.block_saved[b] = take(A.block_saved_bytes[b]);
+        }
+    }
+    A.bytes = off;
+    return A;
+}
+
+struct Work {
+    char *block; size_t block_bytes;   // workspace of the Block runtime
+    char *dense; size_t dense_bytes;   // BatchNorm / weight-gradient partial records
+    float *ga, *gb, *gc;               // gradient temporaries, max over levels of n * widest channel count
+    float *gskip[PTV2_MAX_STAGES + 1]; // gradient of the encoder output at level i (two contributions)
+    size_t bytes;
+};
+
+Work carve_work(const ptv2_model *M, void *base) {
+    Work W;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    const int S = M->num_stages;
+    W.block_bytes = 0;
+    size_t widest = 0;
+    W.dense_bytes = 0;
+    for (int q = 0; q <= 2 * S; ++q) {
+        const ptv2_seq &s = M->seq[q];
+        if (s.depth < 1) continue;
+        const int n = M->level[s.level].n;
+        W.block_bytes = std::max(W.block_bytes, ptv2_block_workspace_bytes(n, s.k, s.c, s.g));
+        widest = std::max(widest, (size_t)n * s.c);
+    }
+    auto note = [&](const ptv2_linbn &L, int n) {
+        widest = std::max(widest, (size_t)n * std::max(L.cin, L.cout));
+        W.dense_bytes = std::max(W.dense_bytes, dense_workspace_bytes(n, std::max(L.cin, L.cout), std::max(L.cin, L.cout)));
+    };
+    note(M->embed, M->level[0].n);
+    note(M->head, M->level[0].n);
+    for (int i = 0; i < S; ++i) {
+        note(M->down[i], M->level[i].n);
+        note(M->up[i], M->level[i + 1].n);
+        note(M->up_skip[i], M->level[i].n);
+    }
+    W.dense_bytes = std::max(W.dense_bytes, dense_workspace_bytes(M->level[0].n, std::max(M->num_classes, M->head.cout),
+                                                                  std::max(M->in_channels, M->head.cout)));
+    W.block = take(W.block_bytes);
+    W.dense = take(W.dense_bytes);
+    W.ga = (float *)take(sizeof(float) * widest);
+    W.gb = (float *)take(sizeof(float) * widest);
+    W.gc = (float *)take(sizeof(float) * widest);
+    for (int i = 0; i <= S; ++i) {
+        const int c = i == 0 ? M->embed.cout : M->down[i - 1].cout;
+        W.gskip[i] = (float *)take(sizeof(float) * (size_t)M->level[i].n * c);
+    }
+    W.bytes = off;
+    return W;
+}
+
+#define RUN(call)                        \
+    do {                                 \
+        int rc_ = (call);                \
+        if (rc_ != PTV2_OK) return rc_;  \
+    } while (0)
+
+bool use_batch(const ptv2_model *M, const ptv2_linbn &L) { return M->training || !L.run_mean || !L.run_var; }
+
+// h = x W^T + b (row GEMM, or the narrow kernel when cin is not a multiple of 4); y = ReLU(BN(h)).  `y` may differ from
+// the arena slot (the skip branch of the unpool writes the unpool's output buffer).
+int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S, int n, const float *x, float *y, const Work &W,
+                  void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (L.cin % 4 == 0 && L.cout % 4 == 0) {
+        RUN(rows_gemm_hip_launcher(n, L.cout, L.cin, x, L.w, 0, L.b, S.h, 0, stream));
+    } else {
+        const size_t lds = sizeof(float) * ((size_t)L.cout * L.cin + L.cout);
+        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(grid_for((long long)n * L.cout)), dim3(TPB), lds, st, (long long)n, L.cin,
+                           L.cout, x, L.w, L.b, S.h);
+    }
+    if (use_batch(M, L)) {
+        const bool track = M->training && L.run_mean && L.run_var;
+        RUN(bn_forward_hip_launcher(n, L.cout, S.h, L.gamma, L.beta, 1, S.mean, S.rstd, track ? L.run_mean : nullptr,
+                                    track ? L.run_var : nullptr, track ? L.batches : nullptr, M->eps, M->momentum, nullptr, nullptr,
+                                    y, W.dense, W.dense_bytes, stream));
+    } else {
+        hipLaunchKernelGGL(bn_eval_moments_kernel, dim3(divup(L.cout, 256)), dim3(256), 0, st, L.cout, (const float *)L.run_mean,
+                           (const float *)L.run_var, M->eps, S.mean, S.rstd);
+        RUN(bn_apply_hip_launcher(n, L.cout, S.h, S.mean, S.rstd, L.gamma, L.beta, 1, y, stream));
+    }
+    return PTV2_OK;
+}
+
+// gy (n,cout) -> BatchNorm + ReLU backward -> gh (tmp); dgamma, dbeta; dW, db from (gh, x); gx (n,cin) = gh W (+)= when
+// `accumulate`; gx == NULL: the input needs no gradient (the patch embedding)
+int linbn_backward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S, int n, const float *x, const float *gy, float *gh,
+                   float *gx, int accumulate, const Work &W, void *stream) {
+    RUN(bn_backward_hip_launcher(n, L.cout, S.h, gy, S.mean, S.rstd, L.gamma, L.beta, 1, use_batch(M, L) ? 1 : 0, gh, L.ggamma,
+                                 L.gbeta, W.dense, W.dense_bytes, stream));
+    if (gx) {
+        if (L.cin % 4 != 0 || L.cout % 4 != 0) return PTV2_ERR_ARG;
+        RUN(rows_gemm_hip_launcher(n, L.cin, L.cout, gh, L.w, 1, nullptr, gx, accumulate, stream));
+    }
+    RUN(linear_wgrad_hip_launcher(n, L.cout, L.cin, gh, x, L.gw, L.b ? L.gb : nullptr, W.dense, W.dense_bytes, stream));
+    return PTV2_OK;
+}
+
+void fill_block(const ptv2_model *M, int q, int j, const Arena &A, const float *x, ptv2_block *B) {
+    const ptv2_seq &s = M->seq[q];
+    const ptv2_level &lv = M->level[s.level];
+    const int b = s.first_block + j;
+    const ptv2_model_block &mb = M->block[b];
+    B->n = lv.n; B->k = s.k; B->c = s.c; B->g = s.g; B->training = M->training;
+    B->eps = M->eps; B->momentum = M->momentum;
+    B->x = x; B->coord = lv.coord; B->idx = s.idx; B->mu = s.mu; B->cov = s.cov; B->rowscale = M->training ? mb.rowscale : nullptr;
+    for (int i = 0; i < PTV2_BLK_NPARAM; ++i) B->param[i] = mb.param[i];
+    for (int i = 0; i < PTV2_BLK_NBN; ++i) {
+        B->run_mean[i] = mb.run_mean[i]; B->run_var[i] = mb.run_var[i]; B->batches[i] = mb.batches[i];
+    }
+    B->y = A.block_y[b]; B->saved = A.block_saved[b]; B->saved_bytes = A.block_saved_bytes[b];
+}
+
+// input of block j of sequence q = output of block j-1, or the sequence's input
+const float *seq_forward(const ptv2_model *M, int q, const Arena &A, const float *x, const Work &W, void *stream, int *rc) {
+    const ptv2_seq &s = M->seq[q];
+    for (int j = 0; j < s.depth; ++j) {
+        ptv2_block B;
+        fill_block(M, q, j, A, x, &B);
+        *rc = ptv2_block_forward_hip_launcher(&B, W.block, W.block_bytes, stream);
+        if (*rc != PTV2_OK) return nullptr;
+        x = B.y;
+    }
+    *rc = PTV2_OK;
+    return x;
+}
+
+// gy: gradient of the sequence's output, in one of the ping-pong buffers; returns the buffer holding the gradient of the
+// sequence's input (gx_first, when given, receives it directly: the last hop writes there)
+float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_in, float *gy, float *other, const Work &W,
+                    void *stream, int *rc) {
+    const ptv2_seq &s = M->seq[q];
+    for (int j = s.depth - 1; j >= 0; --j) {
+        ptv2_block B;
+        const float *x = j == 0 ? x_in : A.block_y[s.first_block + j - 1];
+        fill_block(M, q, j, A, x, &B);
+        ptv2_block_grads G{};
+        G.gy = gy; G.inv_ptr = s.inv_ptr; G.inv_rows = s.inv_rows; G.gx = other; G.gparam = nullptr;
+        for (int i = 0; i < PTV2_BLK_NPARAM; ++i) G.gp[i] = M->block[s.first_block + j].gparam[i];
+        *rc = ptv2_block_backward_hip_launcher(&B, &G, W.block, W.block_bytes, stream);
+        if (*rc != PTV2_OK) return nullptr;
+        std::swap(gy, other);
+    }
+    *rc = PTV2_OK;
+    return gy;
+}
+
+}  // namespace
+
+extern "C" size_t ptv2_model_saved_bytes(const ptv2_model *M) {
+    if (!model_ok(M)) return 0;
+    return carve(M, nullptr).bytes + 256;
+}
+
+extern "C" size_t ptv2_model_workspace_bytes(const ptv2_model *M) {
+    if (!model_ok(M)) return 0;
+    return carve_work(M, nullptr).bytes + 256;
+}
+
+extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!model_ok(M) || !M->saved) return PTV2_ERR_ARG;
+    const Arena A = carve(M, M->saved);
+    if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
+    const Work W = carve_work(M, workspace);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = M->num_stages;
+    int rc = PTV2_OK;
+    RUN(linbn_forward(M, M->embed, A.embed, M->level[0].n, M->feat, A.embed.y, W, stream));
+    const float *x = seq_forward(M, 0, A, A.embed.y, W, stream, &rc);
+    if (rc != PTV2_OK) return rc;
+    const float *skip[PTV2_MAX_STAGES + 1];
+    skip[0] = x;
+    for (int i = 0; i < S; ++i) {
+        const ptv2_level &lv = M->level[i];
+        if (!lv.order || !lv.idx_ptr) return PTV2_ERR_ARG;
+        RUN(linbn_forward(M, M->down[i], A.down[i], lv.n, x, A.down[i].y, W, stream));
+        RUN(pool_max_forward_hip_launcher(M->level[i + 1].n, M->down[i].cout, A.down[i].y, lv.order, lv.idx_ptr, A.pooled[i],
+                                          A.arg[i], stream));
+        x = seq_forward(M, 1 + i, A, A.pooled[i], W, stream, &rc);
+        if (rc != PTV2_OK) return rc;
+        skip[i + 1] = x;
+    }
+    for (int i = S - 1; i >= 0; --i) {
+        const ptv2_level &lv = M->level[i];
+        const int c = M->up[i].cout;
+        if (M->up_skip[i].cout != c || c % 4 != 0) return PTV2_ERR_ARG;
+        RUN(linbn_forward(M, M->up[i], A.up[i], M->level[i + 1].n, x, A.up[i].y, W, stream));
+        float *out = A.up_skip[i].y;  // skip branch first, the unpooled rows are added onto it
+        RUN(linbn_forward(M, M->up_skip[i], A.up_skip[i], lv.n, skip[i], out, W, stream));
+        if (M->interp) {
+            if (!lv.up_idx || !lv.up_w) return PTV2_ERR_ARG;
+            RUN(interpolation_forward_hip_launcher(lv.n, c, 3, A.up[i].y, lv.up_idx, lv.up_w, out, stream));
+        } else {
+            if (!lv.cluster) return PTV2_ERR_ARG;
+            const long long total4 = (long long)lv.n * (c / 4);
+            hipLaunchKernelGGL(gather_add_rows_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, total4, c / 4,
+                               (const float4 *)A.up[i].y, lv.cluster, (float4 *)out);
+        }
+        x = seq_forward(M, 1 + S + i, A, out, W, stream, &rc);
+        if (rc != PTV2_OK) return rc;
+    }
+    RUN(linbn_forward(M, M->head, A.head, M->level[0].n, x, A.head.y, W, stream));
+    {
+        const int c0 = M->head.cout, nc = M->num_classes;
+        const size_t lds = sizeof(float) * ((size_t)nc * c0 + nc);
+        hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(grid_for((long long)M->level[0].n * nc)), dim3(TPB), lds, st,
+                           (long long)M->level[0].n, c0, nc, (const float *)A.head.y, M->head_w, M->head_b, M->logits);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    if (!model_ok(M) || !M->saved || !g_logits || !M->g_head_w) return PTV2_ERR_ARG;
+    const Arena A = carve(M, M->saved);
+    if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
+    const Work W = carve_work(M, workspace);
+    if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = M->num_stages, n0 = M->level[0].n;
+    int rc = PTV2_OK;
+    // the sequences' inputs and outputs as the forward wired them
+    auto seq_out = [&](int q, const float *in) {
+        const ptv2_seq &s = M->seq[q];
+        return s.depth > 0 ? (const float *)A.block_y[s.first_block + s.depth - 1] : in;
+    };
+    const float *skip[PTV2_MAX_STAGES + 1];
+    skip[0] = seq_out(0, A.embed.y);
+    for (int i = 0; i < S; ++i) skip[i + 1] = seq_out(1 + i, A.pooled[i]);
+    const float *dec_in[PTV2_MAX_STAGES + 1];  // input of UnpoolWithSkip i = output of decoder stage i+1 (or the deepest skip)
+    dec_in[S] = skip[S];
+    for (int i = S - 1; i >= 0; --i) dec_in[i] = seq_out(1 + S + i, A.up_skip[i].y);  // dec_in[i] = output of decoder stage i
+
+    // Gradient buffers: ga / gb ping-pong along the chain, gc holds the gradient in front of a BatchNorm (the operand of
+    // the weight gradient), gskip[i] the gradient of the encoder output of level i.
+    float *const ga = W.ga, *const gb = W.gb, *const gc = W.gc;
+    // head: classifier, then Linear + BatchNorm + ReLU -> gb = gradient of decoder stage 0's output
+    {
+        const int c0 = M->head.cout, nc = M->num_classes;
+        hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(grid_for((long long)n0 * c0)), dim3(TPB), sizeof(float) * (size_t)nc * c0, st,
+                           (long long)n0, c0, nc, g_logits, M->head_w, ga);
+        RUN(linear_wgrad_hip_launcher(n0, nc, c0, g_logits, A.head.y, M->g_head_w, M->head_b ? M->g_head_b : nullptr, W.dense,
+                                      W.dense_bytes, stream));
+        RUN(linbn_backward(M, M->head, A.head, n0, dec_in[0], ga, gc, gb, 0, W, stream));
+    }
+    // decoder stages 0 .. S-1 (the forward ran them S-1 .. 0)
+    float *g = gb, *o = ga;
+    for (int i = 0; i < S; ++i) {
+        const ptv2_level &lv = M->level[i];
+        const int c = M->up[i].cout, n_coarse = M->level[i + 1].n;
+        float *gin = seq_backward(M, 1 + S + i, A, A.up_skip[i].y, g, o, W, stream, &rc);  // gradient of the unpool's output
+        if (rc != PTV2_OK) return rc;
+        float *spare = gin == g ? o : g;
+        // skip branch: first contribution to the gradient of skip[i]
+        RUN(linbn_backward(M, M->up_skip[i], A.up_skip[i], lv.n, skip[i], gin, gc, W.gskip[i], 0, W, stream));
+        // unpooled rows: back to the coarse level
+        if (M->interp) {
+            if (!lv.up_inv_ptr || !lv.up_inv_rows) return PTV2_ERR_ARG;
+            RUN(interpolation_backward_gather_hip_launcher(n_coarse, c, 3, gin, lv.up_inv_ptr, lv.up_inv_rows, lv.up_w, spare, stream));
+        } else {
+            RUN(segment_sum_hip_launcher(n_coarse, c, gin, lv.order, lv.idx_ptr, spare, stream));
+        }
+        // proj: gradient of the unpool's input = output of decoder stage i+1, or (i+1 == S) the deepest encoder output;
+        // gin's rows are dead once both branches have read them
+        float *dst = i + 1 == S ? W.gskip[S] : gin;
+        RUN(linbn_backward(M, M->up[i], A.up[i], n_coarse, dec_in[i + 1], spare, gc, dst, 0, W, stream));
+        g = dst;
+        o = spare;
+    }
+    // encoder stages S-1 .. 0: gskip[i+1] is complete (skip branch of the decoder + the pooling of stage i+1)
+    for (int i = S - 1; i >= 0; --i) {
+        const ptv2_level &lv = M->level[i];
+        const int c = M->down[i].cout;
+        float *gp = seq_backward(M, 1 + i, A, A.pooled[i], W.gskip[i + 1], ga, W, stream, &rc);  // ping-pong gskip[i+1] / ga
+        if (rc != PTV2_OK) return rc;
+        // pooling: the gradient of a pooled value goes to its arg-max row (all other rows zero)
+        (void)hipMemsetAsync(gb, 0, sizeof(float) * (size_t)lv.n * c, st);
+        RUN(pool_max_backward_hip_launcher(M->level[i + 1].n, c, gp, A.arg[i], gb, stream));
+        // GridPool.fc: the second contribution to the gradient of skip[i], added by the GEMM's accumulate epilogue
+        RUN(linbn_backward(M, M->down[i], A.down[i], lv.n, skip[i], gb, gc, W.gskip[i], 1, W, stream));
+    }
+    // patch embedding (its input needs no gradient)
+    {
+        float *gp = seq_backward(M, 0, A, A.embed.y, W.gskip[0], ga, W, stream, &rc);
+        if (rc != PTV2_OK) return rc;
+        RUN(linbn_backward(M, M->embed, A.embed, n0, M->feat, gp, gc, nullptr, 0, W, stream));
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}

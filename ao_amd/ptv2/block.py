@@ -41,7 +41,11 @@ class _Blk(ctypes.Structure):  # mirrors ptv2_block
 
 
 class _BlkGrads(ctypes.Structure):  # mirrors ptv2_block_grads
-    _fields_ = [(n_, _P) for n_ in ("gy", "inv_ptr", "inv_rows", "gx", "gparam")]
+    _fields_ = [(n_, _P) for n_ in ("gy", "inv_ptr", "inv_rows", "gx", "gparam")] + [("gp", _P * NPARAM)]
+
+
+_lib.check_struct(0, _Blk)
+_lib.check_struct(1, _BlkGrads)
 
 
 def rows_gemm(x, w, bias=None, w_kmajor=False, out=None, accumulate=False):

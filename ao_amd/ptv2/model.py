@@ -433,6 +433,10 @@ class PointTransformerV2(nn.Module):
         if geometry is None:
             geometry = data_dict.get("geometry")  # prebuilt SceneGeometry (parallel.GeometryPrefetcher)
         geo = geometry if geometry is not None else self.geometry(coord, offset)
+        from . import native_model
+
+        if native_model.supported(self, feat):  # the whole network behind one native call per direction
+            return native_model.forward(self, data_dict, geo)
         lv = geo.levels
         pe = self.patch_embed
         feat = pe.blocks([lv[0].coord, pe.proj(feat), lv[0].offset], lv[0].neighbours(pe.blocks.neighbours))[1]

@@ -1,0 +1,365 @@
+"""PointTransformerV2.forward / backward as ONE native call per direction (ao_amd/csrc/model.hip).
+
+`PointTransformerV2.forward` of model.py dispatches here when the whole network is in the shape the native runtime
+covers (fp32 CUDA parameters, every Block supported by the Block runtime, training or eval).  The module tree keeps its
+nn.Parameters / buffers under the reference's state_dict names (point_transformer_v2m2_base.py:447-554); this file only
+gathers their device pointers into a `ptv2_model` struct (include/ptv2_hip.h), hands the scene geometry over, and wraps
+the two launchers in one autograd node.
+
+Parameter gradients are written by the kernels straight into ONE flat fp32 buffer laid out like
+`optim.FlatAdamW`'s (parameters in `module.parameters()` order, every slot aligned to 4 floats), so the optimizer
+consumes it without a flatten copy.  Two ways to hand them to `.grad`:
+  * "autograd" (default): the parameters are inputs of the autograd node and receive views of the flat buffer through
+    AccumulateGrad -- hooks, DistributedDataParallel and gradient accumulation work as with any module;
+  * "direct" (`backbone.native_param_grads = "direct"`, what bench.py selects for its flat all-reduce): the node assigns
+    `p.grad` itself; 840 AccumulateGrad nodes (~1.4 ms of host time per step) are not built.  Parameter hooks do not
+    fire in this mode; gradients are accumulated (added) when `p.grad` already holds a value.
+"""
+import ctypes
+import os
+
+import torch
+
+from .. import _lib
+from . import block as _block
+from . import gva as _gva
+
+_P, _I, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+MAX_STAGES, MAX_BLOCKS = 5, 40
+NPARAM, NBN = _block.NPARAM, _block.NBN
+
+
+class _LinBn(ctypes.Structure):  # mirrors ptv2_linbn
+    _fields_ = [("cin", _I), ("cout", _I)] + [(n, _P) for n in ("w", "b", "gamma", "beta", "run_mean", "run_var", "batches",
+                                                                 "gw", "gb", "ggamma", "gbeta")]
+
+
+class _Level(ctypes.Structure):  # mirrors ptv2_level
+    _fields_ = [("n", _I), ("b", _I)] + [(n, _P) for n in ("coord", "offset", "order", "idx_ptr", "cluster", "up_idx", "up_w",
+                                                            "up_inv_ptr", "up_inv_rows")]
+
+
+class _Seq(ctypes.Structure):  # mirrors ptv2_seq
+    _fields_ = [(n, _I) for n in ("level", "depth", "first_block", "c", "g", "k")] + [(n, _P) for n in ("idx", "mu", "cov", "inv_ptr",
+                                                                                                       "inv_rows")]
+
+
+class _MBlock(ctypes.Structure):  # mirrors ptv2_model_block
+    _fields_ = [("param", _P * NPARAM), ("run_mean", _P * NBN), ("run_var", _P * NBN), ("batches", _P * NBN),
+                ("gparam", _P * NPARAM), ("rowscale", _P)]
+
+
+class _Model(ctypes.Structure):  # mirrors ptv2_model
+    _fields_ = ([(n, _I) for n in ("num_stages", "in_channels", "num_classes", "training", "interp")]
+                + [("eps", _F), ("momentum", _F), ("level", _Level * (MAX_STAGES + 1)), ("seq", _Seq * (2 * MAX_STAGES + 1)),
+                   ("num_blocks", _I), ("block", _MBlock * MAX_BLOCKS), ("embed", _LinBn), ("down", _LinBn * MAX_STAGES),
+                   ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
+                + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
+                + [("saved_bytes", ctypes.c_size_t)])
+
+
+_lib.register({
+    "ptv2_model_saved_bytes": (_lib._c_size, [_P]),
+    "ptv2_model_workspace_bytes": (_lib._c_size, [_P]),
+    "ptv2_model_forward_hip_launcher": (_lib._c_int, [_P, _P, _lib._c_size, _P]),
+    "ptv2_model_backward_hip_launcher": (_lib._c_int, [_P, _P, _P, _lib._c_size, _P]),
+})
+
+
+_lib.check_struct(2, _Model)
+
+
+def grad_layout(params):
+    """Offsets (in floats) of every parameter's slot in the flat gradient buffer: `module.parameters()` order, each
+    slot aligned to 4 floats (the kernels store float4) -- the layout of optim.FlatAdamW."""
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    return offsets, off
+
+
+class _Runtime:
+    """Everything that does not change between steps: the struct with the parameter pointers filled in, the list of
+    (struct field, gradient slot) pairs, the BlockSequences in ABI order.  Rebuilt when a parameter or buffer moves."""
+
+    def __init__(self, model):
+        self.sequences = ([model.patch_embed.blocks] + [e.blocks for e in model.enc_stages]
+                          + [d.blocks for d in model.dec_stages])
+        S = model.num_stages
+        self.S = S
+        self.params = list(model.parameters())
+        self.offsets, self.total = grad_layout(self.params)
+        index = {id(p): i for i, p in enumerate(self.params)}
+        M = _Model()
+        M.num_stages, M.in_channels, M.num_classes = S, model.in_channels, model.num_classes
+        M.interp = 1 if model.unpool_backend == "interp" else 0
+        bns = []
+        self.grad_fields = []  # (setter, parameter index): where each gradient slot's pointer goes in the struct
+        self.tensor_slots = []  # (owner dict, name) of every tensor whose pointer is cached in the struct
+        owners = {}
+        for m in model.modules():
+            for name, t in m._parameters.items():
+                if t is not None:
+                    owners[id(t)] = (m._parameters, name)
+
+        def ptr(t):
+            if t is None:
+                return None
+            self.tensor_slots.append(owners[id(t)])
+            return t.data_ptr()
+
+        def buf(bn, name):
+            t = bn._buffers.get(name)
+            if t is None:
+                return None
+            self.tensor_slots.append((bn._buffers, name))
+            return t.data_ptr()
+
+        def linbn(dst, linear, bn):
+            dst.cout, dst.cin = linear.weight.shape
+            dst.w, dst.b, dst.gamma, dst.beta = ptr(linear.weight), ptr(linear.bias), ptr(bn.weight), ptr(bn.bias)
+            dst.run_mean, dst.run_var, dst.batches = buf(bn, "running_mean"), buf(bn, "running_var"), buf(bn, "num_batches_tracked")
+            for field, p in (("gw", linear.weight), ("gb", linear.bias), ("ggamma", bn.weight), ("gbeta", bn.bias)):
+                if p is not None:
+                    self.grad_fields.append((dst, field, None, index[id(p)]))
+            bns.append(bn)
+
+        linbn(M.embed, model.patch_embed.proj[0], model.patch_embed.proj[1].norm)
+        for i in range(S):
+            enc, dec = model.enc_stages[i], model.dec_stages[i]
+            linbn(M.down[i], enc.down.fc, enc.down.norm.norm)
+            linbn(M.up[i], dec.up.proj[0], dec.up.proj[1].norm)
+            linbn(M.up_skip[i], dec.up.proj_skip[0], dec.up.proj_skip[1].norm)
+        linbn(M.head, model.seg_head[0], model.seg_head[1].norm)
+        cls = model.seg_head[3]
+        M.head_w, M.head_b = ptr(cls.weight), ptr(cls.bias)
+        self.grad_fields.append((M, "g_head_w", None, index[id(cls.weight)]))
+        if cls.bias is not None:
+            self.grad_fields.append((M, "g_head_b", None, index[id(cls.bias)]))
+        nb = 0
+        self.block_modules = []
+        for q, seq in enumerate(self.sequences):
+            sq = M.seq[q]
+            sq.level = 0 if q == 0 else (q if q <= S else q - S - 1)
+            sq.depth, sq.first_block, sq.k = len(seq.blocks), nb, seq.neighbours
+            for blk in seq.blocks:
+                a = blk.attn
+                sq.c, sq.g = a.embed_channels, a.groups
+                params, blk_bns = _block.block_params(blk)
+                mb = M.block[nb]
+                for i, p in enumerate(params):
+                    mb.param[i] = ptr(p)
+                    if p is not None:
+                        self.grad_fields.append((mb.gparam, None, i, index[id(p)]))
+                for i, bn in enumerate(blk_bns):
+                    mb.run_mean[i], mb.run_var[i] = buf(bn, "running_mean"), buf(bn, "running_var")
+                    mb.batches[i] = buf(bn, "num_batches_tracked") if bn.track_running_stats else None
+                bns.extend(blk_bns)
+                self.block_modules.append(blk)
+                nb += 1
+        M.num_blocks = nb
+        b0 = bns[0]
+        M.eps, M.momentum = float(b0.eps), float(b0.momentum if b0.momentum is not None else 0.1)
+        self.uniform_bn = all(bn.affine and bn.momentum is not None and bn.eps == b0.eps and bn.momentum == b0.momentum
+                              and (bn.running_mean is None) == (b0.running_mean is None) for bn in bns)
+        self.has_running = b0.running_mean is not None
+        self.static_ok = (self.uniform_bn and nb <= MAX_BLOCKS and S <= MAX_STAGES and len(self.grad_fields) == len(self.params)
+                          and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in self.params)
+                          and all(_block.plan(blk).static_ok and (blk.attn.attn_drop_rate == 0.0) for blk in self.block_modules)
+                          and all(_gva.supported(blk.attn.embed_channels, blk.attn.groups, seq.neighbours)
+                                  for seq in self.sequences for blk in seq.blocks)
+                          and isinstance(model.seg_head, torch.nn.Sequential) and M.embed.cout % 4 == 0)
+        self.M = M
+        self.key = _block._pointer_key(self.tensor_slots)
+        self.droppath = [[b.drop_path.drop_prob if hasattr(b.drop_path, "drop_prob") else 0.0 for b in seq.blocks]
+                         for seq in self.sequences]
+        self._grad_buf = None   # persistent flat gradient buffer + its per-parameter views (direct mode / cached views)
+        self._grad_views = None
+        self._keep_cache = {}
+
+    # -- per step ------------------------------------------------------------------------------------------------
+    def fill_geometry(self, geo):
+        M, S = self.M, self.S
+        for i, lv in enumerate(geo.levels):
+            L = M.level[i]
+            L.n, L.b = lv.coord.shape[0], lv.offset.numel()
+            L.coord, L.offset = lv.coord.data_ptr(), lv.offset.data_ptr()
+            L.order = _lib.ptr(lv.order32) or None
+            L.idx_ptr = _lib.ptr(lv.idx_ptr32) or None
+            L.cluster = _lib.ptr(lv.cluster) or None
+            L.up_idx, L.up_w = _lib.ptr(lv.up_idx) or None, _lib.ptr(lv.up_weight) or None
+            if lv.up_idx is not None:
+                inv_ptr, inv_rows = _gva.inverse_table(lv.up_idx)
+                L.up_inv_ptr, L.up_inv_rows = inv_ptr.data_ptr(), inv_rows.data_ptr()
+            else:
+                L.up_inv_ptr = L.up_inv_rows = None
+        keep = []
+        for q, seq in enumerate(self.sequences):
+            sq = M.seq[q]
+            lv = geo.levels[sq.level]
+            idx = lv.neighbours(sq.k)
+            sq.idx = idx.data_ptr()
+            mu, cov = _gva._pos_moments(_gva._HipImpl, lv.coord, idx)
+            inv_ptr, inv_rows = _gva.inverse_table(idx)
+            sq.mu, sq.cov, sq.inv_ptr, sq.inv_rows = mu.data_ptr(), cov.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr()
+            keep += [idx, mu, cov, inv_ptr, inv_rows]
+        return keep
+
+    def draw_droppath(self, geo, device):
+        """Per-point DropPath factors (timm DropPath on an (N,C) tensor, point_transformer_v2m2_base.py:160-162,175) of
+        every block in ONE draw: Bernoulli(keep_b) / keep_b for the rows of block b, 0-rate blocks skipped."""
+        sizes = tuple(lv.coord.shape[0] for lv in geo.levels)
+        entry = self._keep_cache.get(sizes)
+        if entry is None:
+            spans, probs, off, nb = [], [], 0, 0
+            for q, rates in enumerate(self.droppath):
+                n = sizes[self.M.seq[q].level]
+                for r in rates:
+                    if r > 0.0:
+                        spans.append((nb, off, n))
+                        probs.append(torch.full((n,), 1.0 - r, dtype=torch.float32))
+                        off += n
+                    nb += 1
+            keep = torch.cat(probs).to(device) if probs else None
+            entry = (spans, keep)
+            self._keep_cache = {sizes: entry}  # scenes change size every batch: keep the latest layout only
+        spans, keep = entry
+        for mb in self.M.block[: self.M.num_blocks]:
+            mb.rowscale = None
+        if keep is None:
+            return None
+        scales = torch.bernoulli(keep).div_(keep)
+        base = scales.data_ptr()
+        for nb, off, n in spans:
+            self.M.block[nb].rowscale = base + 4 * off
+        return scales
+
+    def grad_buffer(self, device, fresh):
+        """(flat buffer, per-parameter views).  "direct" mode reuses one persistent pair step after step (`.grad` then
+        aliases a buffer that the next backward overwrites -- the mode's documented contract); `fresh` allocates a
+        private pair: always in "autograd" mode (callers of torch.autograd.grad may hold the returned tensors), and
+        for gradient accumulation over several backwards."""
+        if fresh or self._grad_buf is None or self._grad_buf.device != device:
+            flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+            views = []
+            for p, off in zip(self.params, self.offsets):
+                views.append(flat[off:off + p.numel()].view(p.shape))
+            if fresh:
+                return flat, views
+            self._grad_buf, self._grad_views = flat, views
+        return self._grad_buf, self._grad_views
+
+    def point_grads(self, flat):
+        base = flat.data_ptr()
+        offs = self.offsets
+        for obj, field, i, pi in self.grad_fields:
+            if field is None:
+                obj[i] = base + 4 * offs[pi]
+            else:
+                setattr(obj, field, base + 4 * offs[pi])
+
+
+def runtime(model):
+    rt = model.__dict__.get("_ao_runtime")
+    if rt is not None:
+        try:
+            fresh = rt.key == _block._pointer_key(rt.tensor_slots)
+        except (KeyError, AttributeError):
+            fresh = False
+        if fresh:
+            return rt
+    rt = _Runtime(model)
+    model.__dict__["_ao_runtime"] = rt
+    return rt
+
+
+def supported(model, feat):
+    if os.environ.get("AO_AMD_MODEL", "native") != "native" or os.environ.get("AO_AMD_BLOCK", "native") != "native":
+        return False
+    if os.environ.get("AO_AMD_GVA", "fused") != "fused":
+        return False
+    if not (feat.is_cuda and feat.dim() == 2 and feat.dtype in (torch.float32, torch.bfloat16, torch.float16) and feat.shape[0] >= 2):
+        return False
+    rt = runtime(model)
+    if not rt.static_ok or (not model.training and not rt.has_running):
+        return False
+    return not any(b.enable_checkpoint for b in rt.block_modules)
+
+
+class _NativeModel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, anchor, rt, geo, training, mode, *params):
+        feat = feat.contiguous()
+        dev = feat.device
+        L = _lib.lib()
+        M = rt.M
+        keep = rt.fill_geometry(geo)
+        M.training = int(training)
+        scales = rt.draw_droppath(geo, dev) if training else None
+        n0 = feat.shape[0]
+        logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
+        M.feat, M.logits = feat.data_ptr(), logits.data_ptr()
+        M.saved, M.saved_bytes = None, 0
+        need = L.ptv2_model_saved_bytes(ctypes.addressof(M))
+        if need == 0:
+            raise RuntimeError("ao_amd: ptv2_model rejected by the native runtime (ptv2_model_saved_bytes == 0)")
+        saved = torch.empty(need, dtype=torch.uint8, device=dev)
+        M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
+        ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
+        rc = L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "ptv2_model_forward_hip_launcher")
+        ctx.rt, ctx.geo, ctx.keep, ctx.mode, ctx.training = rt, geo, (keep, scales, feat, saved), mode, training
+        ctx.rowscale_ptrs = [mb.rowscale for mb in M.block[: M.num_blocks]]
+        return logits
+
+    @staticmethod
+    def backward(ctx, g_logits):
+        rt = ctx.rt
+        keep, scales, feat, saved = ctx.keep
+        dev = feat.device
+        L = _lib.lib()
+        M = rt.M
+        rt.fill_geometry(ctx.geo)  # the struct is shared between calls: restore this call's tables
+        M.training = int(ctx.training)
+        for mb, rs in zip(M.block[: M.num_blocks], ctx.rowscale_ptrs):
+            mb.rowscale = rs
+        M.feat, M.logits = feat.data_ptr(), None
+        M.logits = g_logits.data_ptr()  # unused by the backward; keeps the struct valid
+        M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
+        direct = ctx.mode == "direct"
+        accumulate = direct and rt.params[0].grad is not None
+        flat, views = rt.grad_buffer(dev, fresh=accumulate or not direct)
+        if flat is rt._grad_buf:
+            flat.zero_()
+        rt.point_grads(flat)
+        g_logits = g_logits.contiguous().float()
+        ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
+        rc = L.ptv2_model_backward_hip_launcher(ctypes.addressof(M), g_logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "ptv2_model_backward_hip_launcher")
+        if direct:
+            if accumulate:
+                torch._foreach_add_([p.grad for p in rt.params], views)
+            else:
+                for p, v in zip(rt.params, views):
+                    p.grad = v
+            return (None,) * (6 + len(rt.params))
+        return (None,) * 6 + tuple(views)
+
+
+def forward(model, data_dict, geo):
+    """PointTransformerV2.forward on the native runtime (call `supported` first)."""
+    rt = runtime(model)
+    feat = data_dict["feat"]
+    training = model.training or not rt.has_running
+    mode = getattr(model, "native_param_grads", "autograd")
+    with torch.autocast("cuda", enabled=False):  # the runtime computes in fp32 (see block.block_forward)
+        if not torch.is_grad_enabled():
+            return _NativeModel.apply(feat.float(), None, rt, geo, training, mode)
+        if mode == "direct":
+            anchor = model.__dict__.get("_ao_anchor")
+            if anchor is None or anchor.device != feat.device:
+                anchor = torch.zeros((), device=feat.device, requires_grad=True)
+                model.__dict__["_ao_anchor"] = anchor
+            return _NativeModel.apply(feat.float(), anchor, rt, geo, training, mode)
+        return _NativeModel.apply(feat.float(), None, rt, geo, training, mode, *rt.params)

@@ -25,27 +25,46 @@ class FlatAdamW(torch.optim.Optimizer):
         self._params = self.param_groups[0]["params"]
         dev = self._params[0].device
         assert all(p.device == dev and p.dtype == torch.float32 for p in self._params)
+        # every parameter owns a slot aligned to 4 floats (the gradient kernels store float4): the layout of
+        # native_model.grad_layout, so that the native model backward can write its gradients straight into a buffer
+        # this optimizer consumes without a copy
         self._sizes = [p.numel() for p in self._params]
-        total = sum(self._sizes)
-        self._n = (total + 3) // 4 * 4
+        self._offsets, off = [], 0
+        for k in self._sizes:
+            self._offsets.append(off)
+            off += (k + 3) // 4 * 4
+        self._n = off
         flat = torch.zeros(self._n, dtype=torch.float32, device=dev)
-        off = 0
         with torch.no_grad():
-            for p, k in zip(self._params, self._sizes):
-                view = flat[off:off + k].view_as(p)
+            for p, k, o in zip(self._params, self._sizes, self._offsets):
+                view = flat[o:o + k].view_as(p)
                 view.copy_(p.data)
                 p.data = view
-                off += k
         self.flat_param = flat
         self.flat_grad = torch.zeros_like(flat)
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self._total = total
         self._step = 0
 
+    def _slots(self, flat):
+        """Per-parameter 1-D views of a flat buffer in this optimizer's layout."""
+        return [flat[o:o + k] for k, o in zip(self._sizes, self._offsets)]
+
     def flatten_grads(self):
-        """One multi-tensor copy of every `.grad` into the flat gradient buffer (missing gradients count as zero)."""
-        views = self.flat_grad[:self._total].split(self._sizes)
+        """The gradients as one flat buffer in this optimizer's layout.  When every `.grad` already aliases one such
+        buffer (the native model backward writes them that way, ao_amd/ptv2/native_model.py) that buffer is returned
+        as it is; otherwise one multi-tensor copy gathers them (missing gradients count as zero)."""
+        g0 = self._params[0].grad
+        if g0 is not None and g0.is_contiguous():
+            base = g0.data_ptr() - 4 * self._offsets[0]
+            try:
+                aliased = all(p.grad.data_ptr() == base + 4 * o for p, o in zip(self._params, self._offsets))
+            except AttributeError:  # a parameter without a gradient
+                aliased = False
+            start = g0.storage_offset() - self._offsets[0]
+            if aliased and start >= 0 and g0.untyped_storage().nbytes() >= 4 * (start + self._n):
+                return torch.empty(0, dtype=torch.float32, device=g0.device).set_(g0.untyped_storage(), start, (self._n,), (1,))
+        views = self._slots(self.flat_grad)
         dst = [v for v, p in zip(views, self._params) if p.grad is not None]
         src = [p.grad.reshape(-1) for p in self._params if p.grad is not None]
         if len(dst) != len(self._params):
@@ -61,8 +80,7 @@ class FlatAdamW(torch.optim.Optimizer):
         group["params"] = list(range(len(self._params)))
         state = {}
         if self._step > 0:
-            m = self.exp_avg[:self._total].split(self._sizes)
-            v = self.exp_avg_sq[:self._total].split(self._sizes)
+            m, v = self._slots(self.exp_avg), self._slots(self.exp_avg_sq)
             for i, p in enumerate(self._params):
                 state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": m[i].view_as(p).clone(),
                             "exp_avg_sq": v[i].view_as(p).clone()}
@@ -84,8 +102,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         steps = set()
-        m = self.exp_avg[:self._total].split(self._sizes)
-        v = self.exp_avg_sq[:self._total].split(self._sizes)
+        m, v = self._slots(self.exp_avg), self._slots(self.exp_avg_sq)
         for i, (pid, p) in enumerate(zip(ids, self._params)):
             st = state.get(pid, state.get(str(pid)))
             if st is None:

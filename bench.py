@@ -339,6 +339,9 @@ def child_main(args):
         from ao_amd.ptv2.optim import FlatAdamW
 
         opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+        # the native model backward writes every parameter gradient into one flat buffer in the optimizer's layout and
+        # assigns `.grad` itself (ao_amd/ptv2/native_model.py): no AccumulateGrad nodes, no flatten copy
+        seg.backbone.native_param_grads = os.environ.get("AO_AMD_PARAM_GRADS", "direct")
     else:
         opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
     data = make_batch(rank, args.scenes, args.points, device, cfg["in_channels"], cfg["num_classes"])

@@ -472,7 +472,8 @@ typedef struct ptv2_block_grads {
     const float *gy;               /* (n,c) */
     const int *inv_ptr, *inv_rows; /* inverse neighbour table (may be NULL) */
     float *gx;                     /* (n,c) */
-    float *gparam;                 /* flat parameter gradients */
+    float *gparam;                 /* flat parameter gradients (layout: ptv2_block_param_layout), or NULL: */
+    float *gp[PTV2_BLK_NPARAM];    /* ... one destination per parameter (float4-aligned; NULL for absent biases) */
 } ptv2_block_grads;
 size_t ptv2_block_saved_bytes(int n, int k, int c, int g);
 size_t ptv2_block_workspace_bytes(int n, int k, int c, int g);
@@ -480,6 +481,79 @@ int ptv2_block_param_layout(int c, int g, long long *offsets /* [PTV2_BLK_NPARAM
 int ptv2_block_forward_hip_launcher(const ptv2_block *blk, void *workspace, size_t workspace_bytes, void *stream);
 int ptv2_block_backward_hip_launcher(const ptv2_block *blk, const ptv2_block_grads *grads, void *workspace,
                                      size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------ whole model, one call --
+ * PointTransformerV2.forward / backward (point_transformer_v2m2_base.py:556-576: patch embedding, S encoder stages of
+ * GridPool + BlockSequence, S decoder stages of UnpoolWithSkip + BlockSequence, segmentation head) behind ONE launcher
+ * per direction.  Every kernel of the step between `feat` and `seg_logits` is enqueued from native code on the caller's
+ * stream: no python / autograd dispatch between the stages (the step was host-bound on it: ~9 ms of host time beside
+ * ~4 ms of launch calls), no torch glue kernels (zero fills, adds, copies).  Geometry (neighbour tables, pooling CSR,
+ * interpolation tables) is the caller's, built once per batch (ao_amd/ptv2/geometry.py); parameter gradients are written
+ * straight to the destinations the caller names (e.g. slots of an optimizer's flat gradient buffer).
+ *   ptv2_linbn : Sequential(Linear, PointBatchNorm, ReLU) (GridPool.fc/norm :240-242, UnpoolWithSkip.proj /
+ *                proj_skip :293-302, GVAPatchEmbed.proj :424-428, seg_head[0:3] :545-550); g* = gradient destinations
+ *   level i    : resolution i (0 = input); its link to level i+1 (pooling CSR, cluster map, 3-NN interpolation tables)
+ *   seq        : 0 = patch_embed.blocks (level 0); 1+i = enc_stages[i].blocks (level i+1); 1+S+i = dec_stages[i].blocks
+ *                (level i); blocks first_block .. first_block+depth-1 of `block[]`
+ *   saved      : ptv2_model_saved_bytes() bytes written by the forward, read by the backward. */
+#define PTV2_MAX_STAGES 5
+#define PTV2_MAX_BLOCKS 40
+typedef struct ptv2_linbn {
+    int cin, cout;
+    const float *w, *b;                /* (cout,cin); (cout) or NULL */
+    const float *gamma, *beta;         /* (cout) */
+    float *run_mean, *run_var;         /* running buffers (NULL: batch statistics always) */
+    long long *batches;
+    float *gw, *gb, *ggamma, *gbeta;   /* backward only */
+} ptv2_linbn;
+typedef struct ptv2_level {
+    int n, b;
+    const float *coord;                /* (n,3) */
+    const int *offset;                 /* (b) */
+    const int *order, *idx_ptr;        /* CSR of the pooling to level i+1: (n), (n_{i+1} + 1) */
+    const long long *cluster;          /* (n) point -> cluster, "map" unpool */
+    const int *up_idx;                 /* (n,3) into level i+1, "interp" unpool */
+    const float *up_w;                 /* (n,3) */
+    const int *up_inv_ptr, *up_inv_rows; /* inverse table of up_idx: (n_{i+1} + 1), (3 n) */
+} ptv2_level;
+typedef struct ptv2_seq {
+    int level, depth, first_block, c, g, k;
+    const int *idx;                    /* (n,k) */
+    const double *mu, *cov;            /* position moments of the table */
+    const int *inv_ptr, *inv_rows;     /* inverse neighbour table */
+} ptv2_seq;
+typedef struct ptv2_model_block {
+    const float *param[PTV2_BLK_NPARAM];
+    float *run_mean[PTV2_BLK_NBN], *run_var[PTV2_BLK_NBN];
+    long long *batches[PTV2_BLK_NBN];
+    float *gparam[PTV2_BLK_NPARAM];    /* backward only */
+    const float *rowscale;             /* (n) DropPath factors of this block or NULL */
+} ptv2_model_block;
+typedef struct ptv2_model {
+    int num_stages, in_channels, num_classes, training, interp; /* interp != 0: "interp" unpool, else "map" */
+    float eps, momentum;
+    ptv2_level level[PTV2_MAX_STAGES + 1];
+    ptv2_seq seq[2 * PTV2_MAX_STAGES + 1];
+    int num_blocks;
+    ptv2_model_block block[PTV2_MAX_BLOCKS];
+    ptv2_linbn embed, down[PTV2_MAX_STAGES], up[PTV2_MAX_STAGES], up_skip[PTV2_MAX_STAGES], head;
+    const float *head_w, *head_b;      /* seg_head[3]: (num_classes, c0), (num_classes) */
+    float *g_head_w, *g_head_b;        /* backward only */
+    const float *feat;                 /* (n0, in_channels) */
+    float *logits;                     /* (n0, num_classes) */
+    void *saved;
+    size_t saved_bytes;
+} ptv2_model;
+size_t ptv2_model_saved_bytes(const ptv2_model *m);
+size_t ptv2_model_workspace_bytes(const ptv2_model *m);
+int ptv2_model_forward_hip_launcher(const ptv2_model *m, void *workspace, size_t workspace_bytes, void *stream);
+/* g_logits (n0, num_classes); the gradient with respect to `feat` is not formed (the input needs none) */
+int ptv2_model_backward_hip_launcher(const ptv2_model *m, const float *g_logits, void *workspace, size_t workspace_bytes,
+                                     void *stream);
+
+/* sizeof(ptv2_block) [0], sizeof(ptv2_block_grads) [1], sizeof(ptv2_model) [2] as this library was compiled: bindings
+ * that mirror the structs (ctypes) compare it with their own at load time. */
+long long ptv2_struct_bytes(int which);
 
 /* ------------------------------------------------ segmentation loss --
  * nn.CrossEntropyLoss(ignore_index) of DefaultSegmentor (pointcept/models/default.py:239-251): mean over the labelled

@@ -88,7 +88,7 @@ def _worker(rank, world, port, out_dir):
         dopt.zero_grad(set_to_none=True)
         dloss.backward()
         if _ == 0:  # the averaged gradient itself: summed flat buffer x grad_scale == DDP's mean (Adam hides a scale)
-            mean0 = [(v * scale).view_as(p).clone() for v, p in zip(flat[:fopt._total].split(fopt._sizes), fopt._params)]
+            mean0 = [(v * scale).view_as(p).clone() for v, p in zip(fopt._slots(flat), fopt._params)]
             ddp0 = [p.grad.clone() for p in ddp_model.parameters()]
         fopt.step(flat_grad=flat, grad_scale=scale)
         dopt.step()

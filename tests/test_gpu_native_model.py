@@ -1,0 +1,142 @@
+"""GPU: the whole-model native runtime (ao_amd/csrc/model.hip: PointTransformerV2.forward / backward as one call per
+direction, point_transformer_v2m2_base.py:556-576) against the same module evaluated stage by stage in python
+(AO_AMD_MODEL=python: one native call per Block, autograd nodes for GridPool / Unpool / head) -- which the fixture tests
+of tests/test_gpu_model.py pin to the reference nn.Module.  Logits 1e-5 (same kernels, same order except the unpool's
+add), every parameter gradient in relative L2; the two ways of delivering parameter gradients; the optimizer's zero-copy
+path; eval mode; DropPath."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ptv2_ref as M
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _data(seeds, points, cfg):
+    from ao_amd import synth
+
+    b = synth.scene_batch(seeds, point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"])
+    return {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+
+
+def _model(cfg, seed, train=True):
+    import ao_amd.ptv2 as ptv2
+
+    m = ptv2.PointTransformerV2(**cfg).cuda()
+    m.load_state_dict(M.init_state(cfg, seed=seed), strict=True)
+    return m.train(train)
+
+
+@pytest.mark.parametrize("tag,points", [("s3dis", 6000), ("scannet", 5000), ("s3dis", 40000)])
+def test_native_model_matches_stagewise_python(monkeypatch, tag, points):
+    from ao_amd.ptv2 import native_model
+
+    cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.0)
+    data = _data([1, 2], points, cfg)
+    res = {}
+    for mode in ("native", "python"):
+        monkeypatch.setenv("AO_AMD_MODEL", mode)
+        model = _model(cfg, seed=17)
+        assert native_model.supported(model, data["feat"]) == (mode == "native")
+        logits = model(data)
+        loss = F.cross_entropy(logits, data["segment"], ignore_index=-1)
+        grads = torch.autograd.grad(loss, list(model.parameters()))
+        res[mode] = (logits.detach(), grads, {k: v.clone() for k, v in model.state_dict().items()})
+    ln, gn, sn = res["native"]
+    lp, gp, sp = res["python"]
+    np.testing.assert_allclose(ln.cpu().numpy(), lp.cpu().numpy(), rtol=0, atol=2e-5)
+    names = [n for n, _ in model.named_parameters()]
+    for nm, a, b in zip(names, gn, gp):
+        assert a.shape == b.shape
+        assert rel(a, b) < 2e-3 or float((a - b).abs().max()) < 2e-6, (nm, rel(a, b), float((a - b).abs().max()))
+    for k in sp:  # BatchNorm running statistics / batch counters after one training forward
+        np.testing.assert_allclose(sn[k].cpu().numpy(), sp[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_native_model_eval_and_no_grad(monkeypatch):
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.3)
+    data = _data([3], 8000, cfg)
+    out = {}
+    for mode in ("native", "python"):
+        monkeypatch.setenv("AO_AMD_MODEL", mode)
+        model = _model(cfg, seed=5, train=False)
+        with torch.no_grad():
+            out[mode] = model(data)
+    np.testing.assert_allclose(out["native"].cpu().numpy(), out["python"].cpu().numpy(), rtol=0, atol=2e-5)
+
+
+def test_direct_parameter_gradients_and_zero_copy_optimizer():
+    """`native_param_grads = "direct"`: the node assigns `.grad` itself (no AccumulateGrad), gradients alias one flat
+    buffer in FlatAdamW's layout, the optimizer consumes it without a copy; a second backward without zero_grad adds."""
+    from ao_amd.ptv2.optim import FlatAdamW
+
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    data = _data([4], 5000, cfg)
+    ref = _model(cfg, seed=9)
+    loss = F.cross_entropy(ref(data), data["segment"], ignore_index=-1)
+    loss.backward()
+    want = [p.grad.clone() for p in ref.parameters()]
+
+    model = _model(cfg, seed=9)
+    model.native_param_grads = "direct"
+    opt = FlatAdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+    F.cross_entropy(model(data), data["segment"], ignore_index=-1).backward()
+    got = [p.grad for p in model.parameters()]
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)  # the same kernels wrote both
+    flat = opt.flatten_grads()
+    assert flat.data_ptr() == got[0].data_ptr() and flat.numel() == opt._n  # zero copy: the buffer itself
+    assert flat.data_ptr() != opt.flat_grad.data_ptr()
+    # accumulation: a second backward onto existing gradients adds
+    model.load_state_dict(M.init_state(cfg, seed=9), strict=True)  # undo the running-statistics update
+    F.cross_entropy(model(data), data["segment"], ignore_index=-1).backward()
+    for p, b in zip(model.parameters(), want):
+        assert rel(p.grad, 2 * b) < 1e-6
+    # after zero_grad the optimizer step equals torch.optim.AdamW's on the same gradients
+    opt.zero_grad(set_to_none=True)
+    F.cross_entropy(model(data), data["segment"], ignore_index=-1).backward()
+    before = [p.detach().clone() for p in model.parameters()]
+    grads = [p.grad.clone() for p in model.parameters()]
+    opt.step(flat_grad=opt.flatten_grads())
+    twin = [torch.nn.Parameter(b.clone()) for b in before]
+    topt = torch.optim.AdamW(twin, lr=0.006, weight_decay=0.05)
+    for t, g in zip(twin, grads):
+        t.grad = g
+    topt.step()
+    for p, t in zip(model.parameters(), twin):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), t.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_droppath_rows_pass_the_identity_through():
+    """DropPath is per point (timm DropPath on (N,C), :160-162): with rate r a fraction ~r of a block's rows keeps its
+    input; the native runtime draws all blocks' factors in one call -- statistics and determinism under a seed."""
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.3)
+    data = _data([6], 6000, cfg)
+    model = _model(cfg, seed=3)
+    torch.manual_seed(123)
+    a = model(data).detach()
+    model.load_state_dict(M.init_state(cfg, seed=3), strict=True)
+    torch.manual_seed(123)
+    b = model(data).detach()
+    assert torch.equal(a, b)
+    model.load_state_dict(M.init_state(cfg, seed=3), strict=True)
+    torch.manual_seed(124)
+    c = model(data).detach()
+    assert not torch.equal(a, c)
+    from ao_amd.ptv2 import native_model
+
+    rt = native_model.runtime(model)
+    geo = model.geometry(data["coord"], data["offset"].int())
+    scales = rt.draw_droppath(geo, data["coord"].device)
+    rates = [r for seq in rt.droppath for r in seq if r > 0]
+    assert len(rates) == 11 and abs(max(rates) - 0.3) < 1e-6  # linspace(0, 0.3, 10) encoder + linspace(0, 0.3, 3) decoder, zeros skipped
+    zero_frac = float((scales == 0).float().mean())
+    assert 0.05 < zero_frac < 0.3
+    assert torch.all((scales == 0) | (scales > 1.0))

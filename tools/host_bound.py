@@ -9,7 +9,9 @@ pts = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 seg = ptv2.DefaultSegmentor(dict(ptv2.S3DIS_BACKBONE)).to(dev).train()
-opt = torch.optim.AdamW(seg.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+from ao_amd.ptv2.optim import FlatAdamW
+opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+seg.backbone.native_param_grads = os.environ.get("AO_AMD_PARAM_GRADS", "direct")
 b = synth.scene_batch([0], point_max=pts, room=1)
 data = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
 
@@ -28,7 +30,7 @@ def step(marks=None):
     if pre:
         pre.start(data["coord"], data["offset"])
     t2 = time.perf_counter()
-    opt.step()
+    opt.step(flat_grad=opt.flatten_grads())
     t3 = time.perf_counter()
     if marks is not None:
         marks.append((t1 - t, t2 - t1, t3 - t2))
