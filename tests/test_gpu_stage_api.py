@@ -94,5 +94,5 @@ def test_stage_return_contracts():
     for dec in (dec_map, dec_int):
         out = dec(p1, p0, cluster)
         assert out[0] is coord and out[1].shape == (coord.shape[0], 48) and out[2] is p0[2]
-        out[1].sum().backward()  # both unpool backwards run (ordered per-cluster sum / inverse-table gather)
+        out[1].sum().backward(retain_graph=True)  # both unpool backwards run (ordered per-cluster sum / inverse-table gather)
     assert all(p.grad is not None for p in dec_int.parameters())
