@@ -21,6 +21,7 @@ _SIGNATURES = {
     "ptv2_abi_version": (_c_int, []),
     "ptv2_build_info": (ctypes.c_char_p, []),
     "ptv2_struct_bytes": (ctypes.c_longlong, [_c_int]),
+    "ptv2_matmul_precision": (_c_int, [_c_int]),
     "ptv2_profile_enable": (_c_int, [_c_int]),
     "ptv2_profile_select": (_c_int, [_c_int]),
     "ptv2_profile_stride": (_c_int, [_c_int]),
@@ -89,7 +90,7 @@ _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace 
 _lib = None
 # bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
 # mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
-EXPECTED_ABI = 4
+EXPECTED_ABI = 5
 
 
 def build(verbose=False):

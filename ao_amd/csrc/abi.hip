@@ -6,7 +6,7 @@
 
 #include "common.h"
 
-extern "C" int ptv2_abi_version(void) { return 4; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 5; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 // sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
 // layout drift between the header and a python mirror is an import error, not a misread pointer
@@ -17,6 +17,16 @@ extern "C" long long ptv2_struct_bytes(int which) {
         case 2: return (long long)sizeof(ptv2_model);
         default: return -1;
     }
+}
+
+namespace { thread_local int g_matmul_bf16 = 0; }
+int ptv2_matmul_bf16(void) { return g_matmul_bf16; }
+void ptv2_set_matmul_bf16(int on) { g_matmul_bf16 = on ? 1 : 0; }
+// for callers of the stand-alone launchers (rows_gemm_*, linear_wgrad_*): returns the previous setting of this thread
+extern "C" int ptv2_matmul_precision(int bf16) {
+    const int prev = g_matmul_bf16;
+    if (bf16 >= 0) g_matmul_bf16 = bf16 ? 1 : 0;
+    return prev;
 }
 
 #ifndef PTV2_SRC_HASH

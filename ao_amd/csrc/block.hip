@@ -195,6 +195,7 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
 
 extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *workspace, size_t workspace_bytes, void *stream) {
     if (!args_ok(B)) return PTV2_ERR_ARG;
+    const PtvMatmulScope precision(B->matmul_bf16);
     const int n = B->n, k = B->k, c = B->c, g = B->g;
     const Saved S = carve_saved(B->saved, n, k, c, g);
     if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;
@@ -251,6 +252,7 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
 extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_block_grads *G, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
     if (!args_ok(B) || !G || !G->gy || !G->gx) return PTV2_ERR_ARG;
+    const PtvMatmulScope precision(B->matmul_bf16);
     const int n = B->n, k = B->k, c = B->c, g = B->g;
     const Saved S = carve_saved(B->saved, n, k, c, g);
     if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;

@@ -34,6 +34,26 @@ struct PtvScopedTimer {
     ~PtvScopedTimer() { if (on) ptv2_profile_end(kid, st, bytes); }
 };
 
+// Matmul operand precision of the calling thread's launches (abi.hip): 0 = fp32 MFMA (V_MFMA_F32_16X16X4_F32, exact fp32),
+// 1 = bf16 MFMA (V_MFMA_F32_16X16X32_BF16: operands rounded to bf16 on their way into the matrix core, fp32
+// accumulation) -- what torch.autocast(dtype=bfloat16) does to the nn.Linear layers of the reference
+// (pointcept/engines/train_sam_pp2s.py:178-180).  Set by the Block / model launchers from their `matmul_bf16` field for the
+// duration of the call; the row GEMM and the weight-gradient launchers read it.
+int ptv2_matmul_bf16(void);
+void ptv2_set_matmul_bf16(int on);
+struct PtvMatmulScope {
+    int prev;
+    explicit PtvMatmulScope(int on) : prev(ptv2_matmul_bf16()) { ptv2_set_matmul_bf16(on); }
+    ~PtvMatmulScope() { ptv2_set_matmul_bf16(prev); }
+};
+typedef __bf16 ptv2_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ ptv2_bf16x8 ptv2_pack_bf16(float4 lo, float4 hi) {  // v_cvt_pk_bf16_f32 x 4 (round to nearest even)
+    ptv2_bf16x8 r;
+    r[0] = (__bf16)lo.x; r[1] = (__bf16)lo.y; r[2] = (__bf16)lo.z; r[3] = (__bf16)lo.w;
+    r[4] = (__bf16)hi.x; r[5] = (__bf16)hi.y; r[6] = (__bf16)hi.z; r[7] = (__bf16)hi.w;
+    return r;
+}
+
 // Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
 #define PTV2_NUM_COUNTERS 64
 enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE };

@@ -399,6 +399,9 @@ struct WgradMulti {
     const float *xsc[6], *xsh[6];  // != NULL: the X operand of pair z is ReLU(x * xsc + xsh) (fused BatchNorm + ReLU)
 };
 
+// BF16: the U = 8 k-steps of a trip (8 rows per lane and fragment) are exactly the 8-per-lane operand of
+// V_MFMA_F32_16X16X32_BF16: 8 fp32 MFMAs per tile pair become one instruction on bf16-rounded operands.
+template <bool BF16>
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
                                                            const float *__restrict__ gY, long long ldy, long long sy,
                                                            const float *__restrict__ X, long long ldx, long long sx,
@@ -452,15 +455,33 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 #pragma unroll
                 for (int m = 0; m < WG_MT; ++m) b[u][m] = fmaxf(__builtin_fmaf(b[u][m], xsc_[m], xsh_[m]), 0.f);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
+        if constexpr (BF16) {
+            ptv2_bf16x8 ab[WG_MT], bb[WG_MT];
 #pragma unroll
             for (int m = 0; m < WG_MT; ++m) {
-                bsum[m] += a[u][m];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    bsum[m] += a[u][m];
+                    ab[m][u] = (__bf16)a[u][m];
+                    bb[m][u] = (__bf16)b[u][m];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < WG_MT; ++m)
 #pragma unroll
                 for (int t = 0; t < WG_MT; ++t)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], b[u][t], acc[m][t], 0, 0, 0);
-            }
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[m], bb[t], acc[m][t], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < WG_MT; ++m) {
+                    bsum[m] += a[u][m];
+#pragma unroll
+                    for (int t = 0; t < WG_MT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], b[u][t], acc[m][t], 0, 0, 0);
+                }
+        }
     }
     // combine the 4 waves (fixed order) and write the partial tile
 #pragma unroll
@@ -581,11 +602,19 @@ extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin
 }
 
 // rows per split-K workgroup of the weight gradient
-static int wg_chunk(int n) {
+// `tiles` = output tiles x products of the launch.  A workgroup costs ~10 us of fixed work (operand latency, the
+// 40 KB cross-wave reduction, its partial record) however few rows it sums, and three fit a compute unit: at the deep
+// levels (n ~ 4 500, 80 tile-products) 256-row chunks made 1 440 workgroups = two full rounds of that fixed cost for 18
+// records to finalize.  Target ~3 workgroups per compute unit in ONE round; never fewer than 256 rows per workgroup.
+static int wg_chunk(int n, int tiles) {
     static const int forced = [] { const char *e = getenv("AO_AMD_WG_CHUNK"); return e ? atoi(e) : 0; }();
     if (forced >= WG_CHUNK_MIN) return forced;
-    (void)n;
-    return WG_CHUNK;
+    static const int target = [] { const char *e = getenv("AO_AMD_WG_TARGET"); return e ? atoi(e) : 768; }();
+    if (target <= 0) return WG_CHUNK;
+    const int chunks = std::max(1, target / std::max(1, tiles));
+    const long long rows = ((long long)n + chunks - 1) / chunks;
+    const long long chunk = std::max<long long>(WG_CHUNK, (rows + 127) / 128 * 128);
+    return (int)std::min<long long>(chunk, 1 << 20);
 }
 
 static int bn_grid(int n, int c) {
@@ -945,21 +974,25 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
                                                  long long sy, const float *X, long long ldx, long long sx, float *dW,
                                                  float *db, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || batch < 1) return PTV2_ERR_ARG;
-    const int chunk = wg_chunk(n);
+    const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
+    const int chunk = wg_chunk(n, tiles_o * tiles_i * batch);
     const int chunks = (n + chunk - 1) / chunk;
     const size_t need = sizeof(float) * (size_t)chunks * batch * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < need) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     float *part_b = part;  // non-null flag: bias partials live behind the weight partials of each chunk record
-    const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     dim3 grid(chunks, tiles_o * tiles_i, batch);
     {
         // algorithmic bytes, strict: every operand read once, every result written once (the split-K partial
         // records of this implementation are its own overhead, not the op's)
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0)));
-        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
-                           db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
+        if (ptv2_matmul_bf16())
+            hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
+                               db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
+        else
+            hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
+                               db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
     }
     if (db) launch_finalize(st, (const float *)part, chunks, batch * cout * cin + batch * cout,
                             gva::MapSplit2<float>{dW, db, batch * cout * cin});
@@ -990,7 +1023,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                                                const float *const *xsc, const float *const *xsh, void *workspace,
                                                size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 6 || !gY || !X || !dW) return PTV2_ERR_ARG;
-    const int chunk = wg_chunk(n);
+    const int chunk = wg_chunk(n, ((cout + WG_TILE - 1) / WG_TILE) * ((cin + WG_TILE - 1) / WG_TILE) * count);
     const int chunks = (n + chunk - 1) / chunk;
     const size_t rec = (size_t)count * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)chunks * rec) return PTV2_ERR_WORKSPACE;
@@ -1017,8 +1050,12 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         }
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
                                                (double)count * cout * (cin + 1)));
-        hipLaunchKernelGGL(linear_wgrad_kernel, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
-                           (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
+        if (ptv2_matmul_bf16())
+            hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
+                               (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
+        else
+            hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
+                               (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
     }
     launch_finalize(st, (const float *)part, chunks, (int)rec, MapWgradMulti{m, cout * cin, cout});
     PTV2_CHECK_LAUNCH();

@@ -53,7 +53,10 @@ __device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16
     return v;
 }
 
-template <int BN, bool W_KMAJOR, int KC>
+// BF16: the same kernel with bf16 matrix-core operands.  A lane owns KC / 4 consecutive reduction indices of its row /
+// column per chunk -- exactly the 8-per-lane operand layout of V_MFMA_F32_16X16X32_BF16 -- so the 8 fp32 MFMAs of
+// a 32-index chunk become one instruction on operands rounded to bf16 (fp32 accumulation, fp32 in memory).
+template <int BN, bool W_KMAJOR, int KC, bool BF16>
 __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k, const float *__restrict__ X0,
                                                             const float *__restrict__ W0,
                                                             const float *__restrict__ bias0, float *__restrict__ Y0,
@@ -154,15 +157,30 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             float4 xr[RUN];
 #pragma unroll
             for (int j = 0; j < RUN; ++j) xr[j] = *(const float4 *)(px + 4 * j);
+            if constexpr (BF16) {
+                ptv2_bf16x8 xb[RUN / 2];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+                for (int j = 0; j < RUN / 2; ++j) xb[j] = ptv2_pack_bf16(xr[2 * j], xr[2 * j + 1]);
 #pragma unroll
-                for (int j = 0; j < RUN; ++j) {
-                    const float4 w4 = *(const float4 *)(pw + t * 16 * PITCH + 4 * j);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, xr[j].x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, xr[j].y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, xr[j].z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, xr[j].w, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < RUN / 2; ++j) {
+                        const float4 w0 = *(const float4 *)(pw + t * 16 * PITCH + 8 * j);
+                        const float4 w1 = *(const float4 *)(pw + t * 16 * PITCH + 8 * j + 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ptv2_pack_bf16(w0, w1), xb[j], acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int j = 0; j < RUN; ++j) {
+                        const float4 w4 = *(const float4 *)(pw + t * 16 * PITCH + 4 * j);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, xr[j].x, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, xr[j].y, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, xr[j].z, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, xr[j].w, acc[t], 0, 0, 0);
+                    }
                 }
             }
             if (more) {
@@ -255,8 +273,12 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
 template <int BN, bool KM, int KC>
 static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const float *X, const float *W, const float *bias, float *Y,
                        int accumulate, int ncb, const gemm::GemmMulti &gm) {
-    hipLaunchKernelGGL((gemm::rows_gemm_kernel<BN, KM, KC>), grid, dim3(gemm::THREADS), 0, st, m, n, k, X, W, bias, Y, accumulate,
-                       ncb, gm);
+    if (ptv2_matmul_bf16())
+        hipLaunchKernelGGL((gemm::rows_gemm_kernel<BN, KM, KC, true>), grid, dim3(gemm::THREADS), 0, st, m, n, k, X, W, bias, Y,
+                           accumulate, ncb, gm);
+    else
+        hipLaunchKernelGGL((gemm::rows_gemm_kernel<BN, KM, KC, false>), grid, dim3(gemm::THREADS), 0, st, m, n, k, X, W, bias, Y,
+                           accumulate, ncb, gm);
 }
 
 static void launch_gemm(bool n48, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,

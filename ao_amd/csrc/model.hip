@@ -328,6 +328,7 @@ void fill_block(const ptv2_model *M, int q, int j, const Arena &A, const float *
         B->run_mean[i] = mb.run_mean[i]; B->run_var[i] = mb.run_var[i]; B->batches[i] = mb.batches[i];
     }
     B->y = A.block_y[b]; B->saved = A.block_saved[b]; B->saved_bytes = A.block_saved_bytes[b];
+    B->matmul_bf16 = M->matmul_bf16;
 }
 
 // input of block j of sequence q = output of block j-1, or the sequence's input
@@ -382,6 +383,7 @@ extern "C" size_t ptv2_model_workspace_bytes(const ptv2_model *M) {
 
 extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
     if (!model_ok(M) || !M->saved) return PTV2_ERR_ARG;
+    const PtvMatmulScope precision(M->matmul_bf16);
     const Arena A = carve(M, M->saved);
     if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
     const Work W = carve_work(M, workspace);
@@ -437,6 +439,7 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
 extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
     if (!model_ok(M) || !M->saved || !g_logits || !M->g_head_w) return PTV2_ERR_ARG;
+    const PtvMatmulScope precision(M->matmul_bf16);
     const Arena A = carve(M, M->saved);
     if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
     const Work W = carve_work(M, workspace);

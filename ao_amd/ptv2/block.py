@@ -37,7 +37,7 @@ class _Blk(ctypes.Structure):  # mirrors ptv2_block
                 + [("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
                 + [(n_, _P) for n_ in ("x", "coord", "idx", "mu", "cov", "rowscale")]
                 + [("param", _P * NPARAM), ("run_mean", _P * NBN), ("run_var", _P * NBN), ("batches", _P * NBN),
-                   ("y", _P), ("saved", _P), ("saved_bytes", ctypes.c_size_t)])
+                   ("y", _P), ("saved", _P), ("saved_bytes", ctypes.c_size_t), ("matmul_bf16", ctypes.c_int)])
 
 
 class _BlkGrads(ctypes.Structure):  # mirrors ptv2_block_grads
@@ -176,8 +176,9 @@ def supported(blk, feat, idx):
     return _gva.supported(p.c, p.g, idx.shape[1])
 
 
-def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training):
+def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16=False):
     args = p.args
+    args.matmul_bf16 = int(bf16)
     args.n, args.k = idx.shape
     args.training = int(training)
     args.x, args.coord, args.idx = x.data_ptr(), coord.data_ptr(), idx.data_ptr()
@@ -188,19 +189,19 @@ def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training):
 
 class _NativeBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, coord, idx, mu, cov, inv, rowscale, training, *params):
+    def forward(ctx, x, p, coord, idx, mu, cov, inv, rowscale, training, bf16, *params):
         x = x.contiguous()
         n, k = idx.shape
         dev = x.device
         L = _lib.lib()
         y = torch.empty((n, p.c), dtype=torch.float32, device=dev)
         saved = torch.empty(L.ptv2_block_saved_bytes(n, k, p.c, p.g), dtype=torch.uint8, device=dev)
-        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training)
+        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16)
         ws = _lib.workspace(L.ptv2_block_workspace_bytes(n, k, p.c, p.g), dev)
         rc = L.ptv2_block_forward_hip_launcher(ctypes.addressof(args), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "ptv2_block_forward_hip_launcher")
         ctx.save_for_backward(x, coord, idx, mu, cov, rowscale, y, saved)
-        ctx.plan, ctx.inv, ctx.training = p, inv, training
+        ctx.plan, ctx.inv, ctx.training, ctx.bf16 = p, inv, training, bf16
         return y
 
     @staticmethod
@@ -211,7 +212,7 @@ class _NativeBlock(torch.autograd.Function):
         dev = x.device
         L = _lib.lib()
         gy = gy.contiguous()
-        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, ctx.training)
+        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, ctx.training, ctx.bf16)
         gx = torch.empty_like(x)
         gflat = torch.empty(p.off[NPARAM], dtype=torch.float32, device=dev)
         inv_ptr, inv_rows = ctx.inv if ctx.inv is not None else _gva.inverse_table(idx)
@@ -230,7 +231,7 @@ class _NativeBlock(torch.autograd.Function):
             if slot != prm.numel():
                 chunk = chunk[:prm.numel()]
             gp.append(chunk if prm.dim() == 1 else chunk.view(prm.shape))
-        return (gx, None, None, None, None, None, None, None, None, *gp)
+        return (gx, None, None, None, None, None, None, None, None, None, *gp)
 
 
 def block_forward(blk, feat, coord, idx, rowscale):
@@ -241,7 +242,10 @@ def block_forward(blk, feat, coord, idx, rowscale):
     if training:
         mu, cov = _gva._pos_moments(_gva._HipImpl, coord, idx)
     inv = _gva.inverse_table(idx) if torch.is_grad_enabled() else None
-    # under torch.autocast the Block still computes in fp32 (a superset of the reference's mixed precision: its
-    # BatchNorm / softmax are fp32 there too, only the Linear products would drop to bf16)
+    # under torch.autocast the Linear products run on the bf16 matrix cores (native_model.matmul_bf16); BatchNorm,
+    # softmax, accumulation and the activations in memory stay fp32, as autocast keeps them
+    from .native_model import matmul_bf16
+
+    bf16 = matmul_bf16()
     with torch.autocast("cuda", enabled=False):
-        return _NativeBlock.apply(feat.float(), p, coord, idx, mu, cov, inv, rowscale, training, *p.params)
+        return _NativeBlock.apply(feat.float(), p, coord, idx, mu, cov, inv, rowscale, training, bf16, *p.params)

@@ -55,7 +55,7 @@ class _Model(ctypes.Structure):  # mirrors ptv2_model
                    ("num_blocks", _I), ("block", _MBlock * MAX_BLOCKS), ("embed", _LinBn), ("down", _LinBn * MAX_STAGES),
                    ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
                 + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
-                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P)])
+                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I)])
 
 
 _lib.register({
@@ -295,13 +295,13 @@ def supported(model, feat):
 
 class _NativeModel(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, anchor, rt, geo, training, mode, *params):
+    def forward(ctx, feat, anchor, rt, geo, training, mode, bf16, *params):
         feat = feat.contiguous()
         dev = feat.device
         L = _lib.lib()
         M = rt.M
         keep = rt.fill_geometry(geo)
-        M.training = int(training)
+        M.training, M.matmul_bf16 = int(training), int(bf16)
         scales = rt.draw_droppath(geo, dev) if training else None
         n0 = feat.shape[0]
         logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
@@ -315,7 +315,7 @@ class _NativeModel(torch.autograd.Function):
         ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
         rc = L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "ptv2_model_forward_hip_launcher")
-        ctx.rt, ctx.geo, ctx.keep, ctx.mode, ctx.training = rt, geo, (keep, scales, feat, saved), mode, training
+        ctx.rt, ctx.geo, ctx.keep, ctx.mode, ctx.training, ctx.bf16 = rt, geo, (keep, scales, feat, saved), mode, training, bf16
         ctx.rowscale_ptrs = [mb.rowscale for mb in M.block[: M.num_blocks]]
         return logits
 
@@ -327,7 +327,7 @@ class _NativeModel(torch.autograd.Function):
         L = _lib.lib()
         M = rt.M
         rt.fill_geometry(ctx.geo)  # the struct is shared between calls: restore this call's tables
-        M.training = int(ctx.training)
+        M.training, M.matmul_bf16 = int(ctx.training), int(ctx.bf16)
         for mb, rs in zip(M.block[: M.num_blocks], ctx.rowscale_ptrs):
             mb.rowscale = rs
         M.feat, M.logits = feat.data_ptr(), None
@@ -353,8 +353,8 @@ class _NativeModel(torch.autograd.Function):
             else:
                 for p, v in zip(rt.params, views):
                     p.grad = v
-            return (None,) * (6 + len(rt.params))
-        return (None,) * 6 + tuple(views)
+            return (None,) * (7 + len(rt.params))
+        return (None,) * 7 + tuple(views)
 
 
 def forward(model, data_dict, geo):
@@ -363,13 +363,23 @@ def forward(model, data_dict, geo):
     feat = data_dict["feat"]
     training = model.training or not rt.has_running
     mode = getattr(model, "native_param_grads", "autograd")
-    with torch.autocast("cuda", enabled=False):  # the runtime computes in fp32 (see block.block_forward)
+    bf16 = matmul_bf16()
+    with torch.autocast("cuda", enabled=False):  # activations, statistics, softmax and accumulation stay fp32
         if not torch.is_grad_enabled():
-            return _NativeModel.apply(feat.float(), None, rt, geo, training, mode)
+            return _NativeModel.apply(feat.float(), None, rt, geo, training, mode, bf16)
         if mode == "direct":
             anchor = model.__dict__.get("_ao_anchor")
             if anchor is None or anchor.device != feat.device:
                 anchor = torch.zeros((), device=feat.device, requires_grad=True)
                 model.__dict__["_ao_anchor"] = anchor
-            return _NativeModel.apply(feat.float(), anchor, rt, geo, training, mode)
-        return _NativeModel.apply(feat.float(), None, rt, geo, training, mode, *rt.params)
+            return _NativeModel.apply(feat.float(), anchor, rt, geo, training, mode, bf16)
+        return _NativeModel.apply(feat.float(), None, rt, geo, training, mode, bf16, *rt.params)
+
+
+def matmul_bf16():
+    """Under torch.autocast (the reference trainer's `enable_amp`, pointcept/engines/train_sam_pp2s.py:178-180) the
+    nn.Linear products run on the bf16 matrix cores: operands rounded to bf16, fp32 accumulation -- autocast's own
+    arithmetic for Linear.  Everything else (BatchNorm statistics, softmax, coordinates, activations in memory) stays
+    fp32, as autocast keeps it.  A float16 autocast (the reference's default on CUDA) maps to the same bf16 operands:
+    gfx950's fp16 and bf16 MFMA run at one rate and bf16 needs no loss scaling."""
+    return bool(torch.is_autocast_enabled("cuda")) and os.environ.get("AO_AMD_AUTOCAST_MATMUL", "bf16") == "bf16"

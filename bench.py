@@ -424,14 +424,17 @@ def child_main(args):
             "metric": "points/sec fwd+bwd PTv2m2 S3DIS" if args.cfg == "s3dis" else "points/sec fwd+bwd PTv2m2 ScanNet cfg", "value": points_per_step * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # the arithmetic type of the path: the Block runtime computes fp32 also under torch.autocast(bf16)
-            # (--dtype bf16 only exercises the autocast plumbing of the surrounding torch ops)
-            "dtype": "fp32",
+            # the arithmetic type of the matrix products: fp32 MFMA (headline), or under --dtype bf16 (torch.autocast, the
+            # reference trainer's enable_amp) bf16 MFMA operands with fp32 accumulation; storage is fp32 in both
+            "dtype": "bf16" if (args.dtype == "bf16" and os.environ.get("AO_AMD_AUTOCAST_MATMUL", "bf16") == "bf16") else "fp32",
             "data": "synthetic",
             "config": {"workload": "%s semseg-pt-v2m2-0-base, %d scene(s)/GPU x %d pts, train step "
                                    "(geometry+fwd+CE+bwd+AdamW), drop_path 0.3" % (args.cfg, args.scenes, args.points),
                        "points_per_gpu": n_points, "level_sizes": levels, "gva": os.environ.get("AO_AMD_GVA", "default"),
-                       "autocast": args.dtype if args.dtype != "fp32" else None, "parallelism": "dp%d" % world,
+                       "autocast": args.dtype if args.dtype != "fp32" else None,
+                       "precision": ("Linear products on bf16 MFMA (operands rounded to bf16, fp32 accumulate); activations, "
+                                     "BatchNorm statistics, softmax, coordinates fp32" if args.dtype == "bf16" else
+                                     "fp32 MFMA (exact fp32) everywhere"), "parallelism": "dp%d" % world,
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "comm_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": _launcher_name(),

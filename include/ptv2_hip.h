@@ -467,6 +467,9 @@ typedef struct ptv2_block {
     float *y;                  /* (n,c) output */
     void *saved;
     size_t saved_bytes;
+    int matmul_bf16;           /* != 0: the Linear products (fc1, fc3, q/k/v and their input / weight gradients) run on the
+                                * bf16 matrix cores: operands rounded to bf16, fp32 accumulation, fp32 in memory -- the
+                                * arithmetic torch.autocast(bfloat16) gives nn.Linear in the reference trainer */
 } ptv2_block;
 typedef struct ptv2_block_grads {
     const float *gy;               /* (n,c) */
@@ -556,6 +559,7 @@ typedef struct ptv2_model {
     size_t saved_bytes;
     void *side_stream;                 /* backward only, optional: weight gradients run here (see ptv2_block_grads);
                                         * the launcher joins it into `stream` before it returns control of the queue */
+    int matmul_bf16;                   /* as ptv2_block.matmul_bf16, for every Linear of the network */
 } ptv2_model;
 size_t ptv2_model_saved_bytes(const ptv2_model *m);
 size_t ptv2_model_workspace_bytes(const ptv2_model *m);
@@ -563,6 +567,12 @@ int ptv2_model_forward_hip_launcher(const ptv2_model *m, void *workspace, size_t
 /* g_logits (n0, num_classes); the gradient with respect to `feat` is not formed (the input needs none) */
 int ptv2_model_backward_hip_launcher(const ptv2_model *m, const float *g_logits, void *workspace, size_t workspace_bytes,
                                      void *stream);
+
+/* Operand precision of the matrix products launched by the CALLING THREAD through the stand-alone launchers
+ * (rows_gemm_*, linear_wgrad_*): bf16 != 0 -> V_MFMA_F32_16X16X32_BF16 on operands rounded to bf16 (fp32 accumulate,
+ * fp32 in memory), 0 -> exact fp32 MFMA (default), < 0 -> query only.  Returns the previous setting.  The Block / model
+ * launchers take the choice from their `matmul_bf16` field instead. */
+int ptv2_matmul_precision(int bf16);
 
 /* sizeof(ptv2_block) [0], sizeof(ptv2_block_grads) [1], sizeof(ptv2_model) [2] as this library was compiled: bindings
  * that mirror the structs (ctypes) compare it with their own at load time. */

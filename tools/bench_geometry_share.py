@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""How much of the step is the scene geometry?  The bench step with (a) the geometry prefetched on the side stream
+(what bench.py times), (b) the geometry built in line on the compute stream, (c) NO geometry work at all (one prebuilt
+geometry reused: not a valid step, a lower bound for everything else), (d) the geometry alone.
+usage: tools/bench_geometry_share.py [steps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import ao_amd.ptv2 as ptv2
+from ao_amd import synth
+from ao_amd.ptv2 import parallel
+from ao_amd.ptv2.optim import FlatAdamW
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device("cuda")
+b = synth.scene_batch([0], point_max=120000, room=1)
+data = {k: torch.from_numpy(v).to(dev) for k, v in b.items()}
+torch.manual_seed(0)
+seg = ptv2.DefaultSegmentor(ptv2.S3DIS_BACKBONE).to(dev).train()
+seg.backbone.native_param_grads = "direct"
+opt = FlatAdamW(seg.parameters(), lr=0.006, weight_decay=0.05)
+pre = parallel.GeometryPrefetcher(seg.backbone, dev)
+with torch.no_grad():
+    fixed = seg.backbone.geometry(data["coord"], data["offset"])
+
+
+def run(mode):
+    if mode == "prefetch":
+        pre.start(data["coord"], data["offset"])
+
+    def step():
+        if mode == "prefetch":
+            geo = pre.take()
+        elif mode == "inline":
+            with torch.no_grad():
+                geo = seg.backbone.geometry(data["coord"], data["offset"])
+        else:
+            geo = fixed
+        if mode != "geometry_only":
+            loss = seg(dict(data, geometry=geo))["loss"]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            flat = opt.flatten_grads()
+        if mode == "prefetch":
+            pre.start(data["coord"], data["offset"])
+        if mode == "geometry_only":
+            with torch.no_grad():
+                seg.backbone.geometry(data["coord"], data["offset"])
+        else:
+            opt.step(flat_grad=flat)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if mode == "prefetch":
+        pre.take()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+for mode in ("prefetch", "inline", "none", "geometry_only", "prefetch"):
+    print("%-14s %.3f ms/step" % (mode, run(mode)))
