@@ -307,9 +307,11 @@ def test_native_block_is_bitwise_reproducible(monkeypatch, n, c, g):
         assert torch.equal(a, b)
 
 
-def test_native_block_under_autocast_computes_fp32(monkeypatch):
+def test_native_block_under_autocast(monkeypatch):
     """The reference trainer wraps the step in torch.cuda.amp.autocast (reference pointcept/engines/train.py:178): the Block
-    runtime is still taken there and still computes fp32 -- same bits as without autocast."""
+    runtime is still taken there; its Linear products then run on the bf16 matrix cores (operands rounded to bf16, fp32
+    accumulation -- autocast's own arithmetic for nn.Linear) while the activations stay fp32.  AO_AMD_AUTOCAST_MATMUL=fp32
+    keeps exact fp32 products: the same bits as without autocast."""
     from ao_amd import pointops, synth
     from ao_amd.ptv2 import block as native
 
@@ -323,17 +325,21 @@ def test_native_block_under_autocast_computes_fp32(monkeypatch):
     torch.manual_seed(6)
     x0 = torch.randn(n, c, device="cuda").relu_()
     go = torch.randn(n, c, device="cuda")
-    runs = []
-    for amp in (False, True):
+    runs = {}
+    for tag, amp, matmul in (("fp32", False, "bf16"), ("amp_bf16", True, "bf16"), ("amp_fp32", True, "fp32")):
+        monkeypatch.setenv("AO_AMD_AUTOCAST_MATMUL", matmul)
         x = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
             assert native.supported(blk, x, idx)
             y = blk([coord, x, offset], idx)[1]
         assert y.dtype == torch.float32
         grads = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
-        runs.append([y.detach()] + [t.clone() for t in grads])
-    for a, b in zip(*runs):
+        runs[tag] = [y.detach()] + [t.clone() for t in grads]
+    for a, b in zip(runs["fp32"], runs["amp_fp32"]):
         assert torch.equal(a, b)
+    y32, yb = runs["fp32"][0], runs["amp_bf16"][0]
+    assert not torch.equal(y32, yb) and rel(yb, y32) < 2e-2  # bf16 products ran; one Block stays within 2e-2 relative L2
+    assert rel(runs["amp_bf16"][1], runs["fp32"][1]) < 0.1   # input gradient
 
 
 def test_plan_follows_rehomed_parameters_and_buffers():
