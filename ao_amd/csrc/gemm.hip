@@ -106,7 +106,13 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
                     const int r = q / KQ, kq = (q % KQ) * 4;
                     if (n0 + r < n && k0 + kq < k) rw[j] = *(const float4 *)(W + (long long)(n0 + r) * k + k0 + kq);
                 } else {
-                    const int kk = q / (BN / 4), cq = (q - kk * (BN / 4)) * 4;
+                    // consecutive lanes take consecutive reduction indices of one column quad: the transposing LDS store
+                    // below then writes consecutive addresses (conflict-free).  With the lanes along the columns (the
+                    // coalesced order for this load) the four scalar stores hit two banks with every pitch that keeps
+                    // ds_read_b128 aligned: SQ_LDS_BANK_CONFLICT was 0.6 of the LDS-active cycles of these kernels
+                    // (profiles/r02_final_sq_counters.jsonl).  W is at most 1 MB and L2-resident; 16-byte pieces of it
+                    // per lane cost less than the 6-way store conflict.
+                    const int kk = q % KC, cq = (q / KC) * 4;
                     if (k0 + kk < k && n0 + cq < n) rw[j] = *(const float4 *)(W + (long long)(k0 + kk) * n + n0 + cq);
                 }
             }
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
                     const int r = q / KQ, kq = (q % KQ) * 4;
                     *(float4 *)(sW + r * PITCH + kq) = rw[j];
                 } else {
-                    const int kk = q / (BN / 4), cq = (q - kk * (BN / 4)) * 4;
+                    const int kk = q % KC, cq = (q / KC) * 4;
                     sW[(cq + 0) * PITCH + kk] = rw[j].x; sW[(cq + 1) * PITCH + kk] = rw[j].y;
                     sW[(cq + 2) * PITCH + kk] = rw[j].z; sW[(cq + 3) * PITCH + kk] = rw[j].w;
                 }

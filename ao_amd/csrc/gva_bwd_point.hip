@@ -202,11 +202,25 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         stage_store(0, S);
         load_w1(pt0, pt0 < n, u1n);
     }
+    // NW == 1: a wavefront owns its point slot outright -- every LDS record it touches inside the loop (position /
+    // g_out records, its g_A tile, the gz / y transposes) is private to it, so the points of the four wavefronts of a
+    // workgroup need no workgroup barrier between them: program order within the wavefront is the only ordering
+    // required.  Three barriers per point coupled the four waves (each working on a different point) to the slowest
+    // one's memory latency: 43 % of the wave cycles were spent parked (profiles/r02_final_sq_counters.jsonl).
+    auto point_sync = [&]() {
+        if (NW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
+    __syncthreads();  // the parameters and the first records are in LDS
     int cur = 0;
     for (long long base = (long long)blockIdx.x * PW; base < n; base += stride, cur ^= 1) {
         const long long pt = base + p;
         const bool act = pt < n;
-        __syncthreads();  // record `cur` (and, on the first trip, the parameters) is in LDS; last trip's readers are done
+        point_sync();  // record `cur` is in LDS; last trip's readers are done
         const float4 *cPos = sPos + (cur * PW + p) * 16;
         const int *cSrc = sSrc + (cur * PW + p) * 16;
         const float *cGo = sGo + (cur * PW + p) * C;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 for (int i = 0; i < I; ++i) acc = __builtin_fmaf(cGo[lane * I + i], sWp2[C * C + lane * I + i], acc);
                 myGsw[lane] = acc;
             }
-            __syncthreads();
+            point_sync();
         }
         // operands of the first channel chunks of this point, then the requests for the next point
         const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                     gbw[t][r] += gz[t][r];
                 }
         }
-        __syncthreads();
+        point_sync();
 #pragma unroll
         for (int e = 0; e < NTW; ++e) {
             const int te = e * NW + sub;

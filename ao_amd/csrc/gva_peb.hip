@@ -41,14 +41,35 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, int c
     const float4 *wr = (const float4 *)(sW + (size_t)cl * ldw);
     for (long long pt = (long long)blockIdx.x * tp + p; pt < n; pt += (long long)gridDim.x * tp) {
         const float4 *ar = (const float4 *)(A + ((size_t)pt * g + gi) * c);
+        // 8 (then 4) row quads are requested before the first one is consumed: with two loads in flight per lane the
+        // kernel sat parked on memory for 81 % of its wave cycles (profiles/r02_final_sq_counters.jsonl)
         float acc0 = 0.f, acc1 = 0.f;
         int q = 0;
-        for (; q + 1 < cq; q += 2) {
-            const float4 x0 = ar[q], w0 = wr[q], x1 = ar[q + 1], w1 = wr[q + 1];
-            acc0 = __builtin_fmaf(x0.x, w0.x, acc0); acc0 = __builtin_fmaf(x0.y, w0.y, acc0);
-            acc0 = __builtin_fmaf(x0.z, w0.z, acc0); acc0 = __builtin_fmaf(x0.w, w0.w, acc0);
-            acc1 = __builtin_fmaf(x1.x, w1.x, acc1); acc1 = __builtin_fmaf(x1.y, w1.y, acc1);
-            acc1 = __builtin_fmaf(x1.z, w1.z, acc1); acc1 = __builtin_fmaf(x1.w, w1.w, acc1);
+        for (; q + 8 <= cq; q += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ar[q + j];
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float4 w0 = wr[q + j], w1 = wr[q + j + 1];
+                acc0 = __builtin_fmaf(x[j].x, w0.x, acc0); acc0 = __builtin_fmaf(x[j].y, w0.y, acc0);
+                acc0 = __builtin_fmaf(x[j].z, w0.z, acc0); acc0 = __builtin_fmaf(x[j].w, w0.w, acc0);
+                acc1 = __builtin_fmaf(x[j + 1].x, w1.x, acc1); acc1 = __builtin_fmaf(x[j + 1].y, w1.y, acc1);
+                acc1 = __builtin_fmaf(x[j + 1].z, w1.z, acc1); acc1 = __builtin_fmaf(x[j + 1].w, w1.w, acc1);
+            }
+        }
+        for (; q + 4 <= cq; q += 4) {
+            float4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = ar[q + j];
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const float4 w0 = wr[q + j], w1 = wr[q + j + 1];
+                acc0 = __builtin_fmaf(x[j].x, w0.x, acc0); acc0 = __builtin_fmaf(x[j].y, w0.y, acc0);
+                acc0 = __builtin_fmaf(x[j].z, w0.z, acc0); acc0 = __builtin_fmaf(x[j].w, w0.w, acc0);
+                acc1 = __builtin_fmaf(x[j + 1].x, w1.x, acc1); acc1 = __builtin_fmaf(x[j + 1].y, w1.y, acc1);
+                acc1 = __builtin_fmaf(x[j + 1].z, w1.z, acc1); acc1 = __builtin_fmaf(x[j + 1].w, w1.w, acc1);
+            }
         }
         for (; q < cq; ++q) {
             const float4 x0 = ar[q], w0 = wr[q];
