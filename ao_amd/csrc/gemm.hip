@@ -287,10 +287,26 @@ static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const flo
                            accumulate, ncb, gm);
 }
 
-static void launch_gemm(bool n48, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
+// Column-block width.  48 (or 64) columns per workgroup read X once per 48 outputs -- right when X is large.  At the deep
+// levels (m ~ 1 000 - 5 000 rows) that makes 136 - 284 workgroups for 256 compute units: one and a bit rounds of a
+// latency-bound workgroup (e.g. 284 = 256 + 28: the launch takes two workgroup lifetimes for 1.1 rounds of work).  There
+// 16-column blocks give 3 x the workgroups (X, a few MB, is re-read from L2) and the rounds even out.
+static int column_block(int m, int n) {
+    static const int forced = [] { const char *e = getenv("AO_AMD_GEMM_BN"); return e ? atoi(e) : 0; }();
+    const bool n48 = n % 48 == 0;
+    const int wide = n48 ? 48 : 64;
+    if (forced == 16 || forced == 48 || forced == 64) return (forced == 16 && n % 16 == 0) ? 16 : wide;
+    const long long wgs = (((long long)m + gemm::BM - 1) / gemm::BM) * ((n + wide - 1) / wide);
+    return (wgs < 768 && n % 16 == 0) ? 16 : wide;
+}
+
+static void launch_gemm(int bn, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
                         const float *W, const float *bias, float *Y, int accumulate, int ncb, const gemm::GemmMulti &gm) {
 #define GO(BN, KM, KC) launch_one<BN, KM, KC>(grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, gm)
-    if (n48) {
+    if (bn == 16) {
+        if (kmajor) { if (wide_k) GO(16, true, 64); else GO(16, true, 32); }
+        else { if (wide_k) GO(16, false, 64); else GO(16, false, 32); }
+    } else if (bn == 48) {
         if (kmajor) { if (wide_k) GO(48, true, 64); else GO(48, true, 32); }
         else { if (wide_k) GO(48, false, 64); else GO(48, false, 32); }
     } else {
@@ -309,7 +325,7 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
     if (m == 0) return PTV2_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool n48 = n % 48 == 0;  // 48 / 96 / 192 / 384: column blocks of 48 waste nothing
-    const int bn = n48 ? 48 : 64;
+    const int bn = column_block(m, n);
     const int ncb = (n + bn - 1) / bn;
     const long long nrb = ((long long)m + BM - 1) / BM;
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
@@ -317,7 +333,7 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
                          4.0 * ((double)m * (n + k) + (double)n * k));
-        launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
+        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -348,7 +364,7 @@ extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int 
     gm.xsh = xsh;
     hipStream_t st = (hipStream_t)stream;
     const bool n48 = n % 48 == 0;
-    const int bn = n48 ? 48 : 64;
+    const int bn = column_block(m, n);
     const int ncb = (n + bn - 1) / bn;
     const long long nrb = ((long long)m + BM - 1) / BM;
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
@@ -357,7 +373,7 @@ extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int 
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
                          4.0 * count * ((double)m * (n + k) + (double)n * k));
-        launch_gemm(n48, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
+        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
