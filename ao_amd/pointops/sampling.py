@@ -23,10 +23,18 @@ class FarthestPointSampling(Function):
         tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
         L = _lib.lib()
         ws = _lib.workspace(L.farthest_point_sampling_hip_workspace_bytes(b, n), xyz.device)
+        # the multi-workgroup form exchanges its per-iteration arg-max between workgroups that must all be resident; its
+        # spins are bounded and raise this flag instead of hanging (ao_amd/csrc/fps.hip: error_flag, behind the granule
+        # slots).  FPS costs tens of milliseconds and the reference synchronises around it as well: read the flag back.
+        flag = ws[16 * 256 * b:16 * 256 * b + 4].view(torch.int32)
+        flag.zero_()
         rc = L.farthest_point_sampling_hip_launcher(
             b, n_max, xyz.data_ptr(), offset.int().contiguous().data_ptr(), new_offset.int().contiguous().data_ptr(),
             tmp.data_ptr(), idx.data_ptr(), n, m_total, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "farthest_point_sampling_hip_launcher")
+        if int(flag.item()) != 0:
+            raise RuntimeError("ao_amd: farthest_point_sampling: a workgroup gave up waiting for its peers (the cooperative "
+                               "kernel needs all its workgroups resident; other work was holding the compute units)")
         ctx.mark_non_differentiable(idx)
         return idx
 
