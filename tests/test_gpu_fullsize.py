@@ -94,12 +94,18 @@ def test_full_size_block_forward_backward_matches_unfused(monkeypatch, seeds, po
         np.testing.assert_allclose(sd_f[key].cpu().numpy(), sd_u[key].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
 
 
-@pytest.mark.parametrize("seeds,points", [((0,), 120000), ((4, 5), 80000)])
-def test_full_size_model_train_step_matches_unfused(monkeypatch, seeds, points):
+@pytest.mark.parametrize("tag,seeds,points", [("s3dis", (0,), 120000), ("s3dis", (4, 5), 80000), ("scannet", (7, 8), 100000)])
+def test_full_size_model_train_step_matches_unfused(monkeypatch, tag, seeds, points):
+    """("scannet", 2 x 100 000 points): BASELINE.json configs[4]'s shape -- four stages, C up to 512 (G = 64), "map" unpool."""
     import ao_amd.ptv2 as ptv2
+    from ao_amd import synth
 
-    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
-    data = _scene(seeds, points)
+    cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.0)
+    if tag == "s3dis":
+        data = _scene(seeds, points)
+    else:
+        b = synth.scene_batch(list(seeds), point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"], room=1)
+        data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
     state = M.init_state(cfg, seed=13)
     res = {}
     for tag in ("fused", "unfused"):
@@ -120,8 +126,8 @@ def test_full_size_model_train_step_matches_unfused(monkeypatch, seeds, points):
     weights = {nm: g for nm, g in zip(names, gu)}
     weights = {nm: weights.get(nm[:-4] + "weight", weights[nm]) for nm in names}
     worst = _compare_grads(names, gf, gu, 3e-2, weights)
-    print("model %s x %d: max |dlogit| %.2e, loss %.6f / %.6f, worst gradient %s rel L2 %.2e"
-          % (seeds, points, float((lf - lu).abs().max()), loss_f, loss_u, *worst))
+    print("model %s %s x %d: max |dlogit| %.2e, loss %.6f / %.6f, worst gradient %s rel L2 %.2e"
+          % (tag, seeds, points, float((lf - lu).abs().max()), loss_f, loss_u, *worst))
 
 
 def test_model_train_step_matches_the_oracle_at_24k_points():
