@@ -76,3 +76,43 @@ def test_binding_arity_matches_header(lib):
         params = params.strip()
         count = 0 if params in ("", "void") else params.count(",") + 1
         assert count == len(lib._SIGNATURES[name][1]), (name, count, len(lib._SIGNATURES[name][1]))
+
+
+def test_model_runtime_rejects_an_invalid_description(lib):
+    """The whole-model launchers validate their struct before anything is enqueued (no GPU needed to see it): a zeroed
+    ptv2_model has no stages -> saved/workspace size 0 and PTV2_ERR_ARG; the ctypes mirrors have the library's sizeof."""
+    import ctypes
+
+    from ao_amd.ptv2 import block, native_model
+
+    L = lib.lib()
+    assert L.ptv2_struct_bytes(0) == ctypes.sizeof(block._Blk)
+    assert L.ptv2_struct_bytes(1) == ctypes.sizeof(block._BlkGrads)
+    assert L.ptv2_struct_bytes(2) == ctypes.sizeof(native_model._Model)
+    assert L.ptv2_struct_bytes(99) == -1
+    M = native_model._Model()
+    assert L.ptv2_model_saved_bytes(ctypes.addressof(M)) == 0
+    assert L.ptv2_model_workspace_bytes(ctypes.addressof(M)) == 0
+    assert L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), None, 0, None) == 1   # PTV2_ERR_ARG
+    assert L.ptv2_model_backward_hip_launcher(ctypes.addressof(M), None, None, 0, None) == 1
+    # matmul precision switch of the calling thread: set / query / restore
+    prev = L.ptv2_matmul_precision(-1)
+    assert L.ptv2_matmul_precision(1) == prev and L.ptv2_matmul_precision(-1) == 1
+    L.ptv2_matmul_precision(prev)
+    assert L.ptv2_matmul_precision(-1) == prev
+
+
+def test_basket_scatter_host_entry_point(lib):
+    """basket_scatter_rows_host is plain host code: rows in order, last write wins, out-of-range ids rejected untouched."""
+    import numpy as np
+
+    L = lib.lib()
+    dst = np.full((6, 3), -100.0, np.float32)
+    ids = np.array([4, 1, 4], np.int64)
+    src = np.arange(9, dtype=np.float32).reshape(3, 3)
+    assert L.basket_scatter_rows_host(dst.ctypes.data, 6, ids.ctypes.data, src.ctypes.data, 3, 3) == 0
+    assert dst[1].tolist() == [3, 4, 5] and dst[4].tolist() == [6, 7, 8] and (dst[[0, 2, 3, 5]] == -100).all()
+    bad = np.array([0, 6], np.int64)
+    before = dst.copy()
+    assert L.basket_scatter_rows_host(dst.ctypes.data, 6, bad.ctypes.data, src.ctypes.data, 2, 3) == 1
+    assert np.array_equal(dst, before)
