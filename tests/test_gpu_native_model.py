@@ -205,3 +205,40 @@ def test_weight_gradient_side_stream_gives_the_same_bits(monkeypatch):
         res[side] = [g.clone() for g in grads]
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("variant", ["two_stages_no_qkv_bias", "five_stages_map"])
+def test_native_model_on_other_architectures(monkeypatch, variant):
+    """The runtime description is generic in the number of stages, depths, widths, neighbour counts, qkv bias and unpool
+    backend (ptv2_model: up to 5 stages / 40 blocks): two off-config networks, native against stage-by-stage python."""
+    import ao_amd.ptv2 as ptv2
+    from ao_amd import synth
+    from ao_amd.ptv2 import native_model
+
+    if variant == "two_stages_no_qkv_bias":
+        cfg = dict(in_channels=6, num_classes=7, patch_embed_depth=1, patch_embed_channels=48, patch_embed_groups=6,
+                   patch_embed_neighbours=8, enc_depths=(1, 3), enc_channels=(96, 192), enc_groups=(12, 24),
+                   enc_neighbours=(16, 8), dec_depths=(2, 1), dec_channels=(48, 96), dec_groups=(6, 12), dec_neighbours=(8, 16),
+                   grid_sizes=(0.12, 0.3), attn_qkv_bias=False, pe_multiplier=False, pe_bias=True, attn_drop_rate=0.0,
+                   drop_path_rate=0.0, enable_checkpoint=False, unpool_backend="interp")
+    else:
+        cfg = dict(in_channels=9, num_classes=20, patch_embed_depth=1, patch_embed_channels=48, patch_embed_groups=6,
+                   patch_embed_neighbours=16, enc_depths=(1, 1, 1, 1, 1), enc_channels=(48, 96, 96, 192, 384),
+                   enc_groups=(6, 12, 12, 24, 48), enc_neighbours=(16, 16, 16, 16, 16), dec_depths=(1, 1, 1, 1, 1),
+                   dec_channels=(48, 48, 96, 96, 192), dec_groups=(6, 6, 12, 12, 24), dec_neighbours=(16, 16, 16, 16, 16),
+                   grid_sizes=(0.08, 0.16, 0.3, 0.6, 1.2), attn_qkv_bias=True, pe_multiplier=False, pe_bias=True,
+                   attn_drop_rate=0.0, drop_path_rate=0.0, enable_checkpoint=False, unpool_backend="map")
+    b = synth.scene_batch([1, 2], point_max=9000, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"])
+    data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    res = {}
+    for mode in ("native", "python"):
+        monkeypatch.setenv("AO_AMD_MODEL", mode)
+        torch.manual_seed(5)
+        model = ptv2.PointTransformerV2(**cfg).cuda().train()
+        assert native_model.supported(model, data["feat"]) == (mode == "native")
+        logits = model(data)
+        loss = F.cross_entropy(logits, data["segment"], ignore_index=-1)
+        res[mode] = (logits.detach(), torch.autograd.grad(loss, list(model.parameters())))
+    np.testing.assert_allclose(res["native"][0].cpu().numpy(), res["python"][0].cpu().numpy(), rtol=0, atol=2e-5)
+    for (nm, _), a, b_ in zip(model.named_parameters(), res["native"][1], res["python"][1]):
+        assert rel(a, b_) < 2e-3 or float((a - b_).abs().max()) < 2e-6, (nm, rel(a, b_))
