@@ -8,6 +8,7 @@
 // workgroup streams a tile of T = 256/I points of A[g] through LDS once per group (coalesced,
 // read-once: the kernel is HBM-bound on A) and each thread owns one output element.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gva_common.h"
 
@@ -176,7 +177,11 @@ extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A,
                                             const float *sw, const float *out_v, float *out, void *stream) {
     if (n < 0 || c < 4 || g < 1 || c % g != 0 || c % 4 != 0) return PTV2_ERR_ARG;
     if (n == 0) return PTV2_OK;
-    const int ct = c <= 128 ? c : 64;  // output channels per workgroup
+    // output channels per workgroup.  Wide C: 32 (not 64) -- the 64-channel stage of Wp2 rows is 99 KB of LDS at C = 384,
+    // one workgroup per CU and the kernel parked on its A-row loads; 32 channels leave room for three (58 -> 37 us at
+    // C = 384, 34 -> 21 us at C = 512, unchanged at C = 192)
+    static const int ct_wide = [] { const char *e = getenv("AO_AMD_PEB_CT"); return e ? atoi(e) : 32; }();
+    const int ct = c <= 128 ? c : ct_wide;
     if (ct > TPB) return PTV2_ERR_ARG;
     const size_t lds = sizeof(float) * (size_t)ct * (c + 4);
     if (lds > 160 * 1024) return PTV2_ERR_ARG;
