@@ -70,6 +70,8 @@ _SIGNATURES = {
                                 + [_c_size, _vp]),
     "bn_backward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
     "bn_backward_pair_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
+    "bn_backward_records_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6 + [_c_int] * 2 + [_vp] * 4 + [_c_int, _vp]),
+    "rows_gemm_bnbwd_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 2 + [_c_int] + [_vp] * 6 + [_c_int] + [_vp] * 2),
     "linear_wgrad_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5 + [_c_size, _vp]),
     "linear_wgrad_multi_hip_launcher": (_c_int, [_c_int] * 4 + [_vp] * 7 + [_c_size, _vp]),
     "skinny_linear_forward_xf_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),

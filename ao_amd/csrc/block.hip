@@ -284,9 +284,20 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                           batch[6], g_h3, G->gx, GP(PTV2_BLK_N3_G), GP(PTV2_BLK_N3_B), W.dense, W.dense_bytes,
                                           stream));
     // fc3 input gradient -> g_f2 (ta); norm2 + ReLU -> g_attn (tb)
-    RUN(rows_gemm_hip_launcher(n, c, c, g_h3, P[PTV2_BLK_FC3_W], 1, nullptr, ta, 0, stream));
-    RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], tb,
-                                 GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
+    // (at <= 512 row blocks the GEMM's epilogue leaves the reduce records of the BatchNorm backward that consumes its output)
+    const int nrb = (n + 63) / 64;
+    const bool epi = nrb <= 512 && !getenv("AO_AMD_BN_BWD_SEPARATE");
+    if (epi) {
+        const float *xs[1] = {g_h3}, *ws[1] = {P[PTV2_BLK_FC3_W]};
+        RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G],
+                                         P[PTV2_BLK_N2_B], 1, W.stat[0], stream));
+        RUN(bn_backward_records_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5],
+                                             tb, GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.stat[0], nrb, stream));
+    } else {
+        RUN(rows_gemm_hip_launcher(n, c, c, g_h3, P[PTV2_BLK_FC3_W], 1, nullptr, ta, 0, stream));
+        RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], tb,
+                                     GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
+    }
     // attention: gq (ta), gk (g_h1's buffer, free until the end of the chain), gv
     float *gq = ta, *gk = g_h1;
     ptv2_gva_block V;
@@ -312,14 +323,21 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                      GP(PTV2_BLK_QN_G), GP(PTV2_BLK_QN_B), W.dense, W.dense_bytes, stream));
     }
     // g_f1 (tb) = g_hq Wq + g_hk Wk + gv Wv
+    // norm1 + ReLU -> g_h1; fc1: gx += g_h1 fc1
     {
         const float *xs[3] = {g_hq, g_hk, gv}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
-        float *ys[3] = {tb, nullptr, nullptr};
-        RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 1, xs, ws, 1, nullptr, ys, 0, stream));
+        if (epi) {
+            RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 3, xs, ws, 1, tb, S.h1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G],
+                                             P[PTV2_BLK_N1_B], 1, W.stat[0], stream));
+            RUN(bn_backward_records_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1,
+                                                 batch[0], g_h1, GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.stat[0], nrb, stream));
+        } else {
+            float *ys[3] = {tb, nullptr, nullptr};
+            RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 1, xs, ws, 1, nullptr, ys, 0, stream));
+            RUN(bn_backward_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], g_h1,
+                                         GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.dense, W.dense_bytes, stream));
+        }
     }
-    // norm1 + ReLU -> g_h1; fc1: gx += g_h1 fc1
-    RUN(bn_backward_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], g_h1,
-                                 GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.dense, W.dense_bytes, stream));
     RUN(rows_gemm_hip_launcher(n, c, c, g_h1, P[PTV2_BLK_FC1_W], 1, nullptr, G->gx, 1, stream));
     // the five (c,c) weight gradients: fc3 (X = f2 = ReLU(BN2(attn))), linear_q / k / v (X = f1 = ReLU(BN1(h1))), fc1 (X = x)
     {

@@ -854,6 +854,26 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     return PTV2_OK;
 }
 
+// bn_backward whose reduce pass already ran in the epilogue of the GEMM that produced gy (rows_gemm_bnbwd_hip_launcher left
+// nrec records of [2][c] in `records`): finalize + apply only
+extern "C" int bn_backward_records_hip_launcher(int n, int c, const float *x, const float *gy, const float *mean,
+                                                const float *rstd, const float *gamma, const float *beta, int relu,
+                                                int training, float *gx, float *dgamma, float *dbeta, const float *records,
+                                                int nrec, void *stream) {
+    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024 || !records || nrec < 1) return PTV2_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    launch_finalize(st, records, nrec, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
+    const long long total4 = (long long)n * (c >> 2);
+    const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
+    {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean,
+                           rstd, gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx, BnSecond{});
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 struct MapBnPair {  // record [dbeta0 c | dgamma0 c | dbeta1 c | dgamma1 c]
     float *db0, *dg0, *db1, *dg1;
     int c;

@@ -39,6 +39,12 @@ struct GemmMulti {
     // centred sum of squares of the block's rows) for the BatchNorm behind it
     const float *xsc, *xsh;
     float *stats[3];
+    // backward twin of `stats`: Y is the gradient entering a BatchNorm (+ ReLU) whose input was bnx (m,n); the epilogue
+    // leaves per-row-block records [2][n] of sum g' and sum g' * xhat (g' = Y masked by the ReLU) in brec -- the reduce
+    // pass of that BatchNorm's backward (dense.hip: bn_bwd_reduce_kernel) without its own launch and its two tensor reads
+    const float *bnx, *bnm, *bnr, *bng, *bnb;
+    int bnrelu;
+    float *brec;
 };
 
 template <int CTRL>
@@ -217,6 +223,48 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             *dst = v;
         }
     }
+    if (multi.count && multi.brec) {
+        float *sS = sX;  // [4 waves][2][BN]
+        const bool rv = row < m;
+        const int cl = (lane >> 4) * 4;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + t * 16 + cl;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), e = d;
+            if (rv && col < n) {
+                const float4 xv = *(const float4 *)(multi.bnx + row * n + col);
+                const float4 mm = *(const float4 *)(multi.bnm + col), rs = *(const float4 *)(multi.bnr + col);
+                float4 h;
+                h.x = (xv.x - mm.x) * rs.x; h.y = (xv.y - mm.y) * rs.y; h.z = (xv.z - mm.z) * rs.z; h.w = (xv.w - mm.w) * rs.w;
+                d = val[t];
+                if (multi.bnrelu) {
+                    const float4 gg = *(const float4 *)(multi.bng + col), bb = *(const float4 *)(multi.bnb + col);
+                    if (__builtin_fmaf(h.x, gg.x, bb.x) <= 0.f) d.x = 0.f;
+                    if (__builtin_fmaf(h.y, gg.y, bb.y) <= 0.f) d.y = 0.f;
+                    if (__builtin_fmaf(h.z, gg.z, bb.z) <= 0.f) d.z = 0.f;
+                    if (__builtin_fmaf(h.w, gg.w, bb.w) <= 0.f) d.w = 0.f;
+                }
+                e = make_float4(d.x * h.x, d.y * h.y, d.z * h.z, d.w * h.w);
+            }
+            const float ax = row16_sum(d.x), ay = row16_sum(d.y), az = row16_sum(d.z), aw = row16_sum(d.w);
+            const float bx = row16_sum(e.x), by = row16_sum(e.y), bz = row16_sum(e.z), bw = row16_sum(e.w);
+            if ((lane & 15) == 0) {
+                *(float4 *)(sS + (wid * 2 + 0) * BN + t * 16 + cl) = make_float4(ax, ay, az, aw);
+                *(float4 *)(sS + (wid * 2 + 1) * BN + t * 16 + cl) = make_float4(bx, by, bz, bw);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += THREADS) {
+            const int which = e / BN, cc = e - which * BN;
+            if (n0 + cc < n) {
+                float a = sS[which * BN + cc];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) a += sS[(w * 2 + which) * BN + cc];
+                multi.brec[(size_t)rb * 2 * n + (size_t)which * n + n0 + cc] = a;
+            }
+        }
+    }
     float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
     if (stats) {
         // column statistics of this 64-row block: sum, then sum of squares about the block mean (two passes over
@@ -384,4 +432,39 @@ extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int 
                                             int accumulate, void *stream) {
     return rows_gemm_fused_hip_launcher(m, n, k, count, sum, X, W, w_kmajor, bias, Y, accumulate, nullptr, nullptr, nullptr,
                                         stream);
+}
+
+// rows_gemm_multi (sum or single) whose output Y[0] is the gradient entering a BatchNorm (+ ReLU) with input bn_x: also
+// leaves that BatchNorm's backward-reduce records (ceil(m / 64) records of [2][n]: sum g', sum g' xhat) in `records`,
+// to be finished by bn_backward_records_hip_launcher
+extern "C" int rows_gemm_bnbwd_hip_launcher(int m, int n, int k, int count, const float *const *X, const float *const *W,
+                                            int w_kmajor, float *Y, const float *bn_x, const float *bn_mean, const float *bn_rstd,
+                                            const float *bn_gamma, const float *bn_beta, int relu, float *records, void *stream) {
+    using namespace gemm;
+    if (m < 0 || n < 4 || k < 4 || n % 4 != 0 || k % 4 != 0 || count < 1 || count > 3 || !X || !W || !Y) return PTV2_ERR_ARG;
+    if (!bn_x || !bn_mean || !bn_rstd || !records || (relu && (!bn_gamma || !bn_beta))) return PTV2_ERR_ARG;
+    if (m == 0) return PTV2_OK;
+    GemmMulti gm{};
+    gm.count = count;
+    gm.sum = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!X[i] || !W[i]) return PTV2_ERR_ARG;
+        gm.X[i] = X[i]; gm.W[i] = W[i];
+    }
+    gm.Y[0] = Y;
+    gm.bnx = bn_x; gm.bnm = bn_mean; gm.bnr = bn_rstd; gm.bng = bn_gamma; gm.bnb = bn_beta; gm.bnrelu = relu; gm.brec = records;
+    hipStream_t st = (hipStream_t)stream;
+    const bool n48 = n % 48 == 0;
+    const int bn = column_block(m, n);
+    const int ncb = (n + bn - 1) / bn;
+    const long long nrb = ((long long)m + BM - 1) / BM;
+    if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
+    const dim3 grid((unsigned)(nrb * ncb), 1);
+    {
+        PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
+                         4.0 * ((double)m * (2 * n + count * k) + (double)count * n * k));
+        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], nullptr, Y, 0, ncb, gm);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
 }

@@ -149,8 +149,31 @@ __device__ __forceinline__ void finalize_columns(const float *part, int nblk, in
     }
 }
 
+// few records, many columns (split-K weight gradients at the deep levels: 5-9 chunk records of 10^5 - 10^6 outputs):
+// one thread per column walks the records -- the sliced form above would launch 16 threads per column of which at most
+// nblk load anything (11 550 workgroups of 1 024 threads for 737 k columns: 24 us; this form: 2 880 of 256)
+template <class Map>
+__global__ __launch_bounds__(256) void finalize_flat_kernel(const float *__restrict__ part, int nblk, int len, Map map) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= len) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        a0 += (double)part[(size_t)b * len + j];
+        a1 += (double)part[(size_t)(b + 1) * len + j];
+        a2 += (double)part[(size_t)(b + 2) * len + j];
+        a3 += (double)part[(size_t)(b + 3) * len + j];
+    }
+    for (; b < nblk; ++b) a0 += (double)part[(size_t)b * len + j];
+    map(j, (a0 + a1) + (a2 + a3));
+}
+
 template <class Map>
 inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len, Map map) {
+    if (nblk <= 32 && len >= 16384) {
+        hipLaunchKernelGGL(finalize_flat_kernel<Map>, dim3((len + 255) / 256), dim3(256), 0, st, part, nblk, len, map);
+        return;
+    }
     hipLaunchKernelGGL(finalize_kernel<Map>, dim3((len + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS * FIN_SLICES), 0, st,
                        part, nblk, len, map);
 }

@@ -361,6 +361,19 @@ int bn_backward_pair_hip_launcher(int n, int c, const float *const *x, const flo
                                   const float *const *beta, int relu, int training, float *const *gx,
                                   float *const *dgamma, float *const *dbeta, void *workspace, size_t workspace_bytes,
                                   void *stream);
+/* The reduce pass of a BatchNorm (+ ReLU) backward inside the GEMM that produces its incoming gradient:
+ *   rows_gemm_bnbwd: Y (m,n) = sum_i X[i] op(W[i]) (count <= 3 pairs, as rows_gemm_multi with sum != 0), and `records`
+ *     receives ceil(m / 64) records of [2][n] floats: column sums of g' and of g' * xhat over the record's 64 rows, with
+ *     g' = Y masked by ReLU(BN(bn_x)) when relu != 0 and xhat = (bn_x - bn_mean) * bn_rstd;
+ *   bn_backward_records: bn_backward without its reduce launch -- merges nrec such records into dgamma / dbeta (fixed
+ *     order, float64) and applies.  Together: 3 launches instead of 4, two (m,n) tensor reads less. */
+int rows_gemm_bnbwd_hip_launcher(int m, int n, int k, int count, const float *const *X, const float *const *W,
+                                 int w_kmajor, float *Y, const float *bn_x, const float *bn_mean, const float *bn_rstd,
+                                 const float *bn_gamma, const float *bn_beta, int relu, float *records, void *stream);
+int bn_backward_records_hip_launcher(int n, int c, const float *x, const float *gy, const float *mean,
+                                     const float *rstd, const float *gamma, const float *beta, int relu,
+                                     int training, float *gx, float *dgamma, float *dbeta, const float *records,
+                                     int nrec, void *stream);
 /* Block tail fused into the Block's last BatchNorm (point_transformer_v2m2_base.py:174-176):
  * y = ReLU(residual + rowscale[n] * BN(x)); rowscale (n) = per-point DropPath factor or NULL.  Backward returns
  * the BN input gradient gx, the residual gradient g_residual = gy * (y > 0), dgamma, dbeta. */

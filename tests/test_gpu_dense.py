@@ -112,3 +112,50 @@ def test_bn_residual_relu(n, c, training, drop):
     g = torch.autograd.grad(y, [x, ident, mine.weight, mine.bias], go)
     for a, b, nm in zip(g, g_ref, ("gx", "gident", "dgamma", "dbeta")):
         assert rel(a, b) < 1e-3, (nm, rel(a, b))
+
+
+@pytest.mark.parametrize("n,c,count", [(18905, 96, 1), (4501, 192, 3), (1074, 384, 3), (37, 48, 1), (30001, 48, 3)])
+@pytest.mark.parametrize("training", [True, False])
+def test_gemm_epilogue_bn_backward_records(n, c, count, training):
+    """rows_gemm_bnbwd + bn_backward_records (the reduce pass of a BatchNorm + ReLU backward inside the GEMM that produces
+    its incoming gradient) against torch autograd of  relu(bn(x))  fed with  gy = sum_i X_i W_i."""
+    from ao_amd import _lib
+
+    L = _lib.lib()
+    torch.manual_seed(n + c)
+    dev = "cuda"
+    X = [torch.randn(n, c, device=dev) for _ in range(count)]
+    W = [torch.randn(c, c, device=dev) / c ** 0.5 for _ in range(count)]
+    x = (torch.randn(n, c, device=dev) * 1.5 + 0.3).requires_grad_(True)
+    bn = nn.BatchNorm1d(c).to(dev).train(training)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0.3, 0.2)
+        bn.running_var.uniform_(1.5, 3)
+    gy_ref = sum(a @ w for a, w in zip(X, W))
+    if training:
+        mean = x.detach().mean(0)
+        rstd = (x.detach().var(0, unbiased=False) + bn.eps).rsqrt()
+    else:
+        mean, rstd = bn.running_mean.clone(), (bn.running_var + bn.eps).rsqrt()
+    F.relu(bn(x)).backward(gy_ref)
+
+    gy = torch.empty(n, c, device=dev)
+    nrec = (n + 63) // 64
+    rec = torch.full((nrec * 2 * c + 64,), float("nan"), device=dev)
+    gx, dg, db = torch.empty(n, c, device=dev), torch.empty(c, device=dev), torch.empty(c, device=dev)
+    import ctypes
+    arr = ctypes.c_void_p * count
+    xs, ws = arr(*[t.data_ptr() for t in X]), arr(*[t.data_ptr() for t in W])
+    g, b = bn.weight.detach(), bn.bias.detach()
+    _lib.check(L.rows_gemm_bnbwd_hip_launcher(n, c, c, count, xs, ws, 1, gy.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                                              rstd.data_ptr(), g.data_ptr(), b.data_ptr(), 1, rec.data_ptr(),
+                                              _lib.stream_ptr()), "rows_gemm_bnbwd")
+    _lib.check(L.bn_backward_records_hip_launcher(n, c, x.data_ptr(), gy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                  g.data_ptr(), b.data_ptr(), 1, int(training), gx.data_ptr(), dg.data_ptr(),
+                                                  db.data_ptr(), rec.data_ptr(), nrec, _lib.stream_ptr()), "bn_backward_records")
+    torch.cuda.synchronize()
+    assert rel(gy, gy_ref) < 2e-6
+    assert rel(gx, x.grad) < 2e-5, rel(gx, x.grad)
+    assert rel(dg, bn.weight.grad) < 2e-5 and rel(db, bn.bias.grad) < 2e-5

@@ -425,11 +425,14 @@ def test_equal_steps_miou_against_the_literal_op_sequence(ptv2, monkeypatch):
           "bf16: loss -> %.4f, mIoU %.4f (held-out %.4f)"
           % (lf[0], np.mean(lf[-6:]), mf, hf, np.mean(lu[-6:]), mu, hu, np.mean(lb[-6:]), mb, hb))
     # the bf16 matrix-core path learns the same thing
-    assert abs(mb - mf) < 0.06 and np.mean(lb[-6:]) < 0.35 * lb[0] and abs(hb - hf) < 0.12  # measured 0.7382 vs 0.7046
+    # (train-scene mIoU is the stable figure: measured 0.7195 / 0.7382 vs 0.6973 / 0.7046; the ONE held-out scene moves by
+    # +-0.13 between two fp32 runs that differ only in a summation order -- 0.32 / 0.36 / 0.46 in one run -- so it is bounded
+    # loosely: it only has to show that the network generalises at all in every mode)
+    assert abs(mb - mf) < 0.06 and np.mean(lb[-6:]) < 0.35 * lb[0] and abs(hb - hf) < 0.25 and min(hb, hf, hu) > 0.2
     assert abs(lf[0] - lu[0]) < 2e-5  # same first forward
     assert np.mean(lf[-6:]) < 0.35 * lf[0] and np.mean(lu[-6:]) < 0.35 * lu[0]  # both learn
     assert abs(np.mean(lf[-6:]) - np.mean(lu[-6:])) < 0.25 * np.mean(lu[-6:]) + 0.02
     # mIoU over the scenes trained on (eval mode): the stable measure of what was learnt.  The single held-out scene is
     # printed and loosely bounded only: its mIoU moves by ~0.05 between two runs of the literal path alone (that path's
     # index_put backward uses float atomics), e.g. 0.3408 and 0.3509 in two runs against 0.3400 here.
-    assert abs(mf - mu) < 0.02 and mf > 0.6 and abs(hf - hu) < 0.12  # measured 0.7046 vs 0.7091 / 0.6987 (two runs)
+    assert abs(mf - mu) < 0.02 and mf > 0.6 and abs(hf - hu) < 0.25  # (held-out: see above) measured 0.7046 vs 0.7091 / 0.6987 (two runs)
