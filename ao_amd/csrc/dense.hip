@@ -65,23 +65,25 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
 }
 
 // finalize: column sums of (x-x0) and (x-x0)^2 over the per-block partials -> mean, rstd, running statistics
-__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_kernel(
+template <int COLS>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float *__restrict__ part, int nblk, int c, int n, const float *__restrict__ x0, float eps, float momentum,
     float *__restrict__ mean, float *__restrict__ rstd, float *run_mean, float *run_var, long long *batches,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ sc, float *__restrict__ sh) {
-    __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
-    const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
-    const int ch = blockIdx.x * gva::FIN_COLS + col;
+    constexpr int SLICES = 1024 / COLS;
+    __shared__ double s1[SLICES][COLS], s2[SLICES][COLS];
+    const int col = threadIdx.x & (COLS - 1), sl = threadIdx.x / COLS;
+    const int ch = blockIdx.x * COLS + col;
     double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
     if (ch < c) {
         int k = sl;
-        for (; k + gva::FIN_SLICES < nblk; k += 2 * gva::FIN_SLICES) {
+        for (; k + SLICES < nblk; k += 2 * SLICES) {
             a += (double)part[(size_t)k * 2 * c + ch];
             b += (double)part[(size_t)k * 2 * c + c + ch];
-            a2 += (double)part[(size_t)(k + gva::FIN_SLICES) * 2 * c + ch];
-            b2 += (double)part[(size_t)(k + gva::FIN_SLICES) * 2 * c + c + ch];
+            a2 += (double)part[(size_t)(k + SLICES) * 2 * c + ch];
+            b2 += (double)part[(size_t)(k + SLICES) * 2 * c + c + ch];
         }
-        for (; k < nblk; k += gva::FIN_SLICES) {
+        for (; k < nblk; k += SLICES) {
             a += (double)part[(size_t)k * 2 * c + ch];
             b += (double)part[(size_t)k * 2 * c + c + ch];
         }
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_ke
     if (sl == 0 && ch < c) {
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        for (int t = 0; t < SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
         const double d = t1 / n;                       // mean of the shifted samples
         const double m = (double)x0[ch] + d;
         double var = t2 / n - d * d;
@@ -144,29 +146,37 @@ __device__ __forceinline__ void bn_tiles_emit(const BnTileSet &S, int ch, double
     }
 }
 
-__global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_finalize_tiles_kernel(BnTileSet A, BnTileSet B, int nrb, int c,
-                                                                                           int n, float eps, float momentum) {
-    __shared__ double s1[gva::FIN_SLICES][gva::FIN_COLS], s2[gva::FIN_SLICES][gva::FIN_COLS];
+template <int COLS>
+__global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, BnTileSet B, int nrb, int c, int n, float eps,
+                                                                 float momentum) {
+    constexpr int SLICES = 1024 / COLS;
+    __shared__ double s1[SLICES][COLS], s2[SLICES][COLS];
     const BnTileSet &S = blockIdx.z ? B : A;
     const float *__restrict__ part = S.part;
-    const int col = threadIdx.x & (gva::FIN_COLS - 1), sl = threadIdx.x / gva::FIN_COLS;
-    const int ch = blockIdx.x * gva::FIN_COLS + col;
-    double a = 0.0, b = 0.0;
+    const int col = threadIdx.x & (COLS - 1), sl = threadIdx.x / COLS;
+    const int ch = blockIdx.x * COLS + col;
+    double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
     if (ch < c) {
-        for (int k = sl; k < nrb; k += gva::FIN_SLICES) {
+        auto rec = [&](int k, double &sa, double &sq) {
             const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
             const double sb = (double)part[(size_t)k * 2 * c + ch];
-            a += sb;
-            b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
+            sa += sb;
+            sq += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
+        };
+        int k = sl;
+        for (; k + SLICES < nrb; k += 2 * SLICES) {  // two independent chains: the loads of both records are in flight
+            rec(k, a, b);
+            rec(k + SLICES, a2, b2);
         }
+        for (; k < nrb; k += SLICES) rec(k, a, b);
     }
-    s1[sl][col] = a;
-    s2[sl][col] = b;
+    s1[sl][col] = a + a2;
+    s2[sl][col] = b + b2;
     __syncthreads();
     if (sl == 0 && ch < c) {
         double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-        for (int t = 0; t < gva::FIN_SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        for (int t = 0; t < SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
         bn_tiles_emit(S, ch, t1, t2, n, eps, momentum);
     }
 }
@@ -636,9 +646,12 @@ static int bn_stats_impl(int n, int c, const float *x, float *mean, float *rstd,
         PtvScopedTimer t(KID_BN_STATS, st, 4.0 * n * c);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + gva::FIN_COLS - 1) / gva::FIN_COLS),
-                       dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, st, (const float *)part, nblk, c, n, x, eps, momentum, mean,
-                       rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
+    if (nblk >= 64)
+        hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((c + 15) / 16), dim3(1024), 0, st, (const float *)part, nblk, c, n, x, eps,
+                           momentum, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3((c + 63) / 64), dim3(1024), 0, st, (const float *)part, nblk, c, n, x, eps,
+                           momentum, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
@@ -728,8 +741,12 @@ static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, floa
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
-    hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3(cb, 1, count), dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream, A, B,
-                       nrb_all, c, n, eps, momentum);
+    if (nrb_all >= 64)  // many records: 16 columns x 64 record slices per workgroup
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel<16>, dim3((c + 15) / 16, 1, count), dim3(1024), 0, (hipStream_t)stream, A, B,
+                           nrb_all, c, n, eps, momentum);
+    else
+        hipLaunchKernelGGL(bn_finalize_tiles_kernel<64>, dim3(cb, 1, count), dim3(1024), 0, (hipStream_t)stream, A, B, nrb_all, c, n,
+                           eps, momentum);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -62,23 +62,26 @@ __device__ __forceinline__ float wave_sum(float v) {
 // `Map` receives (column, sum) and writes the value wherever the stage wants it.
 constexpr int FIN_COLS = 64, FIN_SLICES = 16;
 
-template <class Map>
-__global__ __launch_bounds__(FIN_COLS *FIN_SLICES) void finalize_kernel(const float *__restrict__ part, int nblk,
-                                                                        int len, Map map) {
-    __shared__ double s_acc[FIN_SLICES][FIN_COLS];
-    const int col = threadIdx.x & (FIN_COLS - 1), sl = threadIdx.x / FIN_COLS;
-    const int j = blockIdx.x * FIN_COLS + col;
+// COLS x (1024 / COLS) row slices per 1024-thread block.  COLS = 64: wide records; COLS = 16: narrow records with many
+// blocks (a few hundred columns, hundreds to thousands of records: the 64-column form left such a sum to 2 - 8 workgroups
+// whose threads each walked 20 - 130 records, 8 - 13 us on the critical path of every Block)
+template <class Map, int COLS = FIN_COLS>
+__global__ __launch_bounds__(1024) void finalize_kernel(const float *__restrict__ part, int nblk, int len, Map map) {
+    constexpr int SLICES = 1024 / COLS;
+    __shared__ double s_acc[SLICES][COLS];
+    const int col = threadIdx.x & (COLS - 1), sl = threadIdx.x / COLS;
+    const int j = blockIdx.x * COLS + col;
     // four independent chains per thread (fixed association: ((a0+a1)+(a2+a3))) keep the loads in flight
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (j < len) {
         int b = sl;
-        for (; b + 3 * FIN_SLICES < nblk; b += 4 * FIN_SLICES) {
+        for (; b + 3 * SLICES < nblk; b += 4 * SLICES) {
             a0 += (double)part[(size_t)b * len + j];
-            a1 += (double)part[(size_t)(b + FIN_SLICES) * len + j];
-            a2 += (double)part[(size_t)(b + 2 * FIN_SLICES) * len + j];
-            a3 += (double)part[(size_t)(b + 3 * FIN_SLICES) * len + j];
+            a1 += (double)part[(size_t)(b + SLICES) * len + j];
+            a2 += (double)part[(size_t)(b + 2 * SLICES) * len + j];
+            a3 += (double)part[(size_t)(b + 3 * SLICES) * len + j];
         }
-        for (; b < nblk; b += FIN_SLICES) a0 += (double)part[(size_t)b * len + j];
+        for (; b < nblk; b += SLICES) a0 += (double)part[(size_t)b * len + j];
     }
     const double acc = (a0 + a1) + (a2 + a3);
     s_acc[sl][col] = acc;
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(FIN_COLS *FIN_SLICES) void finalize_kernel(const fl
     if (sl == 0 && j < len) {
         double v = 0.0;
 #pragma unroll
-        for (int t = 0; t < FIN_SLICES; ++t) v += s_acc[t][col];
+        for (int t = 0; t < SLICES; ++t) v += s_acc[t][col];
         map(j, v);
     }
 }
@@ -174,7 +177,11 @@ inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len
         hipLaunchKernelGGL(finalize_flat_kernel<Map>, dim3((len + 255) / 256), dim3(256), 0, st, part, nblk, len, map);
         return;
     }
-    hipLaunchKernelGGL(finalize_kernel<Map>, dim3((len + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS * FIN_SLICES), 0, st,
+    if (len <= 2048 && nblk >= 128) {
+        hipLaunchKernelGGL((finalize_kernel<Map, 16>), dim3((len + 15) / 16), dim3(1024), 0, st, part, nblk, len, map);
+        return;
+    }
+    hipLaunchKernelGGL((finalize_kernel<Map, FIN_COLS>), dim3((len + FIN_COLS - 1) / FIN_COLS), dim3(FIN_COLS * FIN_SLICES), 0, st,
                        part, nblk, len, map);
 }
 
