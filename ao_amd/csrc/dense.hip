@@ -732,7 +732,7 @@ static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, floa
     }
     const BnTileSet A = sets[0], B = sets[count - 1];
     const unsigned cb = (unsigned)((c + gva::FIN_COLS - 1) / gva::FIN_COLS);
-    if (nrb_all > 512) {  // two levels: 16 folding blocks per 64 columns, then a one-thread-per-column finish
+    if (nrb_all > 4096) {  // two levels: 16 folding blocks per 64 columns, then a one-thread-per-column finish
         const int ny = 16;
         hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(cb, ny, count), dim3(gva::FIN_COLS * gva::FIN_SLICES), 0, (hipStream_t)stream,
                            A, B, nrb_all, c, n);

@@ -993,7 +993,7 @@ int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const f
 #undef CASE
         default: return PTV2_ERR_ARG;
     }
-    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3(1), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
+    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3((g + FLS_GROUPS - 1) / FLS_GROUPS), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
     return PTV2_OK;
 }
 

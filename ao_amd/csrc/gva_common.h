@@ -248,35 +248,42 @@ __device__ __forceinline__ void finalize_logit_sums(const float *part, int nblk,
     }
 }
 
-// the same as a launch of its own (large grids): one workgroup; its 1024 threads are split into S = 1024 / (2g) record
-// slices per column (2g <= 128), four independent chains per thread, slice sums combined in slice order
+// the same as a launch of its own (large grids): a workgroup owns 4 groups = 8 of the 2g record columns (T1 and T2 of a
+// group are finished by the same workgroup, which then folds that group's BatchNorm), 128 record slices each; slice sums
+// are combined in slice order.  One 1024-thread workgroup for all columns walked nblk * 2g / 1024 records per thread:
+// 8 - 9 us on the critical path of every attention block.
+constexpr int FLS_GROUPS = 4, FLS_SLICES = 1024 / (2 * FLS_GROUPS);
 static __global__ __launch_bounds__(1024) void finalize_logit_sums_kernel(const float *__restrict__ part, int nblk, int g, double *T1,
                                                                           double *T2, FoldWFwdArgs F) {
-    __shared__ double s_acc[1024];
-    __shared__ double s_sum[128];
-    const int len = 2 * g, S = 1024 / len;
-    const int col = threadIdx.x % len, sl = threadIdx.x / len;
+    __shared__ double s_acc[FLS_SLICES][2 * FLS_GROUPS];
+    __shared__ double s_sum[2 * FLS_GROUPS];
+    const int len = 2 * g;
+    const int cl = threadIdx.x % (2 * FLS_GROUPS), sl = threadIdx.x / (2 * FLS_GROUPS);
+    const int j = blockIdx.x * FLS_GROUPS + (cl % FLS_GROUPS);  // group
+    const int col = cl < FLS_GROUPS ? j : g + j;                // its T1 or T2 column
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (sl < S) {
+    if (j < g) {
         int b = sl;
-        for (; b + 3 * S < nblk; b += 4 * S) {
+        for (; b + 3 * FLS_SLICES < nblk; b += 4 * FLS_SLICES) {
             a0 += (double)part[(size_t)b * len + col];
-            a1 += (double)part[(size_t)(b + S) * len + col];
-            a2 += (double)part[(size_t)(b + 2 * S) * len + col];
-            a3 += (double)part[(size_t)(b + 3 * S) * len + col];
+            a1 += (double)part[(size_t)(b + FLS_SLICES) * len + col];
+            a2 += (double)part[(size_t)(b + 2 * FLS_SLICES) * len + col];
+            a3 += (double)part[(size_t)(b + 3 * FLS_SLICES) * len + col];
         }
-        for (; b < nblk; b += S) a0 += (double)part[(size_t)b * len + col];
+        for (; b < nblk; b += FLS_SLICES) a0 += (double)part[(size_t)b * len + col];
     }
-    s_acc[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    s_acc[sl][cl] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if ((int)threadIdx.x < len) {
+    if (sl == 0) {
         double v = 0.0;
-        for (int t = 0; t < S; ++t) v += s_acc[t * len + threadIdx.x];
-        s_sum[threadIdx.x] = v;
-        if ((int)threadIdx.x < g) T1[threadIdx.x] = v; else T2[threadIdx.x - g] = v;
+#pragma unroll 16
+        for (int t = 0; t < FLS_SLICES; ++t) v += s_acc[t][cl];
+        s_sum[cl] = v;
+        if (j < g) { if (cl < FLS_GROUPS) T1[j] = v; else T2[j] = v; }
     }
     __syncthreads();
-    if (F.sc && (int)threadIdx.x < g) fold_w_fwd_channel(F, threadIdx.x, s_sum[threadIdx.x], s_sum[g + threadIdx.x]);
+    if (F.sc && (int)threadIdx.x < FLS_GROUPS && (int)(blockIdx.x * FLS_GROUPS + threadIdx.x) < g)
+        fold_w_fwd_channel(F, blockIdx.x * FLS_GROUPS + threadIdx.x, s_sum[threadIdx.x], s_sum[FLS_GROUPS + threadIdx.x]);
 }
 
 }  // namespace gva

@@ -253,7 +253,7 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
         GVA_DISPATCH_G(g, CALL)
     }
 #undef CALL
-    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3(1), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
+    if (!own_final) hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3((g + FLS_GROUPS - 1) / FLS_GROUPS), dim3(1024), 0, st, (const float *)part, nblk, g, T1, T2, F);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
