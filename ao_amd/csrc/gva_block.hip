@@ -171,6 +171,10 @@ int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, 
                                const float *const *xsh, float *const *y, void *stream);
 int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_bwd_point_local(int k, int c, int g);
+int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
+                              const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
+                              const gva::FoldWBwdArgs &F, const int *inv_ptr, const int *inv_rows, float *gkW, float *gqW, float *ga,
+                              float *gb, float *gM, float *gcW, void *workspace, size_t workspace_bytes, void *stream);
 int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
                                      const float *Ww2, const float *bw2, const float *v, const float *a, const float *b,
                                      const float *coord, const int *idx, const float *w, const float *g_out, const float *Wp2,
@@ -303,14 +307,12 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
                                                 B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
                                                 W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
-    // 3. BatchNorm over the logits
-    RUN(gva_fold_w_backward_hip_launcher(g, B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, W.gT1, W.gT2,
-                                         G->ggamma_w, G->gbeta_w, stream));
-    // 4. logits stage
+    // 3. + 4. BatchNorm over the logits (its backward is evaluated in the prologue of the rows kernel), logits stage
     if (!G->inv_ptr) (void)hipMemsetAsync(W.gkW, 0, sizeof(float) * (size_t)n * g, st);
-    RUN(gva_logits_backward_hip_launcher(n, k, c, g, B->a, B->b, B->M, B->coord, B->idx, B->W1, W.gW1, W.gT1, W.gT2,
-                                         G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage,
-                                         W.stage_bytes, stream));
+    RUN(gva_logits_backward_foldw(n, k, c, g, B->a, B->b, B->M, B->coord, B->idx, B->W1, W.gW1, nullptr, nullptr,
+                                  FoldWBwdArgs{B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, G->ggamma_w,
+                                               G->gbeta_w},
+                                  G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage, W.stage_bytes, stream));
     // 6. projections kW = k Ww1^T, qW = q Ww1^T
     {
         const float *gys[2] = {W.gkW, W.gqW};

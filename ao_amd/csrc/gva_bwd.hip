@@ -42,13 +42,29 @@ __global__ __launch_bounds__(TPB) void logits_bwd_rows_kernel(long long rows, co
                                                               const float *__restrict__ gW1,
                                                               const double *__restrict__ gT1,
                                                               const double *__restrict__ gT2, float *__restrict__ gWt,
-                                                              float *part, unsigned *counter, float *__restrict__ gcW) {
+                                                              float *part, unsigned *counter, float *__restrict__ gcW,
+                                                              FoldWBwdArgs F) {
     constexpr int U = (G % 4 == 0) ? G : (G % 2 == 0 ? 2 * G : 4 * G);  // floats per unit = lcm(4, G)
     constexpr int UQ = U / 4;                                           // float4 per unit
     __shared__ float s_w[WPB][G];
     float t[G], c1[G], c2[G];
+    if (F.gsc) {  // gT1 / gT2 from the BatchNorm fold's backward, evaluated here: one group per thread, shared through LDS
+        __shared__ float s_c[2][G];
+        if (threadIdx.x < G) {
+            double t1, t2;
+            float gg, gb;
+            fold_w_bwd_channel(F, threadIdx.x, t1, t2, gg, gb);
+            s_c[0][threadIdx.x] = (float)t1;
+            s_c[1][threadIdx.x] = 2.f * (float)t2;
+            if (blockIdx.x == 0) { F.ggamma[threadIdx.x] = gg; F.gbeta[threadIdx.x] = gb; }
+        }
+        __syncthreads();
 #pragma unroll
-    for (int g = 0; g < G; ++g) { t[g] = 0.f; c1[g] = (float)gT1[g]; c2[g] = 2.f * (float)gT2[g]; }
+        for (int g = 0; g < G; ++g) { t[g] = 0.f; c1[g] = s_c[0][g]; c2[g] = s_c[1][g]; }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) { t[g] = 0.f; c1[g] = (float)gT1[g]; c2[g] = 2.f * (float)gT2[g]; }
+    }
     const long long total = rows * G, units = total / U;  // rows * G is a multiple of U whenever rows % (U / G) == 0
     for (long long u = (long long)blockIdx.x * TPB + threadIdx.x; u < units; u += (long long)gridDim.x * TPB) {
         const float4 *pw = (const float4 *)(W1 + u * U), *pg = (const float4 *)(gW1 + u * U);
@@ -258,12 +274,27 @@ int gva_logits_params_point_launch(int n, int k, int c, int g, const float *a, c
 
 extern "C" size_t gva_workspace_bytes(int n, int k, int c, int g);
 
+// F.gsc != NULL: gT1 / gT2 are not read; the rows kernel derives them from the fold_w backward (and writes the BatchNorm's
+// parameter gradients) -- internal to the block runtime (gva_block.hip)
+int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
+                              const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
+                              const gva::FoldWBwdArgs &F, const int *inv_ptr, const int *inv_rows, float *gkW, float *gqW, float *ga,
+                              float *gb, float *gM, float *gcW, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, const float *a, const float *b,
                                                 const float *M, const float *coord, const int *idx,
                                                 const float *W1, const float *gW1, const double *gT1,
                                                 const double *gT2, const int *inv_ptr, const int *inv_rows,
                                                 float *gkW, float *gqW, float *ga, float *gb, float *gM, float *gcW,
                                                 void *workspace, size_t workspace_bytes, void *stream) {
+    return gva_logits_backward_foldw(n, k, c, g, a, b, M, coord, idx, W1, gW1, gT1, gT2, gva::FoldWBwdArgs{}, inv_ptr, inv_rows, gkW,
+                                     gqW, ga, gb, gM, gcW, workspace, workspace_bytes, stream);
+}
+
+int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
+                              const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
+                              const gva::FoldWBwdArgs &F, const int *inv_ptr, const int *inv_rows, float *gkW, float *gqW, float *ga,
+                              float *gb, float *gM, float *gcW, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 0 || k < 1 || c < 1 || g < 1) return PTV2_ERR_ARG;
     if (!workspace || workspace_bytes < gva_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
     if (n == 0) return PTV2_OK;
@@ -274,7 +305,7 @@ extern "C" int gva_logits_backward_hip_launcher(int n, int k, int c, int g, cons
     const int nb_rows = stage_grid(rows * g / 16, TPB);  // ~4 float4 per thread
 #define CALL(GG) \
     hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part, \
-                       cnt ? cnt + CNT_LOGITS_BWD_ROWS : nullptr, gcW)
+                       cnt ? cnt + CNT_LOGITS_BWD_ROWS : nullptr, gcW, F)
     const bool own_final = (size_t)nb_rows * g <= FUSED_FINAL_MAX;
     unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
     if (own_final && !cnt) return PTV2_ERR_LAUNCH;

@@ -237,6 +237,36 @@ __device__ inline void fold_w_fwd_channel(const FoldWFwdArgs &A, int j, double t
     A.rstd_out[j] = rstd;
 }
 
+// Backward of fold_w (the BatchNorm over the logits) for group j: gradients of the column sums T1, T2 that the rows kernel of
+// the logits backward folds into every row gradient, and the BatchNorm's own parameter gradients.  gsc == NULL: absent (the
+// caller supplies gT1 / gT2 arrays).  The block runtime passes it to the rows kernel, which evaluates it in its prologue
+// (g <= 64 values per thread) instead of waiting for a launch of its own (gva_fold.hip: fold_w_bwd_kernel).
+struct FoldWBwdArgs {
+    const float *gamma;
+    const double *mean, *rstd;
+    int training;
+    double rows;
+    const float *gsc, *gsh;
+    float *ggamma, *gbeta;
+};
+
+__device__ __forceinline__ void fold_w_bwd_channel(const FoldWBwdArgs &A, int j, double &gT1, double &gT2, float &ggamma,
+                                                   float &gbeta) {
+    const double mean = A.mean[j], rstd = A.rstd[j], gam = A.gamma[j];
+    const double gs = (double)A.gsc[j] - (double)A.gsh[j] * mean;  // d/ds of (sc = s, sh = beta - mean s)
+    gbeta = A.gsh[j];
+    ggamma = (float)(gs * rstd);
+    if (A.training) {
+        const double gvar = gs * gam * (-0.5) * rstd * rstd * rstd;
+        const double gmean = -(double)A.gsh[j] * gam * rstd + gvar * (-2.0 * mean);
+        gT1 = gmean / A.rows;
+        gT2 = gvar / A.rows;
+    } else {
+        gT1 = 0.0;
+        gT2 = 0.0;
+    }
+}
+
 // "last block" tail of the logits kernels: column sums -> T1, T2 (-> folded affine)
 __device__ __forceinline__ void finalize_logit_sums(const float *part, int nblk, int g, double *T1, double *T2,
                                                     const FoldWFwdArgs &F) {

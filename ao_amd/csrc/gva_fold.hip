@@ -38,19 +38,8 @@ __global__ void fold_w_bwd_kernel(int g, const float *__restrict__ gamma, const 
                                   float *__restrict__ gbeta) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= g) return;
-    const double mean = mean_in[j], rstd = rstd_in[j], gam = gamma[j];
-    const double gs = (double)gsc[j] - (double)gsh[j] * mean;  // d/ds of (sc = s, sh = beta - mean s)
-    gbeta[j] = gsh[j];
-    ggamma[j] = (float)(gs * rstd);
-    if (training) {
-        const double gvar = gs * gam * (-0.5) * rstd * rstd * rstd;
-        const double gmean = -(double)gsh[j] * gam * rstd + gvar * (-2.0 * mean);
-        gT1[j] = gmean / rows;
-        gT2[j] = gvar / rows;
-    } else {
-        gT1[j] = 0.0;
-        gT2[j] = 0.0;
-    }
+    const FoldWBwdArgs A{gamma, mean_in, rstd_in, training, rows, gsc, gsh, ggamma, gbeta};
+    fold_w_bwd_channel(A, j, gT1[j], gT2[j], ggamma[j], gbeta[j]);
 }
 
 }  // namespace gva
