@@ -4,7 +4,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "common.h"
+#include "gva_common.h"
 
 extern "C" int ptv2_abi_version(void) { return 5; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
@@ -28,6 +28,41 @@ extern "C" int ptv2_matmul_precision(int bf16) {
     if (bf16 >= 0) g_matmul_bf16 = bf16 ? 1 : 0;
     return prev;
 }
+
+// ---- riders (gva_common.h): per-thread queue of finalizes that a later, independent launch carries
+namespace gva {
+namespace {
+thread_local int g_defer_depth = 0;
+thread_local PtvRiders g_pending{};
+__global__ __launch_bounds__(256) void rider_kernel(PtvRiders Rs) { rider_run(Rs, blockIdx.x); }
+void launch_alone(const PtvRider &r, hipStream_t st) {
+    PtvRiders one{};
+    one.count = 1;
+    one.r[0] = r;
+    hipLaunchKernelGGL(rider_kernel, dim3(r.blocks), dim3(256), 0, st, one);
+}
+}  // namespace
+bool ptv2_rider_defer_active() { return g_defer_depth > 0; }
+void ptv2_rider_defer_depth(int delta) { g_defer_depth += delta; }
+void ptv2_rider_defer(const PtvRider &r, hipStream_t st) {
+    if (g_pending.count == 3) {  // full: the oldest goes out on its own
+        launch_alone(g_pending.r[0], st);
+        g_pending.r[0] = g_pending.r[1];
+        g_pending.r[1] = g_pending.r[2];
+        g_pending.count = 2;
+    }
+    g_pending.r[g_pending.count++] = r;
+}
+PtvRiders ptv2_rider_take() {
+    const PtvRiders out = g_pending;
+    g_pending.count = 0;
+    return out;
+}
+void ptv2_rider_flush(hipStream_t st) {
+    for (int i = 0; i < g_pending.count; ++i) launch_alone(g_pending.r[i], st);
+    g_pending.count = 0;
+}
+}  // namespace gva
 
 #ifndef PTV2_SRC_HASH
 #define PTV2_SRC_HASH "unknown"

@@ -580,11 +580,16 @@ __global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, i
 
 // gx[n,i] = sum_o gy[n,o] W[o,i]; one lane per float4 of gx
 __global__ __launch_bounds__(TPB) void skinny_bwd_kernel(long long n, int cin, int cout, const float *gy,
-                                                         const float *__restrict__ W, float *gx, const float *gy2, float *gx2) {
+                                                         const float *__restrict__ W, float *gx, const float *gy2, float *gx2,
+                                                         int main_blocks, gva::PtvRiders Rs) {
+    if ((int)blockIdx.x >= main_blocks) {  // trailing workgroups: deferred parameter-gradient sums (gva_common.h, riders)
+        if (blockIdx.y == 0) gva::rider_run(Rs, (int)blockIdx.x - main_blocks);
+        return;
+    }
     if (blockIdx.y) { gy = gy2; gx = gx2; }
     const int cq = cin >> 2;
     const long long total = n * cq;
-    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)main_blocks * TPB) {
         const long long row = e / cq;
         const int q = (int)(e - row * cq);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -986,7 +991,7 @@ extern "C" int skinny_linear_backward_hip_launcher(int n, int cin, int cout, con
     {
         PtvScopedTimer t(KID_SKINNY_BWD, (hipStream_t)stream, 4.0 * n * (cin + cout));
         hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy, W, gx,
-                           (const float *)nullptr, (float *)nullptr);
+                           (const float *)nullptr, (float *)nullptr, nblk, gva::PtvRiders{});
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -1000,8 +1005,11 @@ int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy
     const int nblk = (int)std::min<long long>((total + TPB - 1) / TPB, 256 * 16);
     {
         PtvScopedTimer t(KID_SKINNY_BWD, (hipStream_t)stream, 8.0 * n * (cin + cout));
-        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk, 2), dim3(TPB), 0, (hipStream_t)stream, (long long)n, cin, cout, gy[0], W,
-                           gx[0], gy[1], gx[1]);
+        // the parameter-gradient sums queued by the stages before (logits parameters, kW / qW weights) ride along: gx
+        // depends on none of them
+        const gva::PtvRiders Rs = gva::ptv2_rider_take();
+        hipLaunchKernelGGL(skinny_bwd_kernel, dim3(nblk + gva::rider_blocks(Rs), 2), dim3(TPB), 0, (hipStream_t)stream, (long long)n,
+                           cin, cout, gy[0], W, gx[0], gy[1], gx[1], nblk, Rs);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -1052,6 +1060,18 @@ struct MapWgradMulti {  // record = [count][cout*cin] weights, then [count][cout
         }
     }
 };
+
+
+namespace gva {
+template <> struct RiderOf<MapWgradMulti> {  // only the two-product, bias-free form (kW / qW) can ride
+    static constexpr bool ok = true;
+    static PtvRider make(const MapWgradMulti &m) {
+        PtvRider r{};
+        if (m.m.count == 2 && !m.m.db[0] && !m.m.db[1]) { r.kind = RIDER_WGRAD2; r.p[0] = m.m.dW[0]; r.p[1] = m.m.dW[1]; r.i0 = m.wlen; }
+        return r;
+    }
+};
+}  // namespace gva
 
 // count (<= 6) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
 // shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))

@@ -403,11 +403,15 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
                                                                const float *__restrict__ g_out,
                                                                const int *__restrict__ inv_ptr,
                                                                const int *__restrict__ inv_rows,
-                                                               float *__restrict__ gv) {
+                                                               float *__restrict__ gv, int main_blocks, PtvRiders Rs) {
+    if ((int)blockIdx.x >= main_blocks) {  // trailing workgroups: deferred parameter-gradient sums (gva_common.h, riders)
+        rider_run(Rs, (int)blockIdx.x - main_blocks);
+        return;
+    }
     constexpr int V = I >= 4 ? 4 : I;  // channels per thread
     const int cv = c / V;
     const long long total = (long long)n * cv;
-    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
+    for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)main_blocks * TPB) {
         const int j = (int)(e / cv), ch = (int)(e - (long long)j * cv) * V;
         const int gl = ch / I;
         float acc[V];
@@ -454,8 +458,10 @@ static void launch_bwd_gv(hipStream_t st, int n, int k, int c, int g, const floa
                           const int *inv_rows, float *gv) {
     const int I = c / g;
     const int V = I >= 4 ? 4 : I;
-    const dim3 grid((unsigned)std::min<long long>(((long long)n * (c / V) + TPB - 1) / TPB, MAX_BLOCKS * 4));
-#define GVCASE(II) case II: hipLaunchKernelGGL(aggregate_bwd_gv_kernel<II>, grid, dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv); break;
+    const int main_blocks = (int)std::min<long long>(((long long)n * (c / V) + TPB - 1) / TPB, MAX_BLOCKS * 4);
+    const PtvRiders Rs = ptv2_rider_take();  // gv depends on none of the parameter-gradient sums queued before this launch
+    const dim3 grid((unsigned)(main_blocks + rider_blocks(Rs)));
+#define GVCASE(II) case II: hipLaunchKernelGGL(aggregate_bwd_gv_kernel<II>, grid, dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv, main_blocks, Rs); break;
     switch (I) { GVCASE(1) GVCASE(2) GVCASE(4) GVCASE(8) GVCASE(16) GVCASE(32) GVCASE(64) default: break; }
 #undef GVCASE
 }
@@ -571,6 +577,7 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
         {
             // W1, idx, coord, g_out, g_sw, v rows (unique once), g_A in; gW1 out
             PtvScopedTimer t(KID_BWD_POINT + (g == 6 ? 0 : g == 12 ? 1 : g == 24 ? 2 : g == 48 ? 3 : 4), st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
+            const PtvDeferScope defer;  // its record sums ride on the gv launch below (which needs none of them)
             const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
                                                 gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st, g_fused_Wp2,
                                                 g_fused_bp2);

@@ -186,6 +186,7 @@ namespace {
 struct BlockWs {  // carve the block workspace
     char *stage; size_t stage_bytes;       // scratch handed to the stage launchers
     float *out_v, *gA, *g_sw, *gW1, *gkW, *gqW, *ga2, *gb2, *ga1, *gb1, *gM, *gcW, *gsc, *gsh, *gWw1_k, *gWw1_q, *part;
+    char *wp2_part, *kq_part; size_t wp2_bytes, kq_bytes;  // split-K records whose sums ride on a later launch (riders)
     double *T1, *T2, *gT1, *gT2;
     size_t bytes;
 };
@@ -217,6 +218,10 @@ BlockWs carve(void *base, int n, int k, int c, int g) {
     w.gWw1_k = (float *)take(sizeof(float) * (size_t)g * c);
     w.gWw1_q = (float *)take(sizeof(float) * (size_t)g * c);
     w.part = (float *)take(sizeof(float) * (size_t)MAX_BLOCKS * c);
+    w.wp2_bytes = dense_workspace_bytes(n, c, c);
+    w.wp2_part = take(w.wp2_bytes);
+    w.kq_bytes = dense_workspace_bytes(n, 2 * g, c);
+    w.kq_part = take(w.kq_bytes);
     w.T1 = (double *)take(sizeof(double) * g);
     w.T2 = (double *)take(sizeof(double) * g);
     w.gT1 = (double *)take(sizeof(double) * g);
@@ -282,13 +287,20 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
+    ptv2_rider_flush(st);  // (nothing is queued on entry unless an earlier call on this thread failed half-way)
     // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
     //    grad Wp2 (direct part), grad bp2 (direct part)
     const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");
     if (!fused_peb) RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
-    RUN(linear_wgrad_strided_hip_launcher(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, nullptr, W.stage,
-                                          W.stage_bytes, stream));
     {
+        // the sum of its split-K records (needed by fold_m_bwd only) rides on the gv launch of the aggregation stage: records
+        // in a region of their own, which nothing before that launch overwrites
+        const PtvDeferScope defer;
+        RUN(linear_wgrad_strided_hip_launcher(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, nullptr, W.wp2_part,
+                                              W.wp2_bytes, stream));
+    }
+    {
+        const PtvDeferScope defer;  // (its record sum rides on the gv launch as well)
         const int rl = std::max(1, TPB / c);
         const int nblk = (int)std::min<long long>(((long long)n + rl * 8 - 1) / (rl * 8), MAX_BLOCKS);
         const bool own_final = (size_t)nblk * c <= FUSED_FINAL_MAX;
@@ -309,22 +321,28 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
                                                 W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
     // 3. + 4. BatchNorm over the logits (its backward is evaluated in the prologue of the rows kernel), logits stage
     if (!G->inv_ptr) (void)hipMemsetAsync(W.gkW, 0, sizeof(float) * (size_t)n * g, st);
+    // the parameter-gradient sums of this stage and of the kW / qW weight gradient ride on the skinny_bwd launch below
+    {
+    const PtvDeferScope defer;
     RUN(gva_logits_backward_foldw(n, k, c, g, B->a, B->b, B->M, B->coord, B->idx, B->W1, W.gW1, nullptr, nullptr,
                                   FoldWBwdArgs{B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, G->ggamma_w,
                                                G->gbeta_w},
                                   G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage, W.stage_bytes, stream));
-    // 6. projections kW = k Ww1^T, qW = q Ww1^T
+    // 6. projections kW = k Ww1^T, qW = q Ww1^T: weight gradient first (its records in a region of their own), then the
+    //    input gradients -- the launch that carries the queued sums
+    {
+        const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
+        float *dws[2] = {W.gWw1_k, W.gWw1_q};
+        const float *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
+        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.kq_part, W.kq_bytes, stream));
+    }
+    }
     {
         const float *gys[2] = {W.gkW, W.gqW};
         float *gxs[2] = {G->gk, G->gq};
         RUN(skinny_linear_backward_pair(n, c, g, gys, B->Ww1, gxs, stream));
     }
-    {
-        const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
-        float *dws[2] = {W.gWw1_k, W.gWw1_q};
-        const float *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
-        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.stage, W.stage_bytes, stream));
-    }
+    ptv2_rider_flush(st);  // anything still queued (paths without a carrying launch) before the glue reads the sums
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1; in the same launch the
     //    folded BN_p backward (both stages contribute to the gradient of (a, b))
     {

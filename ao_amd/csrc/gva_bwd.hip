@@ -241,17 +241,7 @@ __global__ __launch_bounds__(TPB) void logits_bwd_params_kernel(int n, int k, in
     }
 }
 
-// final: partials [nblk][c][G+4] -> gM (c,G), ga (c,3), gb (c)
-struct MapLogitsParams {
-    float *gM, *ga, *gb;
-    int g;
-    __device__ void operator()(int e, double v) const {
-        const int per = g + 4, ch = e / per, j = e - ch * per;
-        if (j < g) gM[ch * g + j] = (float)v;
-        else if (j < g + 3) ga[ch * 3 + (j - g)] = (float)v;
-        else gb[ch] = (float)v;
-    }
-};
+
 
 }  // namespace gva
 

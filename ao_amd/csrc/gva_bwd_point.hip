@@ -909,19 +909,7 @@ int launch_params_point(int n, int k, const float *a, const float *b, const floa
     return PTV2_OK;
 }
 
-struct MapBwdPoint {  // columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
-    float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
-    int c, g;
-    __device__ void operator()(int e, double v) const {
-        if (e < 4 * c) {
-            const int ch = e >> 2, j = e & 3;
-            if (j < 3) ga[ch * 3 + j] = (float)v; else gb[ch] = (float)v;
-        } else if (e < 4 * c + g) gsc[e - 4 * c] = (float)v;
-        else if (e < 4 * c + 2 * g) gsh[e - 4 * c - g] = (float)v;
-        else if (e < 4 * c + 2 * g + g * g) gWw2[e - 4 * c - 2 * g] = (float)v;
-        else gbw2[e - 4 * c - 2 * g - g * g] = (float)v;
-    }
-};
+
 
 template <int G, int C, int NW>
 int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2,

@@ -152,6 +152,35 @@ __device__ __forceinline__ void finalize_columns(const float *part, int nblk, in
     }
 }
 
+// ---- riders --------------------------------------------------------------------------------------------------------
+// A finalize whose result only a LATER stage needs (parameter gradients: nothing on the backward's critical path reads
+// them) does not deserve a launch boundary of its own on that path (~5 us each, 5 per attention block).  Inside a
+// PtvDeferScope launch_finalize() queues such a sum instead of launching it; the next designated host launch (one that
+// neither reads its outputs nor overwrites its records) takes the queue and appends workgroups that run it beside its
+// own work.  ptv2_rider_flush() launches whatever is still queued as a kernel of its own.
+enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRAD2 };
+struct PtvRider {
+    const float *part;
+    int nblk, len, kind, blocks;
+    float *p[6];
+    int i0, i1;
+};
+struct PtvRiders {
+    int count;
+    PtvRider r[3];
+};
+template <class Map> struct RiderOf { static constexpr bool ok = false; static PtvRider make(const Map &) { return PtvRider{}; } };
+// host side (abi.hip; per host thread)
+bool ptv2_rider_defer_active();
+void ptv2_rider_defer_depth(int delta);
+void ptv2_rider_defer(const PtvRider &r, hipStream_t st);  // queue of 3: a fourth flushes the oldest as its own launch
+PtvRiders ptv2_rider_take();                               // the pending sums, for a host launch to carry
+void ptv2_rider_flush(hipStream_t st);                     // whatever is pending, as launches of their own
+struct PtvDeferScope {
+    PtvDeferScope() { ptv2_rider_defer_depth(1); }
+    ~PtvDeferScope() { ptv2_rider_defer_depth(-1); }
+};
+
 // few records, many columns (split-K weight gradients at the deep levels: 5-9 chunk records of 10^5 - 10^6 outputs):
 // one thread per column walks the records -- the sliced form above would launch 16 threads per column of which at most
 // nblk load anything (11 550 workgroups of 1 024 threads for 737 k columns: 24 us; this form: 2 880 of 256)
@@ -173,6 +202,15 @@ __global__ __launch_bounds__(256) void finalize_flat_kernel(const float *__restr
 
 template <class Map>
 inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len, Map map) {
+    if (RiderOf<Map>::ok && ptv2_rider_defer_active()) {  // the caller lets an independent later launch carry this sum
+        PtvRider r = RiderOf<Map>::make(map);
+        if (r.kind != RIDER_NONE) {
+            r.part = part; r.nblk = nblk; r.len = len;
+            r.blocks = nblk <= 32 ? (len + 255) / 256 : (len + 15) / 16;
+            ptv2_rider_defer(r, st);
+            return;
+        }
+    }
     if (nblk <= 32 && len >= 16384) {
         hipLaunchKernelGGL(finalize_flat_kernel<Map>, dim3((len + 255) / 256), dim3(256), 0, st, part, nblk, len, map);
         return;
@@ -198,6 +236,128 @@ struct MapSplit2 {  // columns [0,len1) -> out1, rest -> out2
         if (j < len1) out1[j] = (T)v; else out2[j - len1] = (T)v;
     }
 };
+
+template <> struct RiderOf<MapVec<float>> {
+    static constexpr bool ok = true;
+    static PtvRider make(const MapVec<float> &m) { PtvRider r{}; r.kind = RIDER_VEC; r.p[0] = m.out; return r; }
+};
+
+// logits backward: partials [nblk][c][G+4] -> gM (c,G), ga (c,3), gb (c)
+struct MapLogitsParams {
+    float *gM, *ga, *gb;
+    int g;
+    __device__ void operator()(int e, double v) const {
+        const int per = g + 4, ch = e / per, j = e - ch * per;
+        if (j < g) gM[ch * g + j] = (float)v;
+        else if (j < g + 3) ga[ch * 3 + (j - g)] = (float)v;
+        else gb[ch] = (float)v;
+    }
+};
+template <> struct RiderOf<MapLogitsParams> {
+    static constexpr bool ok = true;
+    static PtvRider make(const MapLogitsParams &m) {
+        PtvRider r{}; r.kind = RIDER_LOGITS_PARAMS; r.p[0] = m.gM; r.p[1] = m.ga; r.p[2] = m.gb; r.i0 = m.g; return r;
+    }
+};
+
+// fused softmax / aggregation backward: columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
+struct MapBwdPoint {
+    float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
+    int c, g;
+    __device__ void operator()(int e, double v) const {
+        if (e < 4 * c) {
+            const int ch = e >> 2, j = e & 3;
+            if (j < 3) ga[ch * 3 + j] = (float)v; else gb[ch] = (float)v;
+        } else if (e < 4 * c + g) gsc[e - 4 * c] = (float)v;
+        else if (e < 4 * c + 2 * g) gsh[e - 4 * c - g] = (float)v;
+        else if (e < 4 * c + 2 * g + g * g) gWw2[e - 4 * c - 2 * g] = (float)v;
+        else gbw2[e - 4 * c - 2 * g - g * g] = (float)v;
+    }
+};
+
+template <> struct RiderOf<MapBwdPoint> {
+    static constexpr bool ok = true;
+    static PtvRider make(const MapBwdPoint &m) {
+        PtvRider r{}; r.kind = RIDER_BWD_POINT;
+        r.p[0] = m.ga; r.p[1] = m.gb; r.p[2] = m.gsc; r.p[3] = m.gsh; r.p[4] = m.gWw2; r.p[5] = m.gbw2; r.i0 = m.c; r.i1 = m.g;
+        return r;
+    }
+};
+
+// two weight gradients of one shape from one split-K record [2][wlen] (the kW / qW projections)
+struct MapWgrad2 {
+    float *dW0, *dW1;
+    int wlen;
+    __device__ void operator()(int e, double v) const { (e < wlen ? dW0 : dW1)[e < wlen ? e : e - wlen] = (float)v; }
+};
+
+// column sums [rb * COLS, ...) of a rider's records by one 256-thread workgroup: one thread per column for few records,
+// 16 columns x 16 record slices otherwise (slice sums combined in slice order: fixed association, as finalize_kernel)
+template <class Map>
+__device__ __forceinline__ void rider_columns(const PtvRider &R, int rb, Map map) {
+    const float *__restrict__ part = R.part;
+    const int len = R.len, nblk = R.nblk;
+    if (nblk <= 32) {
+        const int j = rb * 256 + threadIdx.x;
+        if (j >= len) return;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = 0;
+        for (; b + 3 < nblk; b += 4) {
+            a0 += (double)part[(size_t)b * len + j];
+            a1 += (double)part[(size_t)(b + 1) * len + j];
+            a2 += (double)part[(size_t)(b + 2) * len + j];
+            a3 += (double)part[(size_t)(b + 3) * len + j];
+        }
+        for (; b < nblk; ++b) a0 += (double)part[(size_t)b * len + j];
+        map(j, (a0 + a1) + (a2 + a3));
+        return;
+    }
+    __shared__ double s_rider[16][16];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int j = rb * 16 + col;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (j < len) {
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += (double)part[(size_t)b * len + j];
+            a1 += (double)part[(size_t)(b + 16) * len + j];
+            a2 += (double)part[(size_t)(b + 32) * len + j];
+            a3 += (double)part[(size_t)(b + 48) * len + j];
+        }
+        for (; b < nblk; b += 16) a0 += (double)part[(size_t)b * len + j];
+    }
+    s_rider[sl][col] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && j < len) {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v += s_rider[t][col];
+        map(j, v);
+    }
+}
+
+// workgroup `rb` of the riders' workgroups (a host kernel's blockIdx.x - its own workgroup count); blockDim.x == 256
+__device__ __forceinline__ void rider_run(const PtvRiders &Rs, int rb) {
+    for (int i = 0; i < Rs.count; ++i) {
+        const PtvRider &R = Rs.r[i];
+        if (rb < R.blocks) {
+            switch (R.kind) {  // uniform over the workgroup
+                case RIDER_VEC: rider_columns(R, rb, MapVec<float>{R.p[0]}); break;
+                case RIDER_LOGITS_PARAMS: rider_columns(R, rb, MapLogitsParams{R.p[0], R.p[1], R.p[2], R.i0}); break;
+                case RIDER_BWD_POINT: rider_columns(R, rb, MapBwdPoint{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.i0, R.i1}); break;
+                case RIDER_WGRAD2: rider_columns(R, rb, MapWgrad2{R.p[0], R.p[1], R.i0}); break;
+                default: break;
+            }
+            return;
+        }
+        rb -= R.blocks;
+    }
+}
+inline int rider_blocks(const PtvRiders &Rs) {
+    int b = 0;
+    for (int i = 0; i < Rs.count; ++i) b += Rs.r[i].blocks;
+    return b;
+}
 
 // BatchNorm over the (N*K, G) logits from their column sums T1, T2 (gva_fold.hip: fold_w).  sc == NULL: absent.
 // The block runtime passes it to the logits stage, whose final reduction then also emits the folded affine
