@@ -193,6 +193,23 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
     return PTV2_OK;
 }
 
+int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream);
+
+// internal to the library (model.hip): the parameter-only folds of `count` Blocks in one launch per 8 Blocks, ahead of the
+// forward; the Blocks are then run inside ptv2_gva_set_prefolded(1)
+int ptv2_blocks_fold_forward(int count, const ptv2_block *blocks, void *stream) {
+    if (count < 0 || count > PTV2_MAX_BLOCKS || (count && !blocks)) return PTV2_ERR_ARG;
+    ptv2_gva_block V[PTV2_MAX_BLOCKS];
+    for (int i = 0; i < count; ++i) {
+        const ptv2_block *B = blocks + i;
+        if (!args_ok(B)) return PTV2_ERR_ARG;
+        const Saved S = carve_saved(B->saved, B->n, B->k, B->c, B->g);
+        if (B->saved_bytes < S.bytes) return PTV2_ERR_WORKSPACE;
+        fill_gva(B, S, &V[i]);
+    }
+    return gva_fold_forward_batched(count, V, stream);
+}
+
 extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *workspace, size_t workspace_bytes, void *stream) {
     if (!args_ok(B)) return PTV2_ERR_ARG;
     const PtvMatmulScope precision(B->matmul_bf16);

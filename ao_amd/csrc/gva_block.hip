@@ -17,17 +17,17 @@ namespace gva {
 // one wavefront per output, lanes over the reduction index (the outputs are few, the reduction is long).
 // The workgroups from index mblocks on run the (independent, equally parameter-sized) BN_p fold of the same block:
 // one launch instead of two
-__global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
-                                                         const float *__restrict__ bp2, const float *__restrict__ Ww1,
-                                                         const float *__restrict__ bw1, float *__restrict__ M,
-                                                         float *__restrict__ cW, int mblocks, FoldPFwdArgs P) {
-    if ((int)blockIdx.x >= mblocks) {
-        const int ch = ((int)blockIdx.x - mblocks) * TPB + threadIdx.x;
+__device__ __forceinline__ void fold_m_fwd_body(int bid, int c, int g, const float *__restrict__ Wp2,
+                                                const float *__restrict__ bp2, const float *__restrict__ Ww1,
+                                                const float *__restrict__ bw1, float *__restrict__ M, float *__restrict__ cW,
+                                                int mblocks, const FoldPFwdArgs &P) {
+    if (bid >= mblocks) {
+        const int ch = (bid - mblocks) * TPB + threadIdx.x;
         if (ch < P.c) fold_p_fwd_channel(P, ch);
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int e = (blockIdx.x * TPB + threadIdx.x) >> 6;  // wave index = output index
+    const int e = (bid * TPB + threadIdx.x) >> 6;  // wave index = output index
     if (e < c * g) {
         const int cp = e / g, gi = e - cp * g;
         float acc = 0.f;
@@ -40,6 +40,37 @@ __global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const flo
         for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
         acc = wave_sum(acc);
         if (lane == 0) cW[gi] = acc + bw1[gi];
+    }
+}
+
+__global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
+                                                         const float *__restrict__ bp2, const float *__restrict__ Ww1,
+                                                         const float *__restrict__ bw1, float *__restrict__ M,
+                                                         float *__restrict__ cW, int mblocks, FoldPFwdArgs P) {
+    fold_m_fwd_body((int)blockIdx.x, c, g, Wp2, bp2, Ww1, bw1, M, cW, mblocks, P);
+}
+
+// the same for up to 8 attention blocks in one launch: these folds read parameters (and the position moments of the
+// level) only, so the model runtime runs all of them ahead of the forward instead of one launch inside every Block
+struct FoldFwdItem {
+    int c, g, mblocks, blocks;
+    const float *Wp2, *bp2, *Ww1, *bw1;
+    float *M, *cW;
+    FoldPFwdArgs P;
+};
+struct FoldFwdBatch {
+    int count;
+    FoldFwdItem item[8];
+};
+__global__ __launch_bounds__(TPB) void fold_m_fwd_batched_kernel(FoldFwdBatch B) {
+    int bid = (int)blockIdx.x;
+    for (int i = 0; i < B.count; ++i) {
+        const FoldFwdItem &it = B.item[i];
+        if (bid < it.blocks) {
+            fold_m_fwd_body(bid, it.c, it.g, it.Wp2, it.bp2, it.Ww1, it.bw1, it.M, it.cW, it.mblocks, it.P);
+            return;
+        }
+        bid -= it.blocks;
     }
 }
 
@@ -242,6 +273,37 @@ extern "C" size_t gva_block_workspace_bytes(int n, int k, int c, int g) {
     return carve(nullptr, n, k, c, g).bytes + 1024;
 }
 
+namespace { thread_local int g_prefolded = 0; }
+// internal to the library (block.hip / model.hip): the folds of the blocks that follow have been run by
+// gva_fold_forward_batched for this forward already
+void ptv2_gva_set_prefolded(int on) { g_prefolded = on; }
+
+static FoldPFwdArgs fold_p_args(const ptv2_gva_block *B) {
+    return FoldPFwdArgs{B->c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p, B->run_var_p, B->batches_p,
+                        B->training, (double)B->n * B->k, B->eps_p, B->momentum_p, B->a, B->b, B->rstd_p};
+}
+
+int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream) {
+    for (int i0 = 0; i0 < count; i0 += 8) {
+        FoldFwdBatch batch{};
+        int total = 0;
+        for (int i = i0; i < count && i < i0 + 8; ++i) {
+            const ptv2_gva_block *B = blocks + i;
+            if (B->n < 1 || B->c < 4 || B->g < 1) return PTV2_ERR_ARG;
+            FoldFwdItem &it = batch.item[batch.count++];
+            it.c = B->c; it.g = B->g;
+            it.mblocks = divup(((long long)B->c * B->g + B->g) * WAVE, TPB);
+            it.blocks = it.mblocks + divup(B->c, TPB);
+            it.Wp2 = B->Wp2; it.bp2 = B->bp2; it.Ww1 = B->Ww1; it.bw1 = B->bw1; it.M = B->M; it.cW = B->cW;
+            it.P = fold_p_args(B);
+            total += it.blocks;
+        }
+        hipLaunchKernelGGL(fold_m_fwd_batched_kernel, dim3(total), dim3(TPB), 0, (hipStream_t)stream, batch);
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *workspace, size_t workspace_bytes,
                                               void *stream) {
     if (!B) return PTV2_ERR_ARG;
@@ -252,12 +314,10 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
-    {
+    if (!g_prefolded) {
         const int mblocks = divup(((long long)c * g + g) * WAVE, TPB);
         hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1, B->bw1,
-                           B->M, B->cW, mblocks,
-                           FoldPFwdArgs{c, B->Wp1, B->bp1, B->gamma_p, B->beta_p, B->mu, B->cov, B->run_mean_p, B->run_var_p,
-                                        B->batches_p, B->training, rows, B->eps_p, B->momentum_p, B->a, B->b, B->rstd_p});
+                           B->M, B->cW, mblocks, fold_p_args(B));
     }
     {
         const float *xs[2] = {B->key, B->q}, *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};

@@ -22,6 +22,9 @@
 
 #include "common.h"
 
+int ptv2_blocks_fold_forward(int count, const ptv2_block *blocks, void *stream);  // block.hip
+void ptv2_gva_set_prefolded(int on);                                                // gva_block.hip
+
 namespace {
 
 constexpr int TPB = 256;
@@ -448,6 +451,19 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
     hipStream_t st = (hipStream_t)stream;
     const int S = M->num_stages;
     int rc = PTV2_OK;
+    // the parameter-only folds of every attention block, all at once (they were one 5 us launch on the critical path of
+    // each Block)
+    {
+        std::vector<ptv2_block> blocks;
+        for (int q = 0; q <= 2 * S; ++q)
+            for (int j = 0; j < M->seq[q].depth; ++j) {
+                ptv2_block B;
+                fill_block(M, q, j, A, M->feat /* unused by the folds */, &B);
+                blocks.push_back(B);
+            }
+        RUN(ptv2_blocks_fold_forward((int)blocks.size(), blocks.data(), stream));
+    }
+    struct Prefolded { Prefolded() { ptv2_gva_set_prefolded(1); } ~Prefolded() { ptv2_gva_set_prefolded(0); } } prefolded;
     RUN(linbn_forward(M, M->embed, A.embed, M->level[0].n, M->feat, A.embed.y, W, stream));
     const float *x = seq_forward(M, 0, A, A.embed.y, W, stream, &rc);
     if (rc != PTV2_OK) return rc;
