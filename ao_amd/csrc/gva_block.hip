@@ -88,9 +88,13 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         if (ch < P.c) fold_p_bwd_channel(P, ch);
         return;
     }
+    // Both products walk gM (c',g) along g and a weight matrix along its rows, so that a wavefront's loads are whole cache
+    // lines: with the lanes along c' (stride g floats) every load instruction touched 64 lines -- 7 M line requests for
+    // the 14 MFLOP of a C = 384 block, 44 us.
     const long long n1 = (long long)g * c, n2 = (long long)c * c;
-    const int wblocks = (int)((n1 + WPB - 1) / WPB);  // the first blocks: one wavefront per gWw1 output (a length-c dot
-    if ((int)blockIdx.x < wblocks) {                  // product whose Wp2 row is read coalesced across the lanes)
+    const bool wide = c >= 256;  // narrow levels: one wavefront per gWw1 output (short chains, the strided column is small)
+    const int wblocks = wide ? (int)((n1 + TPB - 1) / TPB) : (int)((n1 + WPB - 1) / WPB);
+    if ((int)blockIdx.x < wblocks && !wide) {
         const long long o = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
         if (o < n1) {
             const int lane = threadIdx.x & 63;
@@ -102,14 +106,34 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         }
         return;
     }
+    if ((int)blockIdx.x < wblocks) {  // wide: one thread per gWw1 output, g fastest
+        const long long o = (long long)blockIdx.x * TPB + threadIdx.x;
+        if (o < n1) {
+            const int ci = (int)(o / g), gi = (int)(o - (long long)ci * g);
+            const float *wrow = Wp2 + (size_t)ci * c;  // shared by the g threads of this ci (broadcast)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int cp = 0;
+            for (; cp + 3 < c; cp += 4) {
+                a0 = __builtin_fmaf(gM[(size_t)cp * g + gi], wrow[cp], a0);
+                a1 = __builtin_fmaf(gM[(size_t)(cp + 1) * g + gi], wrow[cp + 1], a1);
+                a2 = __builtin_fmaf(gM[(size_t)(cp + 2) * g + gi], wrow[cp + 2], a2);
+                a3 = __builtin_fmaf(gM[(size_t)(cp + 3) * g + gi], wrow[cp + 3], a3);
+            }
+            for (; cp < c; ++cp) a0 = __builtin_fmaf(gM[(size_t)cp * g + gi], wrow[cp], a0);
+            const size_t oo = (size_t)gi * c + ci;
+            gWw1[oo] = ((a0 + a1) + (a2 + a3)) + gcW[gi] * bp2[ci] + gWw1_k[oo] + gWw1_q[oo];
+        }
+        return;
+    }
     const long long e = n1 + (long long)(blockIdx.x - wblocks) * TPB + threadIdx.x;
     if (false) {
     } else if (e < n1 + n2) {
         const long long r = e - n1;
-        const int ci = (int)(r / c), cp = (int)(r - (long long)ci * c);
-        float acc = gWp2[r];
-        for (int gi = 0; gi < g; ++gi) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], gM[(size_t)cp * g + gi], acc);
-        gWp2[r] = acc;
+        const int cp = (int)(r / c), ci = (int)(r - (long long)cp * c);  // ci fastest: Ww1 rows coalesced, gM row broadcast
+        const float *mrow = gM + (size_t)cp * g;
+        float acc = 0.f;
+        for (int gi = 0; gi < g; ++gi) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], mrow[gi], acc);
+        gWp2[(size_t)ci * c + cp] += acc;
     } else if (e < n1 + n2 + c) {
         const int ci = (int)(e - n1 - n2);
         float acc = gbp2[ci];
@@ -406,7 +430,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1; in the same launch the
     //    folded BN_p backward (both stages contribute to the gradient of (a, b))
     {
-        const int mblocks = divup((long long)g * c, WPB) + divup((long long)c * c + c + g, TPB);
+        const int mblocks = divup((long long)g * c, c >= 256 ? TPB : WPB) + divup((long long)c * c + c + g, TPB);
         hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1,
                            (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k, (const float *)W.gWw1_q, G->gWw1,
                            G->gWp2, G->gbp2, G->gbw1, mblocks,
