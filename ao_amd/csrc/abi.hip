@@ -1,4 +1,5 @@
 // ao_amd/csrc/abi.hip -- library identification and the optional per-kernel timer (host only).
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -42,14 +43,16 @@ void launch_alone(const PtvRider &r, hipStream_t st) {
     hipLaunchKernelGGL(rider_kernel, dim3(r.blocks), dim3(256), 0, st, one);
 }
 }  // namespace
-bool ptv2_rider_defer_active() { return g_defer_depth > 0; }
+bool ptv2_rider_defer_active() {
+    static const bool off = [] { const char *e = getenv("AO_AMD_RIDERS"); return e && e[0] == '0'; }();  // A/B switch (tests)
+    return g_defer_depth > 0 && !off;
+}
 void ptv2_rider_defer_depth(int delta) { g_defer_depth += delta; }
 void ptv2_rider_defer(const PtvRider &r, hipStream_t st) {
-    if (g_pending.count == 3) {  // full: the oldest goes out on its own
+    if (g_pending.count == RIDER_QUEUE) {  // full: the oldest goes out on its own
         launch_alone(g_pending.r[0], st);
-        g_pending.r[0] = g_pending.r[1];
-        g_pending.r[1] = g_pending.r[2];
-        g_pending.count = 2;
+        for (int i = 1; i < RIDER_QUEUE; ++i) g_pending.r[i - 1] = g_pending.r[i];
+        g_pending.count = RIDER_QUEUE - 1;
     }
     g_pending.r[g_pending.count++] = r;
 }

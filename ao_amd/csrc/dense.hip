@@ -1063,11 +1063,13 @@ struct MapWgradMulti {  // record = [count][cout*cin] weights, then [count][cout
 
 
 namespace gva {
-template <> struct RiderOf<MapWgradMulti> {  // only the two-product, bias-free form (kW / qW) can ride
+template <> struct RiderOf<MapWgradMulti> {
     static constexpr bool ok = true;
     static PtvRider make(const MapWgradMulti &m) {
         PtvRider r{};
-        if (m.m.count == 2 && !m.m.db[0] && !m.m.db[1]) { r.kind = RIDER_WGRAD2; r.p[0] = m.m.dW[0]; r.p[1] = m.m.dW[1]; r.i0 = m.wlen; }
+        r.kind = RIDER_WGRADN;
+        for (int i = 0; i < 6; ++i) { r.p[i] = i < m.m.count ? m.m.dW[i] : nullptr; r.p[6 + i] = i < m.m.count ? m.m.db[i] : nullptr; }
+        r.i0 = m.wlen; r.i1 = m.cout; r.i2 = m.m.count;
         return r;
     }
 };

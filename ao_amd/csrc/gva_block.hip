@@ -371,7 +371,6 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
-    ptv2_rider_flush(st);  // (nothing is queued on entry unless an earlier call on this thread failed half-way)
     // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
     //    grad Wp2 (direct part), grad bp2 (direct part)
     const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");

@@ -158,22 +158,23 @@ __device__ __forceinline__ void finalize_columns(const float *part, int nblk, in
 // PtvDeferScope launch_finalize() queues such a sum instead of launching it; the next designated host launch (one that
 // neither reads its outputs nor overwrites its records) takes the queue and appends workgroups that run it beside its
 // own work.  ptv2_rider_flush() launches whatever is still queued as a kernel of its own.
-enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRAD2 };
+enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRADN };
 struct PtvRider {
     const float *part;
     int nblk, len, kind, blocks;
-    float *p[6];
-    int i0, i1;
+    float *p[12];
+    int i0, i1, i2;
 };
+constexpr int RIDER_QUEUE = 4;
 struct PtvRiders {
     int count;
-    PtvRider r[3];
+    PtvRider r[RIDER_QUEUE];
 };
 template <class Map> struct RiderOf { static constexpr bool ok = false; static PtvRider make(const Map &) { return PtvRider{}; } };
 // host side (abi.hip; per host thread)
 bool ptv2_rider_defer_active();
 void ptv2_rider_defer_depth(int delta);
-void ptv2_rider_defer(const PtvRider &r, hipStream_t st);  // queue of 3: a fourth flushes the oldest as its own launch
+void ptv2_rider_defer(const PtvRider &r, hipStream_t st);  // queue of RIDER_QUEUE: one more flushes the oldest as its own launch
 PtvRiders ptv2_rider_take();                               // the pending sums, for a host launch to carry
 void ptv2_rider_flush(hipStream_t st);                     // whatever is pending, as launches of their own
 struct PtvDeferScope {
@@ -284,11 +285,25 @@ template <> struct RiderOf<MapBwdPoint> {
     }
 };
 
-// two weight gradients of one shape from one split-K record [2][wlen] (the kW / qW projections)
-struct MapWgrad2 {
-    float *dW0, *dW1;
-    int wlen;
-    __device__ void operator()(int e, double v) const { (e < wlen ? dW0 : dW1)[e < wlen ? e : e - wlen] = (float)v; }
+// up to six weight gradients (+ bias sums) of one shape from one split-K record [count][wlen] weights, [count][cout] biases.
+// Named fields and compare chains on purpose: an array member indexed with a runtime value is placed in scratch memory,
+// and a host kernel that needs a scratch allocation is dispatched more slowly for ALL of its workgroups (measured:
+// +0.15 ms per step with 120 bytes of scratch in the two host kernels).
+struct MapWgradN {
+    float *w0, *w1, *w2, *w3, *w4, *w5, *b0, *b1, *b2, *b3, *b4, *b5;
+    int count, wlen, cout;
+    __device__ void operator()(int e, double v) const {
+        const int wtot = count * wlen;
+        if (e < wtot) {
+            const int b = e / wlen;
+            float *p = b == 0 ? w0 : b == 1 ? w1 : b == 2 ? w2 : b == 3 ? w3 : b == 4 ? w4 : w5;
+            p[e - b * wlen] = (float)v;
+        } else {
+            const int r = e - wtot, b = r / cout;
+            float *p = b == 0 ? b0 : b == 1 ? b1 : b == 2 ? b2 : b == 3 ? b3 : b == 4 ? b4 : b5;
+            if (p) p[r - b * cout] = (float)v;
+        }
+    }
 };
 
 // column sums [rb * COLS, ...) of a rider's records by one 256-thread workgroup: one thread per column for few records,
@@ -345,7 +360,10 @@ __device__ __forceinline__ void rider_run(const PtvRiders &Rs, int rb) {
                 case RIDER_VEC: rider_columns(R, rb, MapVec<float>{R.p[0]}); break;
                 case RIDER_LOGITS_PARAMS: rider_columns(R, rb, MapLogitsParams{R.p[0], R.p[1], R.p[2], R.i0}); break;
                 case RIDER_BWD_POINT: rider_columns(R, rb, MapBwdPoint{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.i0, R.i1}); break;
-                case RIDER_WGRAD2: rider_columns(R, rb, MapWgrad2{R.p[0], R.p[1], R.i0}); break;
+                case RIDER_WGRADN:
+                    rider_columns(R, rb, MapWgradN{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.p[6], R.p[7], R.p[8], R.p[9],
+                                                   R.p[10], R.p[11], R.i2, R.i0, R.i1});
+                    break;
                 default: break;
             }
             return;
