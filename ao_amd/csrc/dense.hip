@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     __syncthreads();
     if (sl == 0 && ch < c) {
         double t1 = 0.0, t2 = 0.0;
-#pragma unroll
+#pragma unroll 8
         for (int t = 0; t < SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
         const double d = t1 / n;                       // mean of the shifted samples
         const double m = (double)x0[ch] + d;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, Bn
     __syncthreads();
     if (sl == 0 && ch < c) {
         double t1 = 0.0, t2 = 0.0;
-#pragma unroll
+#pragma unroll 8
         for (int t = 0; t < SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
         bn_tiles_emit(S, ch, t1, t2, n, eps, momentum);
     }
