@@ -35,6 +35,7 @@ _SIGNATURES = {
     "farthest_point_sampling_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_size, _vp]),
     "grouping_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
     "grouping_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
+    "interpolation_weights_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
     "interpolation_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
     "interpolation_backward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 5),
     "interpolation_backward_gather_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 6),

@@ -309,6 +309,38 @@ extern "C" int grouping_backward_hip_launcher(int m, int nsample, int c, const f
     return PTV2_OK;
 }
 
+// weights of the inverse-distance interpolation from the k-NN's squared distances, and the reference's wrap of a missing
+// neighbour: w_s = (1 / (sqrt(d2_s) + 1e-8)) / sum_t (1 / (sqrt(d2_t) + 1e-8)) (libs/pointops/functions/interpolation.py:
+// 13-16, sums in slot order); idx < 0 -> idx + n (torch's negative indexing, :21).  One launch for what the python
+// statement spends nine on.
+__global__ __launch_bounds__(256) void interpolation_weights_kernel(long long m, int k, int n, const float *__restrict__ dist2,
+                                                                    int *__restrict__ idx, float *__restrict__ weight) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < m; i += (long long)gridDim.x * 256) {
+        float r[8];
+        float norm = 0.f;
+        for (int s = 0; s < k; ++s) {
+            r[s & 7] = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(dist2[i * k + s]), 1e-8f));
+            norm = __fadd_rn(norm, r[s & 7]);
+        }
+        for (int s = 0; s < k; ++s) {
+            weight[i * k + s] = __fdiv_rn(r[s & 7], norm);
+            const int j = idx[i * k + s];
+            if (j < 0) idx[i * k + s] = j + n;
+        }
+    }
+}
+
+extern "C" int interpolation_weights_hip_launcher(int m, int k, int n, const float *dist2, int *idx, float *weight, void *stream) {
+    if (m < 0 || k < 1 || k > 8 || n < 0) return PTV2_ERR_ARG;
+    if (m == 0) return PTV2_OK;
+    if (!dist2 || !idx || !weight) return PTV2_ERR_ARG;
+    const int nblk = (int)std::min<long long>(((long long)m + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(interpolation_weights_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long long)m, k, n, dist2, idx,
+                       weight);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 extern "C" int interpolation_forward_hip_launcher(int n, int c, int k, const float *input, const int *idx,
                                                   const float *weight, float *output, void *stream) {
     if (n < 0 || c < 0 || k < 0) return PTV2_ERR_ARG;

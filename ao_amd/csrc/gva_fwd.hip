@@ -192,6 +192,53 @@ extern "C" int gva_pos_stats_hip_launcher(int n, int k, const float *coord, cons
     return PTV2_OK;
 }
 
+// (mu, cov) of the masked relative positions in one finalize: column sums of the records in float64 (9 columns x 113
+// record slices, slice sums combined in slice order), then mu = s1 / rows, cov = s2 / rows - mu mu^T as the python path
+// computes them (separately rounded product and difference)
+__global__ __launch_bounds__(1024) void pos_moments_finalize_kernel(const float *__restrict__ part, int nblk, double rows,
+                                                                    double *__restrict__ mu, double *__restrict__ cov) {
+    constexpr int SL = 113;
+    __shared__ double s_acc[SL][9];
+    __shared__ double s_sum[9];
+    const int col = threadIdx.x % 9, sl = threadIdx.x / 9;
+    if (sl < SL) {
+        double a = 0.0;
+        for (int b = sl; b < nblk; b += SL) a += (double)part[(size_t)b * 9 + col];
+        s_acc[sl][col] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double v = 0.0;
+        for (int t = 0; t < SL; ++t) v += s_acc[t][threadIdx.x];
+        s_sum[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const int r[6] = {0, 0, 0, 1, 1, 2}, c[6] = {0, 1, 2, 1, 2, 2};
+        if (threadIdx.x < 3) mu[threadIdx.x] = s_sum[threadIdx.x] / rows;
+        if (threadIdx.x >= 3) {
+            const int a = r[threadIdx.x - 3], b = c[threadIdx.x - 3];
+            const double ma = s_sum[a] / rows, mb = s_sum[b] / rows;
+            const double v = __dsub_rn(s_sum[threadIdx.x] / rows, __dmul_rn(ma, mb));
+            cov[a * 3 + b] = v;
+            cov[b * 3 + a] = v;
+        }
+    }
+}
+
+extern "C" int gva_pos_moments_hip_launcher(int n, int k, const float *coord, const int *idx, double *mu, double *cov,
+                                            void *workspace, size_t workspace_bytes, void *stream) {
+    if (n < 1 || k < 1 || !coord || !idx || !mu || !cov) return PTV2_ERR_ARG;
+    if (!workspace || workspace_bytes < sizeof(float) * 9 * 2048) return PTV2_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    const int nblk = stage_grid((long long)n * k, TPB * 4);
+    hipLaunchKernelGGL(pos_stats_kernel, dim3(nblk), dim3(TPB), 0, st, n, k, coord, idx, part);
+    hipLaunchKernelGGL(pos_moments_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float *)part, nblk, (double)n * k, mu, cov);
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 #define GVA_DISPATCH_G(g, CALL)            \
     switch (g) {                           \
         case 6: { CALL(6); break; }        \

@@ -15,6 +15,7 @@ import torch
 
 from .. import _lib, pointops
 from ..pointops.interpolation import interpolation_index_weight
+from ..pointops.query import knn_query_dist2
 
 
 @dataclass
@@ -36,7 +37,7 @@ class Level:
         that works at this resolution (encoder and decoder)."""
         if k not in self.knn:
             with torch.no_grad():
-                idx = pointops.knn_query(k, self.coord, self.offset)[0]
+                idx = knn_query_dist2(k, self.coord, self.offset)[0]  # (the table only: no sqrt of the distances)
                 # table-only quantities the fused attention needs (their host syncs belong to the geometry phase)
                 from . import gva
                 if gva.supported(8 * 6, 6, k):

@@ -33,6 +33,7 @@ from .layers import skinny_linear
 
 _SIG = {
     "gva_pos_stats_hip_launcher": (_lib._c_int, [_lib._c_int] * 2 + [_lib._vp] * 5 + [_lib._c_size, _lib._vp]),
+    "gva_pos_moments_hip_launcher": (_lib._c_int, [_lib._c_int] * 2 + [_lib._vp] * 5 + [_lib._c_size, _lib._vp]),
     "gva_logits_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 12 + [_lib._c_size, _lib._vp]),
     "gva_logits_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 18 + [_lib._c_size, _lib._vp]),
     "gva_aggregate_workspace_bytes": (_lib._c_size, [_lib._c_int] * 4),
@@ -73,6 +74,20 @@ class _HipImpl:
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "gva_pos_stats_hip_launcher")
         return s1, s2.view(3, 3)
+
+    @staticmethod
+    def pos_moments(coord, idx):
+        """(mu (3,), cov (3,3)) float64 in two launches (the statistics kernel + one finalize that also forms them)."""
+        _lib.require_cuda(coord, idx)
+        n, k = idx.shape
+        mu = torch.empty(3, dtype=torch.float64, device=coord.device)
+        cov = torch.empty(9, dtype=torch.float64, device=coord.device)
+        L = _lib.lib()
+        ws = _lib.workspace(L.gva_workspace_bytes(n, k, 8, 1), coord.device)
+        rc = L.gva_pos_moments_hip_launcher(n, k, coord.data_ptr(), idx.data_ptr(), mu.data_ptr(), cov.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "gva_pos_moments_hip_launcher")
+        return mu, cov.view(3, 3)
 
     @staticmethod
     def logits(kW, qW, a, b, M, cW, coord, idx):
@@ -506,10 +521,13 @@ def _pos_moments(impl, coord, idx):
     if cached is not None and cached[0] == (coord.data_ptr(), idx._version):
         return cached[1], cached[2]
     with torch.no_grad():
-        s1, s2 = impl.pos_stats(coord, idx)
-        rows = idx.shape[0] * idx.shape[1]
-        mu = s1 / rows
-        cov = s2 / rows - torch.outer(mu, mu)
+        if hasattr(impl, "pos_moments"):
+            mu, cov = impl.pos_moments(coord, idx)
+        else:
+            s1, s2 = impl.pos_stats(coord, idx)
+            rows = idx.shape[0] * idx.shape[1]
+            mu = s1 / rows
+            cov = s2 / rows - torch.outer(mu, mu)
     try:
         idx._ao_pos_moments = ((coord.data_ptr(), idx._version), mu, cov)
     except AttributeError:

@@ -104,6 +104,10 @@ int grouping_backward_hip_launcher(int m, int nsample, int c, const float *grad_
  * forward: output[n,:] += sum_i input[idx[n,i],:] * weight[n,i]     output (n,c) [zeroed]
  * backward: grad_input[idx[n,i],:] += grad_output[n,:] * weight[n,i]  grad_input (m,c) [zeroed]
  */
+/* weights of the inverse-distance interpolation from knn_query's SQUARED distances (m,k), k <= 8:
+ * weight[i,s] = (1 / (sqrt(d2) + 1e-8)) / sum_s(...) (libs/pointops/functions/interpolation.py:13-16); idx (m,k) is
+ * updated in place: -1 (coarse segment shorter than k) -> idx + n, the reference's negative indexing (:21). */
+int interpolation_weights_hip_launcher(int m, int k, int n, const float *dist2, int *idx, float *weight, void *stream);
 int interpolation_forward_hip_launcher(int n, int c, int k, const float *input, const int *idx,
                                        const float *weight, float *output, void *stream);
 int interpolation_backward_hip_launcher(int n, int c, int k, const float *grad_output,
@@ -187,6 +191,9 @@ size_t gva_workspace_bytes(int n, int k, int c, int g);
 /* s1[3] = sum pos, s2[9] = sum pos pos^T over all n*k slots (float64, device) */
 int gva_pos_stats_hip_launcher(int n, int k, const float *coord, const int *idx, double *s1,
                                double *s2, void *workspace, size_t workspace_bytes, void *stream);
+/* the same reduced to what the folds need, in two launches: mu (3) = s1 / (n k), cov (9) = s2 / (n k) - mu mu^T, float64 */
+int gva_pos_moments_hip_launcher(int n, int k, const float *coord, const int *idx, double *mu, double *cov,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 /* W1 (n,k,g) = kW[idx]*mask - qW + P M + cW ; T1[g] = sum W1, T2[g] = sum W1^2 (float64) */
 int gva_logits_forward_hip_launcher(int n, int k, int c, int g, const float *kW, const float *qW,
                                     const float *a, const float *b, const float *M, const float *cW,
