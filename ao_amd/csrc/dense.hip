@@ -559,7 +559,22 @@ __global__ __launch_bounds__(TPB) void skinny_fwd_kernel(long long n, int cin, i
         const float4 *xr = (const float4 *)(x + row * cin), *wr = (const float4 *)(sW + (size_t)o * ldw);
         float acc = 0.f;
         if (xsc) {
-            for (int q = 0; q < cq; ++q) {
+            int q = 0;
+            for (; q + 4 <= cq; q += 4) {  // four row quads in flight per trip (cq is a multiple of 4 for C = 48 ... 512)
+                float4 av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[u] = xr[q + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 a = av[u];
+                    const float4 w = wr[q + u], s4 = ((const float4 *)sSc)[q + u], h4 = ((const float4 *)sSh)[q + u];
+                    a.x = fmaxf(__builtin_fmaf(a.x, s4.x, h4.x), 0.f); a.y = fmaxf(__builtin_fmaf(a.y, s4.y, h4.y), 0.f);
+                    a.z = fmaxf(__builtin_fmaf(a.z, s4.z, h4.z), 0.f); a.w = fmaxf(__builtin_fmaf(a.w, s4.w, h4.w), 0.f);
+                    acc = __builtin_fmaf(a.x, w.x, acc); acc = __builtin_fmaf(a.y, w.y, acc);
+                    acc = __builtin_fmaf(a.z, w.z, acc); acc = __builtin_fmaf(a.w, w.w, acc);
+                }
+            }
+            for (; q < cq; ++q) {
                 float4 a = xr[q];
                 const float4 w = wr[q], s4 = ((const float4 *)sSc)[q], h4 = ((const float4 *)sSh)[q];
                 a.x = fmaxf(__builtin_fmaf(a.x, s4.x, h4.x), 0.f); a.y = fmaxf(__builtin_fmaf(a.y, s4.y, h4.y), 0.f);
@@ -593,9 +608,26 @@ __global__ __launch_bounds__(TPB) void skinny_bwd_kernel(long long n, int cin, i
         const long long row = e / cq;
         const int q = (int)(e - row * cq);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int o = 0; o < cout; ++o) {
-            const float s = gy[row * cout + o];
-            const float4 w = *(const float4 *)(W + (size_t)o * cin + 4 * q);
+        // six outputs per trip (G = 6, 12, 24, 48 ...): their twelve loads are in flight together -- one output per trip
+        // waited for its own two loads every time, and the kernel sat parked on memory for 89 % of its wave cycles
+        // (profiles/r02_final_sq_counters.jsonl)
+        const float *g = gy + row * cout;
+        const float *wc = W + 4 * q;
+        int o = 0;
+        for (; o + 6 <= cout; o += 6) {
+            float sv[6];
+            float4 wv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { sv[u] = g[o + u]; wv[u] = *(const float4 *)(wc + (size_t)(o + u) * cin); }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                acc.x = __builtin_fmaf(sv[u], wv[u].x, acc.x); acc.y = __builtin_fmaf(sv[u], wv[u].y, acc.y);
+                acc.z = __builtin_fmaf(sv[u], wv[u].z, acc.z); acc.w = __builtin_fmaf(sv[u], wv[u].w, acc.w);
+            }
+        }
+        for (; o < cout; ++o) {
+            const float s = g[o];
+            const float4 w = *(const float4 *)(wc + (size_t)o * cin);
             acc.x = __builtin_fmaf(s, w.x, acc.x); acc.y = __builtin_fmaf(s, w.y, acc.y);
             acc.z = __builtin_fmaf(s, w.z, acc.z); acc.w = __builtin_fmaf(s, w.w, acc.w);
         }
@@ -634,7 +666,7 @@ static int wg_chunk(int n, int tiles) {
 
 static int bn_grid(int n, int c) {
     const int rl = std::max(1, TPB / (c >> 2));
-    long long b = ((long long)n + rl * 4 - 1) / (rl * 4);
+    long long b = ((long long)n + rl * 4 - 1) / (rl * 4);  // (8 rows per lane: the same; 16: +0.1 ms per step)
     return (int)std::max<long long>(1, std::min<long long>(b, MAX_BLK));
 }
 

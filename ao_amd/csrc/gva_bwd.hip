@@ -292,7 +292,9 @@ int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const 
     const long long rows = (long long)n * k;
     float *part = (float *)workspace;
     float *gWt = (float *)((char *)workspace + rows_offset_bytes(c, g));
-    const int nb_rows = stage_grid(rows * g / 16, TPB);  // ~4 float4 per thread
+    // ~16 float4 per thread: with 4 the launch was thousands of single-shot workgroups whose records the last one to
+    // arrive then had to sum (83-88 % of the wave cycles parked; 13.45 -> 13.35 ms per step with a quarter of the grid)
+    const int nb_rows = stage_grid(rows * g / 64, TPB);
 #define CALL(GG) \
     hipLaunchKernelGGL(logits_bwd_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, W1, gW1, gT1, gT2, gWt, part, \
                        cnt ? cnt + CNT_LOGITS_BWD_ROWS : nullptr, gcW, F)
