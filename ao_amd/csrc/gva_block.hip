@@ -156,9 +156,21 @@ __global__ __launch_bounds__(TPB) void bp2_grad_kernel(int n, int c, int g, cons
     for (int cb = 0; cb < c; cb += TPB) {  // channels beyond 256 in further passes
         const int ch = cb + (c >= TPB ? threadIdx.x : ch0);
         float acc = 0.f;
-        if (ch < c && (c >= TPB || r < rl))
-            for (long long row = (long long)blockIdx.x * rl + (c >= TPB ? 0 : r); row < n; row += (long long)gridDim.x * rl)
-                acc = __builtin_fmaf(g_out[row * c + ch], sw[row * g + ch / I], acc);
+        if (ch < c && (c >= TPB || r < rl)) {
+            // (a lane has ~8 rows: all of their loads in flight at once; row by row the kernel was parked on memory for 81 %
+            // of its wave cycles)
+            const long long step = (long long)gridDim.x * rl;
+            long long row = (long long)blockIdx.x * rl + (c >= TPB ? 0 : r);
+            for (; row + 3 * step < n; row += 4 * step) {
+                const float g0 = g_out[row * c + ch], g1 = g_out[(row + step) * c + ch];
+                const float g2 = g_out[(row + 2 * step) * c + ch], g3 = g_out[(row + 3 * step) * c + ch];
+                const float s0 = sw[row * g + ch / I], s1 = sw[(row + step) * g + ch / I];
+                const float s2 = sw[(row + 2 * step) * g + ch / I], s3 = sw[(row + 3 * step) * g + ch / I];
+                acc = __builtin_fmaf(g0, s0, acc); acc = __builtin_fmaf(g1, s1, acc);
+                acc = __builtin_fmaf(g2, s2, acc); acc = __builtin_fmaf(g3, s3, acc);
+            }
+            for (; row < n; row += step) acc = __builtin_fmaf(g_out[row * c + ch], sw[row * g + ch / I], acc);
+        }
         lds[threadIdx.x] = acc;
         __syncthreads();
         if (c >= TPB) {
