@@ -9,7 +9,7 @@ d = sys.argv[1]
 f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_collection.csv'))[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
-    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
     if r['Counter_Name'] == 'GRBM_GUI_ACTIVE': cnt[k] += 1
 rows = []

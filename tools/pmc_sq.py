@@ -19,7 +19,7 @@ f = (glob.glob(d + '/*/*_counter_collection.csv') + glob.glob(d + '/*_counter_co
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(collections.Counter)
 for r in csv.DictReader(open(f)):
-    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
     if pats and not any(p in k for p in pats):
         continue
     acc[k][r['Counter_Name']] += float(r['Counter_Value'])
