@@ -421,11 +421,15 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
         // the list is walked 8 entries at a time: slot ids first, then all weights and gradient rows, then the sums in
         // list order (an entry-by-entry loop pays three dependent memory latencies per entry)
         constexpr int UB = 8;
-        for (int p = p0; p < p1; p += UB) {
-            int r[UB];
-            float wv[UB], t[UB][V];
+        int r[UB], rn[UB];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? inv_rows[p + u] : -1;
+        for (int u = 0; u < UB; ++u) r[u] = p0 + u < p1 ? inv_rows[p0 + u] : -1;
+        for (int p = p0; p < p1; p += UB) {
+            float wv[UB], t[UB][V];
+            // the slot ids of the NEXT batch travel with this batch's weights and gradient rows (one round trip less per
+            // batch after the first)
+#pragma unroll
+            for (int u = 0; u < UB; ++u) rn[u] = p + UB + u < p1 ? inv_rows[p + UB + u] : -1;
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 if (r[u] >= 0) {
@@ -446,6 +450,8 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
 #pragma unroll
                     for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv[u], t[u][i], acc[i]);
                 }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) r[u] = rn[u];
         }
         if (V == 4) *(float4 *)(gv + (long long)j * c + ch) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else

@@ -129,16 +129,20 @@ __global__ __launch_bounds__(TPB) void logits_bwd_gather_kernel(int n, int k, in
             float acc = 0.f;
             const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
             constexpr int UB = 8;  // 8 list entries at a time: ids, then values, then the sums in list order
+            int r[UB], rn[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) r[u] = p0 + u < p1 ? inv_rows[p0 + u] : -1;
             for (int p = p0; p < p1; p += UB) {
-                int r[UB];
                 float t[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? inv_rows[p + u] : -1;
+                for (int u = 0; u < UB; ++u) rn[u] = p + UB + u < p1 ? inv_rows[p + UB + u] : -1;  // next batch's ids ride along
 #pragma unroll
                 for (int u = 0; u < UB; ++u) t[u] = r[u] >= 0 ? gWt[(long long)r[u] * g + gi] : 0.f;
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
                     if (r[u] >= 0) acc += t[u];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) r[u] = rn[u];
             }
             gkW[e] = acc;
         }
