@@ -95,17 +95,34 @@ __global__ __launch_bounds__(TPB) void interpolation_bwd_gather(long long total,
         float acc[VEC];
 #pragma unroll
         for (int t = 0; t < VEC; ++t) acc[t] = 0.f;
-        for (int p = inv_ptr[j]; p < inv_ptr[j + 1]; ++p) {
-            const int r = inv_rows[p];
-            const float w = weight[r];
-            const float *go = grad_output + ((long long)(r / k) * cv + q) * VEC;
-            if (VEC == 4) {
-                const float4 t4 = *(const float4 *)go;
-                acc[0] = __builtin_fmaf(w, t4.x, acc[0]); acc[1] = __builtin_fmaf(w, t4.y, acc[1]);
-                acc[2] = __builtin_fmaf(w, t4.z, acc[2]); acc[3] = __builtin_fmaf(w, t4.w, acc[3]);
-            } else {
-                acc[0] = __builtin_fmaf(w, go[0], acc[0]);
+        // the list is walked 8 entries at a time: slot ids, then all weights and gradient rows, then the sums in list order
+        // (entry by entry a lane paid two dependent memory latencies per entry, ~19 entries per coarse point)
+        constexpr int UB = 8;
+        const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
+        for (int p = p0; p < p1; p += UB) {
+            int r[UB];
+            float w[UB], t[UB][VEC];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? inv_rows[p + u] : -1;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (r[u] >= 0) {
+                    w[u] = weight[r[u]];
+                    const float *go = grad_output + ((long long)(r[u] / k) * cv + q) * VEC;
+                    if (VEC == 4) {
+                        const float4 t4 = *(const float4 *)go;
+                        t[u][0] = t4.x; t[u][1 % VEC] = t4.y; t[u][2 % VEC] = t4.z; t[u][3 % VEC] = t4.w;
+                    } else {
+                        t[u][0] = go[0];
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (r[u] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[i] = __builtin_fmaf(w[u], t[u][i], acc[i]);
+                }
         }
         float *dst = grad_input + (j * cv + q) * VEC;
         if (VEC == 4) *(float4 *)dst = make_float4(acc[0], acc[1], acc[2], acc[3]);
