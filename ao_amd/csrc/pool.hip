@@ -72,13 +72,24 @@ __global__ __launch_bounds__(TPB) void pool_max_fwd(long long total, int cv, con
             int r0 = order[p0];
             float4 best = ((const float4 *)feat)[(size_t)r0 * cv + q];
             int4 bi = make_int4(r0, r0, r0, r0);
-            for (int p = p0 + 1; p < p1; ++p) {
-                const int r = order[p];
-                const float4 v = ((const float4 *)feat)[(size_t)r * cv + q];
-                if (v.x > best.x) { best.x = v.x; bi.x = r; }
-                if (v.y > best.y) { best.y = v.y; bi.y = r; }
-                if (v.z > best.z) { best.z = v.z; bi.z = r; }
-                if (v.w > best.w) { best.w = v.w; bi.w = r; }
+            // members 8 at a time: ids, then their rows, then the comparisons in member order (first wins ties as before)
+            constexpr int UB = 8;
+            for (int p = p0 + 1; p < p1; p += UB) {
+                int r[UB];
+                float4 v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) r[u] = p + u < p1 ? order[p + u] : -1;
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (r[u] >= 0) v[u] = ((const float4 *)feat)[(size_t)r[u] * cv + q];
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (r[u] >= 0) {
+                        if (v[u].x > best.x) { best.x = v[u].x; bi.x = r[u]; }
+                        if (v[u].y > best.y) { best.y = v[u].y; bi.y = r[u]; }
+                        if (v[u].z > best.z) { best.z = v[u].z; bi.z = r[u]; }
+                        if (v[u].w > best.w) { best.w = v[u].w; bi.w = r[u]; }
+                    }
             }
             ((float4 *)out)[e] = best;
             ((int4 *)arg)[e] = bi;
