@@ -31,6 +31,7 @@ _SIGNATURES = {
                                    ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),
     "knn_query_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _vp]),
+    "knn_query_count_pairs": (_c_int, [_vp]),
     "farthest_point_sampling_hip_workspace_bytes": (_c_size, [_c_int] * 2),
     "farthest_point_sampling_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_size, _vp]),
     "grouping_forward_hip_launcher": (_c_int, [_c_int] * 3 + [_vp] * 4),
@@ -93,7 +94,7 @@ _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace 
 _lib = None
 # bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
 # mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
-EXPECTED_ABI = 5
+EXPECTED_ABI = 6
 
 
 def build(verbose=False):

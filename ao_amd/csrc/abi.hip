@@ -7,7 +7,7 @@
 
 #include "gva_common.h"
 
-extern "C" int ptv2_abi_version(void) { return 5; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 6; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 // sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
 // layout drift between the header and a python mirror is an import error, not a misread pointer
@@ -64,6 +64,11 @@ PtvRiders ptv2_rider_take() {
 void ptv2_rider_flush(hipStream_t st) {
     for (int i = 0; i < g_pending.count; ++i) launch_alone(g_pending.r[i], st);
     g_pending.count = 0;
+}
+int ptv2_rider_drop() {
+    const int had = g_pending.count;
+    g_pending.count = 0;
+    return had;
 }
 }  // namespace gva
 

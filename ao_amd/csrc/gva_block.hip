@@ -383,6 +383,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
+    PtvRiderGuard riders;  // an error return below must not leave queued sums (pointers into this call's workspace) behind
     // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
     //    grad Wp2 (direct part), grad bp2 (direct part)
     const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");
@@ -438,6 +439,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         RUN(skinny_linear_backward_pair(n, c, g, gys, B->Ww1, gxs, stream));
     }
     ptv2_rider_flush(st);  // anything still queued (paths without a carrying launch) before the glue reads the sums
+    riders.release();
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1; in the same launch the
     //    folded BN_p backward (both stages contribute to the gradient of (a, b))
     {

@@ -177,6 +177,15 @@ void ptv2_rider_defer_depth(int delta);
 void ptv2_rider_defer(const PtvRider &r, hipStream_t st);  // queue of RIDER_QUEUE: one more flushes the oldest as its own launch
 PtvRiders ptv2_rider_take();                               // the pending sums, for a host launch to carry
 void ptv2_rider_flush(hipStream_t st);                     // whatever is pending, as launches of their own
+int ptv2_rider_drop();                                     // forget whatever is pending (returns how many there were)
+// A function that opens PtvDeferScopes holds one of these: queued riders point into THIS call's workspace records and
+// gradient slots, so an early (error) return must not leave them for the next, unrelated host launch of the thread to run
+struct PtvRiderGuard {
+    bool armed = true;
+    PtvRiderGuard() { (void)ptv2_rider_drop(); }  // the queue is empty on entry by construction; a stale entry is dropped
+    ~PtvRiderGuard() { if (armed) (void)ptv2_rider_drop(); }
+    void release() { armed = false; }
+};
 struct PtvDeferScope {
     PtvDeferScope() { ptv2_rider_defer_depth(1); }
     ~PtvDeferScope() { ptv2_rider_defer_depth(-1); }

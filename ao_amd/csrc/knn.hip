@@ -296,7 +296,8 @@ __device__ __forceinline__ void topk_insert(float (&bd)[KC], int (&bi)[KC], floa
 
 template <int KC>
 __device__ __forceinline__ void scan_range(const float4 *__restrict__ sorted, int p0, int p1, float qx,
-                                           float qy, float qz, float (&bd)[KC], int (&bi)[KC]) {
+                                           float qy, float qz, float (&bd)[KC], int (&bi)[KC], unsigned &visited) {
+    visited += (unsigned)(p1 - p0);  // (dead code unless the COUNT instantiation reads it)
     for (int p = p0; p < p1; ++p) {
         float4 c = sorted[p];
         float d2 = ref_d2(qx, qy, qz, c.x, c.y, c.z);
@@ -304,13 +305,18 @@ __device__ __forceinline__ void scan_range(const float4 *__restrict__ sorted, in
     }
 }
 
-template <int KC>
+// COUNT: the measurement twin (bench.py `ops`): also adds the number of candidate points this query evaluated a distance
+// for to *pairs -- the pairs the grid method really computes, as opposed to the m * n_b pairs of
+// the reference's brute-force scan.  The production instantiation (COUNT = false) carries no trace of it.
+template <int KC, bool COUNT>
 __global__ __launch_bounds__(256) void knn_grid_query_kernel(
     int m, int k, const float4 *__restrict__ sorted, const float *__restrict__ new_xyz,
     const int *__restrict__ offset, const int *__restrict__ new_offset, int b,
     const SegGrid *__restrict__ seg, const int *__restrict__ cell_start, int *__restrict__ idx,
-    float *__restrict__ dist2, int pad_with_start, int self_mode, int *tie_count, int *tie_list) {
+    float *__restrict__ dist2, int pad_with_start, int self_mode, int *tie_count, int *tie_list,
+    unsigned long long *pairs) {
     int t = blockIdx.x * 256 + threadIdx.x;
+    unsigned visited = 0;
     if (t >= m) return;
     int qid, s;
     float qx, qy, qz;
@@ -344,12 +350,12 @@ __global__ __launch_bounds__(256) void knn_grid_query_kernel(
                     const int row = g.cell_base + (z * g.gy + y) * g.gx;
                     const bool full = (R == 1) || (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
                     if (full) {
-                        scan_range<KC>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, bd, bi);
+                        scan_range<KC>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, bd, bi, visited);
                     } else {
                         if (cx - R >= 0)
-                            scan_range<KC>(sorted, cell_start[row + cx - R], cell_start[row + cx - R + 1], qx, qy, qz, bd, bi);
+                            scan_range<KC>(sorted, cell_start[row + cx - R], cell_start[row + cx - R + 1], qx, qy, qz, bd, bi, visited);
                         if (cx + R <= g.gx - 1)
-                            scan_range<KC>(sorted, cell_start[row + cx + R], cell_start[row + cx + R + 1], qx, qy, qz, bd, bi);
+                            scan_range<KC>(sorted, cell_start[row + cx + R], cell_start[row + cx + R + 1], qx, qy, qz, bd, bi, visited);
                     }
                 }
             }
@@ -361,6 +367,7 @@ __global__ __launch_bounds__(256) void knn_grid_query_kernel(
         }
     }
 
+    if (COUNT) atomicAdd(pairs, (unsigned long long)visited);  // one atomic per query: a measurement build, not the timed one
     bool tie = false;
 #pragma unroll
     for (int j = 0; j + 1 < KC; ++j)
@@ -455,16 +462,30 @@ __global__ __launch_bounds__(EX_WAVES *WAVE) void knn_exact_kernel(
     }
 }
 
+thread_local unsigned long long *g_pair_counter = nullptr;
+
 template <int KC>
 void launch_query(hipStream_t st, int m, int k, const Workspace &w, const float *new_xyz,
                   const int *offset, const int *new_offset, int b, int *idx, float *dist2,
                   int pad_with_start, int self_mode) {
-    hipLaunchKernelGGL(knn_grid_query_kernel<KC>, dim3(divup(m, 256)), dim3(256), 0, st, m, k, w.sorted,
-                       new_xyz, offset, new_offset, b, w.seg, w.cell_start, idx, dist2, pad_with_start,
-                       self_mode, w.tie_count, w.tie_list);
+    if (g_pair_counter)
+        hipLaunchKernelGGL((knn_grid_query_kernel<KC, true>), dim3(divup(m, 256)), dim3(256), 0, st, m, k, w.sorted,
+                           new_xyz, offset, new_offset, b, w.seg, w.cell_start, idx, dist2, pad_with_start,
+                           self_mode, w.tie_count, w.tie_list, g_pair_counter);
+    else
+        hipLaunchKernelGGL((knn_grid_query_kernel<KC, false>), dim3(divup(m, 256)), dim3(256), 0, st, m, k, w.sorted,
+                           new_xyz, offset, new_offset, b, w.seg, w.cell_start, idx, dist2, pad_with_start,
+                           self_mode, w.tie_count, w.tie_list, (unsigned long long *)nullptr);
 }
 
 }  // namespace
+
+// measurement hook (bench.py `ops`): while `device_counter` != NULL the calling thread's grid queries run the counting twin
+// of the query kernel, which adds the candidate distances it evaluates to *device_counter (zeroed by the caller)
+extern "C" int knn_query_count_pairs(unsigned long long *device_counter) {
+    g_pair_counter = device_counter;
+    return PTV2_OK;
+}
 
 extern "C" size_t knn_query_hip_workspace_bytes(int m, int n, int b) {
     if (m < 0 || n < 0 || b < 1) return 0;

@@ -579,6 +579,8 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
         g = dst;
         o = spare;
     }
+    // head + decoder parameter gradients are final from here on (their finalizes were enqueued above)
+    if (M->decoder_done_event && hipEventRecord((hipEvent_t)M->decoder_done_event, st) != hipSuccess) return PTV2_ERR_LAUNCH;
     // encoder stages S-1 .. 0: gskip[i+1] is complete (skip branch of the decoder + the pooling of stage i+1)
     for (int i = S - 1; i >= 0; --i) {
         const ptv2_level &lv = M->level[i];

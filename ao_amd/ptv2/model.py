@@ -435,7 +435,7 @@ class PointTransformerV2(nn.Module):
         geo = geometry if geometry is not None else self.geometry(coord, offset)
         from . import native_model
 
-        if native_model.supported(self, feat):  # the whole network behind one native call per direction
+        if native_model.supported(self, feat) and native_model.geometry_supported(geo):  # the whole network behind one native call per direction
             return native_model.forward(self, data_dict, geo)
         lv = geo.levels
         pe = self.patch_embed

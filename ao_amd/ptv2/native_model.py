@@ -55,7 +55,7 @@ class _Model(ctypes.Structure):  # mirrors ptv2_model
                    ("num_blocks", _I), ("block", _MBlock * MAX_BLOCKS), ("embed", _LinBn), ("down", _LinBn * MAX_STAGES),
                    ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
                 + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
-                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I)])
+                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I), ("decoder_done_event", _P)])
 
 
 _lib.register({
@@ -84,6 +84,9 @@ class _Runtime:
     (struct field, gradient slot) pairs, the BlockSequences in ABI order.  Rebuilt when a parameter or buffer moves."""
 
     def __init__(self, model):
+        import weakref
+
+        self.model_ref = weakref.ref(model)  # (the model owns this object: no cycle)
         self.sequences = ([model.patch_embed.blocks] + [e.blocks for e in model.enc_stages]
                           + [d.blocks for d in model.dec_stages])
         S = model.num_stages
@@ -287,10 +290,21 @@ def supported(model, feat):
         return False
     if not (feat.is_cuda and feat.dim() == 2 and feat.dtype in (torch.float32, torch.bfloat16, torch.float16) and feat.shape[0] >= 2):
         return False
+    # the native backward forms no gradient for `feat` (model.hip stops at the patch embedding's weights): a caller whose
+    # features come out of a trainable upstream module takes the stage-wise python path, which does
+    if feat.requires_grad and torch.is_grad_enabled():
+        return False
+    if feat.shape[1] != model.in_channels:
+        raise ValueError("ao_amd: feat has %d channels, the model was built with in_channels=%d" % (feat.shape[1], model.in_channels))
     rt = runtime(model)
     if not rt.static_ok or (not model.training and not rt.has_running):
         return False
     return not any(b.enable_checkpoint for b in rt.block_modules)
+
+
+def geometry_supported(geo):
+    """every level needs >= 2 rows (training-mode BatchNorm, ptv2_block args_ok): tiny clouds take the python path"""
+    return all(int(lv.coord.shape[0]) >= 2 for lv in geo.levels)
 
 
 class _NativeModel(torch.autograd.Function):
@@ -337,6 +351,12 @@ class _NativeModel(torch.autograd.Function):
         # launcher joins it).  Measured on MI355X at 120 k points: 14.92 ms/step against 14.62 ms in line -- the chain's
         # kernels and the weight gradients compete for the same memory system, nothing is gained; kept as an option.
         M.side_stream = rt.side_stream(dev).cuda_stream if os.environ.get("AO_AMD_WGRAD_STREAM", "0") == "1" else None
+        # parallel.FlatGradSync(mode="flat2"): an event the launcher records once the head + decoder gradients are final
+        owner = rt.model_ref()
+        ev = owner.__dict__.get("native_decoder_done_event") if owner is not None else None
+        M.decoder_done_event = ev.cuda_event if ev is not None else None
+        if ev is not None:
+            owner.__dict__["native_decoder_done_count"] = owner.__dict__.get("native_decoder_done_count", 0) + 1
         direct = ctx.mode == "direct"
         accumulate = direct and rt.params[0].grad is not None
         flat, views = rt.grad_buffer(dev, fresh=accumulate or not direct)

@@ -37,10 +37,30 @@ class FlatGradSync:
     reduced once, and written back by one multi-tensor copy.  Parameters are broadcast from rank 0 once, BatchNorm
     buffers stay per process (the reference runs DDP with broadcast_buffers=False and sync_bn=False)."""
 
-    def __init__(self, module, force=False):
+    def __init__(self, module, force=False, mode="flat"):
         self.force = force  # run the flatten / all-reduce / write-back even in a 1-rank group (overhead measurement)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # mode "flat2": the flat buffer goes out in two chunks -- [head + decoder stages] as soon as the native backward
+        # has finished them (an event the launcher records, ptv2_model.decoder_done_event), on a communication stream,
+        # while the encoder's backward still runs; [patch embedding + encoder stages] after the backward.  For the
+        # 45 MB ScanNet-cfg model the first chunk's ~0.5 ms of ring time disappears behind compute; at 15.6 MB (S3DIS
+        # cfg) one collective is as good.  `module` must expose `.backbone` (a PointTransformerV2) or be one.
+        self.split, self.event, self.comm = None, None, None
+        if mode == "flat2":
+            backbone = getattr(module, "backbone", module)
+            names = [n for n, p in module.named_parameters() if p.requires_grad]
+            first = next((i for i, n in enumerate(names) if "dec_stages." in n), None)
+            if first is not None and first > 0 and torch.cuda.is_available() and self.params[0].is_cuda:
+                off = 0
+                for p in self.params[:first]:
+                    off += (p.numel() + 3) // 4 * 4  # optim.FlatAdamW / native_model.grad_layout slots
+                self.split = off
+                self.event = torch.cuda.Event()
+                self.event.record()  # creates the handle the launcher re-records
+                self.comm = torch.cuda.Stream(self.params[0].device)
+                backbone.__dict__["native_decoder_done_event"] = self.event
+                self.backbone, self.seen = backbone, backbone.__dict__.get("native_decoder_done_count", 0)
         if self.world > 1:
             flat = torch._utils._flatten_dense_tensors([p.data for p in self.params])
             dist.broadcast(flat, 0)
@@ -61,7 +81,19 @@ class FlatGradSync:
         """All-reduce (sum) an already flat gradient buffer in place (optim.FlatAdamW.flatten_grads()); the caller
         folds the 1 / world into its update (FlatAdamW.step(flat_grad=..., grad_scale=1 / world))."""
         if self.world > 1 or self.force:
-            dist.all_reduce(flat)
+            # two chunks only when THIS backward went through the native launcher (which re-recorded the event)
+            recorded = self.split is not None and self.backbone.__dict__.get("native_decoder_done_count", 0) != self.seen
+            if recorded:
+                self.seen = self.backbone.__dict__["native_decoder_done_count"]
+            if recorded and 0 < self.split < flat.numel():
+                main = torch.cuda.current_stream(flat.device)
+                self.comm.wait_event(self.event)  # the most recent record: enqueued by the backward that just returned
+                with torch.cuda.stream(self.comm):
+                    dist.all_reduce(flat[self.split:])
+                dist.all_reduce(flat[:self.split])
+                main.wait_stream(self.comm)
+            else:
+                dist.all_reduce(flat)
         return 1.0 / self.world
 
 

@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the kNN / FPS us-per-query lines")
+    ap.add_argument("--spawn-timeout", type=float, default=1800.0,
+                    help="--gpus N without a launcher: seconds after which the remaining ranks are terminated (exit 124)")
     return ap.parse_args()
 
 
@@ -151,20 +153,43 @@ def op_microbench(data):
         torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e3 / reps
 
-    out = {"knn_k16_self_us_per_query": timed(lambda: pointops.knn_query_dist2(16, xyz, off), 10) / n}
-    # against the fp32 VALU peak.  The reference kernel evaluates every (query, point-of-its-cloud) pair
-    # (knn_query_cuda_kernel.cu:88-97), ~8 flop each; the grid method returns the same table while visiting a small
-    # fraction of them, so this is the brute-force-EQUIVALENT pair rate (it may exceed what the VALU could evaluate)
+    t_knn = timed(lambda: pointops.knn_query_dist2(16, xyz, off), 10)
+    out = {"knn_k16_self_us_per_query": t_knn / n}
+    # What the grid method actually evaluates: one more call through the counting twin of the query
+    # kernel (knn_query_count_pairs, include/ptv2_hip.h) adds every candidate distance it computes to a device counter.
+    # A pair costs 3 sub + 1 mul + 2 fma = 8 flop on the vector ALU and one 16-byte read of the cell-sorted float4 copy
+    # (L1 / L2 hits for all but the first lane that touches a cell).  The reference kernel scans all m * n_b pairs
+    # (knn_query_cuda_kernel.cu:88-97); that count is reported beside it, not priced against a peak.
+    from ao_amd import _lib
+    counter = torch.zeros(1, dtype=torch.int64, device=xyz.device)
+    _lib.lib().knn_query_count_pairs(counter.data_ptr())
+    try:
+        pointops.knn_query_dist2(16, xyz, off)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().knn_query_count_pairs(None)
+    pairs = float(counter.item())
     sizes = torch.diff(off.long(), prepend=off.new_zeros(1).long()).double()
-    pairs = float((sizes * sizes).sum())
-    out["knn_k16_self_bruteforce_equiv_pairs_per_s"] = pairs / (out["knn_k16_self_us_per_query"] * n * 1e-6)
-    out["knn_k16_self_equiv_frac_of_fp32_valu_peak"] = out["knn_k16_self_bruteforce_equiv_pairs_per_s"] * 8 / 157.3e12
+    out["knn_k16_self_pairs_evaluated"] = pairs
+    out["knn_k16_self_pairs_evaluated_per_query"] = pairs / n
+    out["knn_k16_self_pairs_evaluated_per_s"] = pairs / (t_knn * 1e-6)
+    out["knn_k16_self_frac_of_fp32_valu_peak"] = out["knn_k16_self_pairs_evaluated_per_s"] * 8 / 157.3e12
+    out["knn_k16_self_candidate_read_GBps"] = pairs * 16 / (t_knn * 1e-6) / 1e9
+    out["knn_k16_self_bruteforce_pairs_of_the_reference_scan"] = float((sizes * sizes).sum())
+    out["knn_k16_self_note"] = ("whole op (grid build + query + tie re-run), HIP-event time; pairs = candidate distances the query kernel "
+                                "computed (counting twin); VALU fraction = pairs x 8 flop / time / 157.3 TFLOP/s; candidate_read = "
+                                "pairs x 16 B of cell-sorted float4 reads (mostly L1/L2 hits: the compulsory HBM bytes are 12n+12m+8mk)")
     if off.numel() == 1:
         coarse = xyz[::6].contiguous()
         coff = torch.tensor([coarse.shape[0]], dtype=torch.int32, device=xyz.device)
         out["knn_k3_cross_us_per_query"] = timed(lambda: pointops.knn_query_dist2(3, coarse, coff, xyz, off), 10) / n
     noff = (off // 4).int()
     out["fps_stride4_us_per_sample"] = timed(lambda: pointops.farthest_point_sampling(xyz, off, noff), 2) / int(noff[-1])
+    # FPS is a chain of m-1 dependent arg-max sweeps; with the cloud resident in the registers of W cooperating workgroups
+    # the floor of one sample is ONE cross-workgroup exchange of an 8-byte data-tagged granule: 0.8 us on an idle chip
+    # (guides/MI355X_MICROARCH.md, price list row handoff-1to1) -- a latency floor, not a bandwidth one
+    out["fps_handoff_floor_us_per_sample"] = 0.8
+    out["fps_frac_of_handoff_floor"] = 0.8 / out["fps_stride4_us_per_sample"]
     return out
 
 
@@ -188,12 +213,22 @@ def cpu_baseline(cfg, sample_points):
         opt.step()
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
-    return dict(value=sample_points / t, unit="points/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 scene cropped to %d points, fwd+bwd+AdamW, median of 2 after 1 warm-up, %.1f s/step; "
-                       "torch-CPU restatement + C kNN (oracle/), drop_path 0.  The full 120 000-point scene of the GPU "
-                       "workload, measured once on this host class (128 threads): 121.7 s/step = 986 points/s "
-                       "(bench.py --cpu-sample-points 120000; the crop keeps the default run within minutes)"
-                       % (sample_points, t))
+    out = dict(value=sample_points / t, unit="points/s", cores=torch.get_num_threads(), kind="port",
+               sample="1 scene cropped to %d points, fwd+bwd+AdamW, median of 2 after 1 warm-up, %.1f s/step; "
+                      "torch-CPU restatement + C kNN (oracle/), drop_path 0" % (sample_points, t))
+    # the FULL 120 000-point scene costs ~2 min per step on the host: measured once with `--cpu-sample-points 120000` and
+    # committed; read from that record (never a literal here), null when the file is absent
+    full = None
+    path = os.path.join(ROOT, "profiles", "r02_cpu_baseline_120k.json")
+    if sample_points >= 120000:
+        full = dict(value=out["value"], cores=out["cores"], s_per_step=t, source="this run")
+    elif os.path.exists(path):
+        rec = json.load(open(path))
+        cb = rec["cpu_baseline"]
+        full = dict(value=cb["value"], cores=cb["cores"], s_per_step=120000 / cb["value"],
+                    source="profiles/r02_cpu_baseline_120k.json (%s; not re-measured in this run)" % rec.get("measured", "?"))
+    out["full_scene_120k"] = full
+    return out
 
 
 def spawn_ranks(args):
@@ -202,8 +237,16 @@ def spawn_ranks(args):
     fresh interpreter.  A child that fails takes the job down: the others are terminated by PID and the parent exits
     with the failing status (reference: pointcept/engines/launch.py:74-87 mp.spawn(..., join) semantics)."""
     n = args.gpus
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
+    # a profiler preload (rocprofv3 sets ROCP_TOOL_LIBRARIES / LD_PRELOAD) initialises the GPU in THIS process before it could
+    # start the ranks, and all ranks would write into one output directory: profile one rank at a time instead
+    preload = os.environ.get("LD_PRELOAD", "")
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in preload or "rocprof" in preload:
+        sys.stderr.write("bench.py: --gpus %d under a profiler preload is refused (the parent would hold the GPU before "
+                         "spawning); profile a single rank: rocprofv3 ... -- python3 bench.py --gpus 1\n" % n)
+        raise SystemExit(2)
+    deadline = time.monotonic() + args.spawn_timeout
+    with socket.socket() as s:  # (bind / close / reuse can race with another process on the host: a rank then fails to
+        s.bind(("127.0.0.1", 0))  # rendezvous, the job exits non-zero and can simply be started again)
         port = s.getsockname()[1]
     children = []
     for rank in range(n):
@@ -238,6 +281,11 @@ def spawn_ranks(args):
                 pending.discard(r)
                 if rc != 0 and failed is None:
                     failed = (r, rc)
+        if failed is None and pending and time.monotonic() > deadline:
+            # a rank that hangs in rendezvous (e.g. its peer died before init) must not block the parent for ever
+            failed = (min(pending), 124)
+            sys.stderr.write("bench.py: no result after %.0f s (--spawn-timeout); terminating ranks %s\n"
+                             % (args.spawn_timeout, sorted(pending)))
         if failed is not None:
             for r in pending:
                 children[r].terminate()
@@ -334,7 +382,7 @@ def child_main(args):
         if use_ddp:
             net = parallel.wrap_ddp(seg, device)
         else:
-            sync = parallel.FlatGradSync(seg, force=force_sync)
+            sync = parallel.FlatGradSync(seg, force=force_sync, mode=os.environ.get("AO_AMD_GRAD_SYNC", "flat"))
     # AdamW(lr 0.006, wd 0.05) as in the reference config; AO_AMD_OPTIM=torch selects torch.optim.AdamW(fused=True)
     # instead of the one-kernel flat form (ao_amd/ptv2/optim.py)
     flat_opt = os.environ.get("AO_AMD_OPTIM", "flat") == "flat" and not use_ddp
@@ -441,7 +489,9 @@ def child_main(args):
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "comm_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": _launcher_name(),
-                       "grad_sync": "ddp" if use_ddp else "flat all-reduce",
+                       "grad_sync": "ddp" if use_ddp else ("flat all-reduce, two chunks (decoder half overlapped with the encoder "
+                                                             "backward)" if (sync is not None and sync.split is not None)
+                                                            else "flat all-reduce"),
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
                        "segmentor": "DefaultSegmentorSAM_Image + LogitBasket (%d puts, %d waits for a staging slot)"
                                     % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",

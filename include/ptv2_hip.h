@@ -71,6 +71,10 @@ int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *ne
                            const int *offset, const int *new_offset, int *idx, float *dist2,
                            int n, int b, int pad_with_start, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* Measurement hook (no reference counterpart; bench.py `ops`): while device_counter != NULL the calling thread's
+ * knn_query_hip_launcher calls run the counting twin of the grid query kernel, which adds the number of candidate
+ * distances it evaluates to *device_counter (64-bit, device memory, zeroed by the caller).  NULL switches it off. */
+int knn_query_count_pairs(unsigned long long *device_counter);
 
 /* ------------------------------------------------------------------ FPS --
  * Replaces farthest_point_sampling_cuda_launcher
@@ -580,6 +584,10 @@ typedef struct ptv2_model {
     void *side_stream;                 /* backward only, optional: weight gradients run here (see ptv2_block_grads);
                                         * the launcher joins it into `stream` before it returns control of the queue */
     int matmul_bf16;                   /* as ptv2_block.matmul_bf16, for every Linear of the network */
+    void *decoder_done_event;          /* backward only, optional hipEvent_t: recorded on `stream` once the head and every
+                                        * decoder stage have written their parameter gradients (the tail of the flat
+                                        * gradient buffer in module.parameters() order) -- a data-parallel caller starts
+                                        * the all-reduce of that half while the encoder's backward still runs */
 } ptv2_model;
 size_t ptv2_model_saved_bytes(const ptv2_model *m);
 size_t ptv2_model_workspace_bytes(const ptv2_model *m);
