@@ -194,6 +194,8 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
 }
 
 int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream);
+int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 // internal to the library (model.hip): the parameter-only folds of `count` Blocks in one launch per 8 Blocks, ahead of the
 // forward; the Blocks are then run inside ptv2_gva_set_prefolded(1)
@@ -251,9 +253,13 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     // grouped vector attention (q, k enter as hq, hk + folded affine)
     ptv2_gva_block V;
     fill_gva(B, S, &V);
-    RUN(gva_block_forward_hip_launcher(&V, W.gva, W.gva_bytes, stream));
-    // norm2 (statistics by a pass over attn) -> fc3 on f2 = ReLU(BN2(attn)) (+ statistics of h3) -> norm3 -> tail
-    RUN(bn_prepare(B, 5, S.attn, nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
+    // (the attention's last stage leaves the tile statistics of its output where the matrix-core form of it runs: h1's
+    // record buffer is free by now)
+    int attn_stats = 0;
+    RUN(gva_block_forward_stats(&V, use_batch(B, 5) ? W.stat[0] : nullptr, &attn_stats, W.gva, W.gva_bytes, stream));
+    // norm2 (statistics from those records, else by a pass over attn) -> fc3 on f2 = ReLU(BN2(attn)) (+ statistics of h3)
+    // -> norm3 -> tail
+    RUN(bn_prepare(B, 5, S.attn, attn_stats ? W.stat[0] : nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
     {
         const float *xs[1] = {S.attn}, *ws[1] = {P[PTV2_BLK_FC3_W]};
         float *ys[1] = {S.h3}, *sts[1] = {st_h3};

@@ -252,6 +252,11 @@ __global__ __launch_bounds__(TPB) void logits_bwd_params_kernel(int n, int k, in
 using namespace gva;
 
 int gva_bwd_point_supported(int k, int c, int g);
+int gva_logits_bwd_fused_supported(int k, int c, int g);
+int gva_logits_bwd_fused_launch(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
+                                const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
+                                const gva::FoldWBwdArgs &F, float *gWt, float *part, size_t part_floats_avail, float *gM, float *ga,
+                                float *gb, float *gcW, hipStream_t st);
 int gva_logits_params_point_launch(int n, int k, int c, int g, const float *a, const float *b, const float *M,
                                    const float *coord, const int *idx, const float *gWt, float *part, int max_blocks,
                                    int *nblk_out, hipStream_t st);
@@ -296,6 +301,25 @@ int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const 
     const long long rows = (long long)n * k;
     float *part = (float *)workspace;
     float *gWt = (float *)((char *)workspace + rows_offset_bytes(c, g));
+    // wide-group levels: rows + parameter gradients in one pipelined MFMA launch (gva_bwd_logits.hip), then the gather
+    const char *lb = getenv("AO_AMD_LOGITS_BWD");  // "staged": the three-kernel form (A/B switch of the tests)
+    const bool fused_off = lb && lb[0] == 's';
+    if (inv_ptr && gva_logits_bwd_fused_supported(k, c, g) && !fused_off && !getenv("AO_AMD_BWD_STAGED")) {
+        {
+            // W1, gW1 in, gWt out, idx, coord; parameter-sized outputs
+            PtvScopedTimer t(KID_LOGITS_BWD_PARAMS, st, 4.0 * ((double)rows * (3 * g + 1) + 3.0 * n));
+            const int rc = gva_logits_bwd_fused_launch(n, k, c, g, a, b, M, coord, idx, W1, gW1, gT1, gT2, F, gWt, part,
+                                                       part_floats(c, g), gM, ga, gb, gcW, st);
+            if (rc != PTV2_OK) return rc;
+        }
+        {
+            PtvScopedTimer t(KID_LOGITS_BWD_GATHER, st, 4.0 * ((double)rows * g + 2.0 * n * g + rows));
+            hipLaunchKernelGGL(logits_bwd_gather_kernel, dim3(stage_grid((long long)n * g, TPB)), dim3(TPB), 0, st, n, k, g,
+                               (const float *)gWt, idx, inv_ptr, inv_rows, gkW, gqW);
+        }
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     // ~16 float4 per thread: with 4 the launch was thousands of single-shot workgroups whose records the last one to
     // arrive then had to sum (83-88 % of the wave cycles parked; 13.45 -> 13.35 ms per step with a quarter of the grid)
     const int nb_rows = stage_grid(rows * g / 64, TPB);

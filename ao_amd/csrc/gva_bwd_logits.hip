@@ -1,0 +1,348 @@
+// ao_amd/csrc/gva_bwd_logits.hip -- logits backward of grouped vector attention for the wide-group levels (G >= 12):
+// the BatchNorm-fold of the row gradient AND the parameter gradients of the logits stage in ONE streaming launch on the
+// matrix cores.
+//
+// Round 2 ran this stage as three kernels per attention block (gva_bwd.hip):
+//   logits_bwd_rows    gWt = gW1 + gT1 + 2 gT2 W1, column sums -> grad cW                      (N K G) in, (N K G) out
+//   logits_bwd_gather  grad kW (inverse table), grad qW                                         reads gWt
+//   logits_bwd_params  grad M (C,G) = P^T gWt, (grad a, grad b) = relu'(P) (gWt M^T) (pos, 1)   reads gWt again
+// with the third one on the vector ALU (thread <-> channel, two G-long register rows: 664 M FMAs at 4.5 k points = 17 us at
+// 100 % VALU utilisation, 50 us measured) and a point-per-wavefront MFMA form that tied with it because every point paid
+// its load latencies in sequence (idx -> coord -> gWt in two layouts) behind two workgroup barriers.
+//
+// Here a wavefront keeps the K = 16 slots of a point as one MFMA dimension (as gva_bwd_point.hip) and the loop is software
+// pipelined: while point i is on the matrix cores the W1 / gW1 rows of point i+1 (both operand layouts), its neighbour
+// coordinates and the neighbour ids of point i+2 are in flight; positions go through a wave-private LDS record (no
+// workgroup barrier anywhere in the loop).  The row gradient gWt is formed in registers from W1 and gW1 (the same fused
+// multiply-add as the rows kernel: bit-identical values), written once for the gather kernel, and consumed in place:
+//   D (s,ch)   = gWt (s,g) M^T (g,ch)          -> gpre = relu'(P) D -> (ga, gb)[ch] += gpre (pos, 1)
+//   gM (ch,g) += P^T (ch,s) gWt (s,g)                                 accumulated in registers over the workgroup's points
+//   gcW (g)   += sum_s gWt (s,g)
+// NW wavefronts share a point, each owning C / NW channels (results of a product feed the next without leaving registers:
+// the D tile of the first product is in the layout the mask and the (ga, gb) sums want).
+#include <algorithm>
+
+#include "gva_common.h"
+
+namespace gva {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f mfma4l(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int G, int C, int NW>
+struct LogitsBwdCfg {
+    static constexpr int GT = (G + 15) / 16, PW = 4 / NW, CW = C / NW, UT = CW / 16, PER = G + 4;
+    static constexpr bool HOIST_M = UT * GT <= 12;  // M fragments of this wavefront's channels stay in registers
+    static constexpr size_t REC = (size_t)C * PER + GT * 16;  // floats of a workgroup record: [C][G+4], then gcW (padded)
+};
+
+// part[blockIdx.x][REC]
+template <int G, int C, int NW>
+__global__ __launch_bounds__(256) void logits_bwd_fused_kernel(int n, int k, const float *__restrict__ a,
+                                                               const float *__restrict__ b, const float *__restrict__ M,
+                                                               const float *__restrict__ coord, const int *__restrict__ idx,
+                                                               const float *__restrict__ W1, const float *__restrict__ gW1,
+                                                               const double *__restrict__ gT1, const double *__restrict__ gT2,
+                                                               float *__restrict__ gWt, float *__restrict__ part, FoldWBwdArgs F) {
+    using K = LogitsBwdCfg<G, C, NW>;
+    constexpr int GT = K::GT, PW = K::PW, CW = K::CW, UT = K::UT, PER = K::PER, G16 = GT * 16;
+    static_assert(G % 4 == 0 && CW % 16 == 0, "layout A loads float4 along g; a wavefront owns whole 16-channel tiles");
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;                                  // [C] (a.xyz, b)
+    float4 *sPos = sAB + C;                              // [4 waves][2][16] wave-private position records
+    float *sC1 = (float *)(sPos + 4 * 2 * 16);           // [G16]
+    float *sC2 = sC1 + G16;                              // [G16]
+    float *sFin = sC2 + G16;                             // [REC]   (PW > 1 only: cross-point-slot sums)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = wid / NW, sub = wid % NW;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int c0 = sub * CW;
+
+    for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    if (tid < G16) {  // c1 = gT1, c2 = 2 gT2: the two statistics paths of BN_w folded into every row gradient
+        float c1 = 0.f, c2 = 0.f;
+        if (tid < G) {
+            if (F.gsc) {
+                double t1, t2;
+                float gg, gb_;
+                fold_w_bwd_channel(F, tid, t1, t2, gg, gb_);
+                c1 = (float)t1;
+                c2 = 2.f * (float)t2;
+                if (blockIdx.x == 0) { F.ggamma[tid] = gg; F.gbeta[tid] = gb_; }
+            } else {
+                c1 = (float)gT1[tid];
+                c2 = 2.f * (float)gT2[tid];
+            }
+        }
+        sC1[tid] = c1;
+        sC2[tid] = c2;
+    }
+    if (PW > 1)
+        for (int e = tid; e < (int)K::REC; e += 256) sFin[e] = 0.f;
+    __syncthreads();
+
+    // constants of this lane: folding constants in both layouts, (a, b) of its channels, M fragments
+    float4 c1A[GT], c2A[GT];
+    float c1B[GT], c2B[GT];
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+        c1A[t] = *(const float4 *)(sC1 + 16 * t + 4 * q);
+        c2A[t] = *(const float4 *)(sC2 + 16 * t + 4 * q);
+        c1B[t] = sC1[16 * t + l15];
+        c2B[t] = sC2[16 * t + l15];
+    }
+    float4 mreg[K::HOIST_M ? UT : 1][K::HOIST_M ? GT : 1];
+    if (K::HOIST_M) {
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const int g0 = 16 * t + 4 * q;
+                mreg[u][t] = g0 < G ? *(const float4 *)(M + (size_t)(c0 + 16 * u + l15) * G + g0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+
+    float4 accAB[UT];
+    v4f accM[UT][GT];
+    float tcw[GT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < GT; ++t) accM[u][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < GT; ++t) tcw[t] = 0.f;
+
+    // ---- loads of one point: rows of W1 / gW1 in the two operand layouts
+    struct Rows { float4 wA[GT], gA[GT]; float wB[4][GT], gB[4][GT]; };
+    auto load_rows = [&](long long pt, Rows &R) {
+        const bool act = pt < n;
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            const int g0 = 16 * t + 4 * q;
+            R.wA[t] = R.gA[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act && l15 < k && g0 < G) {
+                const size_t o = ((size_t)pt * k + l15) * G + g0;
+                R.wA[t] = *(const float4 *)(W1 + o);
+                R.gA[t] = *(const float4 *)(gW1 + o);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int s = 4 * st + q, g = 16 * t + l15;
+                R.wB[st][t] = R.gB[st][t] = 0.f;
+                if (act && s < k && g < G) {
+                    const size_t o = ((size_t)pt * k + s) * G + g;
+                    R.wB[st][t] = W1[o];
+                    R.gB[st][t] = gW1[o];
+                }
+            }
+        }
+    };
+    const long long stride = (long long)gridDim.x * PW;
+    float4 *myPos = sPos + wid * 32;
+    // neighbour ids two points ahead, coordinates one point ahead (lanes 0..15 of every wavefront: its own copy, no barrier)
+    auto load_idx = [&](long long pt) -> int { return (pt < n && lane < 16 && lane < k) ? idx[pt * k + lane] : -1; };
+    auto load_rel = [&](long long pt, int src) -> float4 {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pt < n && lane < 16 && src >= 0) {
+            r.x = coord[3 * (long long)src] - coord[3 * pt];
+            r.y = coord[3 * (long long)src + 1] - coord[3 * pt + 1];
+            r.z = coord[3 * (long long)src + 2] - coord[3 * pt + 2];
+        }
+        return r;
+    };
+    const long long pt0 = (long long)blockIdx.x * PW + p;
+    Rows Rn;
+    load_rows(pt0, Rn);
+    int idx_n = load_idx(pt0 + stride);
+    {
+        const float4 r0 = load_rel(pt0, load_idx(pt0));
+        if (lane < 16) myPos[lane] = r0;
+    }
+    int cur = 0;
+    for (long long pt = pt0; pt < n; pt += stride, cur ^= 1) {  // (no workgroup barrier inside: trip counts may differ per wavefront)
+        const bool act = pt < n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // record `cur` of this wavefront is in LDS
+        // ---- current point: gWt in both layouts from the prefetched rows
+        float uA[GT][4], uB[4][GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) {
+            uA[t][0] = __builtin_fmaf(Rn.wA[t].x, c2A[t].x, Rn.gA[t].x + c1A[t].x);
+            uA[t][1] = __builtin_fmaf(Rn.wA[t].y, c2A[t].y, Rn.gA[t].y + c1A[t].y);
+            uA[t][2] = __builtin_fmaf(Rn.wA[t].z, c2A[t].z, Rn.gA[t].z + c1A[t].z);
+            uA[t][3] = __builtin_fmaf(Rn.wA[t].w, c2A[t].w, Rn.gA[t].w + c1A[t].w);
+            const int g0 = 16 * t + 4 * q;
+            const bool ok = act && l15 < k && g0 < G;
+            if (!ok) uA[t][0] = uA[t][1] = uA[t][2] = uA[t][3] = 0.f;
+            if (ok && sub == 0) *(float4 *)(gWt + ((size_t)pt * k + l15) * G + g0) = make_float4(uA[t][0], uA[t][1], uA[t][2], uA[t][3]);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const bool okb = act && 4 * st + q < k && 16 * t + l15 < G;
+                uB[st][t] = okb ? __builtin_fmaf(Rn.wB[st][t], c2B[t], Rn.gB[st][t] + c1B[t]) : 0.f;
+                if (sub == 0) tcw[t] += uB[st][t];
+            }
+        }
+        // ---- requests for the next points
+        load_rows(pt + stride, Rn);
+        const float4 rel_n = load_rel(pt + stride, idx_n);
+        idx_n = load_idx(pt + 2 * stride);
+        // ---- positions of this point in the two row layouts
+        float4 rp[4], pq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rp[r] = myPos[cur * 16 + 4 * q + r]; pq[r] = myPos[cur * 16 + 4 * r + q]; }
+        float4 mnext[GT];  // (not hoisted: the M fragments of channel tile u+1 are requested while tile u computes)
+        auto load_m = [&](int u, float4 (&m)[GT]) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const int g0 = 16 * t + 4 * q;
+                m[t] = g0 < G ? *(const float4 *)(M + (size_t)(c0 + 16 * u + l15) * G + g0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if (!K::HOIST_M) load_m(0, mnext);
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const int ch = c0 + 16 * u + l15;
+            const float4 ab = sAB[ch];
+            v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
+            float4 mcur[GT];
+            if (!K::HOIST_M) {
+#pragma unroll
+                for (int t = 0; t < GT; ++t) mcur[t] = mnext[t];
+                if (u + 1 < UT) load_m(u + 1, mnext);
+            }
+#pragma unroll
+            for (int t = 0; t < GT; ++t) {
+                const float4 m4 = K::HOIST_M ? mreg[u][t] : mcur[t];
+                d = mfma4l(uA[t][0], m4.x, d);
+                d = mfma4l(uA[t][1], m4.y, d);
+                d = mfma4l(uA[t][2], m4.z, d);
+                d = mfma4l(uA[t][3], m4.w, d);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {  // gM (ch, g) += P^T gWt: contraction over the slots s = 4 st + q
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, pq[st].x, pq[st].y, pq[st].z);
+#pragma unroll
+                for (int t = 0; t < GT; ++t) accM[u][t] = mfma4l(P, uB[st][t], accM[u][t]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // rows s = 4 q + r of column ch
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rp[r].x, rp[r].y, rp[r].z);
+                const float gpre = (P > 0.f && act && 4 * q + r < k) ? d[r] : 0.f;
+                accAB[u].x = __builtin_fmaf(gpre, rp[r].x, accAB[u].x);
+                accAB[u].y = __builtin_fmaf(gpre, rp[r].y, accAB[u].y);
+                accAB[u].z = __builtin_fmaf(gpre, rp[r].z, accAB[u].z);
+                accAB[u].w += gpre;
+            }
+        }
+        if (lane < 16) myPos[(cur ^ 1) * 16 + lane] = rel_n;
+    }
+
+    // ---- workgroup record: [C][G+4] = gM row, ga.xyz, gb; then gcW
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u].x += __shfl_xor(accAB[u].x, 16, WAVE); accAB[u].x += __shfl_xor(accAB[u].x, 32, WAVE);
+        accAB[u].y += __shfl_xor(accAB[u].y, 16, WAVE); accAB[u].y += __shfl_xor(accAB[u].y, 32, WAVE);
+        accAB[u].z += __shfl_xor(accAB[u].z, 16, WAVE); accAB[u].z += __shfl_xor(accAB[u].z, 32, WAVE);
+        accAB[u].w += __shfl_xor(accAB[u].w, 16, WAVE); accAB[u].w += __shfl_xor(accAB[u].w, 32, WAVE);
+    }
+#pragma unroll
+    for (int t = 0; t < GT; ++t) { tcw[t] += __shfl_xor(tcw[t], 16, WAVE); tcw[t] += __shfl_xor(tcw[t], 32, WAVE); }
+    float *rec = part + (size_t)blockIdx.x * K::REC;
+    if (PW == 1) {  // every wavefront owns its channels: straight to the record
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * t + l15, ch = c0 + 16 * u + 4 * q + r;
+                    if (g < G) rec[(size_t)ch * PER + g] = accM[u][t][r];
+                }
+            if (q == 0) {
+                float *d = rec + (size_t)(c0 + 16 * u + l15) * PER + G;
+                d[0] = accAB[u].x; d[1] = accAB[u].y; d[2] = accAB[u].z; d[3] = accAB[u].w;
+            }
+        }
+        if (sub == 0 && q == 0) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t) rec[(size_t)C * PER + 16 * t + l15] = tcw[t];
+        }
+    } else {  // PW point slots share the channels: add up in LDS, one wavefront after the other (fixed order)
+        __syncthreads();
+        for (int turn = 0; turn < 4; ++turn) {
+            if (wid == turn) {
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int g = 16 * t + l15, ch = c0 + 16 * u + 4 * q + r;
+                            if (g < G) sFin[ch * PER + g] += accM[u][t][r];
+                        }
+                    if (q == 0) {
+                        float *d = sFin + (c0 + 16 * u + l15) * PER + G;
+                        d[0] += accAB[u].x; d[1] += accAB[u].y; d[2] += accAB[u].z; d[3] += accAB[u].w;
+                    }
+                }
+                if (sub == 0 && q == 0) {
+#pragma unroll
+                    for (int t = 0; t < GT; ++t) sFin[C * PER + 16 * t + l15] += tcw[t];
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < (int)K::REC; e += 256) rec[e] = sFin[e];
+    }
+}
+
+template <int G, int C, int NW>
+int launch_logits_bwd_fused(int n, int k, const float *a, const float *b, const float *M, const float *coord, const int *idx,
+                            const float *W1, const float *gW1, const double *gT1, const double *gT2, const FoldWBwdArgs &F,
+                            float *gWt, float *part, size_t part_floats_avail, float *gM, float *ga, float *gb, float *gcW,
+                            hipStream_t st) {
+    using K = LogitsBwdCfg<G, C, NW>;
+    const size_t lds = sizeof(float4) * (C + 4 * 2 * 16) + sizeof(float) * (2 * K::GT * 16 + (K::PW > 1 ? K::REC : 0));
+    auto kern = logits_bwd_fused_kernel<G, C, NW>;
+    // exactly the co-resident workgroups (every one stages its constants once, then walks its points; as gva_bwd_point)
+    static int resident = 0;
+    if (!resident) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = std::max(64, std::min(occ * cus, 512));
+    }
+    const long long groups = ((long long)n + K::PW - 1) / K::PW;
+    long long cap = std::min<long long>(resident, (long long)(part_floats_avail / K::REC));
+    if (cap < 1) return PTV2_ERR_WORKSPACE;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, a, b, M, coord, idx, W1, gW1, gT1, gT2, gWt, part, F);
+    launch_finalize(st, (const float *)part, nblk, (int)K::REC, MapLogitsFused{gM, ga, gb, gcW, G, C});
+    return PTV2_OK;
+}
+
+}  // namespace gva
+
+// 1 when (k, c, g) has an instantiation of the fused rows + parameter-gradient kernel
+int gva_logits_bwd_fused_supported(int k, int c, int g) {
+    if (k < 1 || k > 16) return 0;
+    // (64, 512) -- the ScanNet cfg's deepest level, a few dozen points -- would need 128 accumulator registers per lane and
+    // spills: it stays on the staged kernels of gva_bwd.hip
+    return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
+}
+
+int gva_logits_bwd_fused_launch(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
+                                const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
+                                const gva::FoldWBwdArgs &F, float *gWt, float *part, size_t part_floats_avail, float *gM, float *ga,
+                                float *gb, float *gcW, hipStream_t st) {
+    using namespace gva;
+#define ARGS n, k, a, b, M, coord, idx, W1, gW1, gT1, gT2, F, gWt, part, part_floats_avail, gM, ga, gb, gcW, st
+    if (g == 12 && c == 96) return launch_logits_bwd_fused<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return launch_logits_bwd_fused<24, 192, 4>(ARGS);  // (2 waves per point: 306 registers, 1 wave / SIMD)
+    if (g == 48 && c == 384) return launch_logits_bwd_fused<48, 384, 4>(ARGS);
+#undef ARGS
+    return PTV2_ERR_ARG;
+}

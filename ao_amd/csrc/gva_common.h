@@ -158,7 +158,7 @@ __device__ __forceinline__ void finalize_columns(const float *part, int nblk, in
 // PtvDeferScope launch_finalize() queues such a sum instead of launching it; the next designated host launch (one that
 // neither reads its outputs nor overwrites its records) takes the queue and appends workgroups that run it beside its
 // own work.  ptv2_rider_flush() launches whatever is still queued as a kernel of its own.
-enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRADN };
+enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRADN, RIDER_LOGITS_FUSED };
 struct PtvRider {
     const float *part;
     int nblk, len, kind, blocks;
@@ -270,6 +270,28 @@ template <> struct RiderOf<MapLogitsParams> {
     }
 };
 
+// fused logits backward (gva_bwd_logits.hip): columns [0, c (g+4)) as MapLogitsParams, then 16-padded grad cW
+struct MapLogitsFused {
+    float *gM, *ga, *gb, *gcW;
+    int g, c;
+    __device__ void operator()(int e, double v) const {
+        const int per = g + 4, np = c * per;
+        if (e < np) {
+            const int ch = e / per, j = e - ch * per;
+            if (j < g) gM[ch * g + j] = (float)v;
+            else if (j < g + 3) ga[ch * 3 + (j - g)] = (float)v;
+            else gb[ch] = (float)v;
+        } else if (e - np < g) gcW[e - np] = (float)v;
+    }
+};
+template <> struct RiderOf<MapLogitsFused> {
+    static constexpr bool ok = true;
+    static PtvRider make(const MapLogitsFused &m) {
+        PtvRider r{}; r.kind = RIDER_LOGITS_FUSED; r.p[0] = m.gM; r.p[1] = m.ga; r.p[2] = m.gb; r.p[3] = m.gcW; r.i0 = m.g; r.i1 = m.c;
+        return r;
+    }
+};
+
 // fused softmax / aggregation backward: columns of the workgroup record -> ga (c,3), gb (c), gsc, gsh, gWw2 (g,g), gbw2
 struct MapBwdPoint {
     float *ga, *gb, *gsc, *gsh, *gWw2, *gbw2;
@@ -368,6 +390,7 @@ __device__ __forceinline__ void rider_run(const PtvRiders &Rs, int rb) {
             switch (R.kind) {  // uniform over the workgroup
                 case RIDER_VEC: rider_columns(R, rb, MapVec<float>{R.p[0]}); break;
                 case RIDER_LOGITS_PARAMS: rider_columns(R, rb, MapLogitsParams{R.p[0], R.p[1], R.p[2], R.i0}); break;
+                case RIDER_LOGITS_FUSED: rider_columns(R, rb, MapLogitsFused{R.p[0], R.p[1], R.p[2], R.p[3], R.i0, R.i1}); break;
                 case RIDER_BWD_POINT: rider_columns(R, rb, MapBwdPoint{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.i0, R.i1}); break;
                 case RIDER_WGRADN:
                     rider_columns(R, rb, MapWgradN{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.p[6], R.p[7], R.p[8], R.p[9],

@@ -82,6 +82,153 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, int c
     }
 }
 
+// ---- the same product on the matrix cores (I = C / G = 8, every PT-v2m2 configuration) -----------------------------------
+// Per group the projection is a (points x C') x (C' x 8) product.  One lane per output element (above) makes the 8 lanes of
+// a group read the SAME 16 bytes of an A row per load instruction: a wavefront's request touches 8 rows x 16 B, the kernel
+// is bound by the vector memory pipeline's line lookups (40 us for the 83 MB of A at 4.5 k points, 2 TB/s from cache).
+// Here a wavefront owns 16 points; lane (point l15, quarter q) streams its quarter of the point's A row as float4 (every
+// line consumed whole by one lane), the 8 Wp2 rows of the group come from LDS as the A operand of V_MFMA_F32_16X16X4_F32
+// (rows 8..15 of the tile are padding), and the result tile leaves 4 consecutive outputs of a point in each lane of q < 2
+// (float4 store).  The next group's A rows are in flight while the current group is on the matrix core.
+// A workgroup = one 64-row block x `gpw` groups; with stats != NULL its epilogue leaves the column statistics of `out` for
+// this row block (sum, sum of squares about the block mean: the records of gemm.hip's epilogue, merged by
+// bn_tiles_finalize) -- norm2's statistics pass and its read of `out` disappear.
+typedef float v4f_peb __attribute__((ext_vector_type(4)));
+template <int CTRL>
+__device__ __forceinline__ float peb_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float peb_row16_sum(float v) {  // all-reduce over the 16 lanes that share lane >> 4
+    v += peb_dpp<0xB1>(v);
+    v += peb_dpp<0x4E>(v);
+    v += peb_dpp<0x141>(v);
+    v += peb_dpp<0x140>(v);
+    return v;
+}
+
+constexpr int PEB_MAX_GPW = 6;
+template <int C>
+__global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, int gpw, const float *__restrict__ A,
+                                                           const float *__restrict__ Wp2, const float *__restrict__ bp2,
+                                                           const float *__restrict__ sw, const float *__restrict__ out_v,
+                                                           float *__restrict__ out, float *__restrict__ stats) {
+    constexpr int QF = C / 16;                      // float4 per lane and group (a lane owns C / 4 consecutive c')
+    constexpr int CH = QF <= 12 ? QF : QF / 2;      // float4 per lane and chunk (register budget: two chunks resident)
+    constexpr int NCH = QF / CH;                    // chunks per group
+    constexpr int LDW = C + 4;
+    extern __shared__ float4 lds4[];
+    float *sW = (float *)lds4;                      // [gpw * 8][C + 4]
+    float *sS = sW + (size_t)gpw * 8 * LDW;         // [4 waves][gpw * 8]   (statistics)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int g0 = blockIdx.y * gpw;
+    const int ng = g - g0 < gpw ? g - g0 : gpw;     // groups of this workgroup
+    const long long row0 = (long long)blockIdx.x * 64;
+    for (int e = tid; e < ng * 8 * (C / 4); e += TPB) {
+        const int r = e / (C / 4), c4 = e - r * (C / 4);
+        *(float4 *)(sW + (size_t)r * LDW + 4 * c4) = *(const float4 *)(Wp2 + ((size_t)g0 * 8 + r) * C + 4 * c4);
+    }
+    const long long pt = row0 + wid * 16 + l15;
+    const bool rv = pt < n;
+    const float *arow = A + ((size_t)(rv ? pt : 0) * g + g0) * C + q * (C / 4);
+    auto fetch = [&](int item, float4 (&x)[CH]) {  // item = group * NCH + chunk
+        const int gl = item / NCH, ck = item - gl * NCH;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            x[j] = (rv && gl < ng) ? *(const float4 *)(arow + (size_t)gl * C + 4 * (ck * CH + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 xn[CH];
+    fetch(0, xn);
+    __syncthreads();
+    float4 val[PEB_MAX_GPW];
+    const int items = ng * NCH;
+    v4f_peb acc = (v4f_peb){0.f, 0.f, 0.f, 0.f};
+    for (int item = 0; item < items; ++item) {
+        const int gl = item / NCH, ck = item - gl * NCH;
+        float4 x[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) x[j] = xn[j];
+        if (item + 1 < items) fetch(item + 1, xn);
+        const float *wr = sW + (size_t)(gl * 8 + (l15 & 7)) * LDW + q * (C / 4) + 4 * ck * CH;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float4 w4 = *(const float4 *)(wr + 4 * j);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x[j].w, acc, 0, 0, 0);
+        }
+        if (ck == NCH - 1) {  // D[i][j]: i = output 4 q + reg (q < 2 valid), j = point l15
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rv && q < 2) {
+                const int col = (g0 + gl) * 8 + 4 * q;
+                const float4 ov = *(const float4 *)(out_v + (size_t)pt * C + col), bb = *(const float4 *)(bp2 + col);
+                const float s = sw[(size_t)pt * g + g0 + gl];
+                v.x = ov.x + acc[0] + bb.x * s; v.y = ov.y + acc[1] + bb.y * s;
+                v.z = ov.z + acc[2] + bb.z * s; v.w = ov.w + acc[3] + bb.w * s;
+                *(float4 *)(out + (size_t)pt * C + col) = v;
+            }
+#pragma unroll
+            for (int t = 0; t < PEB_MAX_GPW; ++t)
+                if (t == gl) val[t] = v;
+            acc = (v4f_peb){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    if (!stats) return;
+    // column statistics of this 64-row block for the ng * 8 columns [g0 * 8, ...): two passes over the register values
+    const int cnt = (int)((n - row0) < 64 ? (n - row0) : 64);
+    const int ncol = ng * 8;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PEB_MAX_GPW; ++t)
+        if (t < ng) {
+            const float sx = peb_row16_sum(val[t].x), sy = peb_row16_sum(val[t].y), sz = peb_row16_sum(val[t].z), s_w = peb_row16_sum(val[t].w);
+            if (l15 == 0 && q < 2) *(float4 *)(sS + wid * ncol + t * 8 + 4 * q) = make_float4(sx, sy, sz, s_w);
+        }
+    __syncthreads();
+    float4 mean[PEB_MAX_GPW];
+#pragma unroll
+    for (int t = 0; t < PEB_MAX_GPW; ++t)
+        if (t < ng) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 2) {
+                a = *(const float4 *)(sS + t * 8 + 4 * q);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 o = *(const float4 *)(sS + w * ncol + t * 8 + 4 * q);
+                    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                }
+            }
+            mean[t] = a;  // block sums for now
+        }
+    __syncthreads();
+    const float inv = 1.0f / (float)cnt;
+    float *rec = stats + (size_t)blockIdx.x * 2 * C + (size_t)g0 * 8;
+#pragma unroll
+    for (int t = 0; t < PEB_MAX_GPW; ++t)
+        if (t < ng) {
+            if (wid == 0 && l15 == 0 && q < 2) *(float4 *)(rec + t * 8 + 4 * q) = mean[t];
+            const bool ok = rv && q < 2;
+            const float dx = ok ? val[t].x - mean[t].x * inv : 0.f, dy = ok ? val[t].y - mean[t].y * inv : 0.f;
+            const float dz = ok ? val[t].z - mean[t].z * inv : 0.f, dw = ok ? val[t].w - mean[t].w * inv : 0.f;
+            const float qx = peb_row16_sum(dx * dx), qy = peb_row16_sum(dy * dy), qz = peb_row16_sum(dz * dz), qw = peb_row16_sum(dw * dw);
+            if (l15 == 0 && q < 2) *(float4 *)(sS + wid * ncol + t * 8 + 4 * q) = make_float4(qx, qy, qz, qw);
+        }
+    __syncthreads();
+    if (wid == 0 && l15 == 0 && q < 2) {
+#pragma unroll
+        for (int t = 0; t < PEB_MAX_GPW; ++t)
+            if (t < ng) {
+                float4 a = *(const float4 *)(sS + t * 8 + 4 * q);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const float4 o = *(const float4 *)(sS + w * ncol + t * 8 + 4 * q);
+                    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                }
+                *(float4 *)(rec + C + t * 8 + 4 * q) = a;
+            }
+    }
+}
+
 // gA[n,g,c'] = sum_i gO[n, g*I+i] * Wp2[g*I+i, c'] ;  g_sw[n,g] = sum_i gO[n, g*I+i] * bp2[g*I+i]
 // A thread owns one (group, float4 of c') for all of its points -- the launcher makes the thread count a multiple of
 // g * c / 4 -- so its I rows of Wp2 stay in registers; re-reading them per output (8 x the bytes written, from L2) held
@@ -173,10 +320,49 @@ using namespace gva;
         default: return PTV2_ERR_ARG;  \
     }
 
+// internal (gva_block.hip): stats != NULL asks for the per-64-row-block column statistics of `out` (bn_tiles_floats(n, c)
+// floats; see peb_fwd_mfma_kernel); *stats_done tells whether this call produced them (the matrix-core form only)
+int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,
+                          const float *out_v, float *out, float *stats, int *stats_done, void *stream);
+
 extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const float *Wp2, const float *bp2,
                                             const float *sw, const float *out_v, float *out, void *stream) {
+    return gva_peb_forward_stats(n, c, g, A, Wp2, bp2, sw, out_v, out, nullptr, nullptr, stream);
+}
+
+template <int C>
+static void launch_peb_mfma(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
+                            float *out, float *stats, hipStream_t st) {
+    const int nrb = (n + 63) / 64;
+    // groups per workgroup: as many as keep >= ~512 workgroups in the launch (each stages its Wp2 rows once), at most 6
+    int gpw = PEB_MAX_GPW;
+    while (gpw > 1 && (long long)nrb * ((g + gpw - 1) / gpw) < 512) --gpw;
+    const size_t lds = sizeof(float) * ((size_t)gpw * 8 * (C + 4) + 4 * gpw * 8);
+    auto kern = peb_fwd_mfma_kernel<C>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nrb, (g + gpw - 1) / gpw), dim3(TPB), lds, st, n, g, gpw, A, Wp2, bp2, sw, out_v, out, stats);
+}
+
+int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,
+                          const float *out_v, float *out, float *stats, int *stats_done, void *stream) {
     if (n < 0 || c < 4 || g < 1 || c % g != 0 || c % 4 != 0) return PTV2_ERR_ARG;
+    if (stats_done) *stats_done = 0;
     if (n == 0) return PTV2_OK;
+    const char *form = getenv("AO_AMD_PEB");  // "flat": the one-lane-per-output kernel (A/B switch of the tests)
+    if (c / g == 8 && (c == 48 || c == 96 || c == 192 || c == 384 || c == 512) && !(form && form[0] == 'f')) {
+        hipStream_t st = (hipStream_t)stream;
+        PtvScopedTimer t(KID_PEB_FWD, st, 4.0 * ((double)n * g * c + 2.0 * n * c + (double)n * g + (double)c * c));
+        switch (c) {
+            case 48: launch_peb_mfma<48>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 96: launch_peb_mfma<96>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 192: launch_peb_mfma<192>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 384: launch_peb_mfma<384>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            default: launch_peb_mfma<512>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        }
+        if (stats && stats_done) *stats_done = 1;
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     // output channels per workgroup.  Wide C: 32 (not 64) -- the 64-channel stage of Wp2 rows is 99 KB of LDS at C = 384,
     // one workgroup per CU and the kernel parked on its A-row loads; 32 channels leave room for three (58 -> 37 us at
     // C = 384, 34 -> 21 us at C = 512, unchanged at C = 192)

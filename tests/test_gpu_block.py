@@ -380,3 +380,34 @@ def test_plan_follows_rehomed_parameters_and_buffers():
         y3 = blk([coord, feat, off], idx)[1].clone()
         twin.load_state_dict(copy.deepcopy(blk.state_dict()))
         assert not torch.allclose(y3, y2) and torch.allclose(twin([coord, feat, off], idx)[1], y3, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,c,g", [(3000, 96, 12), (4501, 192, 24), (1074, 384, 48)])
+def test_fused_logits_backward_equals_the_staged_kernels(monkeypatch, n, c, g):
+    """gva_bwd_logits.hip (round 3): rows + parameter gradients of the logits stage in one pipelined MFMA launch, against the
+    three staged kernels of gva_bwd.hip (AO_AMD_LOGITS_BWD=staged) inside the same native Block.  The row gradient gWt is
+    the same fused multiply-add in both, so everything downstream of it -- the input gradient, the q / k projections -- is
+    bit-identical; the parameter gradients of the stage (grad M -> linear_p_bias / weight_encoding, BN_p, grad cW) differ in
+    summation order only.  Includes clouds shorter than K (masked -1 slots)."""
+    from ao_amd import pointops, synth
+
+    k = 16
+    sizes = [n - 30, 9, 21]
+    coord = torch.from_numpy(np.concatenate([synth.room_cloud(max(m, 64), seed=40 + i)[:m] for i, m in enumerate(sizes)])).cuda()
+    offset = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(k, coord, offset)
+    torch.manual_seed(3)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    go = torch.randn(n, c, device="cuda")
+    blk, _ = _block_pair(c, g, 0.0, seed=21)
+    blk.train()
+    res = {}
+    for mode in ("fused", "staged"):
+        monkeypatch.setenv("AO_AMD_LOGITS_BWD", mode)
+        x = x0.clone().requires_grad_(True)
+        y = blk([coord, x, offset], idx)[1]
+        res[mode] = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+    names = ["x"] + [nm for nm, _ in blk.named_parameters()]
+    assert torch.equal(res["fused"][0], res["staged"][0])  # the chain through gWt is the same arithmetic
+    for nm, a, b in zip(names, res["fused"], res["staged"]):
+        assert rel(a, b) < 2e-5 or float((a - b).abs().max()) < 2e-6, (nm, rel(a, b), float((a - b).abs().max()))
