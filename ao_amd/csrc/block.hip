@@ -194,6 +194,9 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
 }
 
 int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream);
+int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
+                            float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream);
 int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
                             void *stream);
 
@@ -265,9 +268,19 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
         float *ys[1] = {S.h3}, *sts[1] = {st_h3};
         RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, S.bsc[5], S.bsh[5], sts, stream));
     }
-    RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
-    RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
-                                       B->y, stream));
+    // norm3 + tail: at the deep levels the apply kernel merges the tile records itself (one launch instead of two)
+    int tail_done = 0;
+    if (st_h3) {
+        const bool track = B->training && B->run_mean[6] && B->run_var[6];
+        tail_done = bn_tiles_apply_residual(n, c, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S.mean[6], S.rstd[6], S.bsc[6], S.bsh[6],
+                                            track ? B->run_mean[6] : nullptr, track ? B->run_var[6] : nullptr,
+                                            track ? B->batches[6] : nullptr, B->eps, B->momentum, S.h3, B->x, B->rowscale, B->y, stream);
+    }
+    if (!tail_done) {
+        RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
+        RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
+                                           B->y, stream));
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -164,6 +164,25 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, Bn
             sq += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
         };
         int k = sl;
+        // eight records (16 loads) in flight per trip, added in the order of the two-chain loop below (same bits): at the full
+        // resolution (1 875 records, 3-6 workgroups) that loop was 15 dependent trips, 12.5 us on the critical path of every
+        // BatchNorm of a level-0 Block
+        for (; k + 7 * SLICES < nrb; k += 8 * SLICES) {
+            float s[8], m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s[u] = part[(size_t)(k + u * SLICES) * 2 * c + ch];
+                m[u] = part[(size_t)(k + u * SLICES) * 2 * c + c + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + u * SLICES;
+                const int cnt = (n - kk * 64) < 64 ? (n - kk * 64) : 64;
+                const double sb = (double)s[u];
+                if (u & 1) { a2 += sb; b2 += (double)m[u] + sb * sb / (double)cnt; }
+                else { a += sb; b += (double)m[u] + sb * sb / (double)cnt; }
+            }
+        }
         for (; k + SLICES < nrb; k += 2 * SLICES) {  // two independent chains: the loads of both records are in flight
             rec(k, a, b);
             rec(k + SLICES, a2, b2);
@@ -392,6 +411,200 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int
     }
 }
 
+constexpr int FA_COLS = 32, FA_ROWS = 128;  // consumer-side record sums: stripe width (columns), rows per workgroup
+
+// ------------------------------- BN forward tail: tile-record merge + residual apply in one launch --
+// The Block tail y = ReLU(x + rowscale * BN3(h3)) at the deep levels: the workgroups of the apply kernel (64-column stripe x
+// 128 rows) merge the stripe's tile records of the producing GEMM themselves (parallel-variance identity in float64, as
+// bn_finalize_tiles_kernel) instead of waiting for a finalize launch; the row-chunk-0 workgroups deliver mean / rstd /
+// folded affine / running statistics for the backward and the optimizer.
+template <int DUMMY>
+__global__ __launch_bounds__(TPB) void bn_tiles_apply_residual_kernel(BnTileSet S, int nrb, int n, int c, float eps, float momentum,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ residual,
+                                                                      const float *__restrict__ rowscale, float *__restrict__ y) {
+    constexpr int SL = TPB / FA_COLS;  // record slices
+    __shared__ double s_a[SL][FA_COLS], s_b[SL][FA_COLS];
+    __shared__ __attribute__((aligned(16))) float s_mean[FA_COLS], s_rstd[FA_COLS];
+    const int col0 = blockIdx.x * FA_COLS;
+    const int ncol = (c - col0) < FA_COLS ? (c - col0) : FA_COLS;
+    {
+        const int cj = threadIdx.x & (FA_COLS - 1), sl = threadIdx.x / FA_COLS;
+        double a = 0.0, b = 0.0;
+        if (cj < ncol) {
+            const float *p = S.part + col0 + cj;
+            int k = sl;
+            for (; k + 3 * SL < nrb; k += 4 * SL) {  // four records (eight loads) of this slice in flight
+                float sv[4], mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { sv[u] = p[(size_t)(k + u * SL) * 2 * c]; mv[u] = p[(size_t)(k + u * SL) * 2 * c + c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = k + u * SL;
+                    const int cnt = (n - kk * 64) < 64 ? (n - kk * 64) : 64;
+                    const double sb = (double)sv[u];
+                    a += sb;
+                    b += (double)mv[u] + sb * sb / (double)cnt;
+                }
+            }
+            for (; k < nrb; k += SL) {
+                const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+                const double sb = (double)p[(size_t)k * 2 * c];
+                a += sb;
+                b += (double)p[(size_t)k * 2 * c + c] + sb * sb / (double)cnt;
+            }
+        }
+        s_a[sl][cj] = a;
+        s_b[sl][cj] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < FA_COLS) {
+        const int cj = threadIdx.x;
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) { t1 += s_a[t][cj]; t2 += s_b[t][cj]; }
+        const double m = t1 / n;
+        double var = t2 / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        s_mean[cj] = (float)m;
+        s_rstd[cj] = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.y == 0 && cj < ncol) bn_tiles_emit(S, col0 + cj, t1, t2, n, eps, momentum);
+    }
+    __syncthreads();
+    constexpr int QW = FA_COLS / 4, RL = TPB / QW;  // column quads of the stripe x row lanes
+    const int cq = c >> 2, q = threadIdx.x % QW, rl = threadIdx.x / QW;
+    const int qcol = (col0 >> 2) + q;
+    if (4 * q >= ncol) return;
+    const float4 m = *(const float4 *)(s_mean + 4 * q), r = *(const float4 *)(s_rstd + 4 * q);
+    const float4 g = ((const float4 *)S.gamma)[qcol], b = ((const float4 *)S.beta)[qcol];
+    const long long r0 = (long long)blockIdx.y * FA_ROWS;
+    const long long r1 = (r0 + FA_ROWS) < (long long)n ? (r0 + FA_ROWS) : (long long)n;
+    for (long long row = r0 + rl; row < r1; row += RL) {
+        const long long e = row * cq + qcol;
+        const float rsc = rowscale ? rowscale[row] : 1.f;
+        const float4 v = ((const float4 *)x)[e], res = ((const float4 *)residual)[e];
+        float4 o;
+        o.x = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.x - m.x) * r.x, g.x, b.x), res.x), 0.f);
+        o.y = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.y - m.y) * r.y, g.y, b.y), res.y), 0.f);
+        o.z = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.z - m.z) * r.z, g.z, b.z), res.z), 0.f);
+        o.w = fmaxf(__builtin_fmaf(rsc, __builtin_fmaf((v.w - m.w) * r.w, g.w, b.w), res.w), 0.f);
+        ((float4 *)y)[e] = o;
+    }
+}
+
+// ---------------------------------------- BN backward: finalize + apply in one launch --
+// Deep levels (n <= ~8 k rows: a few dozen reduce records).  The BatchNorm backward was reduce -> finalize -> apply, the
+// last two 5 us launches each of which is almost all launch boundary.  Here the apply kernel's workgroups own a 64-column
+// stripe x a chunk of rows and first sum the stripe's 2 x 64 record columns themselves (nrec records of the reduce pass or
+// of the producing GEMM's epilogue; <= 256 records x 128 columns = 128 KB of L2 reads per workgroup, a ~2 us prologue that
+// every workgroup runs concurrently), then apply.  The row-chunk-0 workgroups also deliver dbeta / dgamma.  Column sums:
+// thread (column, slice of 2) walks its records in float64, slices combined in slice order -- fixed association, bitwise
+// reproducible.  blockIdx.z selects one of two independent BatchNorms of the same shape (linear_q / linear_k).
+struct BnFinApply {
+    const float *part; int nrec, rec_floats, off;   // record r, set columns: part[r * rec_floats + off + (0..c-1: dbeta, c..2c-1: dgamma)]
+    const float *x, *gy, *mean, *rstd, *gamma, *beta;
+    float *gx, *dbeta, *dgamma;
+    // residual tail (bn_backward_residual): the ReLU mask comes from y > 0, d * rowscale enters the BatchNorm, d itself is
+    // the residual gradient
+    const float *y, *rowscale;
+    float *g_residual;
+};
+
+template <bool RESIDUAL>
+__global__ __launch_bounds__(TPB) void bn_bwd_finapply_kernel(int n, int c, int relu, int training, float inv_n, BnFinApply A0,
+                                                              BnFinApply A1) {
+    const BnFinApply &A = blockIdx.z ? A1 : A0;
+    constexpr int SL = TPB / (2 * FA_COLS);  // record slices
+    __shared__ double s_part[SL][2 * FA_COLS];
+    __shared__ __attribute__((aligned(16))) float s_db[FA_COLS], s_dg[FA_COLS];
+    const int col0 = blockIdx.x * FA_COLS;
+    const int ncol = (c - col0) < FA_COLS ? (c - col0) : FA_COLS;
+    {   // column sums of this stripe: thread -> (record column j of 2 * FA_COLS, slice sl of SL)
+        const int j = threadIdx.x & (2 * FA_COLS - 1), sl = threadIdx.x / (2 * FA_COLS);
+        const int which = j / FA_COLS, cj = j - which * FA_COLS;  // 0: dbeta, 1: dgamma
+        double acc = 0.0;
+        if (cj < ncol) {
+            const float *p = A.part + A.off + (size_t)which * c + col0 + cj;
+            const size_t rs = (size_t)A.rec_floats;
+            int r = sl;
+            for (; r + 7 * SL < A.nrec; r += 8 * SL) {  // eight records of this slice in flight (one chain: fixed order)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * SL) * rs];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (double)v[u];
+            }
+            for (; r < A.nrec; r += SL) acc += (double)p[(size_t)r * rs];
+        }
+        s_part[sl][j] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * FA_COLS) {
+        const int j = threadIdx.x, which = j / FA_COLS, cj = j - which * FA_COLS;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < SL; ++u) t += s_part[u][j];
+        const float v = (float)t;
+        (which ? s_dg : s_db)[cj] = v;
+        if (blockIdx.y == 0 && cj < ncol) (which ? A.dgamma : A.dbeta)[col0 + cj] = v;
+    }
+    __syncthreads();
+    constexpr int QW = FA_COLS / 4, RL = TPB / QW;  // column quads of the stripe x row lanes
+    const int cq = c >> 2, q = threadIdx.x % QW, rl = threadIdx.x / QW;
+    const int qcol = (col0 >> 2) + q;
+    if (4 * q >= ncol) return;
+    const float4 m = ((const float4 *)A.mean)[qcol], rs = ((const float4 *)A.rstd)[qcol], g = ((const float4 *)A.gamma)[qcol];
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!RESIDUAL && relu) b = ((const float4 *)A.beta)[qcol];
+    const float4 db = *(const float4 *)(s_db + 4 * q), dg = *(const float4 *)(s_dg + 4 * q);
+    const long long r0 = (long long)blockIdx.y * FA_ROWS;
+    const long long r1 = (r0 + FA_ROWS) < (long long)n ? (r0 + FA_ROWS) : (long long)n;
+    for (long long row = r0 + rl; row < r1; row += RL) {
+        const long long e = row * cq + qcol;
+        const float4 v = ((const float4 *)A.x)[e];
+        float4 d = ((const float4 *)A.gy)[e];
+        float4 h;
+        h.x = (v.x - m.x) * rs.x; h.y = (v.y - m.y) * rs.y; h.z = (v.z - m.z) * rs.z; h.w = (v.w - m.w) * rs.w;
+        if (RESIDUAL) {
+            const float4 o = ((const float4 *)A.y)[e];
+            const float rsc = A.rowscale ? A.rowscale[row] : 1.f;
+            d.x = o.x > 0.f ? d.x : 0.f; d.y = o.y > 0.f ? d.y : 0.f; d.z = o.z > 0.f ? d.z : 0.f; d.w = o.w > 0.f ? d.w : 0.f;
+            ((float4 *)A.g_residual)[e] = d;
+            d.x *= rsc; d.y *= rsc; d.z *= rsc; d.w *= rsc;
+        } else if (relu) {
+            if (__builtin_fmaf(h.x, g.x, b.x) <= 0.f) d.x = 0.f;
+            if (__builtin_fmaf(h.y, g.y, b.y) <= 0.f) d.y = 0.f;
+            if (__builtin_fmaf(h.z, g.z, b.z) <= 0.f) d.z = 0.f;
+            if (__builtin_fmaf(h.w, g.w, b.w) <= 0.f) d.w = 0.f;
+        }
+        float4 o;
+        if (training) {
+            o.x = g.x * rs.x * (d.x - db.x * inv_n - h.x * dg.x * inv_n);
+            o.y = g.y * rs.y * (d.y - db.y * inv_n - h.y * dg.y * inv_n);
+            o.z = g.z * rs.z * (d.z - db.z * inv_n - h.z * dg.z * inv_n);
+            o.w = g.w * rs.w * (d.w - db.w * inv_n - h.w * dg.w * inv_n);
+        } else {
+            o.x = g.x * rs.x * d.x; o.y = g.y * rs.y * d.y; o.z = g.z * rs.z * d.z; o.w = g.w * rs.w * d.w;
+        }
+        ((float4 *)A.gx)[e] = o;
+    }
+}
+
+// records few enough for the consumer-side sum (and the A/B switch of the tests: AO_AMD_BN_FINAPPLY=0)
+static bool finapply_ok(int n, int nrec) {
+    const char *e = getenv("AO_AMD_BN_FINAPPLY");
+    return nrec <= 256 && n <= 16384 && !(e && e[0] == '0');
+}
+
+static void launch_finapply(hipStream_t st, int n, int c, int relu, int training, bool residual, int sets, const BnFinApply &A0,
+                            const BnFinApply &A1) {
+    const dim3 grid((unsigned)((c + FA_COLS - 1) / FA_COLS), (unsigned)((n + FA_ROWS - 1) / FA_ROWS), (unsigned)sets);
+    if (residual)
+        hipLaunchKernelGGL(bn_bwd_finapply_kernel<true>, grid, dim3(TPB), 0, st, n, c, relu, training, 1.0f / (float)n, A0, A1);
+    else
+        hipLaunchKernelGGL(bn_bwd_finapply_kernel<false>, grid, dim3(TPB), 0, st, n, c, relu, training, 1.0f / (float)n, A0, A1);
+}
+
 // --------------------------------------------------------------- Linear wgrad --
 // dW[b][o][i] = sum_n gY[n*ldy + b*sy + o] * X[n*ldx + b*sx + i];  db[b][o] = sum_n gY[...]   (b < batch)
 // fp32 MFMA 16x16x4 (exact f32 FMA chain): the reduction index n is the MFMA k; both operand fragments are
@@ -434,6 +647,9 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 #pragma unroll
         for (int t = 0; t < WG_MT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // (measured and rejected, round 3: columns 3 lc + m per lane so that a lane's three operand values of a k-step are ONE
+    // 12-byte load and a row is read as 192 contiguous bytes -- 16 instead of 48 vector-memory instructions per trip: slower at
+    // every shape, 34 -> 38 us at 4.5 k x 192 x 5 products, 58 -> 71 us at 120 k x 48 x 5; three 64-byte segments stay)
     bool mo[WG_MT], mi[WG_MT];
     const float *xs = multi.count ? multi.xsc[bz] : nullptr, *xh = multi.count ? multi.xsh[bz] : nullptr;
     float xsc_[WG_MT], xsh_[WG_MT];
@@ -667,7 +883,8 @@ static int wg_chunk(int n, int tiles) {
 static int bn_grid(int n, int c) {
     const int rl = std::max(1, TPB / (c >> 2));
     long long b = ((long long)n + rl * 4 - 1) / (rl * 4);  // (8 rows per lane: the same; 16: +0.1 ms per step)
-    return (int)std::max<long long>(1, std::min<long long>(b, MAX_BLK));
+    // deep levels: at most 128 records, which the apply kernel's workgroups then sum themselves (bn_bwd_finapply_kernel)
+    return (int)std::max<long long>(1, std::min<long long>(b, n <= 16384 ? 128 : MAX_BLK));
 }
 
 // statistics pass + finalize; gamma / beta / sc / sh != NULL additionally emit the folded affine
@@ -810,6 +1027,24 @@ int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const 
     return bn_tiles_finalize_sets(n, c, 2, S, eps, momentum, stream);
 }
 
+// internal (block.hip): BatchNorm statistics from the producing GEMM's tile records AND the Block tail
+// y = ReLU(residual + rowscale * BN(x)) in one launch when the records are few (deep levels); returns 0 when it declines
+int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
+                            float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream) {
+    const int nrb = (n + 63) / 64;
+    const char *e = getenv("AO_AMD_BN_FINAPPLY");
+    if (nrb > 256 || c % 4 != 0 || (e && e[0] == '0')) return 0;
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr};
+    const dim3 grid((unsigned)((c + FA_COLS - 1) / FA_COLS), (unsigned)((n + FA_ROWS - 1) / FA_ROWS));
+    {
+        PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 12.0 * n * c);
+        hipLaunchKernelGGL(bn_tiles_apply_residual_kernel<0>, grid, dim3(TPB), 0, (hipStream_t)stream, S, nrb, n, c, eps, momentum, x,
+                           residual, rowscale, y);
+    }
+    return 1;
+}
+
 extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
                                      const float *gamma, const float *beta, int relu, float *y, void *stream) {
     if (n < 0 || c < 4 || c % 4 != 0) return PTV2_ERR_ARG;
@@ -870,6 +1105,13 @@ extern "C" int bn_backward_residual_hip_launcher(int n, int c, const float *x, c
         hipLaunchKernelGGL(bn_bwd_reduce_residual_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, y,
                            rowscale, mean, rstd, part);
     }
+    if (finapply_ok(n, nblk)) {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 20.0 * n * c);
+        const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, nullptr, gx, dbeta, dgamma, y, rowscale, g_residual};
+        launch_finapply(st, n, c, 1, training, true, 1, A, A);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
@@ -896,6 +1138,13 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean,
                            rstd, gamma, beta, relu, part, BnSecond{});
     }
+    if (finapply_ok(n, nblk)) {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, beta, gx, dbeta, dgamma, nullptr, nullptr, nullptr};
+        launch_finapply(st, n, c, relu, training, false, 1, A, A);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
@@ -916,6 +1165,13 @@ extern "C" int bn_backward_records_hip_launcher(int n, int c, const float *x, co
                                                 int nrec, void *stream) {
     if (n < 1 || c < 4 || c % 4 != 0 || c > 1024 || !records || nrec < 1) return PTV2_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (finapply_ok(n, nrec)) {
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        const BnFinApply A{records, nrec, 2 * c, 0, x, gy, mean, rstd, gamma, beta, gx, dbeta, dgamma, nullptr, nullptr, nullptr};
+        launch_finapply(st, n, c, relu, training, false, 1, A, A);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     launch_finalize(st, records, nrec, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
@@ -955,6 +1211,16 @@ extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 16.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, 2), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x[0], gy[0], mean[0],
                            rstd[0], gamma[0], beta[0], relu, part, sec);
+    }
+    if (finapply_ok(n, nblk)) {  // record of a block: [set 0: dbeta c | dgamma c][set 1: ...]
+        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 24.0 * n * c);
+        const BnFinApply A0{part, nblk, 4 * c, 0, x[0], gy[0], mean[0], rstd[0], gamma[0], beta[0], gx[0], dbeta[0], dgamma[0], nullptr,
+                            nullptr, nullptr};
+        const BnFinApply A1{part, nblk, 4 * c, 2 * c, x[1], gy[1], mean[1], rstd[1], gamma[1], beta[1], gx[1], dbeta[1], dgamma[1],
+                            nullptr, nullptr, nullptr};
+        launch_finapply(st, n, c, relu, training, false, 2, A0, A1);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
     }
     launch_finalize(st, (const float *)part, nblk, 4 * c, MapBnPair{dbeta[0], dgamma[0], dbeta[1], dgamma[1], c});
     const long long total4 = (long long)n * (c >> 2);

@@ -107,21 +107,29 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         return;
     }
     if ((int)blockIdx.x < wblocks) {  // wide: one thread per gWw1 output, g fastest
+        // 16 independent chains per thread, all 32 loads of a trip in flight: with 4 chains the loop was c / 4 dependent L2
+        // round trips (28 us at C = 384 for 14 MFLOP, profiles/r02_final_step_sequence.txt)
         const long long o = (long long)blockIdx.x * TPB + threadIdx.x;
         if (o < n1) {
             const int ci = (int)(o / g), gi = (int)(o - (long long)ci * g);
             const float *wrow = Wp2 + (size_t)ci * c;  // shared by the g threads of this ci (broadcast)
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            float acc[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
             int cp = 0;
-            for (; cp + 3 < c; cp += 4) {
-                a0 = __builtin_fmaf(gM[(size_t)cp * g + gi], wrow[cp], a0);
-                a1 = __builtin_fmaf(gM[(size_t)(cp + 1) * g + gi], wrow[cp + 1], a1);
-                a2 = __builtin_fmaf(gM[(size_t)(cp + 2) * g + gi], wrow[cp + 2], a2);
-                a3 = __builtin_fmaf(gM[(size_t)(cp + 3) * g + gi], wrow[cp + 3], a3);
+            for (; cp + 15 < c; cp += 16) {
+                float m[16], w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { m[u] = gM[(size_t)(cp + u) * g + gi]; w[u] = wrow[cp + u]; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u] = __builtin_fmaf(m[u], w[u], acc[u]);
             }
-            for (; cp < c; ++cp) a0 = __builtin_fmaf(gM[(size_t)cp * g + gi], wrow[cp], a0);
+            for (; cp < c; ++cp) acc[0] = __builtin_fmaf(gM[(size_t)cp * g + gi], wrow[cp], acc[0]);
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t += acc[u];
             const size_t oo = (size_t)gi * c + ci;
-            gWw1[oo] = ((a0 + a1) + (a2 + a3)) + gcW[gi] * bp2[ci] + gWw1_k[oo] + gWw1_q[oo];
+            gWw1[oo] = t + gcW[gi] * bp2[ci] + gWw1_k[oo] + gWw1_q[oo];
         }
         return;
     }
@@ -131,9 +139,17 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         const long long r = e - n1;
         const int cp = (int)(r / c), ci = (int)(r - (long long)cp * c);  // ci fastest: Ww1 rows coalesced, gM row broadcast
         const float *mrow = gM + (size_t)cp * g;
-        float acc = 0.f;
-        for (int gi = 0; gi < g; ++gi) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], mrow[gi], acc);
-        gWp2[(size_t)ci * c + cp] += acc;
+        const float prev = gWp2[(size_t)ci * c + cp];  // (requested before the loop, not behind it)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // g is a multiple of 2; four chains keep the loads of a trip in flight
+        int gi = 0;
+        for (; gi + 3 < g; gi += 4) {
+            a0 = __builtin_fmaf(Ww1[(size_t)gi * c + ci], mrow[gi], a0);
+            a1 = __builtin_fmaf(Ww1[(size_t)(gi + 1) * c + ci], mrow[gi + 1], a1);
+            a2 = __builtin_fmaf(Ww1[(size_t)(gi + 2) * c + ci], mrow[gi + 2], a2);
+            a3 = __builtin_fmaf(Ww1[(size_t)(gi + 3) * c + ci], mrow[gi + 3], a3);
+        }
+        for (; gi < g; ++gi) a0 = __builtin_fmaf(Ww1[(size_t)gi * c + ci], mrow[gi], a0);
+        gWp2[(size_t)ci * c + cp] = prev + ((a0 + a1) + (a2 + a3));
     } else if (e < n1 + n2 + c) {
         const int ci = (int)(e - n1 - n2);
         float acc = gbp2[ci];

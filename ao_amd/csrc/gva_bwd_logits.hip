@@ -346,3 +346,226 @@ int gva_logits_bwd_fused_launch(int n, int k, int c, int g, const float *a, cons
 #undef ARGS
     return PTV2_ERR_ARG;
 }
+
+// ============================================================================ forward ==
+// W1 (s,g) = P (s,ch) M (ch,g) + kW[idx_s] - qW + cW per point on the matrix cores, plus the column sums T1, T2 that BN_w
+// needs -- the pipelined form of attention_logits_point_kernel (gva_bwd_point.hip), used from G = 12 up.
+// Round 2's forms at the deep levels: a flat one-lane-per-slot kernel (G = 12, 24: every workgroup of 64 rows staged the
+// whole C x G matrix M in LDS first, 24 MB of L2 reads at 4.5 k points, then ran 1 344 vector instructions per wavefront:
+// 41 us) and the point kernel (G = 48: its M fragments were requested inside the reduction loop, four steps ahead:
+// 24 dependent L2 round trips per point, 44 us for 1 074 points).
+// Here the M fragments of a wavefront's channels live in registers for the whole launch, a wavefront walks its points with
+// the next point's neighbour coordinates (ids two points ahead) and the current point's kW rows / qW row in flight behind
+// the products, and nothing in the loop synchronises more than the NW wavefronts that share a point.
+namespace gva {
+
+template <int G, int C, int NW>
+__global__ __launch_bounds__(256) void logits_fwd_mfma_kernel(int n, int k, const float *__restrict__ kW,
+                                                              const float *__restrict__ qW, const float *__restrict__ a,
+                                                              const float *__restrict__ b, const float *__restrict__ M,
+                                                              const float *__restrict__ cW, const float *__restrict__ coord,
+                                                              const int *__restrict__ idx, float *__restrict__ W1, float *part,
+                                                              unsigned *counter, double *__restrict__ T1,
+                                                              double *__restrict__ T2, FoldWFwdArgs F) {
+    constexpr int GT = (G + 15) / 16, G16 = GT * 16, PW = 4 / NW, CW = C / NW, KS = CW / 4;
+    constexpr int FT = (GT + NW - 1) / NW;  // g tiles a wavefront finishes (tile tg belongs to wavefront tg % NW of the point)
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;                                  // [C]
+    float4 *sPos = sAB + C;                              // [4 waves][2][16]
+    int *sSrc = (int *)(sPos + 4 * 2 * 16);              // [4 waves][2][16]
+    float *sRed = (float *)(sSrc + 4 * 2 * 16);          // [PW][NW][GT][4][64]   (NW > 1 only)
+    __shared__ float s_w[4][2 * G16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int p = wid / NW, sub = wid % NW;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int c0 = sub * CW;
+    for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    // B operand: M[ch = c0 + 4 ks + q][g = 16 tg + l15], this wavefront's channels, resident
+    float mreg[KS][GT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) {
+            const int g = 16 * tg + l15;
+            mreg[ks][tg] = g < G ? M[(size_t)(c0 + 4 * ks + q) * G + g] : 0.f;
+        }
+    float t1[FT], t2[FT], cw[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const int g = 16 * (f * NW + sub) + l15;
+        t1[f] = t2[f] = 0.f;
+        cw[f] = (f * NW + sub < GT && g < G) ? cW[g] : 0.f;
+    }
+    __syncthreads();
+
+    const long long stride = (long long)gridDim.x * PW;
+    float4 *myPos = sPos + wid * 32;
+    int *mySrc = sSrc + wid * 32;
+    auto load_idx = [&](long long pt) -> int { return (pt < n && lane < 16 && lane < k) ? idx[pt * k + lane] : -1; };
+    auto load_rel = [&](long long pt, int src) -> float4 {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pt < n && lane < 16 && src >= 0) {
+            r.x = coord[3 * (long long)src] - coord[3 * pt];
+            r.y = coord[3 * (long long)src + 1] - coord[3 * pt + 1];
+            r.z = coord[3 * (long long)src + 2] - coord[3 * pt + 2];
+        }
+        return r;
+    };
+    const long long pt0 = (long long)blockIdx.x * PW + p;
+    int idx_n = load_idx(pt0 + stride);
+    {
+        const int i0 = load_idx(pt0);
+        const float4 r0 = load_rel(pt0, i0);
+        if (lane < 16) { myPos[lane] = r0; mySrc[lane] = i0; }
+    }
+    int cur = 0;
+    // (NW > 1: the wavefronts of a point meet at a workgroup barrier, so every wavefront runs the workgroup's trip count)
+    const long long base0 = (long long)blockIdx.x * PW;
+    for (long long base = base0; base < n; base += stride, cur ^= 1) {
+        const long long pt = base + p;
+        const bool act = pt < n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4 myp = myPos[cur * 16 + l15];  // slot l15 of my point: the A operand's row
+        // requests: this point's kW rows and qW row (consumed after the products), the next point's coordinates, ids two ahead
+        float kv[FT][4], qv[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int tg = f * NW + sub, g = 16 * tg + l15;
+            const bool gok = tg < GT && g < G && act;
+            qv[f] = gok ? qW[pt * G + g] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = 4 * q + r;
+                const int src = mySrc[cur * 16 + s];
+                kv[f][r] = (gok && s < k && src >= 0) ? kW[(long long)src * G + g] : 0.f;
+            }
+        }
+        const int src_n = idx_n;
+        const float4 rel_n = load_rel(pt + stride, src_n);
+        idx_n = load_idx(pt + 2 * stride);
+        // products: my channels
+        v4f acc[GT];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg) acc[tg] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float4 ab = sAB[c0 + 4 * ks + q];
+            const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg) acc[tg] = mfma4l(P, mreg[ks][tg], acc[tg]);
+        }
+        if (NW > 1) {  // channel parts -> LDS, the wavefront that owns a g tile adds them up (fixed order)
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sRed[((((size_t)p * NW + sub) * GT + tg) * 4 + r) * 64 + lane] = acc[tg][r];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int tg = f * NW + sub, g = 16 * tg + l15;
+            if (tg < GT) {  // wave-uniform
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (NW > 1) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) t += sRed[((((size_t)p * NW + w) * GT + tg) * 4 + r) * 64 + lane];
+                        v[r] = t;
+                    } else {
+                        float t = 0.f;
+#pragma unroll
+                        for (int tt = 0; tt < GT; ++tt) t = tt == tg ? acc[tt][r] : t;
+                        v[r] = t;
+                    }
+                }
+                if (act && g < G) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int s = 4 * q + r;
+                        if (s < k) {
+                            const float val = v[r] + (kv[f][r] - qv[f]) + cw[f];
+                            W1[(pt * k + s) * G + g] = val;
+                            t1[f] += val;
+                            t2[f] = __builtin_fmaf(val, val, t2[f]);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane < 16) { myPos[(cur ^ 1) * 16 + lane] = rel_n; mySrc[(cur ^ 1) * 16 + lane] = src_n; }
+        if (NW > 1) __syncthreads();  // sRed is rewritten by the next trip
+    }
+    // workgroup record [T1 (G) | T2 (G)]
+    for (int e = tid; e < 4 * 2 * G16; e += 256) (&s_w[0][0])[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        t1[f] += __shfl_xor(t1[f], 16, WAVE); t1[f] += __shfl_xor(t1[f], 32, WAVE);
+        t2[f] += __shfl_xor(t2[f], 16, WAVE); t2[f] += __shfl_xor(t2[f], 32, WAVE);
+        const int tg = f * NW + sub;
+        if (q == 0 && tg < GT) { s_w[wid][16 * tg + l15] = t1[f]; s_w[wid][G16 + 16 * tg + l15] = t2[f]; }
+    }
+    __syncthreads();
+    if (tid < 2 * G) {
+        const int col = tid < G ? tid : G16 + (tid - G);
+        float v = 0.f;
+        for (int wv = 0; wv < 4; ++wv) v += s_w[wv][col];
+        part_store(part + (size_t)blockIdx.x * 2 * G + tid, v);
+    }
+    if (counter && last_block_arrives(counter)) finalize_logit_sums(part, gridDim.x, G, T1, T2, F);
+}
+
+template <int G, int C, int NW>
+int launch_logits_fwd_mfma(int n, int k, const float *kW, const float *qW, const float *a, const float *b, const float *M,
+                           const float *cW, const float *coord, const int *idx, float *W1, float *part, double *T1, double *T2,
+                           const FoldWFwdArgs &F, hipStream_t st) {
+    constexpr int GT = (G + 15) / 16, PW = 4 / NW;
+    const size_t lds = sizeof(float4) * (C + 4 * 2 * 16) + sizeof(int) * 4 * 2 * 16 +
+                       (NW > 1 ? sizeof(float) * (size_t)PW * NW * GT * 4 * 64 : 0);
+    auto kern = logits_fwd_mfma_kernel<G, C, NW>;
+    static int resident = 0;
+    if (!resident) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident = std::max(64, std::min(occ * cus, MAX_BLOCKS));
+    }
+    const long long groups = ((long long)n + PW - 1) / PW;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, resident));
+    const bool own_final = (size_t)nblk * 2 * G <= FUSED_FINAL_MAX;
+    unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
+    if (own_final && !cnt) return PTV2_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, kW, qW, a, b, M, cW, coord, idx, W1, part,
+                       cnt ? cnt + CNT_LOGITS_FWD : nullptr, T1, T2, F);
+    if (!own_final)
+        hipLaunchKernelGGL(finalize_logit_sums_kernel, dim3((G + FLS_GROUPS - 1) / FLS_GROUPS), dim3(1024), 0, st, (const float *)part,
+                           nblk, G, T1, T2, F);
+    return PTV2_OK;
+}
+
+}  // namespace gva
+
+int gva_logits_fwd_mfma_supported(int k, int c, int g) {
+    if (k < 1 || k > 16) return 0;
+    static const bool narrow = [] { const char *e = getenv("AO_AMD_LOGITS_FWD6"); return !(e && e[0] == '0'); }();  // sweep knob
+    if (g == 6 && c == 48) return narrow ? 1 : 0;
+    return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
+}
+
+// part: >= MAX_BLOCKS * 2 g floats
+int gva_logits_fwd_mfma_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                               const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
+                               double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st) {
+    using namespace gva;
+#define ARGS n, k, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st
+    if (g == 6 && c == 48) return launch_logits_fwd_mfma<6, 48, 1>(ARGS);
+    if (g == 12 && c == 96) return launch_logits_fwd_mfma<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return launch_logits_fwd_mfma<24, 192, 1>(ARGS);
+    if (g == 48 && c == 384) return launch_logits_fwd_mfma<48, 384, 4>(ARGS);
+#undef ARGS
+    return PTV2_ERR_ARG;
+}

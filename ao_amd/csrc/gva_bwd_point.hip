@@ -253,7 +253,11 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             point_sync();
         }
         // operands of the first channel chunks of this point, then the requests for the next point
-        const int chq = c0 + q * CS;  // this lane's contiguous channel run: contraction index = (q, step)
+        // contraction index of lane quarter q in chunk ci: channels c0 + 16 ci + 4 q + (0..3).  The four lanes that share a
+        // g_A row / a neighbour's v row read 64 contiguous bytes per instruction; with a contiguous run per lane (chq = c0 +
+        // q CS, round 2) every instruction touched 64 distinct lines and ran at 2.9 TB/s instead of 4.7
+        // (tools/probes/read_pattern_probe.hip)
+        const int chq = c0 + 4 * q;
         const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
         const float *garow[GT];
         bool gaok[GT];
@@ -267,11 +271,11 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : 1;  // chunks in flight (registers: GT >= 2 is at the limit)
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
-            rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 16 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) {
-                if (local) rga[slot][tg] = *(const float4 *)(myGA + (16 * tg + l15) * C + chq + 4 * ci);
-                else rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 4 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (local) rga[slot][tg] = *(const float4 *)(myGA + (16 * tg + l15) * C + chq + 16 * ci);
+                else rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 16 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
 #pragma unroll
@@ -334,11 +338,11 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) ga4[tg] = rga[slot][tg];
             if (ci + PD < NCH) fetch_chunk(ci + PD, slot);
-            const float4 go = *(const float4 *)(cGo + chq + 4 * ci);
+            const float4 go = *(const float4 *)(cGo + chq + 16 * ci);
             const float vve[4] = {vv.x, vv.y, vv.z, vv.w}, goe[4] = {go.x, go.y, go.z, go.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int ch = chq + 4 * ci + e;
+                const int ch = chq + 16 * ci + e;
                 const float4 ab = sAB[ch];
                 const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
                 const int gi = ch / I;
@@ -1029,9 +1033,10 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
     using namespace gva;
     if (!g_A && !(Wp2 && bp2 && gva_bwd_point_local(k, c, g))) return PTV2_ERR_ARG;
 #define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st, Wp2, bp2
+    static const int nw_try = [] { const char *e = getenv("AO_AMD_ABP_NW"); return e ? atoi(e) : 0; }();  // sweep knob
     if (g == 6 && c == 48) return launch_bwd_point<6, 48, 1>(ARGS);
-    if (g == 12 && c == 96) return launch_bwd_point<12, 96, 1>(ARGS);
-    if (g == 24 && c == 192) return launch_bwd_point<24, 192, 2>(ARGS);
+    if (g == 12 && c == 96) return nw_try == 2 ? launch_bwd_point<12, 96, 2>(ARGS) : launch_bwd_point<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return nw_try == 4 ? launch_bwd_point<24, 192, 4>(ARGS) : launch_bwd_point<24, 192, 2>(ARGS);
     if (g == 48 && c == 384) return launch_bwd_point<48, 384, 4>(ARGS);
     if (g == 64 && c == 512) return launch_bwd_point<64, 512, 4>(ARGS);
 #undef ARGS

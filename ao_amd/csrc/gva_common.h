@@ -75,6 +75,15 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const float *__restrict_
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (j < len) {
         int b = sl;
+        // (eight loads in flight per trip, added in the order of the four-chain loop below: the same bits; with many records
+        // -- 1 000-2 000 at the full resolution -- four per trip left the sum a chain of dependent L2 round trips)
+        for (; b + 7 * SLICES < nblk; b += 8 * SLICES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u * SLICES) * len + j];
+            a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+            a0 += (double)v[4]; a1 += (double)v[5]; a2 += (double)v[6]; a3 += (double)v[7];
+        }
         for (; b + 3 * SLICES < nblk; b += 4 * SLICES) {
             a0 += (double)part[(size_t)b * len + j];
             a1 += (double)part[(size_t)(b + SLICES) * len + j];
@@ -216,7 +225,7 @@ inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len
         PtvRider r = RiderOf<Map>::make(map);
         if (r.kind != RIDER_NONE) {
             r.part = part; r.nblk = nblk; r.len = len;
-            r.blocks = nblk <= 32 ? (len + 255) / 256 : (len + 15) / 16;
+            r.blocks = nblk <= 32 ? (len + 255) / 256 : (nblk >= 512 ? (len + 7) / 8 : (len + 15) / 16);  // rider_columns
             ptv2_rider_defer(r, st);
             return;
         }
@@ -358,26 +367,34 @@ __device__ __forceinline__ void rider_columns(const PtvRider &R, int rb, Map map
         map(j, (a0 + a1) + (a2 + a3));
         return;
     }
-    __shared__ double s_rider[16][16];
-    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int j = rb * 16 + col;
+    // 16 columns x 16 record slices, or 8 x 32 from 512 records on (the host side sizes R.blocks accordingly: rider_cols())
+    __shared__ double s_rider[256];
+    const int cols = nblk >= 512 ? 8 : 16, S = 256 / cols;
+    const int col = threadIdx.x & (cols - 1), sl = threadIdx.x / cols;
+    const int j = rb * cols + col;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (j < len) {
         int b = sl;
-        for (; b + 48 < nblk; b += 64) {
-            a0 += (double)part[(size_t)b * len + j];
-            a1 += (double)part[(size_t)(b + 16) * len + j];
-            a2 += (double)part[(size_t)(b + 32) * len + j];
-            a3 += (double)part[(size_t)(b + 48) * len + j];
+        for (; b + 7 * S < nblk; b += 8 * S) {  // eight loads in flight, the four-chain order (see finalize_kernel)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + S * u) * len + j];
+            a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
+            a0 += (double)v[4]; a1 += (double)v[5]; a2 += (double)v[6]; a3 += (double)v[7];
         }
-        for (; b < nblk; b += 16) a0 += (double)part[(size_t)b * len + j];
+        for (; b + 3 * S < nblk; b += 4 * S) {
+            a0 += (double)part[(size_t)b * len + j];
+            a1 += (double)part[(size_t)(b + S) * len + j];
+            a2 += (double)part[(size_t)(b + 2 * S) * len + j];
+            a3 += (double)part[(size_t)(b + 3 * S) * len + j];
+        }
+        for (; b < nblk; b += S) a0 += (double)part[(size_t)b * len + j];
     }
-    s_rider[sl][col] = (a0 + a1) + (a2 + a3);
+    s_rider[sl * cols + col] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (sl == 0 && j < len) {
         double v = 0.0;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v += s_rider[t][col];
+        for (int t = 0; t < S; ++t) v += s_rider[t * cols + col];
         map(j, v);
     }
 }

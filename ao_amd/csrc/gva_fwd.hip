@@ -249,6 +249,10 @@ extern "C" int gva_pos_moments_hip_launcher(int n, int k, const float *coord, co
         default: return PTV2_ERR_ARG;      \
     }
 
+int gva_logits_fwd_mfma_supported(int k, int c, int g);
+int gva_logits_fwd_mfma_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
+                               const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
+                               double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st);
 int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const float *qW, const float *a, const float *b,
                             const float *M, const float *cW, const float *coord, const int *idx, float *W1, float *part,
                             double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st);
@@ -262,6 +266,16 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     const long long rows = (long long)n * k;
+    {
+        const char *lf = getenv("AO_AMD_LOGITS_FWD");  // "staged": round 2's kernels (A/B switch of the tests)
+        if (gva_logits_fwd_mfma_supported(k, c, g) && !(lf && lf[0] == 's') && !getenv("AO_AMD_BWD_STAGED")) {
+            PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
+            const int rc = gva_logits_fwd_mfma_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st);
+            if (rc != PTV2_OK) return rc;
+            PTV2_CHECK_LAUNCH();
+            return PTV2_OK;
+        }
+    }
     if (k <= 16 && c % 4 == 0 && (g == 48 || g == 64) && !getenv("AO_AMD_BWD_STAGED")) {  // pays for wide G only
         PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
         const int rc = gva_logits_point_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st);

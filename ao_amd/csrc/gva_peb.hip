@@ -86,8 +86,8 @@ __global__ __launch_bounds__(TPB) void peb_fwd_kernel(int n, int c, int g, int c
 // Per group the projection is a (points x C') x (C' x 8) product.  One lane per output element (above) makes the 8 lanes of
 // a group read the SAME 16 bytes of an A row per load instruction: a wavefront's request touches 8 rows x 16 B, the kernel
 // is bound by the vector memory pipeline's line lookups (40 us for the 83 MB of A at 4.5 k points, 2 TB/s from cache).
-// Here a wavefront owns 16 points; lane (point l15, quarter q) streams its quarter of the point's A row as float4 (every
-// line consumed whole by one lane), the 8 Wp2 rows of the group come from LDS as the A operand of V_MFMA_F32_16X16X4_F32
+// Here a wavefront owns 16 points; the four lanes (quarters q) of a point stream its A row 64 contiguous bytes per
+// instruction, the 8 Wp2 rows of the group come from LDS as the A operand of V_MFMA_F32_16X16X4_F32
 // (rows 8..15 of the tile are padding), and the result tile leaves 4 consecutive outputs of a point in each lane of q < 2
 // (float4 store).  The next group's A rows are in flight while the current group is on the matrix core.
 // A workgroup = one 64-row block x `gpw` groups; with stats != NULL its epilogue leaves the column statistics of `out` for
@@ -106,16 +106,23 @@ __device__ __forceinline__ float peb_row16_sum(float v) {  // all-reduce over th
     return v;
 }
 
-constexpr int PEB_MAX_GPW = 6;
-template <int C>
-__global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, int gpw, const float *__restrict__ A,
+template <int C, int PEB_MAX_GPW>  // PEB_MAX_GPW: groups per workgroup (compile-time: per-group registers are arrays of it)
+__global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const float *__restrict__ A,
                                                            const float *__restrict__ Wp2, const float *__restrict__ bp2,
                                                            const float *__restrict__ sw, const float *__restrict__ out_v,
                                                            float *__restrict__ out, float *__restrict__ stats) {
-    constexpr int QF = C / 16;                      // float4 per lane and group (a lane owns C / 4 consecutive c')
-    constexpr int CH = QF <= 12 ? QF : QF / 2;      // float4 per lane and chunk (register budget: two chunks resident)
-    constexpr int NCH = QF / CH;                    // chunks per group
+    constexpr int QF = C / 16;                      // float4 per lane and group (a lane owns C / 4 of the c')
+    constexpr int CH = QF <= 6 ? QF : (QF % 6 == 0 ? 6 : 4);  // float4 per lane and item
+    constexpr int NCH = QF / CH;                    // items per group
+    constexpr int ITEMS = PEB_MAX_GPW * NCH;
+    // prefetch distance in items: ~15-18 float4 per lane in flight whatever C is.  One item ahead left 3 float4 (C = 48) to
+    // 12 (C = 192) in flight per lane while every workgroup of the launch -- all co-resident, in lockstep -- sat in the
+    // same phase: the memory system idled through everyone's staging and epilogues (57 us for 138 MB at 120 k points)
+    constexpr int DIST = (CH >= 6 ? 3 : 5) < ITEMS ? (CH >= 6 ? 3 : 5) : (ITEMS > 1 ? ITEMS - 1 : 1);
+    constexpr int RING = DIST + 1;
+    static_assert(QF % CH == 0, "items tile the row");
     constexpr int LDW = C + 4;
+    constexpr int gpw = PEB_MAX_GPW;
     extern __shared__ float4 lds4[];
     float *sW = (float *)lds4;                      // [gpw * 8][C + 4]
     float *sS = sW + (size_t)gpw * 8 * LDW;         // [4 waves][gpw * 8]   (statistics)
@@ -129,47 +136,63 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, int gpw
     }
     const long long pt = row0 + wid * 16 + l15;
     const bool rv = pt < n;
-    const float *arow = A + ((size_t)(rv ? pt : 0) * g + g0) * C + q * (C / 4);
+    // contraction index of lane quarter q in load j: c' = 16 j + 4 q + (0..3) -- the four lanes of a point read 64
+    // contiguous bytes per instruction.  (A lane walking its own quarter of the row, c' = q C/4 + 4 j, touches 64 distinct
+    // 128-byte lines per instruction: 2.9 TB/s against 4.7 TB/s for this form on the same 83 MB,
+    // tools/probes/read_pattern_probe.hip; the one-lane-per-output kernel above has the same 16-byte requests.)
+    const float *arow = A + ((size_t)(rv ? pt : 0) * g + g0) * C + 4 * q;
     auto fetch = [&](int item, float4 (&x)[CH]) {  // item = group * NCH + chunk
         const int gl = item / NCH, ck = item - gl * NCH;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-            x[j] = (rv && gl < ng) ? *(const float4 *)(arow + (size_t)gl * C + 4 * (ck * CH + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[j] = (rv && gl < ng) ? *(const float4 *)(arow + (size_t)gl * C + 16 * (ck * CH + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    float4 xn[CH];
-    fetch(0, xn);
+    float4 x[RING][CH];
+#pragma unroll
+    for (int i = 0; i < DIST && i < ITEMS; ++i) fetch(i, x[i % RING]);
+    // epilogue operands of every group of this workgroup, requested up front
+    float4 ovr[PEB_MAX_GPW];
+    float swr[PEB_MAX_GPW];
+#pragma unroll
+    for (int t = 0; t < PEB_MAX_GPW; ++t) {
+        ovr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        swr[t] = 0.f;
+        if (t < ng && rv && q < 2) {
+            ovr[t] = *(const float4 *)(out_v + (size_t)pt * C + (g0 + t) * 8 + 4 * q);
+            swr[t] = sw[(size_t)pt * g + g0 + t];
+        }
+    }
     __syncthreads();
     float4 val[PEB_MAX_GPW];
-    const int items = ng * NCH;
     v4f_peb acc = (v4f_peb){0.f, 0.f, 0.f, 0.f};
-    for (int item = 0; item < items; ++item) {
-        const int gl = item / NCH, ck = item - gl * NCH;
-        float4 x[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) x[j] = xn[j];
-        if (item + 1 < items) fetch(item + 1, xn);
-        const float *wr = sW + (size_t)(gl * 8 + (l15 & 7)) * LDW + q * (C / 4) + 4 * ck * CH;
+    for (int item = 0; item < ITEMS; ++item) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int gl = item / NCH, ck = item - gl * NCH;
+        if (item + DIST < ITEMS) fetch(item + DIST, x[(item + DIST) % RING]);
+        const float *wr = sW + (size_t)(gl * 8 + (l15 & 7)) * LDW + 4 * q + 16 * ck * CH;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const float4 w4 = *(const float4 *)(wr + 4 * j);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x[j].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x[j].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x[j].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x[j].w, acc, 0, 0, 0);
+            const float4 w4 = *(const float4 *)(wr + 16 * j);
+            const float4 xv = x[item % RING][j];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, xv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, xv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, xv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, xv.w, acc, 0, 0, 0);
         }
         if (ck == NCH - 1) {  // D[i][j]: i = output 4 q + reg (q < 2 valid), j = point l15
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rv && q < 2) {
+            if (rv && q < 2 && gl < ng) {
                 const int col = (g0 + gl) * 8 + 4 * q;
-                const float4 ov = *(const float4 *)(out_v + (size_t)pt * C + col), bb = *(const float4 *)(bp2 + col);
-                const float s = sw[(size_t)pt * g + g0 + gl];
+                const float4 bb = *(const float4 *)(bp2 + col);
+                const float4 ov = ovr[gl];
+                const float s = swr[gl];
                 v.x = ov.x + acc[0] + bb.x * s; v.y = ov.y + acc[1] + bb.y * s;
                 v.z = ov.z + acc[2] + bb.z * s; v.w = ov.w + acc[3] + bb.w * s;
                 *(float4 *)(out + (size_t)pt * C + col) = v;
             }
-#pragma unroll
-            for (int t = 0; t < PEB_MAX_GPW; ++t)
-                if (t == gl) val[t] = v;
+            val[gl] = v;
             acc = (v4f_peb){0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -330,17 +353,31 @@ extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A,
     return gva_peb_forward_stats(n, c, g, A, Wp2, bp2, sw, out_v, out, nullptr, nullptr, stream);
 }
 
+template <int C, int GPW>
+static void launch_peb_mfma_g(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
+                              float *out, float *stats, hipStream_t st) {
+    const int nrb = (n + 63) / 64;
+    const size_t lds = sizeof(float) * ((size_t)GPW * 8 * (C + 4) + 4 * GPW * 8);
+    auto kern = peb_fwd_mfma_kernel<C, GPW>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nrb, (g + GPW - 1) / GPW), dim3(TPB), lds, st, n, g, A, Wp2, bp2, sw, out_v, out, stats);
+}
+
 template <int C>
 static void launch_peb_mfma(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
                             float *out, float *stats, hipStream_t st) {
     const int nrb = (n + 63) / 64;
-    // groups per workgroup: as many as keep >= ~512 workgroups in the launch (each stages its Wp2 rows once), at most 6
-    int gpw = PEB_MAX_GPW;
-    while (gpw > 1 && (long long)nrb * ((g + gpw - 1) / gpw) < 512) --gpw;
-    const size_t lds = sizeof(float) * ((size_t)gpw * 8 * (C + 4) + 4 * gpw * 8);
-    auto kern = peb_fwd_mfma_kernel<C>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(nrb, (g + gpw - 1) / gpw), dim3(TPB), lds, st, n, g, gpw, A, Wp2, bp2, sw, out_v, out, stats);
+    // groups per workgroup: as many (of 6, 3, 2, 1) as keep >= ~512 workgroups in the launch (each stages its Wp2 rows once)
+    const int opts[4] = {6, 3, 2, 1};
+    int gpw = 1;
+    for (int i = 0; i < 4; ++i)
+        if ((long long)nrb * ((g + opts[i] - 1) / opts[i]) >= 512 || opts[i] == 1) { gpw = opts[i]; break; }
+    switch (gpw) {
+        case 6: launch_peb_mfma_g<C, 6>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        case 3: launch_peb_mfma_g<C, 3>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        case 2: launch_peb_mfma_g<C, 2>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        default: launch_peb_mfma_g<C, 1>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+    }
 }
 
 int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,

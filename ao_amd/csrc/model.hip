@@ -204,6 +204,7 @@ Arena carve(const ptv2_model *M, void *base) {
         A.up_skip[i] = linbn(M->up_skip[i], M->level[i].n, true);  // y = the unpool output (skip branch + unpooled rows)
     }
     A.head = linbn(M->head, M->level[0].n, true);
+    size_t shared_saved = 0;  // checkpointing: one region, sized for the largest Block, shared by all of them
     for (int q = 0; q <= 2 * S; ++q) {
         const ptv2_seq &s = M->seq[q];
         const int n = M->level[s.level].n;
@@ -211,8 +212,13 @@ Arena carve(const ptv2_model *M, void *base) {
             const int b = s.first_block + j;
             A.block_y[b] = (float *)take(sizeof(float) * (size_t)n * s.c);
             A.block_saved_bytes[b] = ptv2_block_saved_bytes(n, s.k, s.c, s.g);
-            A.block_saved[b] = take(A.block_saved_bytes[b]);
+            if (M->checkpoint) shared_saved = std::max(shared_saved, A.block_saved_bytes[b]);
+            else A.block_saved[b] = take(A.block_saved_bytes[b]);
         }
+    }
+    if (M->checkpoint) {
+        char *region = take(shared_saved);
+        for (int b = 0; b < M->num_blocks; ++b) A.block_saved[b] = region;
     }
     A.bytes = off;
     return A;
@@ -414,6 +420,15 @@ float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_i
         ptv2_block B;
         const float *x = j == 0 ? x_in : A.block_y[s.first_block + j - 1];
         fill_block(M, q, j, A, x, &B);
+        if (M->checkpoint) {
+            // re-run this Block's forward into the shared region (same kernels, same inputs -> the same activations bit for
+            // bit); the running statistics were updated by the real forward and must not move again
+            ptv2_block R = B;
+            for (int i = 0; i < PTV2_BLK_NBN; ++i)
+                if (M->training) { R.run_mean[i] = nullptr; R.run_var[i] = nullptr; R.batches[i] = nullptr; }
+            *rc = ptv2_block_forward_hip_launcher(&R, W.block, W.block_bytes, stream);
+            if (*rc != PTV2_OK) return nullptr;
+        }
         ptv2_block_grads G{};
         G.gy = gy; G.inv_ptr = s.inv_ptr; G.inv_rows = s.inv_rows; G.gx = other; G.gparam = nullptr;
         for (int i = 0; i < PTV2_BLK_NPARAM; ++i) G.gp[i] = M->block[s.first_block + j].gparam[i];
@@ -453,7 +468,9 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
     int rc = PTV2_OK;
     // the parameter-only folds of every attention block, all at once (they were one 5 us launch on the critical path of
     // each Block)
-    {
+    // (not under checkpointing: the folds live in the Blocks' saved regions, which then are one shared region -- every Block
+    // folds for itself, in its forward and again in its recomputation)
+    if (!M->checkpoint) {
         std::vector<ptv2_block> blocks;
         for (int q = 0; q <= 2 * S; ++q)
             for (int j = 0; j < M->seq[q].depth; ++j) {
@@ -463,7 +480,10 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
             }
         RUN(ptv2_blocks_fold_forward((int)blocks.size(), blocks.data(), stream));
     }
-    struct Prefolded { Prefolded() { ptv2_gva_set_prefolded(1); } ~Prefolded() { ptv2_gva_set_prefolded(0); } } prefolded;
+    struct Prefolded {
+        explicit Prefolded(int on) { ptv2_gva_set_prefolded(on); }
+        ~Prefolded() { ptv2_gva_set_prefolded(0); }
+    } prefolded(M->checkpoint ? 0 : 1);
     RUN(linbn_forward(M, M->embed, A.embed, M->level[0].n, M->feat, A.embed.y, W, stream));
     const float *x = seq_forward(M, 0, A, A.embed.y, W, stream, &rc);
     if (rc != PTV2_OK) return rc;

@@ -129,11 +129,14 @@ class _Plan:
         self.params, self.bns = block_params(blk)
         self.c, self.g = a.embed_channels, a.groups
         b0 = self.bns[0]
-        self.static_ok = (
-            not a.pe_multiplier and a.pe_bias and not blk.enable_checkpoint
+        # static_core: what the whole-model runtime needs of a Block (it implements enable_checkpoint itself,
+        # ptv2_model.checkpoint); static_ok: the per-Block launchers, which leave checkpointing to torch
+        self.static_core = (
+            not a.pe_multiplier and a.pe_bias
             and all(p is None or (p.dtype == torch.float32 and p.is_cuda and p.is_contiguous()) for p in self.params)
             and all(bn.momentum is not None and bn.affine and bn.eps == b0.eps and bn.momentum == b0.momentum
                     and (bn.running_mean is None) == (b0.running_mean is None) for bn in self.bns))
+        self.static_ok = self.static_core and not blk.enable_checkpoint
         self.has_running = b0.running_mean is not None
         self.off = param_layout(self.c, self.g)
         self.slots = [self.off[i + 1] - self.off[i] for i in range(NPARAM)]

@@ -55,7 +55,8 @@ class _Model(ctypes.Structure):  # mirrors ptv2_model
                    ("num_blocks", _I), ("block", _MBlock * MAX_BLOCKS), ("embed", _LinBn), ("down", _LinBn * MAX_STAGES),
                    ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
                 + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
-                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I), ("decoder_done_event", _P)])
+                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I), ("checkpoint", _I),
+                   ("decoder_done_event", _P)])
 
 
 _lib.register({
@@ -169,7 +170,7 @@ class _Runtime:
         self.has_running = b0.running_mean is not None
         self.static_ok = (self.uniform_bn and nb <= MAX_BLOCKS and S <= MAX_STAGES and len(self.grad_fields) == len(self.params)
                           and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in self.params)
-                          and all(_block.plan(blk).static_ok and (blk.attn.attn_drop_rate == 0.0) for blk in self.block_modules)
+                          and all(_block.plan(blk).static_core and (blk.attn.attn_drop_rate == 0.0) for blk in self.block_modules)
                           and all(_gva.supported(blk.attn.embed_channels, blk.attn.groups, seq.neighbours)
                                   for seq in self.sequences for blk in seq.blocks)
                           and isinstance(model.seg_head, torch.nn.Sequential) and M.embed.cout % 4 == 0)
@@ -299,7 +300,7 @@ def supported(model, feat):
     rt = runtime(model)
     if not rt.static_ok or (not model.training and not rt.has_running):
         return False
-    return not any(b.enable_checkpoint for b in rt.block_modules)
+    return True  # (enable_checkpoint is honoured by the native runtime: ptv2_model.checkpoint)
 
 
 def geometry_supported(geo):
@@ -316,6 +317,9 @@ class _NativeModel(torch.autograd.Function):
         M = rt.M
         keep = rt.fill_geometry(geo)
         M.training, M.matmul_bf16 = int(training), int(bf16)
+        # activation checkpointing (reference :169-171: only while training with gradients enabled)
+        M.checkpoint = int(bool(rt.want_checkpoint))  # decided by forward() below (grad mode is off inside this function)
+        ctx.checkpoint = M.checkpoint
         scales = rt.draw_droppath(geo, dev) if training else None
         n0 = feat.shape[0]
         logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
@@ -341,7 +345,7 @@ class _NativeModel(torch.autograd.Function):
         L = _lib.lib()
         M = rt.M
         rt.fill_geometry(ctx.geo)  # the struct is shared between calls: restore this call's tables
-        M.training, M.matmul_bf16 = int(ctx.training), int(ctx.bf16)
+        M.training, M.matmul_bf16, M.checkpoint = int(ctx.training), int(ctx.bf16), int(ctx.checkpoint)
         for mb, rs in zip(M.block[: M.num_blocks], ctx.rowscale_ptrs):
             mb.rowscale = rs
         M.feat, M.logits = feat.data_ptr(), None
@@ -384,6 +388,8 @@ def forward(model, data_dict, geo):
     training = model.training or not rt.has_running
     mode = getattr(model, "native_param_grads", "autograd")
     bf16 = matmul_bf16()
+    # activation checkpointing as the reference applies it (:169-171): only while training with gradients enabled
+    rt.want_checkpoint = bool(training and torch.is_grad_enabled() and any(b.enable_checkpoint for b in rt.block_modules))
     with torch.autocast("cuda", enabled=False):  # activations, statistics, softmax and accumulation stay fp32
         if not torch.is_grad_enabled():
             return _NativeModel.apply(feat.float(), None, rt, geo, training, mode, bf16)

@@ -584,6 +584,11 @@ typedef struct ptv2_model {
     void *side_stream;                 /* backward only, optional: weight gradients run here (see ptv2_block_grads);
                                         * the launcher joins it into `stream` before it returns control of the queue */
     int matmul_bf16;                   /* as ptv2_block.matmul_bf16, for every Linear of the network */
+    int checkpoint;                    /* != 0: activation checkpointing of the Blocks (enable_checkpoint of the reference,
+                                        * point_transformer_v2m2_base.py:169-171): the forward keeps only every Block's
+                                        * output; all Blocks share ONE saved-activation region, and the backward re-runs a
+                                        * Block's forward (without touching the running statistics) right before its
+                                        * backward.  Same results bit for bit, ptv2_model_saved_bytes() shrinks. */
     void *decoder_done_event;          /* backward only, optional hipEvent_t: recorded on `stream` once the head and every
                                         * decoder stage have written their parameter gradients (the tail of the flat
                                         * gradient buffer in module.parameters() order) -- a data-parallel caller starts

@@ -409,5 +409,43 @@ def test_fused_logits_backward_equals_the_staged_kernels(monkeypatch, n, c, g):
         res[mode] = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
     names = ["x"] + [nm for nm, _ in blk.named_parameters()]
     assert torch.equal(res["fused"][0], res["staged"][0])  # the chain through gWt is the same arithmetic
+    # biases in front of a training-mode BatchNorm / the softmax have an exactly-zero true gradient: both forms return the
+    # O(1e-4) rounding noise of a sum of ~50 k cancelling terms (grad cW), in different orders
+    zero_grad = ("attn.linear_q.0.bias", "attn.linear_k.0.bias", "attn.linear_v.bias", "attn.linear_p_bias.0.bias",
+                 "attn.linear_p_bias.3.bias", "attn.weight_encoding.0.bias", "attn.weight_encoding.3.bias")
     for nm, a, b in zip(names, res["fused"], res["staged"]):
-        assert rel(a, b) < 2e-5 or float((a - b).abs().max()) < 2e-6, (nm, rel(a, b), float((a - b).abs().max()))
+        floor = 1e-3 if nm in zero_grad else 2e-6
+        assert rel(a, b) < 2e-5 or float((a - b).abs().max()) < floor, (nm, rel(a, b), float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("n,c,g", [(4501, 192, 24), (1074, 384, 48), (9000, 96, 12), (5000, 48, 6)])
+def test_bn_backward_finalize_in_the_apply_kernel_equals_the_three_launch_form(monkeypatch, n, c, g):
+    """dense.hip (round 3): at the deep levels the BatchNorm backward's record sum runs in the prologue of the apply kernel
+    (bn_bwd_finapply_kernel) instead of a finalize launch of its own -- all four BatchNorm backwards of a Block (norm3 with the
+    residual tail, norm2 and norm1 from the GEMM-epilogue records, the linear_q / linear_k pair).  Against
+    AO_AMD_BN_FINAPPLY=0 (reduce -> finalize -> apply): same arithmetic per element, the column sums differ in summation
+    order only."""
+    from ao_amd import pointops, synth
+
+    k = 16
+    coord = torch.from_numpy(synth.room_cloud(n, seed=n)).cuda()
+    offset = torch.tensor([n], dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(k, coord, offset)
+    torch.manual_seed(5)
+    x0 = torch.randn(n, c, device="cuda").relu_()
+    go = torch.randn(n, c, device="cuda")
+    blk, _ = _block_pair(c, g, 0.3, seed=31)
+    blk.train()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AO_AMD_BN_FINAPPLY", mode)
+        torch.manual_seed(77)  # the DropPath draw
+        x = x0.clone().requires_grad_(True)
+        y = blk([coord, x, offset], idx)[1]
+        res[mode] = torch.autograd.grad(y, [x] + list(blk.parameters()), go)
+    names = ["x"] + [nm for nm, _ in blk.named_parameters()]
+    zero_grad = ("attn.linear_q.0.bias", "attn.linear_k.0.bias", "attn.linear_v.bias", "attn.linear_p_bias.0.bias",
+                 "attn.linear_p_bias.3.bias", "attn.weight_encoding.0.bias", "attn.weight_encoding.3.bias")
+    for nm, a, b in zip(names, res["1"], res["0"]):
+        floor = 1e-3 if nm in zero_grad else 2e-6
+        assert rel(a, b) < 5e-5 or float((a - b).abs().max()) < floor, (nm, rel(a, b), float((a - b).abs().max()))
