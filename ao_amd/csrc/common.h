@@ -56,7 +56,7 @@ __device__ __forceinline__ ptv2_bf16x8 ptv2_pack_bf16(float4 lo, float4 hi) {  /
 
 // Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
 #define PTV2_NUM_COUNTERS 64
-enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE };
+enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE, CNT_BN_TILES = 16 /* .. + 31 */ };
 unsigned *ptv2_stream_counters(hipStream_t st);
 
 // Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):

@@ -200,6 +200,62 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, Bn
     }
 }
 
+// the same for MANY records (the full-resolution level: 1 875 records, c / 16 = 3 column blocks): 3 workgroups walking 29
+// records per thread were 12 us of dependent round trips on the critical path of every BatchNorm of a level-0 Block.  Here
+// NS workgroups per column block each fold a share of the records into one float64 partial (S.fold), and the last of them to
+// arrive (one counter per column block and tensor; the workgroups are few and the partials 256 bytes, so the arrival protocol
+// is cheap here) adds the NS partials in index order and emits.
+constexpr int BNT_NS = 8;
+__global__ __launch_bounds__(1024) void bn_finalize_tiles_split_kernel(BnTileSet A, BnTileSet B, int nrb, int c, int n, float eps,
+                                                                       float momentum, unsigned *counters) {
+    constexpr int COLS = 16, SLICES = 64;
+    __shared__ double s1[SLICES][COLS], s2[SLICES][COLS];
+    __shared__ int s_last;
+    const BnTileSet &S = blockIdx.z ? B : A;
+    const float *__restrict__ part = S.part;
+    const int col = threadIdx.x & (COLS - 1), sl = threadIdx.x / COLS;
+    const int ch = blockIdx.x * COLS + col;
+    double a = 0.0, b = 0.0;
+    if (ch < c) {
+        for (int k = blockIdx.y * SLICES + sl; k < nrb; k += BNT_NS * SLICES) {
+            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const double sb = (double)part[(size_t)k * 2 * c + ch];
+            a += sb;
+            b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
+        }
+    }
+    s1[sl][col] = a;
+    s2[sl][col] = b;
+    __syncthreads();
+    double *fold = S.fold + ((size_t)blockIdx.y * 2) * c;  // [NS][2][c]
+    if (sl == 0 && ch < c) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < SLICES; ++t) { t1 += s1[t][col]; t2 += s2[t][col]; }
+        __hip_atomic_store(fold + ch, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fold + c + ch, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *cnt = counters + blockIdx.z * gridDim.x + blockIdx.x;
+        const unsigned prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == BNT_NS - 1;
+        if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (sl == 0 && ch < c) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int p = 0; p < BNT_NS; ++p) {
+            t1 += __hip_atomic_load(S.fold + ((size_t)p * 2) * c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += __hip_atomic_load(S.fold + ((size_t)p * 2) * c + c + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bn_tiles_emit(S, ch, t1, t2, n, eps, momentum);
+    }
+}
+
 // ------------------------------------------------------------------ BN: apply --
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(long long total4, int cq, const float *__restrict__ x,
                                                        const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -746,6 +802,167 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
     }
 }
 
+// ---- the same reduction with the operands staged through LDS (fp32 matrix cores) ---------------------------------------
+// linear_wgrad_kernel reads its MFMA fragments straight from global memory: 48 four-byte loads per lane and trip (four
+// 64-byte row segments per instruction), 72 MFMAs behind them; its waves sat in issue stalls for 60 % of their cycles with
+// the matrix pipe 23 % busy (profiles/r02_final_sq_counters.jsonl).  Here a workgroup streams 64-row stages of both operand
+// tiles (64 x 48 floats each) with 16-byte loads, every row a contiguous 192-byte run, into a double-buffered LDS image
+// (row pitch 48 floats: the ds_read_b32 fragment reads of lanes (k = lane >> 4, column = lane & 15) fall on 32 distinct
+// banks per half-wave); the next stage's loads are in flight in registers while the current one is on the matrix cores;
+// each wavefront contracts 16 of the stage's 64 rows (4 k-steps x 9 tiles) and the four partial tiles are added through LDS
+// at the end, exactly as in linear_wgrad_kernel (same records, same finalize).  The contraction order over the rows differs
+// from that kernel's (wave w takes rows 16 w .. 16 w + 15 of every stage); results are bitwise reproducible run to run.
+constexpr int WL_ROWS = 64;  // rows per stage
+template <int DUMMY>
+__global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, int cin, int tiles_i,
+                                                               const float *__restrict__ gY, long long ldy, long long sy,
+                                                               const float *__restrict__ X, long long ldx, long long sx,
+                                                               float *__restrict__ part, float *__restrict__ part_b,
+                                                               int batch, WgradMulti multi, int chunk) {
+    extern __shared__ float4 wl_lds4[];
+    float *sA = (float *)wl_lds4;                    // [2][WL_ROWS][WG_TILE]
+    float *sB = sA + 2 * WL_ROWS * WG_TILE;           // [2][WL_ROWS][WG_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int bz = blockIdx.z;
+    const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
+    const float *A = multi.count ? multi.gY[bz] : gY + (long long)bz * sy;
+    const float *B = multi.count ? multi.X[bz] : X + (long long)bz * sx;
+    const long long r0 = (long long)blockIdx.x * chunk;
+    const long long r1 = (r0 + chunk) < (long long)n ? (r0 + chunk) : (long long)n;
+    const int lr = lane >> 4, lc = lane & 15;
+    f32x4 acc[WG_MT][WG_MT];
+    float bsum[WG_MT];
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) {
+        bsum[m] = 0.f;
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float *xs = multi.count ? multi.xsc[bz] : nullptr, *xh = multi.count ? multi.xsh[bz] : nullptr;
+    float xsc_[WG_MT], xsh_[WG_MT];
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) {
+        const bool mi = ti + m * 16 + lc < cin;
+        xsc_[m] = (xs && mi) ? xs[ti + m * 16 + lc] : 1.f;
+        xsh_[m] = (xs && mi) ? xh[ti + m * 16 + lc] : 0.f;
+    }
+    // loader: thread -> float4 slots f = tid + 256 j (j < 3) of a 64 x 12 stage tile, for both operands
+    constexpr int Q = WG_TILE / 4, SLOTS = WL_ROWS * Q / TPB;  // 12 float4 per row, 3 slots per thread
+    float4 ra[SLOTS], rb[SLOTS];
+    auto fetch = [&](long long rs) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int f = tid + TPB * j, row = f / Q, c4 = (f - row * Q) * 4;
+            const long long r = rs + row;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (r < r1) {
+                const float *pa = A + r * ldy + to + c4, *pb = B + r * ldx + ti + c4;
+                if (to + c4 + 3 < cout) va = *(const float4 *)pa;
+                else {
+                    if (to + c4 < cout) va.x = pa[0];
+                    if (to + c4 + 1 < cout) va.y = pa[1];
+                    if (to + c4 + 2 < cout) va.z = pa[2];
+                }
+                if (ti + c4 + 3 < cin) vb = *(const float4 *)pb;
+                else {
+                    if (ti + c4 < cin) vb.x = pb[0];
+                    if (ti + c4 + 1 < cin) vb.y = pb[1];
+                    if (ti + c4 + 2 < cin) vb.z = pb[2];
+                }
+            }
+            ra[j] = va;
+            rb[j] = vb;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+            const int f = tid + TPB * j;  // (row * Q + c4 / 4) * 4 floats = row * WG_TILE + c4: the image is the tile, row-major
+            *(float4 *)(sA + (size_t)buf * WL_ROWS * WG_TILE + 4 * f) = ra[j];
+            *(float4 *)(sB + (size_t)buf * WL_ROWS * WG_TILE + 4 * f) = rb[j];
+        }
+    };
+    fetch(r0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (long long rs = r0; rs < r1; rs += WL_ROWS, buf ^= 1) {
+        const bool more = rs + WL_ROWS < r1;
+        if (more) fetch(rs + WL_ROWS);
+        const float *pa = sA + (size_t)buf * WL_ROWS * WG_TILE + (size_t)(wid * 16 + lr) * WG_TILE + lc;
+        const float *pb = sB + (size_t)buf * WL_ROWS * WG_TILE + (size_t)(wid * 16 + lr) * WG_TILE + lc;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // rows 16 wid + 4 ks + lr of the stage
+            float a[WG_MT], b[WG_MT];
+#pragma unroll
+            for (int m = 0; m < WG_MT; ++m) {
+                a[m] = pa[ks * 4 * WG_TILE + m * 16];
+                b[m] = pb[ks * 4 * WG_TILE + m * 16];
+            }
+            if (xs) {  // fused BatchNorm + ReLU on the X operand; rows past the end meet a == 0
+#pragma unroll
+                for (int m = 0; m < WG_MT; ++m) b[m] = fmaxf(__builtin_fmaf(b[m], xsc_[m], xsh_[m]), 0.f);
+            }
+#pragma unroll
+            for (int m = 0; m < WG_MT; ++m) {
+                bsum[m] += a[m];
+#pragma unroll
+                for (int t = 0; t < WG_MT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
+            }
+        }
+        if (more) {
+            stash(buf ^ 1);  // (the other buffer's readers finished before the barrier that ended the previous trip)
+            __syncthreads();
+        }
+    }
+    // combine the 4 waves (fixed order) and write the partial tile: as linear_wgrad_kernel (the stage buffers are dead)
+    __syncthreads();
+    float(*sRed)[WG_MT * WG_MT * 4 + WG_MT][WAVE + 1] = (float(*)[WG_MT * WG_MT * 4 + WG_MT][WAVE + 1]) wl_lds4;
+#pragma unroll
+    for (int m = 0; m < WG_MT; ++m) {
+        float bs = bsum[m];
+        bs += __shfl_xor(bs, 16, WAVE);
+        bs += __shfl_xor(bs, 32, WAVE);
+        sRed[wid][WG_MT * WG_MT * 4 + m][lane] = bs;
+#pragma unroll
+        for (int t = 0; t < WG_MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sRed[wid][(m * WG_MT + t) * 4 + r][lane] = acc[m][t][r];
+    }
+    __syncthreads();
+    const size_t rec = (size_t)batch * cout * cin + (part_b ? (size_t)batch * cout : 0);
+    float *p = part + (size_t)blockIdx.x * rec + (size_t)bz * cout * cin;
+    for (int e = threadIdx.x; e < WG_MT * WG_MT * 4 * WAVE; e += TPB) {
+        const int q = e / WAVE, l = e - q * WAVE;
+        const int mt = q / 4, r = q - mt * 4, m = mt / WG_MT, t = mt - m * WG_MT;
+        const int o = to + m * 16 + (l >> 4) * 4 + r, i = ti + t * 16 + (l & 15);  // D: row=(lane>>4)*4+reg, col=lane&15
+        if (o < cout && i < cin) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][q][l];
+            p[(size_t)o * cin + i] = v;
+        }
+    }
+    if (part_b && ti == 0 && threadIdx.x < WG_TILE) {
+        const int m = threadIdx.x >> 4, l = threadIdx.x & 15, o = to + threadIdx.x;
+        if (o < cout) {
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][WG_MT * WG_MT * 4 + m][l];
+            part[(size_t)blockIdx.x * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
+        }
+    }
+}
+
+// operands 16-byte aligned with row strides that keep them so: the LDS-staged form applies (fp32 products only)
+static bool wgrad_lds_ok(const void *a, long long ldy, long long sy, const void *b, long long ldx, long long sx) {
+    const char *e = getenv("AO_AMD_WGRAD");  // "direct": the fragment-from-global kernel (A/B switch of the tests)
+    if (e && e[0] == 'd') return false;
+    return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ldy % 4 == 0 && ldx % 4 == 0 && sy % 4 == 0 && sx % 4 == 0;
+}
+constexpr size_t WL_LDS_BYTES = sizeof(float) * std::max<size_t>(4 * (size_t)WL_ROWS * WG_TILE,
+                                                                 (size_t)(TPB / WAVE) * (WG_MT * WG_MT * 4 + WG_MT) * (WAVE + 1));
+
 // ----------------------------------------------------------- skinny projection --
 // y[n,o] = sum_i x[n,i] W[o,i] for cout <= 64 (the G-wide projections kW, qW of the attention logits); the
 // BLAS kernel chosen for an N x 48 x 6 product runs 190 us (profiles/r01_fused_v5_*).  One lane per output,
@@ -992,6 +1209,14 @@ static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, floa
                            A, B, nrb_all, c, n);
         hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((c + 63) / 64, 1, count), dim3(64), 0, (hipStream_t)stream, A, B, ny, c, n,
                            eps, momentum);
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
+    if (nrb_all >= 1024 && ((c + 15) / 16) * count <= 32 && !getenv("AO_AMD_BN_TILES_ONE")) {
+        unsigned *cnt = ptv2_stream_counters((hipStream_t)stream);
+        if (!cnt) return PTV2_ERR_LAUNCH;
+        hipLaunchKernelGGL(bn_finalize_tiles_split_kernel, dim3((c + 15) / 16, BNT_NS, count), dim3(1024), 0, (hipStream_t)stream, A, B,
+                           nrb_all, c, n, eps, momentum, cnt + CNT_BN_TILES);
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
@@ -1333,7 +1558,15 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
-        else
+        else if (wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
+            static const bool once = [] {
+                return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WL_LDS_BYTES) == hipSuccess;
+            }();
+            (void)once;
+            hipLaunchKernelGGL(linear_wgrad_lds_kernel<0>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx,
+                               sx, part, db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
+        } else
             hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
     }
@@ -1407,10 +1640,21 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         }
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
                                                (double)count * cout * (cin + 1)));
+        bool lds_ok = !ptv2_matmul_bf16();
+        for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                                (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
-        else
+        else if (lds_ok) {
+            static const bool once = [] {
+                return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WL_LDS_BYTES) == hipSuccess;
+            }();
+            (void)once;
+            hipLaunchKernelGGL(linear_wgrad_lds_kernel<0>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i,
+                               (const float *)nullptr, (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part,
+                               count, m, chunk);
+        } else
             hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                                (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);
     }

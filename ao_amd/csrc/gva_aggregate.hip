@@ -118,6 +118,10 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k
     }
 }
 
+// (measured and rejected, round 3: per-point LDS pitches of k + 1 position slots / k * G4 + 8 weight floats -- so that the two
+// points a wavefront spans at C = 48 broadcast from different banks, the 13.6 % conflict share of round 2's counters -- and
+// 8-byte weight reads at G = 6: 96 -> 103 us at 120 k points; the kernel is bound by its 16 row gathers per thread and the
+// (N,G,C) store, not by LDS)
 template <int G>
 __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c, int tp, const float *__restrict__ w,
                                                              const float *__restrict__ v, const float *__restrict__ a,
@@ -127,26 +131,20 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
                                                              float *__restrict__ A) {
     extern __shared__ float4 lds4[];
     constexpr int G4 = G4of(G);
-    // per-point pitches: k + 1 position slots, k * G4 + 8 weight floats.  A wavefront spans two points when C < 64 (the
-    // C = 48 level: 5 points per workgroup); with the natural pitches (k float4 = 64 floats, k * G4 = 128 floats) both points'
-    // broadcast reads fell on the same banks: 13.6 % of this kernel's LDS cycles were conflict replays
-    // (profiles/r02_final_sq_counters.jsonl)
-    const int PK = k + 1, WP = k * G4 + 8;
-    float4 *sPos = lds4;                            // [tp][k + 1]  (x,y,z,-)
-    float *sW = (float *)(sPos + (size_t)tp * PK);   // [tp][k * G4 + 8]
-    int *sSrc = (int *)(sW + (size_t)tp * WP);       // [tp*k]
+    float4 *sPos = lds4;                           // [tp*k]  (x,y,z,-)
+    float *sW = (float *)(sPos + (size_t)tp * k);   // [tp*k][G4]
+    int *sSrc = (int *)(sW + (size_t)tp * k * G4);  // [tp*k]
     const int n0 = blockIdx.x * tp;
     const int cnt = (n - n0) < tp ? (n - n0) : tp;
     for (int e = threadIdx.x; e < cnt * k; e += TPB) {
         const int p = e / k;
         const Rel r = rel_pos(coord, idx, (long long)n0 * k + e, n0 + p);
-        sPos[p * PK + (e - p * k)] = make_float4(r.x, r.y, r.z, 0.f);
+        sPos[e] = make_float4(r.x, r.y, r.z, 0.f);
         sSrc[e] = r.src;
     }
     for (int e = threadIdx.x; e < cnt * k * G; e += TPB) {
         const int r = e / G, g = e - r * G;
-        const int p = r / k;
-        sW[p * WP + (r - p * k) * G4 + g] = w[(long long)n0 * k * G + e];
+        sW[r * G4 + g] = w[(long long)n0 * k * G + e];
     }
     __syncthreads();
     const int I = c / G;
@@ -159,9 +157,9 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
         for (int g = 0; g < G; ++g) accA[g] = 0.f;
         float ov = 0.f;
         auto slot = [&](int s, float vv) {
-            const float4 ps = sPos[p * PK + s];
+            const float4 ps = sPos[p * k + s];
             const float P = pe_act(ax, ay, az, bb, ps.x, ps.y, ps.z);
-            const float *wrow = sW + (size_t)p * WP + s * G4;
+            const float *wrow = sW + (size_t)(p * k + s) * G4;
             ov = __builtin_fmaf(wrow[gl], vv, ov);
             if (G % 4 == 0) {
 #pragma unroll
@@ -171,13 +169,6 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
                     accA[g + 1] = __builtin_fmaf(t.y, P, accA[g + 1]);
                     accA[g + 2] = __builtin_fmaf(t.z, P, accA[g + 2]);
                     accA[g + 3] = __builtin_fmaf(t.w, P, accA[g + 3]);
-                }
-            } else if (G % 2 == 0) {  // (G = 6: three 8-byte reads instead of six 4-byte ones)
-#pragma unroll
-                for (int g = 0; g < G; g += 2) {
-                    const float2 t = *(const float2 *)(wrow + g);
-                    accA[g] = __builtin_fmaf(t.x, P, accA[g]);
-                    accA[g + 1] = __builtin_fmaf(t.y, P, accA[g + 1]);
                 }
             } else {
 #pragma unroll
@@ -561,7 +552,7 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
         }
     }
     const int tp = std::max(1, TPB / c);
-    const size_t lds = (size_t)tp * ((k + 1) * sizeof(float4) + sizeof(float) * (k * G4of(g) + 8) + k * sizeof(int));
+    const size_t lds = (size_t)tp * k * (sizeof(float4) + sizeof(float) * G4of(g) + sizeof(int));
     {
         // w + idx + coord in; v rows (each unique row once); out_v and A out
         PtvScopedTimer t(KID_AGG_TILE, st, 4.0 * ((double)rows * (g + 1) + (double)n * (3 + 2 * c) + (double)n * g * c));

@@ -225,7 +225,7 @@ inline void launch_finalize(hipStream_t st, const float *part, int nblk, int len
         PtvRider r = RiderOf<Map>::make(map);
         if (r.kind != RIDER_NONE) {
             r.part = part; r.nblk = nblk; r.len = len;
-            r.blocks = nblk <= 32 ? (len + 255) / 256 : (nblk >= 512 ? (len + 7) / 8 : (len + 15) / 16);  // rider_columns
+            r.blocks = nblk <= 32 ? (len + 255) / 256 : (nblk >= 1024 ? (len + 7) / 8 : (len + 15) / 16);  // rider_columns
             ptv2_rider_defer(r, st);
             return;
         }
@@ -367,9 +367,9 @@ __device__ __forceinline__ void rider_columns(const PtvRider &R, int rb, Map map
         map(j, (a0 + a1) + (a2 + a3));
         return;
     }
-    // 16 columns x 16 record slices, or 8 x 32 from 512 records on (the host side sizes R.blocks accordingly: rider_cols())
+    // 16 columns x 16 record slices, or 8 x 32 from 1 024 records on (the host side sizes R.blocks accordingly)
     __shared__ double s_rider[256];
-    const int cols = nblk >= 512 ? 8 : 16, S = 256 / cols;
+    const int cols = nblk >= 1024 ? 8 : 16, S = 256 / cols;
     const int col = threadIdx.x & (cols - 1), sl = threadIdx.x / cols;
     const int j = rb * cols + col;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
