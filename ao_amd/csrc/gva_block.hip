@@ -7,6 +7,7 @@
 // time vs 30 ms of kernel time); behind this entry point a block costs two host calls.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "gva_common.h"
 #include "gva_fold_p.h"
@@ -76,15 +77,21 @@ __global__ __launch_bounds__(TPB) void fold_m_fwd_batched_kernel(FoldFwdBatch B)
 
 // gWw1[g,c] (+)= sum_c' gM[c',g] Wp2[c,c'] + gcW[g] bp2[c];  gWp2[c,c'] += sum_g Ww1[g,c] gM[c',g];
 // gbp2[c] += sum_g gcW[g] Ww1[g,c];  gbw1 = gcW.   gWw1 accumulates onto the two projection gradients.
-__global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const float *__restrict__ Wp2,
-                                                         const float *__restrict__ bp2, const float *__restrict__ Ww1,
-                                                         const float *__restrict__ gM, const float *__restrict__ gcW,
-                                                         const float *__restrict__ gWw1_k,
-                                                         const float *__restrict__ gWw1_q, float *__restrict__ gWw1,
-                                                         float *gWp2, float *gbp2, float *__restrict__ gbw1, int mblocks,
-                                                         FoldPBwdArgs P) {
-    if ((int)blockIdx.x >= mblocks) {  // the BN_p fold backward of the same block rides along (see fold_m_fwd_kernel)
-        const int ch = ((int)blockIdx.x - mblocks) * TPB + threadIdx.x;
+struct FoldMBwdArgs {
+    int c, g, mblocks, blocks;
+    const float *Wp2, *bp2, *Ww1, *gM, *gcW, *gWw1_k, *gWw1_q;
+    float *gWw1, *gWp2, *gbp2, *gbw1;
+    FoldPBwdArgs P;
+};
+
+__device__ __forceinline__ void fold_m_bwd_body(const int bid, const FoldMBwdArgs &F) {
+    const int c = F.c, g = F.g, mblocks = F.mblocks;
+    const float *__restrict__ Wp2 = F.Wp2, *__restrict__ bp2 = F.bp2, *__restrict__ Ww1 = F.Ww1, *__restrict__ gM = F.gM;
+    const float *__restrict__ gcW = F.gcW, *__restrict__ gWw1_k = F.gWw1_k, *__restrict__ gWw1_q = F.gWw1_q;
+    float *__restrict__ gWw1 = F.gWw1, *gWp2 = F.gWp2, *gbp2 = F.gbp2, *__restrict__ gbw1 = F.gbw1;
+    const FoldPBwdArgs &P = F.P;
+    if (bid >= mblocks) {  // the BN_p fold backward of the same block rides along (see fold_m_fwd_kernel)
+        const int ch = (bid - mblocks) * TPB + threadIdx.x;
         if (ch < P.c) fold_p_bwd_channel(P, ch);
         return;
     }
@@ -94,8 +101,8 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
     const long long n1 = (long long)g * c, n2 = (long long)c * c;
     const bool wide = c >= 256;  // narrow levels: one wavefront per gWw1 output (short chains, the strided column is small)
     const int wblocks = wide ? (int)((n1 + TPB - 1) / TPB) : (int)((n1 + WPB - 1) / WPB);
-    if ((int)blockIdx.x < wblocks && !wide) {
-        const long long o = (long long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    if (bid < wblocks && !wide) {
+        const long long o = (long long)bid * WPB + (threadIdx.x >> 6);
         if (o < n1) {
             const int lane = threadIdx.x & 63;
             const int gi = (int)(o / c), ci = (int)(o - (long long)gi * c);
@@ -106,10 +113,10 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         }
         return;
     }
-    if ((int)blockIdx.x < wblocks) {  // wide: one thread per gWw1 output, g fastest
+    if (bid < wblocks) {  // wide: one thread per gWw1 output, g fastest
         // 16 independent chains per thread, all 32 loads of a trip in flight: with 4 chains the loop was c / 4 dependent L2
         // round trips (28 us at C = 384 for 14 MFLOP, profiles/r02_final_step_sequence.txt)
-        const long long o = (long long)blockIdx.x * TPB + threadIdx.x;
+        const long long o = (long long)bid * TPB + threadIdx.x;
         if (o < n1) {
             const int ci = (int)(o / g), gi = (int)(o - (long long)ci * g);
             const float *wrow = Wp2 + (size_t)ci * c;  // shared by the g threads of this ci (broadcast)
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
         }
         return;
     }
-    const long long e = n1 + (long long)(blockIdx.x - wblocks) * TPB + threadIdx.x;
+    const long long e = n1 + (long long)(bid - wblocks) * TPB + threadIdx.x;
     if (false) {
     } else if (e < n1 + n2) {
         const long long r = e - n1;
@@ -158,6 +165,25 @@ __global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(int c, int g, const flo
     } else if (e < n1 + n2 + c + g) {
         const int gi = (int)(e - n1 - n2 - c);
         gbw1[gi] = gcW[gi];
+    }
+}
+
+__global__ __launch_bounds__(TPB) void fold_m_bwd_kernel(FoldMBwdArgs F) { fold_m_bwd_body((int)blockIdx.x, F); }
+
+// the same for up to 8 attention blocks in one launch: these glue sums produce parameter gradients only (nothing on the
+// backward's chain reads them), so the model runtime queues them and runs all of them at the end of the backward
+struct FoldMBwdBatch {
+    int count;
+    FoldMBwdArgs item[8];
+};
+__global__ __launch_bounds__(TPB) void fold_m_bwd_batched_kernel(FoldMBwdBatch B) {
+    int bid = (int)blockIdx.x;
+    for (int i = 0; i < B.count; ++i) {
+        if (bid < B.item[i].blocks) {
+            fold_m_bwd_body(bid, B.item[i]);
+            return;
+        }
+        bid -= B.item[i].blocks;
     }
 }
 
@@ -325,7 +351,36 @@ extern "C" size_t gva_block_workspace_bytes(int n, int k, int c, int g) {
     return carve(nullptr, n, k, c, g).bytes + 1024;
 }
 
-namespace { thread_local int g_prefolded = 0; }
+namespace {
+thread_local int g_prefolded = 0;
+// deferred M / cW glue (model.hip): while a scratch region is set, gva_block_backward keeps its parameter-sized sums there
+// (instead of in the shared workspace) and queues the glue launch; ptv2_gva_flush_folds() runs the queue in batches of 8
+thread_local float *g_fold_scratch = nullptr;
+thread_local std::vector<gva::FoldMBwdArgs> *g_fold_queue = nullptr;
+}  // namespace
+size_t ptv2_gva_fold_scratch_floats(int c, int g) {
+    return gva::al(sizeof(float) * ((size_t)c * g + g + 2 * (size_t)g * c + 8 * (size_t)c + 64)) / sizeof(float);
+}
+void ptv2_gva_set_fold_scratch(float *p) { g_fold_scratch = p; }
+int ptv2_gva_flush_folds(void *stream) {
+    if (!g_fold_queue || g_fold_queue->empty()) return PTV2_OK;
+    std::vector<gva::FoldMBwdArgs> &Q = *g_fold_queue;
+    for (size_t i0 = 0; i0 < Q.size(); i0 += 8) {
+        gva::FoldMBwdBatch batch{};
+        int total = 0;
+        for (size_t i = i0; i < Q.size() && i < i0 + 8; ++i) {
+            batch.item[batch.count++] = Q[i];
+            total += Q[i].blocks;
+        }
+        hipLaunchKernelGGL(gva::fold_m_bwd_batched_kernel, dim3(total), dim3(gva::TPB), 0, (hipStream_t)stream, batch);
+    }
+    Q.clear();
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+void ptv2_gva_drop_folds() {
+    if (g_fold_queue) g_fold_queue->clear();
+}
 // internal to the library (block.hip / model.hip): the folds of the blocks that follow have been run by
 // gva_fold_forward_batched for this forward already
 void ptv2_gva_set_prefolded(int on) { g_prefolded = on; }
@@ -409,6 +464,17 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     if (n == 0) return PTV2_OK;
     BlockWs W = carve(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
+    if (g_fold_scratch) {  // the glue's operands in the caller's per-Block region: they outlive this call
+        float *p = g_fold_scratch;
+        W.gM = p; p += (size_t)c * g;
+        W.gcW = p; p += g;
+        W.gWw1_k = p; p += (size_t)g * c;
+        W.gWw1_q = p; p += (size_t)g * c;
+        W.ga1 = p; p += 3 * (size_t)c;
+        W.gb1 = p; p += c;
+        W.ga2 = p; p += 3 * (size_t)c;
+        W.gb2 = p;
+    }
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
@@ -472,12 +538,20 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     // 7. M / cW glue: finishes grad Ww1, adds the logits-path parts of grad Wp2 / bp2, grad bw1; in the same launch the
     //    folded BN_p backward (both stages contribute to the gradient of (a, b))
     {
-        const int mblocks = divup((long long)g * c, c >= 256 ? TPB : WPB) + divup((long long)c * c + c + g, TPB);
-        hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1,
-                           (const float *)W.gM, (const float *)W.gcW, (const float *)W.gWw1_k, (const float *)W.gWw1_q, G->gWw1,
-                           G->gWp2, G->gbp2, G->gbw1, mblocks,
-                           FoldPBwdArgs{c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1,
-                                        W.gb1, W.ga2, W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p});
+        FoldMBwdArgs F{};
+        F.c = c; F.g = g;
+        F.mblocks = divup((long long)g * c, c >= 256 ? TPB : WPB) + divup((long long)c * c + c + g, TPB);
+        F.blocks = F.mblocks + divup(c, TPB);
+        F.Wp2 = B->Wp2; F.bp2 = B->bp2; F.Ww1 = B->Ww1; F.gM = W.gM; F.gcW = W.gcW; F.gWw1_k = W.gWw1_k; F.gWw1_q = W.gWw1_q;
+        F.gWw1 = G->gWw1; F.gWp2 = G->gWp2; F.gbp2 = G->gbp2; F.gbw1 = G->gbw1;
+        F.P = FoldPBwdArgs{c, B->Wp1, B->bp1, B->gamma_p, B->mu, B->cov, B->run_mean_p, B->rstd_p, B->training, W.ga1, W.gb1, W.ga2,
+                           W.gb2, G->gWp1, G->gbp1, G->ggamma_p, G->gbeta_p};
+        if (g_fold_scratch) {
+            if (!g_fold_queue) g_fold_queue = new std::vector<FoldMBwdArgs>();
+            g_fold_queue->push_back(F);
+        } else {
+            hipLaunchKernelGGL(fold_m_bwd_kernel, dim3(F.blocks), dim3(TPB), 0, st, F);
+        }
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

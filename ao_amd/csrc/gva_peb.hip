@@ -121,7 +121,10 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
     constexpr int DIST = (CH >= 6 ? 3 : 5) < ITEMS ? (CH >= 6 ? 3 : 5) : (ITEMS > 1 ? ITEMS - 1 : 1);
     constexpr int RING = DIST + 1;
     static_assert(QF % CH == 0, "items tile the row");
-    constexpr int LDW = C + 4;
+    // row pitch C + 8 floats: (C + 8) / 4 is 2 mod 4 for every C in use, which puts the 16-byte slots of the 8 rows x 2
+    // quarters that one ds_read_b128 lane group reads on 16 distinct slots (C + 4: rows r and r + 1 of neighbouring quarters
+    // collided, 20-38 % of this kernel's LDS cycles were replays)
+    constexpr int LDW = C + 8;
     constexpr int gpw = PEB_MAX_GPW;
     extern __shared__ float4 lds4[];
     float *sW = (float *)lds4;                      // [gpw * 8][C + 4]
@@ -357,7 +360,7 @@ template <int C, int GPW>
 static void launch_peb_mfma_g(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
                               float *out, float *stats, hipStream_t st) {
     const int nrb = (n + 63) / 64;
-    const size_t lds = sizeof(float) * ((size_t)GPW * 8 * (C + 4) + 4 * GPW * 8);
+    const size_t lds = sizeof(float) * ((size_t)GPW * 8 * (C + 8) + 4 * GPW * 8);
     auto kern = peb_fwd_mfma_kernel<C, GPW>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(nrb, (g + GPW - 1) / GPW), dim3(TPB), lds, st, n, g, A, Wp2, bp2, sw, out_v, out, stats);

@@ -24,6 +24,10 @@
 
 int ptv2_blocks_fold_forward(int count, const ptv2_block *blocks, void *stream);  // block.hip
 void ptv2_gva_set_prefolded(int on);                                                // gva_block.hip
+size_t ptv2_gva_fold_scratch_floats(int c, int g);  // deferred M / cW glue of the attention backward (gva_block.hip)
+void ptv2_gva_set_fold_scratch(float *p);
+int ptv2_gva_flush_folds(void *stream);
+void ptv2_gva_drop_folds();
 
 namespace {
 
@@ -232,6 +236,7 @@ struct Work {
     // deferred weight gradients (M->side_stream != NULL): operands that must outlive the main chain's buffer reuse
     float *keep_block[PTV2_MAX_BLOCKS];      // 5 (n,c) gradients per Block
     float *keep_gh[3 * PTV2_MAX_STAGES + 2]; // gradient in front of each Linear+BatchNorm: embed, head, down/up/up_skip[i]
+    float *fold_scratch[PTV2_MAX_BLOCKS];    // per-Block operands of the attention's parameter glue, run once at the end
     char *side; size_t side_bytes;           // split-K records of everything enqueued on the side stream
     size_t bytes;
 };
@@ -291,6 +296,11 @@ Work carve_work(const ptv2_model *M, void *base) {
     for (int i = 0; i <= S; ++i) {
         const int c = i == 0 ? M->embed.cout : M->down[i - 1].cout;
         W.gskip[i] = (float *)take(sizeof(float) * (size_t)M->level[i].n * c);
+    }
+    for (int q = 0; q <= 2 * S; ++q) {
+        const ptv2_seq &s = M->seq[q];
+        for (int j = 0; j < s.depth; ++j)
+            W.fold_scratch[s.first_block + j] = (float *)take(sizeof(float) * ptv2_gva_fold_scratch_floats(s.c, s.g));
     }
     W.side = nullptr;
     W.side_bytes = 0;
@@ -436,7 +446,11 @@ float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_i
             G.side_stream = M->side_stream; G.side_event = next_event(); G.keep = W.keep_block[s.first_block + j];
             G.side_workspace = W.side; G.side_workspace_bytes = W.side_bytes;
         }
+        // the attention's parameter-sized glue is queued, not launched (its operands stay in this Block's scratch); not under
+        // checkpointing, where the glue reads a saved vector that the next recomputation overwrites
+        ptv2_gva_set_fold_scratch(M->checkpoint ? nullptr : W.fold_scratch[s.first_block + j]);
         *rc = ptv2_block_backward_hip_launcher(&B, &G, W.block, W.block_bytes, stream);
+        ptv2_gva_set_fold_scratch(nullptr);
         if (*rc != PTV2_OK) return nullptr;
         std::swap(gy, other);
     }
@@ -548,6 +562,8 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
     hipStream_t st = (hipStream_t)stream;
     const int S = M->num_stages, n0 = M->level[0].n;
     int rc = PTV2_OK;
+    ptv2_gva_drop_folds();  // (a previous call that failed half-way may have left entries queued)
+    struct DropFolds { bool armed = true; ~DropFolds() { if (armed) ptv2_gva_drop_folds(); } } drop_folds;
     // the sequences' inputs and outputs as the forward wired them
     auto seq_out = [&](int q, const float *in) {
         const ptv2_seq &s = M->seq[q];
@@ -600,7 +616,10 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
         o = spare;
     }
     // head + decoder parameter gradients are final from here on (their finalizes were enqueued above)
-    if (M->decoder_done_event && hipEventRecord((hipEvent_t)M->decoder_done_event, st) != hipSuccess) return PTV2_ERR_LAUNCH;
+    if (M->decoder_done_event) {
+        RUN(ptv2_gva_flush_folds(stream));  // (the decoder Blocks' queued parameter glue belongs to that half)
+        if (hipEventRecord((hipEvent_t)M->decoder_done_event, st) != hipSuccess) return PTV2_ERR_LAUNCH;
+    }
     // encoder stages S-1 .. 0: gskip[i+1] is complete (skip branch of the decoder + the pooling of stage i+1)
     for (int i = S - 1; i >= 0; --i) {
         const ptv2_level &lv = M->level[i];
@@ -619,6 +638,8 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
         if (rc != PTV2_OK) return rc;
         RUN(linbn_backward(M, M->embed, A.embed, n0, M->feat, gp, gc, GH_EMBED, nullptr, 0, W, stream));
     }
+    RUN(ptv2_gva_flush_folds(stream));  // the queued parameter glue of all attention blocks: two launches
+    drop_folds.armed = false;
     if (M->side_stream) {  // join: whatever follows on the main stream (the optimizer) sees every weight gradient
         hipEvent_t e = next_event();
         if (!e || hipEventRecord(e, (hipStream_t)M->side_stream) != hipSuccess) return PTV2_ERR_LAUNCH;
