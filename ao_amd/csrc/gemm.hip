@@ -356,12 +356,16 @@ static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const flo
 // levels (m ~ 1 000 - 5 000 rows) that makes 136 - 284 workgroups for 256 compute units: one and a bit rounds of a
 // latency-bound workgroup (e.g. 284 = 256 + 28: the launch takes two workgroup lifetimes for 1.1 rounds of work).  There
 // 16-column blocks give 3 x the workgroups (X, a few MB, is re-read from L2) and the rounds even out.
-static int column_block(int m, int n) {
+// `products`: independent products in the launch (blockIdx.y: the q / k / v projections run 3) -- they multiply the
+// workgroup count, so the wide block stays affordable there (4.5 k points x 192: 852 workgroups of 48 columns instead of
+// 2 556 of 16, each re-reading the X tile a third as often)
+static int column_block(int m, int n, int products = 1) {
     static const int forced = [] { const char *e = getenv("AO_AMD_GEMM_BN"); return e ? atoi(e) : 0; }();
+    static const bool count_aware = [] { const char *e = getenv("AO_AMD_GEMM_COUNT_AWARE"); return !(e && e[0] == '0'); }();
     const bool n48 = n % 48 == 0;
     const int wide = n48 ? 48 : 64;
     if (forced == 16 || forced == 48 || forced == 64) return (forced == 16 && n % 16 == 0) ? 16 : wide;
-    const long long wgs = (((long long)m + gemm::BM - 1) / gemm::BM) * ((n + wide - 1) / wide);
+    const long long wgs = (((long long)m + gemm::BM - 1) / gemm::BM) * ((n + wide - 1) / wide) * (count_aware ? products : 1);
     return (wgs < 768 && n % 16 == 0) ? 16 : wide;
 }
 
@@ -429,7 +433,7 @@ extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int 
     gm.xsh = xsh;
     hipStream_t st = (hipStream_t)stream;
     const bool n48 = n % 48 == 0;
-    const int bn = column_block(m, n);
+    const int bn = column_block(m, n, sum ? 1 : count);
     const int ncb = (n + bn - 1) / bn;
     const long long nrb = ((long long)m + BM - 1) / BM;
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;

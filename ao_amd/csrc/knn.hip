@@ -341,21 +341,44 @@ __global__ __launch_bounds__(256) void knn_grid_query_kernel(
         const int cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
         const int cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
         const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+        // Cell culling (round 3): a cell whose box is at least as far from the query as the current (k+1)-th best distance
+        // cannot contribute (a candidate enters only with d2 < bd[KC-1]), so rows of cells are skipped and their x range
+        // clipped before any point is read.  Distances in cell units from the query's UNclamped fractional cell position,
+        // each gap shortened by the same 0.01 cell that covers the rounding of cell_coord() in the ring stop test below.
+        // The list of the k+1 smallest distances -- and with it the tie test -- is unchanged; 135 -> ~80 candidate
+        // distances per query on the 120 k-point scene (bench.py `ops`).
+        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+        const float h2 = g.h * g.h, inv_h2 = g.inv_h * g.inv_h;
+        auto gap = [](float f, int c) { return fmaxf(fmaxf(fmaxf((float)c - f, f - (float)(c + 1)), 0.f) - 0.01f, 0.f); };
         for (int R = 1;; ++R) {
             const int z0 = max(cz - R, 0), z1 = min(cz + R, g.gz - 1);
             const int y0 = max(cy - R, 0), y1 = min(cy + R, g.gy - 1);
             const int xa = max(cx - R, 0), xb = min(cx + R, g.gx - 1);
             for (int z = z0; z <= z1; ++z) {
+                const float dz = gap(fz, z);
                 for (int y = y0; y <= y1; ++y) {
+                    const float dy = gap(fy, y);
+                    const float base2 = (dz * dz + dy * dy) * h2;  // lower bound of d2 for every point of this row of cells
+                    if (base2 >= bd[KC - 1]) continue;
                     const int row = g.cell_base + (z * g.gy + y) * g.gx;
                     const bool full = (R == 1) || (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
                     if (full) {
-                        scan_range<KC>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, bd, bi, visited);
+                        // cells x with gap(fx, x)^2 h^2 + base2 < bd[KC-1]: |x - fx| within r cells (r padded)
+                        const float r = fminf(sqrtf((bd[KC - 1] - base2) * inv_h2) * 1.0001f + 0.03f, 4096.f);
+                        const int xlo = max(xa, (int)floorf(fx - r)), xhi = min(xb, (int)floorf(fx + r));
+                        if (xlo <= xhi)
+                            scan_range<KC>(sorted, cell_start[row + xlo], cell_start[row + xhi + 1], qx, qy, qz, bd, bi, visited);
                     } else {
-                        if (cx - R >= 0)
-                            scan_range<KC>(sorted, cell_start[row + cx - R], cell_start[row + cx - R + 1], qx, qy, qz, bd, bi, visited);
-                        if (cx + R <= g.gx - 1)
-                            scan_range<KC>(sorted, cell_start[row + cx + R], cell_start[row + cx + R + 1], qx, qy, qz, bd, bi, visited);
+                        if (cx - R >= 0) {
+                            const float dx = gap(fx, cx - R);
+                            if (dx * dx * h2 + base2 < bd[KC - 1])
+                                scan_range<KC>(sorted, cell_start[row + cx - R], cell_start[row + cx - R + 1], qx, qy, qz, bd, bi, visited);
+                        }
+                        if (cx + R <= g.gx - 1) {
+                            const float dx = gap(fx, cx + R);
+                            if (dx * dx * h2 + base2 < bd[KC - 1])
+                                scan_range<KC>(sorted, cell_start[row + cx + R], cell_start[row + cx + R + 1], qx, qy, qz, bd, bi, visited);
+                        }
                     }
                 }
             }
