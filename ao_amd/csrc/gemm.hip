@@ -71,6 +71,136 @@ __device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16
     return v;
 }
 
+// Epilogue shared by the row GEMM kernels: bias / accumulate / store, then (optionally) the BatchNorm-backward reduce records
+// and the BatchNorm-forward tile statistics of this 64-row block (see GemmMulti).  `sS`: >= 4 * 2 * BN floats of LDS scratch
+// that no wavefront reads as an operand any more (the callers synchronise inside: every use below follows a barrier).
+template <int BN>
+__device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long long row0, const int rb, const int n0, const int z,
+                                              const bool indep, const int m, const int n, const float *__restrict__ bias,
+                                              float *__restrict__ Y, const int accumulate, const GemmMulti &multi, float *sS_) {
+    constexpr int NT = BN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float *sX = sS_;
+    // D[i][j]: i = output column within the tile = (lane >> 4) * 4 + reg, j = row within the strip = lane & 15
+    const long long row = row0 + wid * 16 + (lane & 15);
+    float4 val[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n0 + t * 16 + (lane >> 4) * 4;
+        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (bias && col < n) {
+            const float4 bb = *(const float4 *)(bias + col);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        val[t] = v;
+        if (row < m && col < n) {
+            float4 *dst = (float4 *)(Y + row * n + col);
+            if (accumulate) {
+                const float4 o = *dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+        }
+    }
+    if (multi.count && multi.brec) {
+        float *sS = sX;  // [4 waves][2][BN]
+        const bool rv = row < m;
+        const int cl = (lane >> 4) * 4;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + t * 16 + cl;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), e = d;
+            if (rv && col < n) {
+                const float4 xv = *(const float4 *)(multi.bnx + row * n + col);
+                const float4 mm = *(const float4 *)(multi.bnm + col), rs = *(const float4 *)(multi.bnr + col);
+                float4 h;
+                h.x = (xv.x - mm.x) * rs.x; h.y = (xv.y - mm.y) * rs.y; h.z = (xv.z - mm.z) * rs.z; h.w = (xv.w - mm.w) * rs.w;
+                d = val[t];
+                if (multi.bnrelu) {
+                    const float4 gg = *(const float4 *)(multi.bng + col), bb = *(const float4 *)(multi.bnb + col);
+                    if (__builtin_fmaf(h.x, gg.x, bb.x) <= 0.f) d.x = 0.f;
+                    if (__builtin_fmaf(h.y, gg.y, bb.y) <= 0.f) d.y = 0.f;
+                    if (__builtin_fmaf(h.z, gg.z, bb.z) <= 0.f) d.z = 0.f;
+                    if (__builtin_fmaf(h.w, gg.w, bb.w) <= 0.f) d.w = 0.f;
+                }
+                e = make_float4(d.x * h.x, d.y * h.y, d.z * h.z, d.w * h.w);
+            }
+            const float ax = row16_sum(d.x), ay = row16_sum(d.y), az = row16_sum(d.z), aw = row16_sum(d.w);
+            const float bx = row16_sum(e.x), by = row16_sum(e.y), bz = row16_sum(e.z), bw = row16_sum(e.w);
+            if ((lane & 15) == 0) {
+                *(float4 *)(sS + (wid * 2 + 0) * BN + t * 16 + cl) = make_float4(ax, ay, az, aw);
+                *(float4 *)(sS + (wid * 2 + 1) * BN + t * 16 + cl) = make_float4(bx, by, bz, bw);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * BN; e += THREADS) {
+            const int which = e / BN, cc = e - which * BN;
+            if (n0 + cc < n) {
+                float a = sS[which * BN + cc];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) a += sS[(w * 2 + which) * BN + cc];
+                multi.brec[(size_t)rb * 2 * n + (size_t)which * n + n0 + cc] = a;
+            }
+        }
+    }
+    float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
+    if (stats) {
+        // column statistics of this 64-row block: sum, then sum of squares about the block mean (two passes over
+        // the register tile; the finalize merges blocks with the parallel-variance formula in double)
+        float *sS = sX;  // [4 waves][BN]: the operand staging is no longer needed
+        const bool rv = row < m;
+        const int cnt = (int)((m - row0) < BM ? (m - row0) : BM);
+        const int cl = (lane >> 4) * 4;  // my 4 columns within a 16-wide tile
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float sx = row16_sum(rv ? val[t].x : 0.f), sy = row16_sum(rv ? val[t].y : 0.f);
+            const float sz = row16_sum(rv ? val[t].z : 0.f), sw = row16_sum(rv ? val[t].w : 0.f);
+            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(sx, sy, sz, sw);
+        }
+        __syncthreads();
+        float4 mean[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 a = *(const float4 *)(sS + t * 16 + cl);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
+            mean[t] = a;  // block sums for now
+        }
+        __syncthreads();
+        const float inv = 1.0f / (float)cnt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = n0 + t * 16 + cl;
+            if (wid == 0 && (lane & 15) == 0 && col < n) *(float4 *)(stats + (size_t)rb * 2 * n + col) = mean[t];
+            const float dx = rv ? val[t].x - mean[t].x * inv : 0.f, dy = rv ? val[t].y - mean[t].y * inv : 0.f;
+            const float dz = rv ? val[t].z - mean[t].z * inv : 0.f, dw = rv ? val[t].w - mean[t].w * inv : 0.f;
+            const float qx = row16_sum(dx * dx), qy = row16_sum(dy * dy), qz = row16_sum(dz * dz), qw = row16_sum(dw * dw);
+            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(qx, qy, qz, qw);
+        }
+        __syncthreads();
+        if (wid == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = n0 + t * 16 + cl;
+                if (col < n) {
+                    float4 a = *(const float4 *)(sS + t * 16 + cl);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) {
+                        const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
+                        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                    }
+                    *(float4 *)(stats + (size_t)rb * 2 * n + n + col) = a;
+                }
+            }
+        }
+    }
+}
+
 // BF16: the same kernel with bf16 matrix-core operands.  A lane owns KC / 4 consecutive reduction indices of its row /
 // column per chunk -- exactly the 8-per-lane operand layout of V_MFMA_F32_16X16X32_BF16 -- so the 8 fp32 MFMAs of
 // a 32-index chunk become one instruction on operands rounded to bf16 (fp32 accumulation, fp32 in memory).
@@ -219,127 +349,152 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             }
         }
     }
-    // D[i][j]: i = output column within the tile = (lane >> 4) * 4 + reg, j = row within the strip = lane & 15
-    const long long row = row0 + wid * 16 + (lane & 15);
-    float4 val[NT];
+    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sX);
+}
+
+// ---- the same product with X read straight into the MFMA operand registers ("direct" form, round 3) -----------------
+// A wavefront's 16-row strip of X is used by that wavefront alone: staging it through LDS bought coalescing only, at the
+// price of a store, a load and two workgroup barriers per 32- / 64-index chunk -- 44-58 % of these kernels' wave cycles were
+// spent parked, 30-40 % in issue stalls (profiles/r02_final_sq_counters.jsonl).  Here lane (row l15, quarter q) loads the
+// float4 at reduction indices 16 j + 4 q .. + 3 of ITS row for every j -- the four lanes of a row read 64 contiguous bytes
+// per instruction, the access pattern that streams strided rows at 4.7 TB/s (tools/probes/read_pattern_probe.hip; a
+// contiguous run per lane, round 1's split-K attempt, reads 64 distinct lines per instruction at 2.9 TB/s) -- all K / 16
+// loads of the strip in flight at once, no chunk loop.  The BN x K weight block is staged in LDS once per workgroup (the
+// only barrier before the epilogue; (k,n)-major weights are transposed on the way in) with row pitch K + 8 floats: the
+// ds_read_b128 operand reads of a lane group fall on 16 distinct slots for every K in use.  Contraction index of lane
+// quarter q in step (j, e): k = 16 j + 4 q + e, identically for both operands.
+template <int BN, bool W_KMAJOR, int K, bool BF16>
+__global__ __launch_bounds__(THREADS) void rows_gemm_direct_kernel(int m, int n, const float *__restrict__ X0,
+                                                                   const float *__restrict__ W0, const float *__restrict__ bias0,
+                                                                   float *__restrict__ Y0, int accumulate, int ncb, GemmMulti multi) {
+    constexpr int NT = BN / 16, QF = K / 16, LDW = K + 8, KQ = K / 4;
+    extern __shared__ float4 gd_lds4[];
+    float *sW = (float *)gd_lds4;            // [BN][K + 8]
+    float *sSc = sW + (size_t)BN * LDW;       // [K] scale, [K] shift of the fused BatchNorm + ReLU on X (when present)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
+    const long long row0 = (long long)rb * BM;
+    const int n0 = cb * BN;
+    const int z = blockIdx.y;
+    const bool indep = multi.count && !multi.sum;
+    const float *bias = indep ? multi.bias[z] : bias0;
+    float *Y = multi.count ? multi.Y[indep ? z : 0] : Y0;
+    const int npair = (multi.count && multi.sum) ? multi.count : 1;
+    const float *X = multi.count ? multi.X[indep ? z : 0] : X0;
+    const float *W = multi.count ? multi.W[indep ? z : 0] : W0;
+    const long long row = row0 + wid * 16 + l15;
+    const bool rv = row < m;
+
+    v4f acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = n0 + t * 16 + (lane >> 4) * 4;
-        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        if (bias && col < n) {
-            const float4 bb = *(const float4 *)(bias + col);
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    if (multi.xsc)
+        for (int e = tid; e < K; e += THREADS) { sSc[e] = multi.xsc[e]; sSc[K + e] = multi.xsh[e]; }
+    for (int pair = 0; pair < npair; ++pair) {
+        if (pair > 0) {
+            X = multi.X[pair];
+            W = multi.W[pair];
+            __syncthreads();  // the previous pair's weight block is still being read
         }
-        val[t] = v;
-        if (row < m && col < n) {
-            float4 *dst = (float4 *)(Y + row * n + col);
-            if (accumulate) {
-                const float4 o = *dst;
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        // my row of X: every load of the strip requested before anything waits
+        float4 x[QF];
+        const float *xr = X + (rv ? row : 0) * K + 4 * q;
+#pragma unroll
+        for (int j = 0; j < QF; ++j) x[j] = rv ? *(const float4 *)(xr + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // the weight block of this column block
+        if (!W_KMAJOR) {
+            for (int e = tid; e < BN * KQ; e += THREADS) {
+                const int r = e / KQ, k4 = e - r * KQ;
+                *(float4 *)(sW + (size_t)r * LDW + 4 * k4) =
+                    n0 + r < n ? *(const float4 *)(W + (long long)(n0 + r) * K + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *dst = v;
+        } else {
+            for (int e = tid; e < (BN / 4) * K; e += THREADS) {
+                const int kk = e % K, cq = (e / K) * 4;  // consecutive lanes: consecutive k of one column quad (conflict-free stores)
+                const float4 w4 = n0 + cq < n ? *(const float4 *)(W + (long long)kk * n + n0 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sW[(size_t)(cq + 0) * LDW + kk] = w4.x; sW[(size_t)(cq + 1) * LDW + kk] = w4.y;
+                sW[(size_t)(cq + 2) * LDW + kk] = w4.z; sW[(size_t)(cq + 3) * LDW + kk] = w4.w;
+            }
         }
-    }
-    if (multi.count && multi.brec) {
-        float *sS = sX;  // [4 waves][2][BN]
-        const bool rv = row < m;
-        const int cl = (lane >> 4) * 4;
         __syncthreads();
+        if (multi.xsc) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = n0 + t * 16 + cl;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), e = d;
-            if (rv && col < n) {
-                const float4 xv = *(const float4 *)(multi.bnx + row * n + col);
-                const float4 mm = *(const float4 *)(multi.bnm + col), rs = *(const float4 *)(multi.bnr + col);
-                float4 h;
-                h.x = (xv.x - mm.x) * rs.x; h.y = (xv.y - mm.y) * rs.y; h.z = (xv.z - mm.z) * rs.z; h.w = (xv.w - mm.w) * rs.w;
-                d = val[t];
-                if (multi.bnrelu) {
-                    const float4 gg = *(const float4 *)(multi.bng + col), bb = *(const float4 *)(multi.bnb + col);
-                    if (__builtin_fmaf(h.x, gg.x, bb.x) <= 0.f) d.x = 0.f;
-                    if (__builtin_fmaf(h.y, gg.y, bb.y) <= 0.f) d.y = 0.f;
-                    if (__builtin_fmaf(h.z, gg.z, bb.z) <= 0.f) d.z = 0.f;
-                    if (__builtin_fmaf(h.w, gg.w, bb.w) <= 0.f) d.w = 0.f;
+            for (int j = 0; j < QF; ++j) {
+                const float4 s4 = *(const float4 *)(sSc + 16 * j + 4 * q), h4 = *(const float4 *)(sSc + K + 16 * j + 4 * q);
+                x[j].x = fmaxf(__builtin_fmaf(x[j].x, s4.x, h4.x), 0.f); x[j].y = fmaxf(__builtin_fmaf(x[j].y, s4.y, h4.y), 0.f);
+                x[j].z = fmaxf(__builtin_fmaf(x[j].z, s4.z, h4.z), 0.f); x[j].w = fmaxf(__builtin_fmaf(x[j].w, s4.w, h4.w), 0.f);
+            }
+        }
+        const float *pw = sW + (size_t)l15 * LDW + 4 * q;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int j = 0; j < QF; j += 2) {
+                const float4 x1 = j + 1 < QF ? x[j + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const ptv2_bf16x8 xb = ptv2_pack_bf16(x[j], x1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w0 = *(const float4 *)(pw + (size_t)t * 16 * LDW + 16 * j);
+                    const float4 w1 = j + 1 < QF ? *(const float4 *)(pw + (size_t)t * 16 * LDW + 16 * (j + 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ptv2_pack_bf16(w0, w1), xb, acc[t], 0, 0, 0);
                 }
-                e = make_float4(d.x * h.x, d.y * h.y, d.z * h.z, d.w * h.w);
             }
-            const float ax = row16_sum(d.x), ay = row16_sum(d.y), az = row16_sum(d.z), aw = row16_sum(d.w);
-            const float bx = row16_sum(e.x), by = row16_sum(e.y), bz = row16_sum(e.z), bw = row16_sum(e.w);
-            if ((lane & 15) == 0) {
-                *(float4 *)(sS + (wid * 2 + 0) * BN + t * 16 + cl) = make_float4(ax, ay, az, aw);
-                *(float4 *)(sS + (wid * 2 + 1) * BN + t * 16 + cl) = make_float4(bx, by, bz, bw);
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * BN; e += THREADS) {
-            const int which = e / BN, cc = e - which * BN;
-            if (n0 + cc < n) {
-                float a = sS[which * BN + cc];
+        } else {
 #pragma unroll
-                for (int w = 1; w < 4; ++w) a += sS[(w * 2 + which) * BN + cc];
-                multi.brec[(size_t)rb * 2 * n + (size_t)which * n + n0 + cc] = a;
-            }
-        }
-    }
-    float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
-    if (stats) {
-        // column statistics of this 64-row block: sum, then sum of squares about the block mean (two passes over
-        // the register tile; the finalize merges blocks with the parallel-variance formula in double)
-        float *sS = sX;  // [4 waves][BN]: the operand staging is no longer needed
-        const bool rv = row < m;
-        const int cnt = (int)((m - row0) < BM ? (m - row0) : BM);
-        const int cl = (lane >> 4) * 4;  // my 4 columns within a 16-wide tile
-        __syncthreads();
+            for (int j = 0; j < QF; ++j) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float sx = row16_sum(rv ? val[t].x : 0.f), sy = row16_sum(rv ? val[t].y : 0.f);
-            const float sz = row16_sum(rv ? val[t].z : 0.f), sw = row16_sum(rv ? val[t].w : 0.f);
-            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(sx, sy, sz, sw);
-        }
-        __syncthreads();
-        float4 mean[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float4 a = *(const float4 *)(sS + t * 16 + cl);
-#pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
-                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-            }
-            mean[t] = a;  // block sums for now
-        }
-        __syncthreads();
-        const float inv = 1.0f / (float)cnt;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = n0 + t * 16 + cl;
-            if (wid == 0 && (lane & 15) == 0 && col < n) *(float4 *)(stats + (size_t)rb * 2 * n + col) = mean[t];
-            const float dx = rv ? val[t].x - mean[t].x * inv : 0.f, dy = rv ? val[t].y - mean[t].y * inv : 0.f;
-            const float dz = rv ? val[t].z - mean[t].z * inv : 0.f, dw = rv ? val[t].w - mean[t].w * inv : 0.f;
-            const float qx = row16_sum(dx * dx), qy = row16_sum(dy * dy), qz = row16_sum(dz * dz), qw = row16_sum(dw * dw);
-            if ((lane & 15) == 0) *(float4 *)(sS + wid * BN + t * 16 + cl) = make_float4(qx, qy, qz, qw);
-        }
-        __syncthreads();
-        if (wid == 0 && (lane & 15) == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int col = n0 + t * 16 + cl;
-                if (col < n) {
-                    float4 a = *(const float4 *)(sS + t * 16 + cl);
-#pragma unroll
-                    for (int w = 1; w < 4; ++w) {
-                        const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
-                        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-                    }
-                    *(float4 *)(stats + (size_t)rb * 2 * n + n + col) = a;
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w4 = *(const float4 *)(pw + (size_t)t * 16 * LDW + 16 * j);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, x[j].x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, x[j].y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, x[j].z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, x[j].w, acc[t], 0, 0, 0);
                 }
             }
         }
     }
+    __syncthreads();  // the weight block is dead: its LDS is the epilogue's scratch
+    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sW);
 }
 
 }  // namespace gemm
+
+template <int BN, bool KM, int K>
+static void launch_direct(dim3 grid, hipStream_t st, int m, int n, const float *X, const float *W, const float *bias, float *Y,
+                          int accumulate, int ncb, const gemm::GemmMulti &gm) {
+    const size_t lds = sizeof(float) * ((size_t)BN * (K + 8) + 2 * K);
+    if (ptv2_matmul_bf16()) {
+        auto kern = gemm::rows_gemm_direct_kernel<BN, KM, K, true>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(gemm::THREADS), lds, st, m, n, X, W, bias, Y, accumulate, ncb, gm);
+    } else {
+        auto kern = gemm::rows_gemm_direct_kernel<BN, KM, K, false>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(gemm::THREADS), lds, st, m, n, X, W, bias, Y, accumulate, ncb, gm);
+    }
+}
+
+// the direct form exists for BN = 16 / 48 and K = 48 / 96 / 192 / 384 (every Linear of the S3DIS / ScanNet configurations
+// except the 512-wide ScanNet level); AO_AMD_GEMM=lds selects the LDS-staged kernel (A/B switch of the tests)
+static bool launch_gemm_direct(int bn, bool kmajor, dim3 grid, hipStream_t st, int m, int n, int k, const float *X, const float *W,
+                               const float *bias, float *Y, int accumulate, int ncb, const gemm::GemmMulti &gm) {
+    const char *e = getenv("AO_AMD_GEMM");
+    if ((e && e[0] == 'l') || (bn != 16 && bn != 48) || (k != 48 && k != 96 && k != 192 && k != 384)) return false;
+    // Where it pays (per (kernel, grid) durations of one step, profiles/r03_*): k = 48 -- the full-resolution level, thousands
+    // of short workgroups whose phases interleave (fc1 / fc3 18.9 -> 17.3 us, q/k/v 48 -> 39 us, input gradients 21.7 -> 19.7)
+    // -- and the 48-column blocks of the q/k/v launch at the deeper levels (26.6 -> 22.6 us at 4.5 k x 192).  The few hundred
+    // workgroups of a deep-level launch are all resident at once and run their load and compute phases in lockstep, where
+    // the chunked loop's prefetch under the MFMAs wins (14.7 vs 20.2 us for the 3-pair input gradient at 4.5 k x 192):
+    // those stay on the LDS-staged kernel.  AO_AMD_GEMM=direct forces the direct form wherever it exists (tests).
+    if (!(e && e[0] == 'd') && !(k == 48 || (!kmajor && bn == 48 && k <= 192))) return false;
+#define GD(BN, KM, KK) launch_direct<BN, KM, KK>(grid, st, m, n, X, W, bias, Y, accumulate, ncb, gm)
+#define GDK(BN, KM)                                                                   \
+    switch (k) { case 48: GD(BN, KM, 48); break; case 96: GD(BN, KM, 96); break; case 192: GD(BN, KM, 192); break; default: GD(BN, KM, 384); break; }
+    if (bn == 16) { if (kmajor) { GDK(16, true) } else { GDK(16, false) } }
+    else { if (kmajor) { GDK(48, true) } else { GDK(48, false) } }
+#undef GDK
+#undef GD
+    return true;
+}
 
 template <int BN, bool KM, int KC>
 static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const float *X, const float *W, const float *bias, float *Y,
@@ -371,6 +526,7 @@ static int column_block(int m, int n, int products = 1) {
 
 static void launch_gemm(int bn, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
                         const float *W, const float *bias, float *Y, int accumulate, int ncb, const gemm::GemmMulti &gm) {
+    if (launch_gemm_direct(bn, kmajor, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, gm)) return;
 #define GO(BN, KM, KC) launch_one<BN, KM, KC>(grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, gm)
     if (bn == 16) {
         if (kmajor) { if (wide_k) GO(16, true, 64); else GO(16, true, 32); }

@@ -18,9 +18,14 @@ def rel(a, b):
 @pytest.mark.parametrize("m,n,k", [(120000, 48, 48), (18905, 96, 96), (4501, 192, 192), (1074, 384, 384), (777, 512, 512),
                                    (1000, 96, 48), (1000, 48, 96), (63, 64, 32), (65, 16, 4), (1, 48, 48), (3000, 384, 192)])
 @pytest.mark.parametrize("kmajor", [False, True])
-def test_rows_gemm(m, n, k, kmajor):
+@pytest.mark.parametrize("form", ["default", "lds", "direct"])
+def test_rows_gemm(m, n, k, kmajor, form, monkeypatch):
+    """`form`: the launcher's own choice, the LDS-staged kernel everywhere, the direct kernel wherever it is instantiated
+    (AO_AMD_GEMM is read per call)."""
     from ao_amd.ptv2.block import rows_gemm
 
+    if form != "default":
+        monkeypatch.setenv("AO_AMD_GEMM", form)
     torch.manual_seed(m + n + k)
     x = torch.randn(m, k, device="cuda")
     w = torch.randn((k, n) if kmajor else (n, k), device="cuda") / k ** 0.5
@@ -447,5 +452,5 @@ def test_bn_backward_finalize_in_the_apply_kernel_equals_the_three_launch_form(m
     zero_grad = ("attn.linear_q.0.bias", "attn.linear_k.0.bias", "attn.linear_v.bias", "attn.linear_p_bias.0.bias",
                  "attn.linear_p_bias.3.bias", "attn.weight_encoding.0.bias", "attn.weight_encoding.3.bias")
     for nm, a, b in zip(names, res["1"], res["0"]):
-        floor = 1e-3 if nm in zero_grad else 2e-6
+        floor = 5e-3 if nm in zero_grad else 2e-6
         assert rel(a, b) < 5e-5 or float((a - b).abs().max()) < floor, (nm, rel(a, b), float((a - b).abs().max()))
