@@ -324,6 +324,217 @@ int launch_logits_bwd_fused(int n, int k, const float *a, const float *b, const 
     return PTV2_OK;
 }
 
+// ---- G = 6 (the full-resolution level, C = 48; k = 16): the same launch for 24-byte rows --------------------------------
+// A point's W1 / gW1 block is 16 x 6 floats = 24 float4: lanes 0..23 load it in one coalesced request each, form gWt in the
+// loaded layout (the same fused multiply-add: bit-identical to the rows kernel), store it for the gather kernel and drop
+// it into a wave-private LDS record from which every lane picks its two operand layouts.  The contraction index of the
+// D product is mapped g = (lane >> 4) + 4 j, so the six groups take two MFMAs (j = 0, 1) instead of the four a 16-wide g
+// tile costs.  One wavefront per point; the four wavefronts of a workgroup add their registers up in LDS at the end.
+template <int C>
+__global__ __launch_bounds__(256) void logits_bwd_fused6_kernel(int n, const float *__restrict__ a, const float *__restrict__ b,
+                                                                const float *__restrict__ M, const float *__restrict__ coord,
+                                                                const int *__restrict__ idx, const float *__restrict__ W1,
+                                                                const float *__restrict__ gW1, const double *__restrict__ gT1,
+                                                                const double *__restrict__ gT2, float *__restrict__ gWt,
+                                                                float *__restrict__ part, FoldWBwdArgs F) {
+    constexpr int G = 6, UT = C / 16, PER = G + 4, REC = C * PER + 16, ROW = 16 * G;
+    static_assert(C % 16 == 0, "a wavefront owns whole 16-channel tiles");
+    extern __shared__ float4 lds4[];
+    float4 *sAB = lds4;                          // [C] (a.xyz, b)
+    float4 *sPos = sAB + C;                      // [4 waves][2][16] wave-private position records
+    float *sC1 = (float *)(sPos + 4 * 2 * 16);   // [16]
+    float *sC2 = sC1 + 16;                       // [16]
+    float *sRow = sC2 + 16;                      // [4 waves][ROW] gWt of the wavefront's current point
+    float *sFin = sRow + 4 * ROW;                // [REC]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+
+    for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
+    if (tid < 16) {  // c1 = gT1, c2 = 2 gT2: the two statistics paths of BN_w folded into every row gradient
+        float c1 = 0.f, c2 = 0.f;
+        if (tid < G) {
+            if (F.gsc) {
+                double t1, t2;
+                float gg, gb_;
+                fold_w_bwd_channel(F, tid, t1, t2, gg, gb_);
+                c1 = (float)t1;
+                c2 = 2.f * (float)t2;
+                if (blockIdx.x == 0) { F.ggamma[tid] = gg; F.gbeta[tid] = gb_; }
+            } else {
+                c1 = (float)gT1[tid];
+                c2 = 2.f * (float)gT2[tid];
+            }
+        }
+        sC1[tid] = c1;
+        sC2[tid] = c2;
+    }
+    for (int e = tid; e < REC; e += 256) sFin[e] = 0.f;
+    __syncthreads();
+
+    // folding constants of the loader layout: element e of float4 number `lane` is group (4 lane + e) % 6
+    float c1L[4], c2L[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { c1L[e] = sC1[(4 * lane + e) % G]; c2L[e] = sC2[(4 * lane + e) % G]; }
+    // M fragments (B operand of the D product): channel 16 u + l15, group q + 4 j
+    float mreg[UT][2];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        mreg[u][0] = M[(size_t)(16 * u + l15) * G + q];
+        mreg[u][1] = q < 2 ? M[(size_t)(16 * u + l15) * G + 4 + q] : 0.f;
+    }
+    float4 accAB[UT];
+    v4f accM[UT];
+    float tcw = 0.f;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) { accAB[u] = make_float4(0.f, 0.f, 0.f, 0.f); accM[u] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+
+    const long long stride = (long long)gridDim.x * 4;
+    float4 *myPos = sPos + wid * 32;
+    float *myRow = sRow + wid * ROW;
+    // Every load of the loop is UNCONDITIONAL (indices clamped to something valid, the value masked afterwards): a load
+    // inside a divergent `if` splits the loop into basic blocks, and the compiler then waits with vmcnt(0) at every join --
+    // the next point's rows, requested a few instructions earlier, were waited for on the spot (2.7 us per point).
+    const long long last = (long long)n - 1;
+    const int l16 = lane & 15, l24 = lane < ROW / 4 ? lane : ROW / 4 - 1;
+    // (and a value that is only used under a divergent condition gets its load sunk into that branch: the four lane
+    // quarters therefore all carry slot l16's id and position and all write the -- identical -- position record)
+    auto load_idx = [&](long long pt) -> int {  // beyond the end: the last point's ids (valid, never used)
+        return idx[(pt < n ? pt : last) * 16 + l16];
+    };
+    struct Raw { float sx, sy, sz, px, py, pz; bool ok; };
+    auto load_raw = [&](long long pt, int src) -> Raw {
+        const long long ps = src >= 0 ? src : 0, pp = pt < n ? pt : last;
+        Raw r;
+        r.sx = coord[3 * ps]; r.sy = coord[3 * ps + 1]; r.sz = coord[3 * ps + 2];
+        r.px = coord[3 * pp]; r.py = coord[3 * pp + 1]; r.pz = coord[3 * pp + 2];
+        r.ok = pt < n && src >= 0;
+        return r;
+    };
+    auto rel_of = [](const Raw &r) { return r.ok ? make_float4(r.sx - r.px, r.sy - r.py, r.sz - r.pz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f); };
+    float4 wn, gn;
+    auto load_rows = [&](long long pt) {
+        const size_t o = (size_t)(pt < n ? pt : last) * ROW + 4 * l24;
+        wn = *(const float4 *)(W1 + o);
+        gn = *(const float4 *)(gW1 + o);
+    };
+    const long long pt0 = (long long)blockIdx.x * 4 + wid;
+    load_rows(pt0);
+    int idx_n = load_idx(pt0 + stride);
+    {
+        const float4 r0 = rel_of(load_raw(pt0, load_idx(pt0)));
+        myPos[l16] = r0;
+    }
+    int cur = 0;
+    for (long long pt = pt0; pt < n; pt += stride, cur ^= 1) {  // (no workgroup barrier inside: trip counts differ per wavefront)
+        // ---- gWt of this point in the loaded layout: to the gather kernel's tensor and to the wave-private record
+        const float4 u4 = make_float4(__builtin_fmaf(wn.x, c2L[0], gn.x + c1L[0]), __builtin_fmaf(wn.y, c2L[1], gn.y + c1L[1]),
+                                      __builtin_fmaf(wn.z, c2L[2], gn.z + c1L[2]), __builtin_fmaf(wn.w, c2L[3], gn.w + c1L[3]));
+        if (lane < ROW / 4) {
+            *(float4 *)(gWt + (size_t)pt * ROW + 4 * lane) = u4;
+            *(float4 *)(myRow + 4 * lane) = u4;
+        }
+        // ---- requests for the next points
+        load_rows(pt + stride);
+        const Raw raw_n = load_raw(pt + stride, idx_n);
+        idx_n = load_idx(pt + 2 * stride);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the gWt record and position record `cur` of this wavefront are in LDS
+        // ---- the two operand layouts
+        const float uA0 = myRow[l15 * G + q];                       // (slot l15, group q + 4 j)
+        const float uA1r = myRow[l15 * G + 4 + (q & 1)];
+        const float uA1 = q < 2 ? uA1r : 0.f;
+        float uB[4];                                                // (slot 4 st + q, group l15)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const float t = myRow[(4 * st + q) * G + (l15 < G ? l15 : 0)];
+            uB[st] = l15 < G ? t : 0.f;
+            tcw += uB[st];
+        }
+        float4 rp[4], pq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { rp[r] = myPos[cur * 16 + 4 * q + r]; pq[r] = myPos[cur * 16 + 4 * r + q]; }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+            const float4 ab = sAB[16 * u + l15];
+            v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
+            d = mfma4l(uA0, mreg[u][0], d);  // D (s, ch) = gWt (s, g) M^T (g, ch)
+            d = mfma4l(uA1, mreg[u][1], d);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {  // gM (ch, g) += P^T gWt: contraction over the slots s = 4 st + q
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, pq[st].x, pq[st].y, pq[st].z);
+                accM[u] = mfma4l(P, uB[st], accM[u]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // rows s = 4 q + r of column ch
+                const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rp[r].x, rp[r].y, rp[r].z);
+                const float gpre = P > 0.f ? d[r] : 0.f;
+                accAB[u].x = __builtin_fmaf(gpre, rp[r].x, accAB[u].x);
+                accAB[u].y = __builtin_fmaf(gpre, rp[r].y, accAB[u].y);
+                accAB[u].z = __builtin_fmaf(gpre, rp[r].z, accAB[u].z);
+                accAB[u].w += gpre;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // every read of the two records is done before they are written again
+        myPos[(cur ^ 1) * 16 + l16] = rel_of(raw_n);
+    }
+
+    // ---- workgroup record: [C][G+4] = gM row, ga.xyz, gb; then gcW -- the four wavefronts in turn (fixed order)
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+        accAB[u].x += __shfl_xor(accAB[u].x, 16, WAVE); accAB[u].x += __shfl_xor(accAB[u].x, 32, WAVE);
+        accAB[u].y += __shfl_xor(accAB[u].y, 16, WAVE); accAB[u].y += __shfl_xor(accAB[u].y, 32, WAVE);
+        accAB[u].z += __shfl_xor(accAB[u].z, 16, WAVE); accAB[u].z += __shfl_xor(accAB[u].z, 32, WAVE);
+        accAB[u].w += __shfl_xor(accAB[u].w, 16, WAVE); accAB[u].w += __shfl_xor(accAB[u].w, 32, WAVE);
+    }
+    tcw += __shfl_xor(tcw, 16, WAVE);
+    tcw += __shfl_xor(tcw, 32, WAVE);
+    __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wid == turn) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (l15 < G) sFin[(16 * u + 4 * q + r) * PER + l15] += accM[u][r];
+                if (q == 0) {
+                    float *d = sFin + (16 * u + l15) * PER + G;
+                    d[0] += accAB[u].x; d[1] += accAB[u].y; d[2] += accAB[u].z; d[3] += accAB[u].w;
+                }
+            }
+            if (q == 0) sFin[C * PER + l15] += tcw;
+        }
+        __syncthreads();
+    }
+    float *rec = part + (size_t)blockIdx.x * REC;
+    for (int e = tid; e < REC; e += 256) rec[e] = sFin[e];
+}
+
+template <int C>
+int launch_logits_bwd_fused6(int n, const float *a, const float *b, const float *M, const float *coord, const int *idx,
+                             const float *W1, const float *gW1, const double *gT1, const double *gT2, const FoldWBwdArgs &F,
+                             float *gWt, float *part, size_t part_floats_avail, float *gM, float *ga, float *gb, float *gcW,
+                             hipStream_t st) {
+    constexpr int REC = C * 10 + 16;
+    const size_t lds = sizeof(float4) * (C + 4 * 2 * 16) + sizeof(float) * (2 * 16 + 4 * 96 + REC);
+    auto kern = logits_bwd_fused6_kernel<C>;
+    static int resident = 0;  // exactly the co-resident workgroups, as launch_logits_bwd_fused
+    if (!resident) {
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        static const int cap = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6_WGS"); return e ? atoi(e) : 1024; }();
+        resident = std::max(64, std::min(occ * cus, cap));
+    }
+    const long long groups = ((long long)n + 3) / 4;
+    long long cap = std::min<long long>(resident, (long long)(part_floats_avail / REC));
+    if (cap < 1) return PTV2_ERR_WORKSPACE;
+    const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, a, b, M, coord, idx, W1, gW1, gT1, gT2, gWt, part, F);
+    launch_finalize(st, (const float *)part, nblk, REC, MapLogitsFused{gM, ga, gb, gcW, 6, C});
+    return PTV2_OK;
+}
+
 }  // namespace gva
 
 // 1 when (k, c, g) has an instantiation of the fused rows + parameter-gradient kernel
@@ -331,6 +542,10 @@ int gva_logits_bwd_fused_supported(int k, int c, int g) {
     if (k < 1 || k > 16) return 0;
     // (64, 512) -- the ScanNet cfg's deepest level, a few dozen points -- would need 128 accumulator registers per lane and
     // spills: it stays on the staged kernels of gva_bwd.hip
+    if (g == 6 && c == 48) {  // (24-byte rows: float4 loads of a point's block need k = 16)
+        static const bool off = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6"); return e && e[0] == '0'; }();
+        return k == 16 && !off;
+    }
     return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
 }
 
@@ -340,6 +555,8 @@ int gva_logits_bwd_fused_launch(int n, int k, int c, int g, const float *a, cons
                                 float *gb, float *gcW, hipStream_t st) {
     using namespace gva;
 #define ARGS n, k, a, b, M, coord, idx, W1, gW1, gT1, gT2, F, gWt, part, part_floats_avail, gM, ga, gb, gcW, st
+    if (g == 6 && c == 48)
+        return launch_logits_bwd_fused6<48>(n, a, b, M, coord, idx, W1, gW1, gT1, gT2, F, gWt, part, part_floats_avail, gM, ga, gb, gcW, st);
     if (g == 12 && c == 96) return launch_logits_bwd_fused<12, 96, 1>(ARGS);
     if (g == 24 && c == 192) return launch_logits_bwd_fused<24, 192, 4>(ARGS);  // (2 waves per point: 306 registers, 1 wave / SIMD)
     if (g == 48 && c == 384) return launch_logits_bwd_fused<48, 384, 4>(ARGS);
@@ -555,6 +772,10 @@ int gva_logits_fwd_mfma_supported(int k, int c, int g) {
     // in use the epilogue stores 24-byte segments from 6 lanes); stays behind the knob
     static const bool narrow = [] { const char *e = getenv("AO_AMD_LOGITS_FWD6"); return e && e[0] == '1'; }();
     if (g == 6 && c == 48) return narrow ? 1 : 0;
+    if (g == 6 && c == 48) {  // (24-byte rows: float4 loads of a point's block need k = 16)
+        static const bool off = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6"); return e && e[0] == '0'; }();
+        return k == 16 && !off;
+    }
     return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
 }
 

@@ -69,7 +69,7 @@ struct BwdPointCfg {
 };
 
 // part[blockIdx.x][PF]: [4C] (ga.xyz, gb) per channel, [G] gsc, [G] gsh, [G*G] gWw2, [G] gbw2
-template <int G, int C, int NW>
+template <int G, int C, int NW, bool LOCAL>
 __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bwd_point_kernel(
     int n, int k, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     // g_sw = <g_out, bp2>_group -- the backward of the grouped projection -- are formed per point in LDS instead of
     // being read from the (N,G,C) tensor a separate launch would have to write (276 of this kernel's ~600 MB at
     // 120 k points, plus that launch)
-    const bool local = NW == 1 && Wp2 != nullptr;
+    // (a template parameter: as a run-time flag every g_A operand was `local ? LDS pointer : global pointer`, i.e. a flat load
+    // in a basic block of its own)
+    constexpr bool local = LOCAL;
+    static_assert(!LOCAL || NW == 1, "the local form needs the point's g_out row in one wavefront");
     constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PW = K::PW, CW = K::CW, CS = K::CS, UT = K::UT, I = K::I,
                   PF = K::PF, LT = K::LT, NTW = K::NTW;
     extern __shared__ float4 lds4[];
@@ -146,50 +149,54 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     // the top of iteration i and lands in registers while point i is processed; the staged part moves to the other
     // half of a double-buffered LDS record at the end of the iteration.  Without this a point costs four serialised
     // HBM latencies (idx -> coord -> W1 -> g_A / v) and the kernel is latency-bound at ~3 waves per SIMD.
+    //
+    // Every global load of the loop is UNCONDITIONAL: indices are clamped to something valid, masked lanes read a zero pad
+    // or have their value discarded where it is consumed one trip later.  A load under a divergent condition (`cond ? *p :
+    // 0`) becomes a basic block of its own, and the compiler's wait-count insertion then drains the whole memory queue
+    // (s_waitcnt vmcnt(0)) at every such join: round 2's form of this loop paid ~15 serialised L2 round trips per point
+    // (the twelve g_A operand loads of the (ga, gb) product one by one), 5.2 us per point and wavefront.  For the same
+    // reason nothing that is prefetched is consumed under a condition in the SAME trip (the load would be sunk to its use):
+    // the staged record is written to LDS at the top of the next trip, by all four lane quarters (identical values).
     constexpr int GOV = (C + WAVE - 1) / WAVE;
-    struct Stage { float x, y, z; int src; float go[GOV]; float gsw; };
-    auto stage_load = [&](long long ptn, bool actn, Stage &S) {
-        S.x = S.y = S.z = 0.f; S.src = -1; S.gsw = 0.f;
+    struct Stage { float sx, sy, sz, px, py, pz; int src; float go[GOV]; float gsw; };  // raw; masked by stage_store
+    const long long lastp = (long long)n - 1;
+    const int lk = l15 < k ? l15 : 0;
+    const int lg = lane % G16 < G ? lane % G16 : 0;
+    const float *gswp = g_sw ? g_sw : g_out;  // (a valid address either way)
+    const float *zpad = ptv2_zero_pad;
+    auto stage_load = [&](long long ptn, Stage &S) {
+        const long long pn = ptn < n ? ptn : lastp;
+        S.src = idx[pn * k + lk];
+        const long long ss = S.src >= 0 ? S.src : 0;
+        S.sx = coord[3 * ss]; S.sy = coord[3 * ss + 1]; S.sz = coord[3 * ss + 2];
+        S.px = coord[3 * pn]; S.py = coord[3 * pn + 1]; S.pz = coord[3 * pn + 2];
 #pragma unroll
-        for (int i = 0; i < GOV; ++i) S.go[i] = 0.f;
-        if (sub == 0 && actn) {
-            if (lane < 16 && lane < k) {
-                const Rel r = rel_pos(coord, idx, ptn * k + lane, (int)ptn);
-                S.x = r.x; S.y = r.y; S.z = r.z; S.src = r.src;
-            }
-#pragma unroll
-            for (int i = 0; i < GOV; ++i)
-                if (lane + WAVE * i < C) S.go[i] = g_out[ptn * C + lane + WAVE * i];
-            if (lane < G && g_sw) S.gsw = g_sw[ptn * G + lane];
-        }
+        for (int i = 0; i < GOV; ++i) S.go[i] = g_out[pn * C + (lane + WAVE * i) % C];
+        S.gsw = gswp[pn * G + lg];
     };
-    auto stage_store = [&](int buf, const Stage &S) {
-        if (sub == 0) {
-            if (lane < 16) {
-                sPos[(buf * PW + p) * 16 + lane] = make_float4(S.x, S.y, S.z, 0.f);
-                sSrc[(buf * PW + p) * 16 + lane] = S.src;
-            }
+    auto stage_store = [&](int buf, long long ptn, const Stage &S, float4 &mypos, int &mysrc) {
+        const bool actn = ptn < n, okl = actn && l15 < k, oks = okl && S.src >= 0;
+        mypos = oks ? make_float4(S.sx - S.px, S.sy - S.py, S.sz - S.pz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        mysrc = okl ? S.src : -1;
+        sPos[(buf * PW + p) * 16 + l15] = mypos;
+        sSrc[(buf * PW + p) * 16 + l15] = mysrc;
 #pragma unroll
-            for (int i = 0; i < GOV; ++i)
-                if (lane + WAVE * i < C) sGo[(buf * PW + p) * C + lane + WAVE * i] = S.go[i];
-            if (lane < G16) sGsw[(buf * PW + p) * G16 + lane] = S.gsw;
-        }
+        for (int i = 0; i < GOV; ++i) sGo[(buf * PW + p) * C + (lane + WAVE * i) % C] = actn ? S.go[i] : 0.f;
+        sGsw[(buf * PW + p) * G16 + lane % G16] = (actn && g_sw && lane % G16 < G) ? S.gsw : 0.f;
     };
-    auto load_w1 = [&](long long ptn, bool actn, float (&u)[GT][4]) {
+    auto load_w1 = [&](long long ptn, float (&u)[GT][4]) {
+        const long long pn = ptn < n ? ptn : lastp;
+        const float *row = W1 + (pn * k + lk) * G;
 #pragma unroll
         for (int t = 0; t < GT; ++t) {
             const int j0 = 16 * t + 4 * q;
-            float4 uu = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (actn && l15 < k) {
-                const float *src = W1 + (ptn * k + l15) * G + j0;
-                if (G % 4 == 0) {
-                    if (j0 < G) uu = *(const float4 *)src;
-                } else {
-                    if (j0 < G) { const float2 t2 = *(const float2 *)src; uu.x = t2.x; uu.y = t2.y; }
-                    if (j0 + 2 < G) { const float2 t2 = *(const float2 *)(src + 2); uu.z = t2.x; uu.w = t2.y; }
-                }
+            if (G % 4 == 0) {
+                const float4 uu = *(const float4 *)(row + (j0 < G ? j0 : 0));
+                u[t][0] = uu.x; u[t][1] = uu.y; u[t][2] = uu.z; u[t][3] = uu.w;
+            } else {
+                const float2 lo = *(const float2 *)(row + (j0 < G ? j0 : 0)), hi = *(const float2 *)(row + (j0 + 2 < G ? j0 + 2 : 0));
+                u[t][0] = lo.x; u[t][1] = lo.y; u[t][2] = hi.x; u[t][3] = hi.y;
             }
-            u[t][0] = uu.x; u[t][1] = uu.y; u[t][2] = uu.z; u[t][3] = uu.w;
         }
     };
 
@@ -198,9 +205,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     float u1n[GT][4];
     {
         const long long pt0 = (long long)blockIdx.x * PW + p;
-        stage_load(pt0, pt0 < n, S);
-        stage_store(0, S);
-        load_w1(pt0, pt0 < n, u1n);
+        stage_load(pt0, S);
+        load_w1(pt0, u1n);
     }
     // NW == 1: a wavefront owns its point slot outright -- every LDS record it touches inside the loop (position /
     // g_out records, its g_A tile, the gz / y transposes) is private to it, so the points of the four wavefronts of a
@@ -215,18 +221,18 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             __syncthreads();
         }
     };
-    __syncthreads();  // the parameters and the first records are in LDS
+    __syncthreads();  // the parameters are in LDS
     int cur = 0;
     for (long long base = (long long)blockIdx.x * PW; base < n; base += stride, cur ^= 1) {
         const long long pt = base + p;
         const bool act = pt < n;
-        point_sync();  // record `cur` is in LDS; last trip's readers are done
+        float4 myp;
+        int mysrc;
+        stage_store(cur, pt, S, myp, mysrc);  // this trip's record (requested one trip ago), written by every lane quarter
+        point_sync();                         // record `cur` is in LDS; last trip's readers are done
         const float4 *cPos = sPos + (cur * PW + p) * 16;
-        const int *cSrc = sSrc + (cur * PW + p) * 16;
         const float *cGo = sGo + (cur * PW + p) * C;
         const float *cGsw = sGsw + (cur * PW + p) * G16;
-        const float4 myp = cPos[l15];
-        const int mysrc = cSrc[l15];
         const bool valid = mysrc >= 0;
         const bool rowok = act && l15 < k;
         const long long row = pt * k + l15;
@@ -258,38 +264,33 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         // q CS, round 2) every instruction touched 64 distinct lines and ran at 2.9 TB/s instead of 4.7
         // (tools/probes/read_pattern_probe.hip)
         const int chq = c0 + 4 * q;
-        const float *vrow = v + (long long)(valid ? mysrc : 0) * C + chq;
+        const float *vrow = (valid && act) ? v + (long long)mysrc * C + chq : zpad;  // (masked lanes read the zero pad)
         const float *garow[GT];
-        bool gaok[GT];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) {
             const int g = 16 * tg + l15;
-            gaok[tg] = act && g < G;
-            garow[tg] = g_A + ((pt * G + (gaok[tg] ? g : 0)) * C + chq);
+            garow[tg] = (act && g < G) ? g_A + ((pt * G + g) * C + chq) : zpad;
         }
         constexpr int NCH = CS / 4;                                   // channel chunks of 4 contraction steps
-        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : 1;  // chunks in flight (registers: GT >= 2 is at the limit)
+        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (NCH < 2 ? NCH : 2);  // chunks in flight (registers: GT >= 2 is near the limit)
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
-            rvv[slot] = (valid && act) ? *(const float4 *)(vrow + 16 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rvv[slot] = *(const float4 *)(vrow + 16 * ci);
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) {
                 if (local) rga[slot][tg] = *(const float4 *)(myGA + (16 * tg + l15) * C + chq + 16 * ci);
-                else rga[slot][tg] = gaok[tg] ? *(const float4 *)(garow[tg] + 16 * ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else rga[slot][tg] = *(const float4 *)(garow[tg] + 16 * ci);
             }
         };
 #pragma unroll
         for (int ci = 0; ci < PD; ++ci) fetch_chunk(ci, ci);
-        {
-            const long long ptn = pt + stride;
-            stage_load(ptn, ptn < n, S);
-        }
         float u1[GT][4], y[GT][4];
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u1[t][r] = u1n[t][r];
-        load_w1(pt + stride, pt + stride < n, u1n);
+            for (int r = 0; r < 4; ++r) u1[t][r] = (rowok && 16 * t + 4 * q + r < G) ? u1n[t][r] : 0.f;
+        stage_load(pt + stride, S);
+        load_w1(pt + stride, u1n);
 
         // ---- y = ReLU(sc W1 + sh) in the layout lane = (s = l15; j = 16 t + 4 q + r)
 #pragma unroll
@@ -355,18 +356,41 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             }
         }
         // ---- (ga, gb) partial sums: gP (s,ch) = w g_A for my channel tiles, rows s = 4 q + r
+        // The B operand (g_A rows g = 16 tg + 4 q + r of column ch) of tile u + 1 is requested before tile u's products: left
+        // to the compiler each of the UT * GT * 4 four-byte loads was issued, waited for and consumed on its own -- 48
+        // serialised L2 round trips per point at (24, 192), the better part of that instance's 15 us per point.
+        const float *bvrow[GT][4];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int g = 16 * tg + 4 * q + r;
+                bvrow[tg][r] = local ? myGA + g * C + c0 + l15 : ((act && g < G) ? g_A + (pt * G + g) * C + c0 + l15 : zpad);
+            }
+        float bvn[GT][4];
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bvn[tg][r] = bvrow[tg][r][0];
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
             const int ch = c0 + 16 * u + l15;
+            float bv[GT][4];
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[tg][r] = bvn[tg][r];
+            if (u + 1 < UT) {
+#pragma unroll
+                for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bvn[tg][r] = bvrow[tg][r][16 * (u + 1)];
+            }
             v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int g = 16 * tg + 4 * q + r;
-                    const float bv = local ? myGA[g * C + ch] : ((act && g < G) ? g_A[(pt * G + g) * C + ch] : 0.f);
-                    d = mfma4(wm[tg][r], bv, d);
-                }
+                for (int r = 0; r < 4; ++r) d = mfma4(wm[tg][r], bv[tg][r], d);
             const float4 ab = sAB[ch];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -451,7 +475,6 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 }
             }
         }
-        stage_store(cur ^ 1, S);  // the next point's record (requested at the top of this iteration)
         // ---- gWw2 (g,j) += gz^T y, gbw2 += sum_s gz: contraction over s needs the (g,s) tiles transposed
         if (sub == 0) {
 #pragma unroll
@@ -922,13 +945,15 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
                      float *ga, float *gb, float *part, size_t part_floats_avail, hipStream_t st, const float *Wp2,
                      const float *bp2) {
     using K = BwdPointCfg<G, C, NW>;
-    const bool local = NW == 1 && Wp2 != nullptr;
+    constexpr bool HAS_LOCAL = G == 6 && C == 48 && NW == 1;  // the one instance where it pays (gva_bwd_point_local)
+    const bool local = Wp2 != nullptr;
+    if (local && !HAS_LOCAL) return PTV2_ERR_ARG;
     const size_t lds = sizeof(float) * (K::lds_floats + (local ? (size_t)C * C + C + 4 * (size_t)K::G16 * C + 4 * K::G16 : 0));
     // grid: exactly the workgroups that are resident at once (occupancy x CUs, at most 512).  Every workgroup stages
     // its weights once and then walks its points; any grid that is not co-resident runs a second, partly empty round
     // (measured at 120 k points, (6,48): 340 us at 512 workgroups, 406 at 1280, 468 at 640; (24,192) at 4.5 k
     // points: 92 / 116 / 111 us)
-    auto kern = attention_bwd_point_kernel<G, C, NW>;
+    auto kern = (HAS_LOCAL && local) ? attention_bwd_point_kernel<G, C, NW, HAS_LOCAL> : attention_bwd_point_kernel<G, C, NW, false>;
     static int resident[2] = {0, 0};
     if (!resident[local]) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -387,7 +387,7 @@ def test_plan_follows_rehomed_parameters_and_buffers():
         assert not torch.allclose(y3, y2) and torch.allclose(twin([coord, feat, off], idx)[1], y3, atol=1e-6)
 
 
-@pytest.mark.parametrize("n,c,g", [(3000, 96, 12), (4501, 192, 24), (1074, 384, 48)])
+@pytest.mark.parametrize("n,c,g", [(3000, 96, 12), (4501, 192, 24), (1074, 384, 48), (20011, 48, 6), (51, 48, 6)])
 def test_fused_logits_backward_equals_the_staged_kernels(monkeypatch, n, c, g):
     """gva_bwd_logits.hip (round 3): rows + parameter gradients of the logits stage in one pipelined MFMA launch, against the
     three staged kernels of gva_bwd.hip (AO_AMD_LOGITS_BWD=staged) inside the same native Block.  The row gradient gWt is
