@@ -54,6 +54,17 @@ __device__ __forceinline__ ptv2_bf16x8 ptv2_pack_bf16(float4 lo, float4 hi) {  /
     return r;
 }
 
+// Target of masked loads: `*(ok ? p : (const T *)ptv2_zero_pad)` keeps a kernel's loads UNCONDITIONAL and still reads 0 in the
+// masked lanes.  A load under a divergent condition (`ok ? *p : 0`) cannot be speculated by the compiler: it becomes a basic
+// block of its own, and the wait-count insertion then drains the whole memory queue (s_waitcnt vmcnt(0)) at the join, i.e.
+// one exposed memory round trip per such load (tools/isa_waits.py counts them).  Zero-initialised, never written;
+// offsets up to 1024 floats are valid.
+static __device__ __attribute__((aligned(16), unused)) float ptv2_zero_pad[1024];
+template <class T>
+__device__ __forceinline__ T ptv2_ld_or_zero(const T *p, bool ok) {
+    return *(ok ? p : (const T *)ptv2_zero_pad);
+}
+
 // Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
 #define PTV2_NUM_COUNTERS 64
 enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE, CNT_BN_TILES = 16 /* .. + 31 */ };

@@ -88,8 +88,8 @@ __device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long lo
     for (int t = 0; t < NT; ++t) {
         const int col = n0 + t * 16 + (lane >> 4) * 4;
         float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        if (bias && col < n) {
-            const float4 bb = *(const float4 *)(bias + col);
+        {
+            const float4 bb = ptv2_ld_or_zero((const float4 *)(bias + col), bias && col < n);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
         }
         val[t] = v;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
         for (int j = 0; j < XLOADS; ++j) {
             const int q = tid + j * THREADS, r = q / KQ, kq = (q % KQ) * 4;
             const long long row = row0 + r;
-            rx[j] = (row < m && k0 + kq < k) ? *(const float4 *)(X + row * k + k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[j] = ptv2_ld_or_zero((const float4 *)(X + row * k + k0 + kq), row < m && k0 + kq < k);
             if (multi.xsc && k0 + kq < k) {
                 const float4 s4 = *(const float4 *)(multi.xsc + k0 + kq), h4 = *(const float4 *)(multi.xsh + k0 + kq);
                 rx[j].x = fmaxf(__builtin_fmaf(rx[j].x, s4.x, h4.x), 0.f);
@@ -248,11 +248,10 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
 #pragma unroll
         for (int j = 0; j < WLOADS; ++j) {
             const int q = tid + j * THREADS;
-            rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < WQ) {
+            {  // (every load unconditional: see ptv2_zero_pad)
                 if (!W_KMAJOR) {
                     const int r = q / KQ, kq = (q % KQ) * 4;
-                    if (n0 + r < n && k0 + kq < k) rw[j] = *(const float4 *)(W + (long long)(n0 + r) * k + k0 + kq);
+                    rw[j] = ptv2_ld_or_zero((const float4 *)(W + (long long)(n0 + r) * k + k0 + kq), q < WQ && n0 + r < n && k0 + kq < k);
                 } else {
                     // consecutive lanes take consecutive reduction indices of one column quad: the transposing LDS store
                     // below then writes consecutive addresses (conflict-free).  With the lanes along the columns (the
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
                     // (profiles/r02_final_sq_counters.jsonl).  W is at most 1 MB and L2-resident; 16-byte pieces of it
                     // per lane cost less than the 6-way store conflict.
                     const int kk = q % KC, cq = (q / KC) * 4;
-                    if (k0 + kk < k && n0 + cq < n) rw[j] = *(const float4 *)(W + (long long)(k0 + kk) * n + n0 + cq);
+                    rw[j] = ptv2_ld_or_zero((const float4 *)(W + (long long)(k0 + kk) * n + n0 + cq), q < WQ && k0 + kk < k && n0 + cq < n);
                 }
             }
         }
@@ -398,22 +397,55 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_direct_kernel(int m, int n,
         }
         // my row of X: every load of the strip requested before anything waits
         float4 x[QF];
-        const float *xr = X + (rv ? row : 0) * K + 4 * q;
+        const float *xr = rv ? X + row * K + 4 * q : ptv2_zero_pad;  // (rows past the end read the zero pad: no branch per load)
 #pragma unroll
-        for (int j = 0; j < QF; ++j) x[j] = rv ? *(const float4 *)(xr + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        // the weight block of this column block
+        for (int j = 0; j < QF; ++j) x[j] = *(const float4 *)(xr + 16 * j);
+        // the weight block of this column block: unrolled in batches of up to 8 unconditional loads, then the LDS stores
+        // (as a run-time loop every 16-byte piece was requested, waited for and stored on its own)
         if (!W_KMAJOR) {
-            for (int e = tid; e < BN * KQ; e += THREADS) {
-                const int r = e / KQ, k4 = e - r * KQ;
-                *(float4 *)(sW + (size_t)r * LDW + 4 * k4) =
-                    n0 + r < n ? *(const float4 *)(W + (long long)(n0 + r) * K + 4 * k4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            constexpr int WL = (BN * KQ + THREADS - 1) / THREADS;
+#pragma unroll
+            for (int b0 = 0; b0 < WL; b0 += 8) {
+                float4 w4[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (b0 + i < WL) {
+                        const int e = tid + (b0 + i) * THREADS, r = e / KQ, k4 = e - r * KQ;
+                        w4[i] = ptv2_ld_or_zero((const float4 *)(W + (long long)(n0 + r) * K + 4 * k4), e < BN * KQ && n0 + r < n);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (b0 + i < WL) {
+                        const int e = tid + (b0 + i) * THREADS, r = e / KQ, k4 = e - r * KQ;
+                        if (e < BN * KQ) *(float4 *)(sW + (size_t)r * LDW + 4 * k4) = w4[i];
+                    }
+                }
             }
         } else {
-            for (int e = tid; e < (BN / 4) * K; e += THREADS) {
-                const int kk = e % K, cq = (e / K) * 4;  // consecutive lanes: consecutive k of one column quad (conflict-free stores)
-                const float4 w4 = n0 + cq < n ? *(const float4 *)(W + (long long)kk * n + n0 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
-                sW[(size_t)(cq + 0) * LDW + kk] = w4.x; sW[(size_t)(cq + 1) * LDW + kk] = w4.y;
-                sW[(size_t)(cq + 2) * LDW + kk] = w4.z; sW[(size_t)(cq + 3) * LDW + kk] = w4.w;
+            constexpr int WL = ((BN / 4) * K + THREADS - 1) / THREADS;
+#pragma unroll
+            for (int b0 = 0; b0 < WL; b0 += 8) {
+                float4 w4[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (b0 + i < WL) {
+                        const int e = tid + (b0 + i) * THREADS;
+                        const int kk = e % K, cq = (e / K) * 4;  // consecutive lanes: consecutive k of one column quad (conflict-free stores)
+                        w4[i] = ptv2_ld_or_zero((const float4 *)(W + (long long)kk * n + n0 + cq), e < (BN / 4) * K && n0 + cq < n);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (b0 + i < WL) {
+                        const int e = tid + (b0 + i) * THREADS;
+                        const int kk = e % K, cq = (e / K) * 4;
+                        if (e < (BN / 4) * K) {
+                            sW[(size_t)(cq + 0) * LDW + kk] = w4[i].x; sW[(size_t)(cq + 1) * LDW + kk] = w4[i].y;
+                            sW[(size_t)(cq + 2) * LDW + kk] = w4[i].z; sW[(size_t)(cq + 3) * LDW + kk] = w4[i].w;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();

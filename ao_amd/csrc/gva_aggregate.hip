@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TPB) void aggregate_tile_kernel(int n, int k, int c
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int src = sSrc[p * 16 + s];
-                vv[s] = src >= 0 ? v[(long long)src * c + ch] : 0.f;
+                vv[s] = ptv2_ld_or_zero(v + (long long)src * c + ch, src >= 0);  // (unconditional: common.h, ptv2_zero_pad)
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) slot(s, vv[s]);
@@ -425,35 +425,36 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
         // the list is walked 8 entries at a time: slot ids first, then all weights and gradient rows, then the sums in
         // list order (an entry-by-entry loop pays three dependent memory latencies per entry)
         constexpr int UB = 8;
+        // (every load unconditional -- index clamped, -1 or'ed in / zero pad for the entries past the end: common.h,
+        // ptv2_zero_pad; as `cond ? load : x` each entry was a basic block of its own, drained one by one)
         int r[UB], rn[UB];
+        const int plast = p1 > 0 ? p1 - 1 : 0;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) r[u] = p0 + u < p1 ? inv_rows[p0 + u] : -1;
+        for (int u = 0; u < UB; ++u) r[u] = inv_rows[p0 + u < p1 ? p0 + u : plast] | (p0 + u < p1 ? 0 : -1);
         for (int p = p0; p < p1; p += UB) {
             float wv[UB], t[UB][V];
             // the slot ids of the NEXT batch travel with this batch's weights and gradient rows (one round trip less per
             // batch after the first)
 #pragma unroll
-            for (int u = 0; u < UB; ++u) rn[u] = p + UB + u < p1 ? inv_rows[p + UB + u] : -1;
+            for (int u = 0; u < UB; ++u) rn[u] = inv_rows[p + UB + u < p1 ? p + UB + u : plast] | (p + UB + u < p1 ? 0 : -1);
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                if (r[u] >= 0) {
-                    wv[u] = w[(long long)r[u] * g + gl];
-                    const float *go = g_out + (long long)(r[u] / k) * c + ch;
-                    if (V == 4) {
-                        const float4 q = *(const float4 *)go;
-                        t[u][0] = q.x; t[u][1 % V] = q.y; t[u][2 % V] = q.z; t[u][3 % V] = q.w;
-                    } else {
+                const bool ok = r[u] >= 0;
+                wv[u] = ptv2_ld_or_zero(w + (long long)r[u] * g + gl, ok);
+                const float *go = g_out + (long long)(r[u] / k) * c + ch;
+                if (V == 4) {
+                    const float4 q = ptv2_ld_or_zero((const float4 *)go, ok);
+                    t[u][0] = q.x; t[u][1 % V] = q.y; t[u][2 % V] = q.z; t[u][3 % V] = q.w;
+                } else {
 #pragma unroll
-                        for (int i = 0; i < V; ++i) t[u][i] = go[i];
-                    }
+                    for (int i = 0; i < V; ++i) t[u][i] = ptv2_ld_or_zero(go + i, ok);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < UB; ++u)
-                if (r[u] >= 0) {
+            for (int u = 0; u < UB; ++u) {  // (entries past the end add w = 0 times 0)
 #pragma unroll
-                    for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv[u], t[u][i], acc[i]);
-                }
+                for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv[u], t[u][i], acc[i]);
+            }
 #pragma unroll
             for (int u = 0; u < UB; ++u) r[u] = rn[u];
         }

@@ -115,51 +115,49 @@ __global__ __launch_bounds__(256) void logits_bwd_fused_kernel(int n, int k, con
     for (int t = 0; t < GT; ++t) tcw[t] = 0.f;
 
     // ---- loads of one point: rows of W1 / gW1 in the two operand layouts
+    // (every load of the loop is unconditional -- the zero pad of common.h for masked lanes, all four lane quarters carrying
+    // slot l15's id and position: see logits_bwd_fused6_kernel below)
     struct Rows { float4 wA[GT], gA[GT]; float wB[4][GT], gB[4][GT]; };
     auto load_rows = [&](long long pt, Rows &R) {
         const bool act = pt < n;
 #pragma unroll
         for (int t = 0; t < GT; ++t) {
             const int g0 = 16 * t + 4 * q;
-            R.wA[t] = R.gA[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act && l15 < k && g0 < G) {
-                const size_t o = ((size_t)pt * k + l15) * G + g0;
-                R.wA[t] = *(const float4 *)(W1 + o);
-                R.gA[t] = *(const float4 *)(gW1 + o);
-            }
+            const bool okA = act && l15 < k && g0 < G;
+            const size_t oA = ((size_t)pt * k + l15) * G + g0;
+            R.wA[t] = ptv2_ld_or_zero((const float4 *)(W1 + oA), okA);
+            R.gA[t] = ptv2_ld_or_zero((const float4 *)(gW1 + oA), okA);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int s = 4 * st + q, g = 16 * t + l15;
-                R.wB[st][t] = R.gB[st][t] = 0.f;
-                if (act && s < k && g < G) {
-                    const size_t o = ((size_t)pt * k + s) * G + g;
-                    R.wB[st][t] = W1[o];
-                    R.gB[st][t] = gW1[o];
-                }
+                const bool okB = act && s < k && g < G;
+                const size_t o = ((size_t)pt * k + s) * G + g;
+                R.wB[st][t] = ptv2_ld_or_zero(W1 + o, okB);
+                R.gB[st][t] = ptv2_ld_or_zero(gW1 + o, okB);
             }
         }
     };
     const long long stride = (long long)gridDim.x * PW;
     float4 *myPos = sPos + wid * 32;
-    // neighbour ids two points ahead, coordinates one point ahead (lanes 0..15 of every wavefront: its own copy, no barrier)
-    auto load_idx = [&](long long pt) -> int { return (pt < n && lane < 16 && lane < k) ? idx[pt * k + lane] : -1; };
-    auto load_rel = [&](long long pt, int src) -> float4 {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pt < n && lane < 16 && src >= 0) {
-            r.x = coord[3 * (long long)src] - coord[3 * pt];
-            r.y = coord[3 * (long long)src + 1] - coord[3 * pt + 1];
-            r.z = coord[3 * (long long)src + 2] - coord[3 * pt + 2];
-        }
+    const long long lastp = (long long)n - 1;
+    const int lk = l15 < k ? l15 : 0;
+    // neighbour ids two points ahead, coordinates one point ahead (every lane quarter: its own copy, no barrier)
+    auto load_idx = [&](long long pt) -> int { return idx[(pt < n ? pt : lastp) * k + lk]; };
+    struct Raw { float sx, sy, sz, px, py, pz; bool ok; };
+    auto load_raw = [&](long long pt, int src) -> Raw {
+        const long long ps = src >= 0 ? src : 0, pp = pt < n ? pt : lastp;
+        Raw r;
+        r.sx = coord[3 * ps]; r.sy = coord[3 * ps + 1]; r.sz = coord[3 * ps + 2];
+        r.px = coord[3 * pp]; r.py = coord[3 * pp + 1]; r.pz = coord[3 * pp + 2];
+        r.ok = pt < n && l15 < k && src >= 0;
         return r;
     };
+    auto rel_of = [](const Raw &r) { return r.ok ? make_float4(r.sx - r.px, r.sy - r.py, r.sz - r.pz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f); };
     const long long pt0 = (long long)blockIdx.x * PW + p;
     Rows Rn;
     load_rows(pt0, Rn);
     int idx_n = load_idx(pt0 + stride);
-    {
-        const float4 r0 = load_rel(pt0, load_idx(pt0));
-        if (lane < 16) myPos[lane] = r0;
-    }
+    myPos[l15] = rel_of(load_raw(pt0, load_idx(pt0)));
     int cur = 0;
     for (long long pt = pt0; pt < n; pt += stride, cur ^= 1) {  // (no workgroup barrier inside: trip counts may differ per wavefront)
         const bool act = pt < n;
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(256) void logits_bwd_fused_kernel(int n, int k, con
         }
         // ---- requests for the next points
         load_rows(pt + stride, Rn);
-        const float4 rel_n = load_rel(pt + stride, idx_n);
+        const Raw raw_n = load_raw(pt + stride, idx_n);
         idx_n = load_idx(pt + 2 * stride);
         // ---- positions of this point in the two row layouts
         float4 rp[4], pq[4];
@@ -197,7 +195,7 @@ __global__ __launch_bounds__(256) void logits_bwd_fused_kernel(int n, int k, con
 #pragma unroll
             for (int t = 0; t < GT; ++t) {
                 const int g0 = 16 * t + 4 * q;
-                m[t] = g0 < G ? *(const float4 *)(M + (size_t)(c0 + 16 * u + l15) * G + g0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                m[t] = ptv2_ld_or_zero((const float4 *)(M + (size_t)(c0 + 16 * u + l15) * G + g0), g0 < G);
             }
         };
         if (!K::HOIST_M) load_m(0, mnext);
@@ -236,7 +234,7 @@ __global__ __launch_bounds__(256) void logits_bwd_fused_kernel(int n, int k, con
                 accAB[u].w += gpre;
             }
         }
-        if (lane < 16) myPos[(cur ^ 1) * 16 + lane] = rel_n;
+        myPos[(cur ^ 1) * 16 + l15] = rel_of(raw_n);  // (the other half of the double buffer: its readers finished a trip ago)
     }
 
     // ---- workgroup record: [C][G+4] = gM row, ga.xyz, gb; then gcW
@@ -618,22 +616,29 @@ __global__ __launch_bounds__(256) void logits_fwd_mfma_kernel(int n, int k, cons
     const long long stride = (long long)gridDim.x * PW;
     float4 *myPos = sPos + wid * 32;
     int *mySrc = sSrc + wid * 32;
-    auto load_idx = [&](long long pt) -> int { return (pt < n && lane < 16 && lane < k) ? idx[pt * k + lane] : -1; };
-    auto load_rel = [&](long long pt, int src) -> float4 {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pt < n && lane < 16 && src >= 0) {
-            r.x = coord[3 * (long long)src] - coord[3 * pt];
-            r.y = coord[3 * (long long)src + 1] - coord[3 * pt + 1];
-            r.z = coord[3 * (long long)src + 2] - coord[3 * pt + 2];
-        }
+    // (every load of the loop is unconditional, every lane quarter carries slot l15's id and position: see ptv2_zero_pad in
+    // common.h and logits_bwd_fused6_kernel above)
+    const long long lastp = (long long)n - 1;
+    const int lk = l15 < k ? l15 : 0;
+    auto load_idx = [&](long long pt) -> int { return idx[(pt < n ? pt : lastp) * k + lk]; };
+    struct Raw { float sx, sy, sz, px, py, pz; bool okl, oks; int src; };
+    auto load_raw = [&](long long pt, int src) -> Raw {
+        const long long ps = src >= 0 ? src : 0, pp = pt < n ? pt : lastp;
+        Raw r;
+        r.sx = coord[3 * ps]; r.sy = coord[3 * ps + 1]; r.sz = coord[3 * ps + 2];
+        r.px = coord[3 * pp]; r.py = coord[3 * pp + 1]; r.pz = coord[3 * pp + 2];
+        r.okl = pt < n && l15 < k;
+        r.oks = r.okl && src >= 0;
+        r.src = src;
         return r;
     };
+    auto rel_of = [](const Raw &r) { return r.oks ? make_float4(r.sx - r.px, r.sy - r.py, r.sz - r.pz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f); };
     const long long pt0 = (long long)blockIdx.x * PW + p;
     int idx_n = load_idx(pt0 + stride);
     {
-        const int i0 = load_idx(pt0);
-        const float4 r0 = load_rel(pt0, i0);
-        if (lane < 16) { myPos[lane] = r0; mySrc[lane] = i0; }
+        const Raw r0 = load_raw(pt0, load_idx(pt0));
+        myPos[l15] = rel_of(r0);
+        mySrc[l15] = r0.okl ? r0.src : -1;
     }
     int cur = 0;
     // (NW > 1: the wavefronts of a point meet at a workgroup barrier, so every wavefront runs the workgroup's trip count)
@@ -650,16 +655,15 @@ __global__ __launch_bounds__(256) void logits_fwd_mfma_kernel(int n, int k, cons
         for (int f = 0; f < FT; ++f) {
             const int tg = f * NW + sub, g = 16 * tg + l15;
             const bool gok = tg < GT && g < G && act;
-            qv[f] = gok ? qW[pt * G + g] : 0.f;
+            qv[f] = ptv2_ld_or_zero(qW + pt * G + g, gok);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = 4 * q + r;
                 const int src = mySrc[cur * 16 + s];
-                kv[f][r] = (gok && s < k && src >= 0) ? kW[(long long)src * G + g] : 0.f;
+                kv[f][r] = ptv2_ld_or_zero(kW + (long long)src * G + g, gok && s < k && src >= 0);
             }
         }
-        const int src_n = idx_n;
-        const float4 rel_n = load_rel(pt + stride, src_n);
+        const Raw raw_n = load_raw(pt + stride, idx_n);
         idx_n = load_idx(pt + 2 * stride);
         // products: my channels
         v4f acc[GT];
@@ -712,7 +716,8 @@ __global__ __launch_bounds__(256) void logits_fwd_mfma_kernel(int n, int k, cons
                 }
             }
         }
-        if (lane < 16) { myPos[(cur ^ 1) * 16 + lane] = rel_n; mySrc[(cur ^ 1) * 16 + lane] = src_n; }
+        myPos[(cur ^ 1) * 16 + l15] = rel_of(raw_n);  // (all four lane quarters: identical values)
+        mySrc[(cur ^ 1) * 16 + l15] = raw_n.okl ? raw_n.src : -1;
         if (NW > 1) __syncthreads();  // sRed is rewritten by the next trip
     }
     // workgroup record [T1 (G) | T2 (G)]

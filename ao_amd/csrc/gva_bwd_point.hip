@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     const int lk = l15 < k ? l15 : 0;
     const int lg = lane % G16 < G ? lane % G16 : 0;
     const float *gswp = g_sw ? g_sw : g_out;  // (a valid address either way)
-    const float *zpad = ptv2_zero_pad;
+    const float *zpad = ptv2_zero_pad;  // (common.h)
     auto stage_load = [&](long long ptn, Stage &S) {
         const long long pn = ptn < n ? ptn : lastp;
         S.src = idx[pn * k + lk];

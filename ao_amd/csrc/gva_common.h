@@ -26,10 +26,6 @@ inline size_t part_floats(int c, int g) {
 }
 inline size_t rows_offset_bytes(int c, int g) { return align_up(sizeof(float) * part_floats(c, g)); }
 
-// Target of masked loads: `(ok ? p : ptv2_zero_pad)[i]` keeps a kernel's loads unconditional (no basic block per load, no
-// drained memory queue at the join) and still reads 0 in the masked lanes.  Zero-initialised, never written; i < 1024.
-static __device__ __attribute__((aligned(16), unused)) float ptv2_zero_pad[1024];
-
 // masked relative position of neighbour slot (n, s)
 struct Rel {
     float x, y, z;

@@ -133,9 +133,26 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
     const int g0 = blockIdx.y * gpw;
     const int ng = g - g0 < gpw ? g - g0 : gpw;     // groups of this workgroup
     const long long row0 = (long long)blockIdx.x * 64;
-    for (int e = tid; e < ng * 8 * (C / 4); e += TPB) {
-        const int r = e / (C / 4), c4 = e - r * (C / 4);
-        *(float4 *)(sW + (size_t)r * LDW + 4 * c4) = *(const float4 *)(Wp2 + ((size_t)g0 * 8 + r) * C + 4 * c4);
+    // (every global load of this kernel is unconditional -- clamped index or the zero pad, common.h: as `cond ? *p : 0` each one
+    // was a basic block of its own and the ring prefetch below was drained with vmcnt(0) at every stage)
+    {
+        constexpr int WL = (PEB_MAX_GPW * 8 * (C / 4) + TPB - 1) / TPB;
+#pragma unroll
+        for (int b0 = 0; b0 < WL; b0 += 8) {
+            float4 w4[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b0 + i < WL) {
+                    const int e = tid + (b0 + i) * TPB, r = e / (C / 4), c4 = e - r * (C / 4);
+                    w4[i] = ptv2_ld_or_zero((const float4 *)(Wp2 + ((size_t)g0 * 8 + r) * C + 4 * c4), r < ng * 8);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b0 + i < WL) {
+                    const int e = tid + (b0 + i) * TPB, r = e / (C / 4), c4 = e - r * (C / 4);
+                    if (r < ng * 8) *(float4 *)(sW + (size_t)r * LDW + 4 * c4) = w4[i];
+                }
+        }
     }
     const long long pt = row0 + wid * 16 + l15;
     const bool rv = pt < n;
@@ -146,24 +163,23 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
     const float *arow = A + ((size_t)(rv ? pt : 0) * g + g0) * C + 4 * q;
     auto fetch = [&](int item, float4 (&x)[CH]) {  // item = group * NCH + chunk
         const int gl = item / NCH, ck = item - gl * NCH;
+        // rows past the end read the zero pad; groups past this workgroup's last repeat group 0 (their products are dropped)
+        const float *src = rv ? arow + (size_t)(gl < ng ? gl : 0) * C : ptv2_zero_pad;
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            x[j] = (rv && gl < ng) ? *(const float4 *)(arow + (size_t)gl * C + 16 * (ck * CH + j)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < CH; ++j) x[j] = *(const float4 *)(src + 16 * (ck * CH + j));
     };
     float4 x[RING][CH];
 #pragma unroll
     for (int i = 0; i < DIST && i < ITEMS; ++i) fetch(i, x[i % RING]);
     // epilogue operands of every group of this workgroup, requested up front
-    float4 ovr[PEB_MAX_GPW];
+    float4 ovr[PEB_MAX_GPW], bbr[PEB_MAX_GPW];
     float swr[PEB_MAX_GPW];
 #pragma unroll
     for (int t = 0; t < PEB_MAX_GPW; ++t) {
-        ovr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        swr[t] = 0.f;
-        if (t < ng && rv && q < 2) {
-            ovr[t] = *(const float4 *)(out_v + (size_t)pt * C + (g0 + t) * 8 + 4 * q);
-            swr[t] = sw[(size_t)pt * g + g0 + t];
-        }
+        const bool ok = t < ng && rv && q < 2;
+        ovr[t] = ptv2_ld_or_zero((const float4 *)(out_v + (size_t)pt * C + (g0 + t) * 8 + 4 * q), ok);
+        swr[t] = ptv2_ld_or_zero(sw + (size_t)pt * g + g0 + t, ok);
+        bbr[t] = ptv2_ld_or_zero((const float4 *)(bp2 + (g0 + t) * 8 + 4 * q), ok);
     }
     __syncthreads();
     float4 val[PEB_MAX_GPW];
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (rv && q < 2 && gl < ng) {
                 const int col = (g0 + gl) * 8 + 4 * q;
-                const float4 bb = *(const float4 *)(bp2 + col);
+                const float4 bb = bbr[gl];
                 const float4 ov = ovr[gl];
                 const float s = swr[gl];
                 v.x = ov.x + acc[0] + bb.x * s; v.y = ov.y + acc[1] + bb.y * s;
