@@ -222,6 +222,14 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         }
     };
     __syncthreads();  // the parameters are in LDS
+    // local form: column `lane` of Wp2 lives in registers for the whole launch (it was re-read from LDS for every point: 48
+    // of the ~100 LDS reads per point and lane at (6, 48))
+    static_assert(!LOCAL || C <= WAVE, "the local form keeps one Wp2 column per lane");
+    float wp2c[LOCAL ? C : 1];
+    if constexpr (LOCAL) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) wp2c[j] = sWp2[j * C + (lane < C ? lane : 0)];
+    }
     int cur = 0;
     for (long long base = (long long)blockIdx.x * PW; base < n; base += stride, cur ^= 1) {
         const long long pt = base + p;
@@ -240,15 +248,19 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int r = 0; r < 4; ++r) rp[r] = cPos[4 * q + r];
 
-        if (local) {  // g_A and g_sw of my point from its g_out row (in LDS) and Wp2 / bp2 (in LDS)
-            for (int cp = lane; cp < C; cp += WAVE) {
+        if constexpr (local) {  // g_A and g_sw of my point from its g_out row (in LDS) and Wp2 (registers) / bp2 (LDS)
+            float go[C];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    float acc = 0.f;
+            for (int j = 0; j < C / 4; ++j) {
+                const float4 t = *(const float4 *)(cGo + 4 * j);  // (the same address in every lane: a broadcast)
+                go[4 * j] = t.x; go[4 * j + 1] = t.y; go[4 * j + 2] = t.z; go[4 * j + 3] = t.w;
+            }
 #pragma unroll
-                    for (int i = 0; i < I; ++i) acc = __builtin_fmaf(cGo[g * I + i], sWp2[(g * I + i) * C + cp], acc);
-                    myGA[g * C + cp] = acc;
-                }
+            for (int g = 0; g < G; ++g) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < I; ++i) acc = __builtin_fmaf(go[g * I + i], wp2c[g * I + i], acc);
+                if (lane < C) myGA[g * C + lane] = acc;
             }
             if (lane < G) {
                 float acc = 0.f;
@@ -321,9 +333,11 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             for (int r = 0; r < 4; ++r) {
                 const float zz = l15 < k ? z[r] + bb[r] : -3.0e38f;
                 const float mx = row16_max(zz);
-                const float e = l15 < k ? expf(zz - mx) : 0.f;
+                // (the backward's re-evaluation of the softmax: hardware exp2 / reciprocal, ~1e-6 relative -- the correctly rounded
+                // expf and division were ~25 vector instructions per weight, a tenth of this loop at G = 6)
+                const float e = l15 < k ? __builtin_amdgcn_exp2f((zz - mx) * 1.44269504088896340736f) : 0.f;
                 const float den = row16_sum(e);
-                sm[tg][r] = e / den;
+                sm[tg][r] = e * __builtin_amdgcn_rcpf(den);
                 wm[tg][r] = valid ? sm[tg][r] : 0.f;
             }
         }
