@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     const int lg = lane % G16 < G ? lane % G16 : 0;
     const float *gswp = g_sw ? g_sw : g_out;  // (a valid address either way)
     const float *zpad = ptv2_zero_pad;  // (common.h)
-    auto stage_load = [&](long long ptn, Stage &S) {
+    auto load_ids = [&](long long ptn) -> int { return idx[(ptn < n ? ptn : lastp) * k + lk]; };  // (raw: slot l15 < k ? l15 : 0)
+    auto stage_load = [&](long long ptn, int srcv, Stage &S) {  // srcv: load_ids(ptn), requested a trip earlier
         const long long pn = ptn < n ? ptn : lastp;
-        S.src = idx[pn * k + lk];
+        S.src = srcv;
         const long long ss = S.src >= 0 ? S.src : 0;
         S.sx = coord[3 * ss]; S.sy = coord[3 * ss + 1]; S.sz = coord[3 * ss + 2];
         S.px = coord[3 * pn]; S.py = coord[3 * pn + 1]; S.pz = coord[3 * pn + 2];
@@ -203,9 +204,32 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     const long long stride = (long long)gridDim.x * PW;
     Stage S;
     float u1n[GT][4];
+    // Request distances: neighbour ids two points ahead; everything addressed by them (coordinates, and at the narrow
+    // instances the first v-row / g_A-row chunks: XPF) one point ahead.  The v rows are a gather from all over the cloud -- ~1 us
+    // from L2 / the Infinity Cache -- and were requested and consumed within the same trip of 4 us.
+    constexpr int NCH = CS / 4;                                   // channel chunks of 4 contraction steps
+    constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (NCH < 2 ? NCH : 2);  // chunks in flight (registers: GT >= 2 is near the limit)
+    constexpr bool XPF = GT == 1;
+    const int chq = c0 + 4 * q;
+    float4 rvvn[XPF ? PD : 1], rgan[XPF && !LOCAL ? PD : 1];
+    auto prefetch_chunks = [&](long long ptn, int srcv) {  // first PD chunks of point ptn (XPF only)
+        const bool actn = ptn < n;
+        const float *vr = (actn && l15 < k && srcv >= 0) ? v + (long long)srcv * C + chq : zpad;
+#pragma unroll
+        for (int ci = 0; ci < PD; ++ci) rvvn[ci] = *(const float4 *)(vr + 16 * ci);
+        if constexpr (!LOCAL) {
+            const float *gr = (actn && l15 < G) ? g_A + ((ptn * G + l15) * C + chq) : zpad;
+#pragma unroll
+            for (int ci = 0; ci < PD; ++ci) rgan[ci] = *(const float4 *)(gr + 16 * ci);
+        }
+    };
+    int src_n;
     {
         const long long pt0 = (long long)blockIdx.x * PW + p;
-        stage_load(pt0, S);
+        const int s0 = load_ids(pt0);
+        src_n = load_ids(pt0 + stride);
+        stage_load(pt0, s0, S);
+        if constexpr (XPF) prefetch_chunks(pt0, s0);
         load_w1(pt0, u1n);
     }
     // NW == 1: a wavefront owns its point slot outright -- every LDS record it touches inside the loop (position /
@@ -275,7 +299,6 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         // g_A row / a neighbour's v row read 64 contiguous bytes per instruction; with a contiguous run per lane (chq = c0 +
         // q CS, round 2) every instruction touched 64 distinct lines and ran at 2.9 TB/s instead of 4.7
         // (tools/probes/read_pattern_probe.hip)
-        const int chq = c0 + 4 * q;
         const float *vrow = (valid && act) ? v + (long long)mysrc * C + chq : zpad;  // (masked lanes read the zero pad)
         const float *garow[GT];
 #pragma unroll
@@ -283,8 +306,6 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             const int g = 16 * tg + l15;
             garow[tg] = (act && g < G) ? g_A + ((pt * G + g) * C + chq) : zpad;
         }
-        constexpr int NCH = CS / 4;                                   // channel chunks of 4 contraction steps
-        constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (NCH < 2 ? NCH : 2);  // chunks in flight (registers: GT >= 2 is near the limit)
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
             rvv[slot] = *(const float4 *)(vrow + 16 * ci);
@@ -294,14 +315,25 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 else rga[slot][tg] = *(const float4 *)(garow[tg] + 16 * ci);
             }
         };
+        if constexpr (XPF) {  // requested a trip ago
 #pragma unroll
-        for (int ci = 0; ci < PD; ++ci) fetch_chunk(ci, ci);
+            for (int ci = 0; ci < PD; ++ci) {
+                rvv[ci] = rvvn[ci];
+                if (local) rga[ci][0] = *(const float4 *)(myGA + l15 * C + chq + 16 * ci);
+                else rga[ci][0] = rgan[ci];
+            }
+        } else {
+#pragma unroll
+            for (int ci = 0; ci < PD; ++ci) fetch_chunk(ci, ci);
+        }
         float u1[GT][4], y[GT][4];
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) u1[t][r] = (rowok && 16 * t + 4 * q + r < G) ? u1n[t][r] : 0.f;
-        stage_load(pt + stride, S);
+        stage_load(pt + stride, src_n, S);
+        if constexpr (XPF) prefetch_chunks(pt + stride, src_n);
+        src_n = load_ids(pt + 2 * stride);
         load_w1(pt + stride, u1n);
 
         // ---- y = ReLU(sc W1 + sh) in the layout lane = (s = l15; j = 16 t + 4 q + r)
