@@ -849,29 +849,15 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
     // loader: thread -> float4 slots f = tid + 256 j (j < 3) of a 64 x 12 stage tile, for both operands
     constexpr int Q = WG_TILE / 4, SLOTS = WL_ROWS * Q / TPB;  // 12 float4 per row, 3 slots per thread
     float4 ra[SLOTS], rb[SLOTS];
+    // (cout and cin are multiples of 4 here -- wgrad_lds_ok: a 16-byte piece is inside the tile or outside it -- and every load
+    // is unconditional: rows past the chunk / pieces past the edge read the zero pad of common.h)
     auto fetch = [&](long long rs) {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
             const int f = tid + TPB * j, row = f / Q, c4 = (f - row * Q) * 4;
             const long long r = rs + row;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (r < r1) {
-                const float *pa = A + r * ldy + to + c4, *pb = B + r * ldx + ti + c4;
-                if (to + c4 + 3 < cout) va = *(const float4 *)pa;
-                else {
-                    if (to + c4 < cout) va.x = pa[0];
-                    if (to + c4 + 1 < cout) va.y = pa[1];
-                    if (to + c4 + 2 < cout) va.z = pa[2];
-                }
-                if (ti + c4 + 3 < cin) vb = *(const float4 *)pb;
-                else {
-                    if (ti + c4 < cin) vb.x = pb[0];
-                    if (ti + c4 + 1 < cin) vb.y = pb[1];
-                    if (ti + c4 + 2 < cin) vb.z = pb[2];
-                }
-            }
-            ra[j] = va;
-            rb[j] = vb;
+            ra[j] = ptv2_ld_or_zero((const float4 *)(A + r * ldy + to + c4), r < r1 && to + c4 < cout);
+            rb[j] = ptv2_ld_or_zero((const float4 *)(B + r * ldx + ti + c4), r < r1 && ti + c4 < cin);
         }
     };
     auto stash = [&](int buf) {
@@ -960,6 +946,7 @@ static bool wgrad_lds_ok(const void *a, long long ldy, long long sy, const void 
     if (e && e[0] == 'd') return false;
     return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ldy % 4 == 0 && ldx % 4 == 0 && sy % 4 == 0 && sx % 4 == 0;
 }
+static bool wgrad_lds_shape_ok(int cout, int cin) { return cout % 4 == 0 && cin % 4 == 0; }
 constexpr size_t WL_LDS_BYTES = sizeof(float) * std::max<size_t>(4 * (size_t)WL_ROWS * WG_TILE,
                                                                  (size_t)(TPB / WAVE) * (WG_MT * WG_MT * 4 + WG_MT) * (WAVE + 1));
 
@@ -1558,7 +1545,7 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
-        else if (wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
+        else if (wgrad_lds_shape_ok(cout, cin) && wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
             static const bool once = [] {
                 return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)WL_LDS_BYTES) == hipSuccess;
@@ -1640,7 +1627,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         }
         PtvScopedTimer t(KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
                                                (double)count * cout * (cin + 1)));
-        bool lds_ok = !ptv2_matmul_bf16();
+        bool lds_ok = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin);
         for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,

@@ -380,6 +380,9 @@ __global__ __launch_bounds__(256) void logits_bwd_fused6_kernel(int n, const flo
         mreg[u][0] = M[(size_t)(16 * u + l15) * G + q];
         mreg[u][1] = q < 2 ? M[(size_t)(16 * u + l15) * G + 4 + q] : 0.f;
     }
+    float4 abr[UT];  // (a, b) of my channels: loop-invariant, kept out of the loop's LDS round trips
+#pragma unroll
+    for (int u = 0; u < UT; ++u) abr[u] = sAB[16 * u + l15];
     float4 accAB[UT];
     v4f accM[UT];
     float tcw = 0.f;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void logits_bwd_fused6_kernel(int n, const flo
         for (int r = 0; r < 4; ++r) { rp[r] = myPos[cur * 16 + 4 * q + r]; pq[r] = myPos[cur * 16 + 4 * r + q]; }
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-            const float4 ab = sAB[16 * u + l15];
+            const float4 ab = abr[u];
             v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
             d = mfma4l(uA0, mreg[u][0], d);  // D (s, ch) = gWt (s, g) M^T (g, ch)
             d = mfma4l(uA1, mreg[u][1], d);
