@@ -129,15 +129,18 @@ __global__ __launch_bounds__(TPB) void logits_bwd_gather_kernel(int n, int k, in
             float acc = 0.f;
             const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
             constexpr int UB = 8;  // 8 list entries at a time: ids, then values, then the sums in list order
+            // (unconditional loads -- clamped index with -1 or'ed in, zero pad: common.h ptv2_zero_pad -- so that a batch is one
+            // round trip, not eight)
             int r[UB], rn[UB];
+            const int plast = p1 > 0 ? p1 - 1 : 0;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) r[u] = p0 + u < p1 ? inv_rows[p0 + u] : -1;
+            for (int u = 0; u < UB; ++u) r[u] = inv_rows[p0 + u < p1 ? p0 + u : plast] | (p0 + u < p1 ? 0 : -1);
             for (int p = p0; p < p1; p += UB) {
                 float t[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) rn[u] = p + UB + u < p1 ? inv_rows[p + UB + u] : -1;  // next batch's ids ride along
+                for (int u = 0; u < UB; ++u) rn[u] = inv_rows[p + UB + u < p1 ? p + UB + u : plast] | (p + UB + u < p1 ? 0 : -1);  // next batch's ids ride along
 #pragma unroll
-                for (int u = 0; u < UB; ++u) t[u] = r[u] >= 0 ? gWt[(long long)r[u] * g + gi] : 0.f;
+                for (int u = 0; u < UB; ++u) t[u] = ptv2_ld_or_zero(gWt + (long long)r[u] * g + gi, r[u] >= 0);
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
                     if (r[u] >= 0) acc += t[u];

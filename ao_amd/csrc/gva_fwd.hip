@@ -91,6 +91,14 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
         Rel r;
         r.x = r.y = r.z = 0.f; r.src = -1;
         if (act) r = rel_pos(coord, idx, row, nn);
+        // the neighbour's kW row and the point's qW row are requested before the channel loop, not after it (they need only
+        // the neighbour id: one exposed memory round trip less per row)
+        float kq[G];
+        if (finisher) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                kq[g] = ptv2_ld_or_zero(kW + (long long)r.src * G + g, act && r.src >= 0) - ptv2_ld_or_zero(qW + (long long)nn * G + g, act);
+        }
         float acc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g] = 0.f;
@@ -131,8 +139,7 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
         if (finisher && act) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float kv = r.src >= 0 ? kW[(long long)r.src * G + g] : 0.f;
-                acc[g] += (kv - qW[(long long)nn * G + g]) + cW[g];
+                acc[g] += kq[g] + cW[g];
                 t1[g] += acc[g];
                 t2[g] = __builtin_fmaf(acc[g], acc[g], t2[g]);
             }
