@@ -20,7 +20,8 @@ enum PtvKernelId {
     KID_KNN_QUERY = 0, KID_LOGITS_FWD, KID_SOFTMAX_ROWS, KID_AGG_TILE, KID_PEB_FWD, KID_PEB_BWD, KID_BWD_TILE,
     KID_BWD_ROWS, KID_BWD_GV, KID_LOGITS_BWD_ROWS, KID_LOGITS_BWD_GATHER, KID_LOGITS_BWD_PARAMS, KID_WGRAD,
     KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_ROWS_GEMM, /* + 0..7: (BN 48|64) x (W (n,k)|(k,n)) x (KC 32|64) */ KID_BWD_POINT = KID_ROWS_GEMM + 8,
-    /* + 0..4 for G = 6, 12, 24, 48, 64 */ KID_COUNT = KID_BWD_POINT + 5
+    /* + 0..4 for G = 6, 12, 24, 48, 64 */ KID_WGRAD_LDS = KID_BWD_POINT + 5 /* the LDS-staged fp32 weight gradient */,
+    KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);
 int ptv2_profile_wants(int kid);

@@ -1541,11 +1541,13 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
     {
         // algorithmic bytes, strict: every operand read once, every result written once (the split-K partial
         // records of this implementation are its own overhead, not the op's)
-        PtvScopedTimer t(KID_WGRAD, st, 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0)));
+        const bool use_lds = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin) && wgrad_lds_ok(gY, ldy, sy, X, ldx, sx);
+        PtvScopedTimer t(use_lds ? KID_WGRAD_LDS : KID_WGRAD, st,
+                         4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0)));
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
-        else if (wgrad_lds_shape_ok(cout, cin) && wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
+        else if (use_lds) {
             static const bool once = [] {
                 return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)WL_LDS_BYTES) == hipSuccess;
@@ -1625,10 +1627,10 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
             for (int j = 0; j < i; ++j) seen |= m.X[j] == m.X[i] && m.xsc[j] == m.xsc[i];
             distinct_x += !seen;
         }
-        PtvScopedTimer t(KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
-                                               (double)count * cout * (cin + 1)));
         bool lds_ok = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin);
         for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
+        PtvScopedTimer t(lds_ok ? KID_WGRAD_LDS : KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
+                                                                       (double)count * cout * (cin + 1)));
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                                (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);

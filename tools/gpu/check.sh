@@ -1,5 +1,6 @@
+# GPU box: the dense / block / model tests, three bench runs (fp32, +bf16), and the per-kernel stats of a short trace.  usage: bash tools/gpu/check.sh [out dir]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03aa; mkdir -p $O
+O=${1:-gpurun_out/check}; mkdir -p $O
 python -m pytest tests/test_gpu_gva_stages.py tests/test_gpu_dense.py tests/test_gpu_block.py tests/test_gpu_model.py tests/test_gpu_native_model.py tests/test_gpu_riders.py tests/test_gpu_bf16.py -m gpu -x -q -k "not equal_steps" > $O/pytest.log 2>&1
 echo "pytest rc $?" >> $O/pytest.log
 tail -4 $O/pytest.log
