@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """How much of the step is the scene geometry?  The bench step with (a) the geometry prefetched on the side stream
-(what bench.py times), (b) the geometry built in line on the compute stream, (c) NO geometry work at all (one prebuilt
+(what bench.py times; `prefetch_early`: enqueued behind the forward instead of behind the backward), (b) the geometry built in line on the compute stream, (c) NO geometry work at all (one prebuilt
 geometry reused: not a valid step, a lower bound for everything else), (d) the geometry alone.
 usage: tools/bench_geometry_share.py [steps]"""
 import os
@@ -29,11 +29,11 @@ with torch.no_grad():
 
 
 def run(mode):
-    if mode == "prefetch":
+    if mode.startswith("prefetch"):
         pre.start(data["coord"], data["offset"])
 
     def step():
-        if mode == "prefetch":
+        if mode.startswith("prefetch"):
             geo = pre.take()
         elif mode == "inline":
             with torch.no_grad():
@@ -42,6 +42,8 @@ def run(mode):
             geo = fixed
         if mode != "geometry_only":
             loss = seg(dict(data, geometry=geo))["loss"]
+            if mode == "prefetch_early":  # enqueued right behind the forward instead of behind the backward
+                pre.start(data["coord"], data["offset"])
             opt.zero_grad(set_to_none=True)
             loss.backward()
             flat = opt.flatten_grads()
@@ -60,10 +62,10 @@ def run(mode):
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    if mode == "prefetch":
+    if mode.startswith("prefetch"):
         pre.take()
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
-for mode in ("prefetch", "inline", "none", "geometry_only", "prefetch"):
+for mode in ("prefetch", "prefetch_early", "inline", "none", "geometry_only", "prefetch", "prefetch_early"):
     print("%-14s %.3f ms/step" % (mode, run(mode)))
