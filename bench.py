@@ -443,12 +443,12 @@ def child_main(args):
         return loss
 
     # roofline leg: the last warm-up steps run with every hand-written kernel bracketed by HIP events to find the
-    # dominant one; inside the timed region only every third launch of that kernel is bracketed (so the
+    # dominant one; inside the timed region only every `timed_stride`-th launch of that kernel is bracketed (so the
     # step time the headline value comes from is not inflated by ~4000 event records)
     survey_steps = 0 if args.no_roofline else min(2, args.warmup)
     for _ in range(args.warmup - survey_steps):
         step()
-    survey, dominant = {}, None
+    survey, dominant, timed_stride = {}, None, 3
     if survey_steps:
         torch.cuda.synchronize(device)
         _lib.kernel_timer(True)
@@ -459,7 +459,17 @@ def child_main(args):
         survey = _lib.kernel_timer_read()
         if survey:
             dominant = max(survey.items(), key=lambda kv: kv[1]["total_us"])[0]
-            _lib.kernel_timer(True, only=dominant, stride=3)  # every 3rd launch: a uniform sample, a third of the events
+            # every stride-th launch of it: a uniform sample over the timed region.  ~6 bracketed launches per step (two event
+            # records each cost ~3 us of queue time: bracketing all 52 weight-gradient launches of a step was 0.1 ms of it);
+            # the stride is co-prime with the launches per step so that every launch position of the step gets sampled
+            import math
+            per_step = max(1, round(survey[dominant]["launches"] / survey_steps))
+            timed_stride = 3
+            if per_step > 18:
+                timed_stride = max(3, per_step // 6) | 1
+                while math.gcd(timed_stride, per_step) != 1:
+                    timed_stride += 2
+            _lib.kernel_timer(True, only=dominant, stride=timed_stride)
     elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points,
                                                           finish=basket.flush if basket is not None else None)
     if not args.no_roofline:
@@ -506,15 +516,26 @@ def child_main(args):
                 # dominant hand-written kernel of the step (largest total time in the survey steps), timed live
                 # over the timed region
                 name, rec = dominant, summ[dominant]
-                achieved = rec["bytes_per_launch"] / (rec["avg_us"] * 1e-6) / 1e9
+                # a bracket is [event record, kernel, event record] on the launch stream: its elapsed time contains the two
+                # records' own queue time.  Calibrated here as the median elapsed time of 200 EMPTY brackets on the same stream
+                # and subtracted, so that the figure is comparable with rocprofv3's kernel duration (profiles/*_kernel_summary)
+                pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+                for a, b in pairs:
+                    a.record()
+                    b.record()
+                torch.cuda.synchronize(device)
+                empty_us = sorted(1e3 * a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+                net_us = max(rec["avg_us"] - empty_us, 0.5 * rec["avg_us"])
+                achieved = rec["bytes_per_launch"] / (net_us * 1e-6) / 1e9
                 traffic, traffic_source = pmc_traffic(name, build_info)
                 out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "traffic_source": traffic_source,
-                                   "avg_us": rec["avg_us"], "launches_timed": rec["launches"],
-                                   "ms_per_step": 3 * rec["total_us"] / 1e3 / args.steps,
+                                   "avg_us": net_us, "avg_us_bracket": rec["avg_us"], "empty_bracket_us": empty_us,
+                                   "launches_timed": rec["launches"],
+                                   "ms_per_step": timed_stride * rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
-                                   "survey_steps": survey_steps, "timed_launch_stride": 3,
+                                   "survey_steps": survey_steps, "timed_launch_stride": timed_stride,
                                    "all_kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                                                        "ms_per_step": round(v["total_us"] / 1e3 / max(survey_steps, 1), 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
