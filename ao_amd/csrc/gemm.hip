@@ -551,9 +551,17 @@ static int column_block(int m, int n, int products = 1) {
     static const bool count_aware = [] { const char *e = getenv("AO_AMD_GEMM_COUNT_AWARE"); return !(e && e[0] == '0'); }();
     const bool n48 = n % 48 == 0;
     const int wide = n48 ? 48 : 64;
+    if (forced == 32 && n % 32 == 0) return 32;
     if (forced == 16 || forced == 48 || forced == 64) return (forced == 16 && n % 16 == 0) ? 16 : wide;
-    const long long wgs = (((long long)m + gemm::BM - 1) / gemm::BM) * ((n + wide - 1) / wide) * (count_aware ? products : 1);
-    return (wgs < 768 && n % 16 == 0) ? 16 : wide;
+    const long long rbs = ((long long)m + gemm::BM - 1) / gemm::BM, prod = count_aware ? products : 1;
+    const long long wgs = rbs * ((n + wide - 1) / wide) * prod;
+    if (wgs >= 768 || n % 16 != 0) return wide;
+    // in between: 32-column blocks when they still give a workgroup per compute unit -- every column block re-reads the X tile
+    // from L2, 12 x with 16 columns at n = 192.  Measured at 120 k points (alternating runs on one box): 11.08 ms without
+    // (AO_AMD_GEMM_MID=0), 11.02 with the threshold at 512 workgroups, 10.98 at 256, 10.99 at 128
+    static const int mid = [] { const char *e = getenv("AO_AMD_GEMM_MID"); return e ? atoi(e) : 256; }();
+    if (mid > 0 && n % 32 == 0 && rbs * (n / 32) * prod >= mid) return 32;
+    return 16;
 }
 
 static void launch_gemm(int bn, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
@@ -563,6 +571,9 @@ static void launch_gemm(int bn, bool kmajor, bool wide_k, dim3 grid, hipStream_t
     if (bn == 16) {
         if (kmajor) { if (wide_k) GO(16, true, 64); else GO(16, true, 32); }
         else { if (wide_k) GO(16, false, 64); else GO(16, false, 32); }
+    } else if (bn == 32) {
+        if (kmajor) { if (wide_k) GO(32, true, 64); else GO(32, true, 32); }
+        else { if (wide_k) GO(32, false, 64); else GO(32, false, 32); }
     } else if (bn == 48) {
         if (kmajor) { if (wide_k) GO(48, true, 64); else GO(48, true, 32); }
         else { if (wide_k) GO(48, false, 64); else GO(48, false, 32); }
