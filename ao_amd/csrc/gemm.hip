@@ -555,7 +555,8 @@ static int column_block(int m, int n, int products = 1) {
     if (forced == 16 || forced == 48 || forced == 64) return (forced == 16 && n % 16 == 0) ? 16 : wide;
     const long long rbs = ((long long)m + gemm::BM - 1) / gemm::BM, prod = count_aware ? products : 1;
     const long long wgs = rbs * ((n + wide - 1) / wide) * prod;
-    if (wgs >= 768 || n % 16 != 0) return wide;
+    static const int wide_min = [] { const char *e = getenv("AO_AMD_GEMM_WIDE"); return e ? atoi(e) : 768; }();
+    if (wgs >= wide_min || n % 16 != 0) return wide;
     // in between: 32-column blocks when they still give a workgroup per compute unit -- every column block re-reads the X tile
     // from L2, 12 x with 16 columns at n = 192.  Measured at 120 k points (alternating runs on one box): 11.08 ms without
     // (AO_AMD_GEMM_MID=0), 11.02 with the threshold at 512 workgroups, 10.98 at 256, 10.99 at 128
