@@ -1080,7 +1080,17 @@ static int wg_chunk(int n, int tiles) {
     if (target <= 0) return WG_CHUNK;
     const int chunks = std::max(1, target / std::max(1, tiles));
     const long long rows = ((long long)n + chunks - 1) / chunks;
-    const long long chunk = std::max<long long>(WG_CHUNK, (rows + 127) / 128 * 128);
+    long long chunk = std::max<long long>(WG_CHUNK, (rows + 127) / 128 * 128);
+    // The grid is (chunks, tiles, products), x fastest, and workgroups go round-robin over the 8 XCDs: with a chunk count that
+    // is a multiple of 8 all tile / product workgroups of a chunk -- which read the same operand rows at the same time --
+    // land on ONE XCD and queue on the same L2 lines (measured with a grid built that way on purpose: 11.34 against 10.98 ms
+    // per step).  Keep the count off the multiples of 8 when more than one workgroup shares a chunk.
+    // (forcing the count ODD -- consecutive tiles walking through all eight XCDs -- measured 0.07-0.09 ms slower than the
+    // counts the rule above produces: 469 / 235 / 134, 74 / 50 / 37, 18 / 12 / 9, 5 / 3 / 2 at the four levels)
+    if (tiles > 1) {
+        int guard = 0;
+        while ((((long long)n + chunk - 1) / chunk) % 8 == 0 && ((long long)n + chunk - 1) / chunk > 1 && guard++ < 16) chunk += 128;
+    }
     return (int)std::min<long long>(chunk, 1 << 20);
 }
 
