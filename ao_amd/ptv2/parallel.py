@@ -152,22 +152,51 @@ class GeometryPrefetcher:
       geo = pre.take()              make the compute stream wait for it, hand it over
     """
 
-    def __init__(self, backbone, device):
+    def __init__(self, backbone, device, threaded=False):
         self.backbone, self.device = backbone, device
         self.stream = torch.cuda.Stream(device)
         self.pending = None
+        # threaded: the geometry is built by a host thread of its own, as a loader worker would.  Building it is ~2 ms of host
+        # time per 120 k-point scene, most of it blocked in the 4-byte read-backs; on the launching thread those 2 ms come out
+        # of the ~3.7 ms the host is ahead of the GPU queue (tools/host_bound.py: 7.5 ms of host issue for an 11.2 ms step),
+        # which a busy host (other tenants on the box) eats first.  The launchers release the GIL (ctypes), so the two threads
+        # overlap where it matters.
+        self.threaded, self.worker, self.result = threaded, None, None
 
-    def start(self, coord, offset, ready=None):
+    def _build(self, coord, offset, ready):
         if ready is not None:  # event after which coord/offset are valid (e.g. the H2D copy of the loader)
             self.stream.wait_event(ready)
-        with torch.cuda.stream(self.stream):
+        with torch.no_grad(), torch.cuda.stream(self.stream):
             geo = self.backbone.geometry(coord, offset)
             done = torch.cuda.Event()
             done.record(self.stream)
-        self.pending = (geo, done)
+        return geo, done
+
+    def start(self, coord, offset, ready=None):
+        if not self.threaded:
+            self.pending = self._build(coord, offset, ready)
+            return
+        import threading
+
+        def run():
+            try:
+                torch.cuda.set_device(self.device)
+                self.result = self._build(coord, offset, ready)
+            except BaseException as e:  # re-raised by take()
+                self.result = e
+
+        self.worker = threading.Thread(target=run, name="ao_amd-geometry", daemon=True)
+        self.pending = "worker"
+        self.worker.start()
 
     def take(self):
         assert self.pending is not None, "GeometryPrefetcher.take() before start()"
+        if self.pending == "worker":
+            self.worker.join()
+            self.worker, self.pending = None, self.result
+            if isinstance(self.pending, BaseException):
+                err, self.pending = self.pending, None
+                raise err
         geo, done = self.pending
         self.pending = None
         main = torch.cuda.current_stream(self.device)

@@ -410,13 +410,18 @@ def child_main(args):
 
     # geometry of batch i+1 (coordinates only) is built on a side stream during the backward of batch i, as a
     # loader would; every step still builds exactly one geometry (AO_AMD_PREFETCH=0: build it inline instead)
-    prefetch = None
-    if os.environ.get("AO_AMD_PREFETCH", "1") == "1":
-        prefetch = parallel.GeometryPrefetcher(seg.backbone, device)
+    # AO_AMD_PREFETCH=1 (default): on the launching thread behind the backward; =thread: on a host thread of its own, started as
+    # soon as the current batch's geometry has been handed over (what a loader worker does; measured equal: 11.02-11.04 ms both
+    # ways on boxes with a host load average of 17-50)
+    prefetch, pf_mode = None, os.environ.get("AO_AMD_PREFETCH", "1")
+    if pf_mode in ("1", "thread"):
+        prefetch = parallel.GeometryPrefetcher(seg.backbone, device, threaded=pf_mode == "thread")
         prefetch.start(data["coord"], data["offset"])
 
     def step():
         batch = data if prefetch is None else dict(data, geometry=prefetch.take())
+        if prefetch is not None and pf_mode == "thread":
+            prefetch.start(data["coord"], data["offset"])
         if autocast is not None:
             with autocast:
                 out = net(batch)
@@ -431,13 +436,13 @@ def child_main(args):
         if flat_opt:  # gradients -> one flat buffer -> (all-reduce) -> one update kernel
             flat = opt.flatten_grads()
             scale = sync.reduce_flat(flat) if sync is not None else 1.0
-            if prefetch is not None:
+            if prefetch is not None and pf_mode == "1":
                 prefetch.start(data["coord"], data["offset"])
             opt.step(flat_grad=flat, grad_scale=scale)
             return loss
         if sync is not None:
             sync.sync()
-        if prefetch is not None:
+        if prefetch is not None and pf_mode == "1":
             prefetch.start(data["coord"], data["offset"])
         opt.step()
         return loss
