@@ -27,22 +27,43 @@ __device__ __forceinline__ void fold_m_fwd_body(int bid, int c, int g, const flo
         if (ch < P.c) fold_p_fwd_channel(P, ch);
         return;
     }
-    const int lane = threadIdx.x & 63;
-    const int e = (bid * TPB + threadIdx.x) >> 6;  // wave index = output index
-    if (e < c * g) {
-        const int cp = e / g, gi = e - cp * g;
+    // A workgroup = 64 consecutive c' of one group g: lane = c' (the rows of Wp2 are read as 256 contiguous bytes), the four
+    // wavefronts split the contraction index and are added through LDS in wave order.  (Round 2's form -- one wavefront per
+    // output, lanes over the contraction index -- read Wp2 down a column: 64 cache lines per load, 48 us for the 15 Blocks.)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tiles_c = (c + WAVE - 1) / WAVE;
+    __shared__ float s_fold[TPB / WAVE][WAVE];
+    if (bid < g * tiles_c) {
+        const int gi = bid / tiles_c, cp = (bid - gi * tiles_c) * WAVE + lane;
+        const int cpl = cp < c ? cp : c - 1;
+        const int per = (c + 3) / 4, c0 = wid * per, c1 = c0 + per < c ? c0 + per : c;
+        const float *w1 = Ww1 + (size_t)gi * c;
         float acc = 0.f;
-        for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Wp2[(size_t)ci * c + cp], Ww1[(size_t)gi * c + ci], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) M[e] = acc;
-    } else if (e < c * g + g) {
-        const int gi = e - c * g;
-        float acc = 0.f;
-        for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) cW[gi] = acc + bw1[gi];
+        int ci = c0;
+        for (; ci + 8 <= c1; ci += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Wp2[(size_t)(ci + u) * c + cpl];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_fmaf(v[u], w1[ci + u], acc);
+        }
+        for (; ci < c1; ++ci) acc = __builtin_fmaf(Wp2[(size_t)ci * c + cpl], w1[ci], acc);
+        s_fold[wid][lane] = acc;
+        __syncthreads();
+        if (wid == 0 && cp < c) M[(size_t)cp * g + gi] = ((s_fold[0][lane] + s_fold[1][lane]) + s_fold[2][lane]) + s_fold[3][lane];
+    } else {
+        const int gi = (bid - g * tiles_c) * (TPB / WAVE) + wid;  // one wavefront per group
+        if (gi < g) {
+            float acc = 0.f;
+            for (int ci = lane; ci < c; ci += WAVE) acc = __builtin_fmaf(Ww1[(size_t)gi * c + ci], bp2[ci], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) cW[gi] = acc + bw1[gi];
+        }
     }
 }
+
+// workgroups of the M / cW part of fold_m_fwd_body
+static int fold_m_blocks(int c, int g) { return g * ((c + WAVE - 1) / WAVE) + (g + TPB / WAVE - 1) / (TPB / WAVE); }
 
 __global__ __launch_bounds__(TPB) void fold_m_fwd_kernel(int c, int g, const float *__restrict__ Wp2,
                                                          const float *__restrict__ bp2, const float *__restrict__ Ww1,
@@ -399,7 +420,7 @@ int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stre
             if (B->n < 1 || B->c < 4 || B->g < 1) return PTV2_ERR_ARG;
             FoldFwdItem &it = batch.item[batch.count++];
             it.c = B->c; it.g = B->g;
-            it.mblocks = divup(((long long)B->c * B->g + B->g) * WAVE, TPB);
+            it.mblocks = fold_m_blocks(B->c, B->g);
             it.blocks = it.mblocks + divup(B->c, TPB);
             it.Wp2 = B->Wp2; it.bp2 = B->bp2; it.Ww1 = B->Ww1; it.bw1 = B->bw1; it.M = B->M; it.cW = B->cW;
             it.P = fold_p_args(B);
@@ -435,7 +456,7 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     if (!g_prefolded) {
-        const int mblocks = divup(((long long)c * g + g) * WAVE, TPB);
+        const int mblocks = fold_m_blocks(c, g);
         hipLaunchKernelGGL(fold_m_fwd_kernel, dim3(mblocks + divup(c, TPB)), dim3(TPB), 0, st, c, g, B->Wp2, B->bp2, B->Ww1, B->bw1,
                            B->M, B->cW, mblocks, fold_p_args(B));
     }
