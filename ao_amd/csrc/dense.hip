@@ -813,12 +813,15 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 // at the end, exactly as in linear_wgrad_kernel (same records, same finalize).  The contraction order over the rows differs
 // from that kernel's (wave w takes rows 16 w .. 16 w + 15 of every stage); results are bitwise reproducible run to run.
 constexpr int WL_ROWS = 64;  // rows per stage
-template <int DUMMY>
+// RS != 0: the bias sums are WEIGHTED by a per-(row, product) scalar: db[b][o] = sum_n gY[n, b, o] * rowscale[n * lds_s + b]
+// (the grouped projection's bias gradient, sum_n g_out[n, ch] sw[n, group(ch)], which was a kernel of its own per Block)
+template <int RS>
 __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, int cin, int tiles_i,
                                                                const float *__restrict__ gY, long long ldy, long long sy,
                                                                const float *__restrict__ X, long long ldx, long long sx,
                                                                float *__restrict__ part, float *__restrict__ part_b,
-                                                               int batch, WgradMulti multi, int chunk) {
+                                                               int batch, WgradMulti multi, int chunk,
+                                                               const float *__restrict__ rowscale, long long lds_s) {
     extern __shared__ float4 wl_lds4[];
     float *sA = (float *)wl_lds4;                    // [2][WL_ROWS][WG_TILE]
     float *sB = sA + 2 * WL_ROWS * WG_TILE;           // [2][WL_ROWS][WG_TILE]
@@ -851,6 +854,7 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
     float4 ra[SLOTS], rb[SLOTS];
     // (cout and cin are multiples of 4 here -- wgrad_lds_ok: a 16-byte piece is inside the tile or outside it -- and every load
     // is unconditional: rows past the chunk / pieces past the edge read the zero pad of common.h)
+    float sn[4], sc_[4];  // (RS) row scalars of the stage in flight / of the stage on the matrix cores: rows 16 wid + 4 ks + lr
     auto fetch = [&](long long rs) {
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
@@ -859,8 +863,19 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
             ra[j] = ptv2_ld_or_zero((const float4 *)(A + r * ldy + to + c4), r < r1 && to + c4 < cout);
             rb[j] = ptv2_ld_or_zero((const float4 *)(B + r * ldx + ti + c4), r < r1 && ti + c4 < cin);
         }
+        if constexpr (RS != 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const long long r = rs + wid * 16 + ks * 4 + lr;
+                sn[ks] = ptv2_ld_or_zero(rowscale + r * lds_s + bz, r < r1);
+            }
+        }
     };
     auto stash = [&](int buf) {
+        if constexpr (RS != 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sc_[ks] = sn[ks];
+        }
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) {
             const int f = tid + TPB * j;  // (row * Q + c4 / 4) * 4 floats = row * WG_TILE + c4: the image is the tile, row-major
@@ -891,7 +906,8 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
             }
 #pragma unroll
             for (int m = 0; m < WG_MT; ++m) {
-                bsum[m] += a[m];
+                if constexpr (RS != 0) bsum[m] = __builtin_fmaf(a[m], sc_[ks], bsum[m]);
+                else bsum[m] += a[m];
 #pragma unroll
                 for (int t = 0; t < WG_MT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[m][t], 0, 0, 0);
             }
@@ -1535,9 +1551,26 @@ int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy
     return PTV2_OK;
 }
 
+// internal (gva_block.hip): rowscale != NULL asks for db[b][o] = sum_n gY[n, b, o] * rowscale[n * lds_s + b] instead of the plain
+// column sums.  Only the LDS-staged fp32 kernel forms them: *weighted says whether it did (1) or whether the caller has to
+// compute db itself (0: db is then not written at all).
+extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch, const float *gY, long long ldy, long long sy,
+                                             const float *X, long long ldx, long long sx, float *dW, float *db,
+                                             const float *rowscale, long long lds_s, int *weighted, void *workspace,
+                                             size_t workspace_bytes, void *stream);
+
 extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int batch, const float *gY, long long ldy,
                                                  long long sy, const float *X, long long ldx, long long sx, float *dW,
                                                  float *db, void *workspace, size_t workspace_bytes, void *stream) {
+    return linear_wgrad_strided_rowscale(n, cout, cin, batch, gY, ldy, sy, X, ldx, sx, dW, db, nullptr, 0, nullptr, workspace,
+                                         workspace_bytes, stream);
+}
+
+extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch, const float *gY, long long ldy, long long sy,
+                                             const float *X, long long ldx, long long sx, float *dW, float *db,
+                                             const float *rowscale, long long lds_s, int *weighted, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+    if (weighted) *weighted = 0;
     if (n < 1 || cout < 1 || cin < 1 || batch < 1) return PTV2_ERR_ARG;
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
     const int chunk = wg_chunk(n, tiles_o * tiles_i * batch);
@@ -1552,8 +1585,11 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
         // algorithmic bytes, strict: every operand read once, every result written once (the split-K partial
         // records of this implementation are its own overhead, not the op's)
         const bool use_lds = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin) && wgrad_lds_ok(gY, ldy, sy, X, ldx, sx);
+        const bool rs = rowscale && db && use_lds;
+        if (rowscale && !rs) db = nullptr;  // (the caller forms the weighted sums itself)
+        if (rs && weighted) *weighted = 1;
         PtvScopedTimer t(use_lds ? KID_WGRAD_LDS : KID_WGRAD, st,
-                         4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0)));
+                         4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0) + (rs ? (double)n : 0.0)));
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
@@ -1563,8 +1599,17 @@ extern "C" int linear_wgrad_strided_hip_launcher(int n, int cout, int cin, int b
                                            (int)WL_LDS_BYTES) == hipSuccess;
             }();
             (void)once;
-            hipLaunchKernelGGL(linear_wgrad_lds_kernel<0>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx,
-                               sx, part, db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
+            if (rs) {
+                static const bool once1 = [] {
+                    return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)WL_LDS_BYTES) == hipSuccess;
+                }();
+                (void)once1;
+                hipLaunchKernelGGL(linear_wgrad_lds_kernel<1>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i, gY, ldy, sy, X,
+                                   ldx, sx, part, part_b, batch, WgradMulti{}, chunk, rowscale, lds_s);
+            } else
+                hipLaunchKernelGGL(linear_wgrad_lds_kernel<0>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i, gY, ldy, sy, X,
+                                   ldx, sx, part, db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk, (const float *)nullptr, 0LL);
         } else
             hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, gY, ldy, sy, X, ldx, sx, part,
                                db ? part_b : (float *)nullptr, batch, WgradMulti{}, chunk);
@@ -1652,7 +1697,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
             (void)once;
             hipLaunchKernelGGL(linear_wgrad_lds_kernel<0>, grid, dim3(TPB), WL_LDS_BYTES, st, n, cout, cin, tiles_i,
                                (const float *)nullptr, (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part,
-                               count, m, chunk);
+                               count, m, chunk, (const float *)nullptr, 0LL);
         } else
             hipLaunchKernelGGL(linear_wgrad_kernel<false>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                                (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);

@@ -272,6 +272,8 @@ int gva_fold_w_backward_hip_launcher(int, const float *, const double *, const d
 int skinny_linear_forward_hip_launcher(int, int, int, const float *, const float *, float *, void *);
 int skinny_linear_backward_hip_launcher(int, int, int, const float *, const float *, float *, void *);
 int linear_wgrad_hip_launcher(int, int, int, const float *, const float *, float *, float *, void *, size_t, void *);
+int linear_wgrad_strided_rowscale(int, int, int, int, const float *, long long, long long, const float *, long long, long long,
+                                  float *, float *, const float *, long long, int *, void *, size_t, void *);
 int linear_wgrad_strided_hip_launcher(int, int, int, int, const float *, long long, long long, const float *, long long,
                                       long long, float *, float *, void *, size_t, void *);
 int gva_logits_forward_hip_launcher(int, int, int, int, const float *, const float *, const float *, const float *,
@@ -504,14 +506,18 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     //    grad Wp2 (direct part), grad bp2 (direct part)
     const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");
     if (!fused_peb) RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
+    int bp2_done = 0;
     {
         // the sum of its split-K records (needed by fold_m_bwd only) rides on the gv launch of the aggregation stage: records
-        // in a region of their own, which nothing before that launch overwrites
+        // in a region of their own, which nothing before that launch overwrites.  The same launch forms the direct part of
+        // grad bp2 = sum_n g_out[n, ch] sw[n, group(ch)] as its weighted bias sums (it reads g_out anyway; that sum was a launch
+        // of its own per Block, bp2_grad_kernel: 15 x 6 us); where the weight gradient cannot (bf16 operands), the kernel below
         const PtvDeferScope defer;
-        RUN(linear_wgrad_strided_hip_launcher(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, nullptr, W.wp2_part,
-                                              W.wp2_bytes, stream));
+        static const bool split = [] { const char *e = getenv("AO_AMD_BP2_GRAD"); return e && e[0] == 's'; }();  // A/B switch
+        RUN(linear_wgrad_strided_rowscale(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, split ? nullptr : G->gbp2,
+                                          split ? nullptr : B->sw, g, &bp2_done, W.wp2_part, W.wp2_bytes, stream));
     }
-    {
+    if (!bp2_done) {
         const PtvDeferScope defer;  // (its record sum rides on the gv launch as well)
         const int rl = std::max(1, TPB / c);
         const int nblk = (int)std::min<long long>(((long long)n + rl * 8 - 1) / (rl * 8), MAX_BLOCKS);

@@ -167,7 +167,7 @@ __device__ __forceinline__ void finalize_columns(const float *part, int nblk, in
 // PtvDeferScope launch_finalize() queues such a sum instead of launching it; the next designated host launch (one that
 // neither reads its outputs nor overwrites its records) takes the queue and appends workgroups that run it beside its
 // own work.  ptv2_rider_flush() launches whatever is still queued as a kernel of its own.
-enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRADN, RIDER_LOGITS_FUSED };
+enum { RIDER_NONE = 0, RIDER_VEC, RIDER_LOGITS_PARAMS, RIDER_BWD_POINT, RIDER_WGRADN, RIDER_LOGITS_FUSED, RIDER_SPLIT2 };
 struct PtvRider {
     const float *part;
     int nblk, len, kind, blocks;
@@ -259,6 +259,12 @@ struct MapSplit2 {  // columns [0,len1) -> out1, rest -> out2
 template <> struct RiderOf<MapVec<float>> {
     static constexpr bool ok = true;
     static PtvRider make(const MapVec<float> &m) { PtvRider r{}; r.kind = RIDER_VEC; r.p[0] = m.out; return r; }
+};
+template <> struct RiderOf<MapSplit2<float>> {
+    static constexpr bool ok = true;
+    static PtvRider make(const MapSplit2<float> &m) {
+        PtvRider r{}; r.kind = RIDER_SPLIT2; r.p[0] = m.out1; r.p[1] = m.out2; r.i0 = m.len1; return r;
+    }
 };
 
 // logits backward: partials [nblk][c][G+4] -> gM (c,G), ga (c,3), gb (c)
@@ -406,6 +412,7 @@ __device__ __forceinline__ void rider_run(const PtvRiders &Rs, int rb) {
         if (rb < R.blocks) {
             switch (R.kind) {  // uniform over the workgroup
                 case RIDER_VEC: rider_columns(R, rb, MapVec<float>{R.p[0]}); break;
+                case RIDER_SPLIT2: rider_columns(R, rb, MapSplit2<float>{R.p[0], R.p[1], R.i0}); break;
                 case RIDER_LOGITS_PARAMS: rider_columns(R, rb, MapLogitsParams{R.p[0], R.p[1], R.p[2], R.i0}); break;
                 case RIDER_LOGITS_FUSED: rider_columns(R, rb, MapLogitsFused{R.p[0], R.p[1], R.p[2], R.p[3], R.i0, R.i1}); break;
                 case RIDER_BWD_POINT: rider_columns(R, rb, MapBwdPoint{R.p[0], R.p[1], R.p[2], R.p[3], R.p[4], R.p[5], R.i0, R.i1}); break;
