@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_stage_api.py tests/test_gpu_block.py tests/test_gpu_model.py tests/test_gpu_native_model.py tests/test_gpu_rccl.py tests/test_gpu_bf16.py -m gpu -x -q -k "not equal_steps" 2>&1 | tail -3
-bash tools/gpu/ab.sh gpurun_out/r03aq/x X=1 AO_AMD_WGRAD_DEFER=0 4
+for i in $(seq 1 40); do AO_AMD_BENCH_ONE_DEVICE=1 AO_AMD_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 2 --points 20000 --no-cpu-baseline --no-ops --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('loss', d['config']['loss'])"; done | sort | uniq -c
