@@ -122,7 +122,9 @@ unsigned *ptv2_stream_counters(hipStream_t st) {
     if (it != g_counters.end()) return it->second;
     unsigned *p = nullptr;
     if (hipMalloc((void **)&p, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, sizeof(unsigned) * PTV2_NUM_COUNTERS) != hipSuccess) return nullptr;
+    // zeroed ON the stream that will use them: a null-stream hipMemset is not ordered against a non-blocking stream (every
+    // torch side stream is one), and the first kernel there could have met the allocation's previous contents
+    if (hipMemsetAsync(p, 0, sizeof(unsigned) * PTV2_NUM_COUNTERS, st) != hipSuccess) return nullptr;
     g_counters[key] = p;
     return p;
 }
