@@ -1,2 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in $(seq 1 40); do AO_AMD_BENCH_ONE_DEVICE=1 AO_AMD_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 3 --warmup 2 --points 20000 --no-cpu-baseline --no-ops --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('loss', d['config']['loss'])"; done | sort | uniq -c
+O=gpurun_out/r03prof2; mkdir -p $O; uptime
+python bench.py --steps 20 --warmup 5 --cfg scannet --scenes 2 --points 100000 --no-cpu-baseline --no-ops > "$O/bench_scannet.json" 2>/dev/null
+python bench.py --steps 20 --warmup 5 --cfg scannet --scenes 2 --points 100000 --dtype bf16 --no-cpu-baseline --no-ops > "$O/bench_scannet_bf16.json" 2>/dev/null
+python bench.py --steps 20 --warmup 5 --scenes 4 --points 80000 --no-cpu-baseline --no-ops > "$O/bench_4x80k.json" 2>/dev/null
+for f in scannet scannet_bf16 4x80k; do python -c "import json,sys; d=json.loads(open('$O/bench_$f.json').read()); print('$f', d['ms_per_step'], d['value'])"; done; uptime
