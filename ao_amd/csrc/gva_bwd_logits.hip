@@ -705,17 +705,18 @@ __global__ __launch_bounds__(256) void logits_fwd_mfma_kernel(int n, int k, cons
                         v[r] = t;
                     }
                 }
-                if (act && g < G) {
+                // (the sums are formed OUTSIDE the store's condition: with every use of the kW / qW rows under `act && g < G` the
+                // compiler sank their loads into that branch, behind the products -- the gather was requested and waited for at
+                // the end of the trip, ~1 us per point exposed)
+                const bool okg = act && g < G;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int s = 4 * q + r;
-                        if (s < k) {
-                            const float val = v[r] + (kv[f][r] - qv[f]) + cw[f];
-                            W1[(pt * k + s) * G + g] = val;
-                            t1[f] += val;
-                            t2[f] = __builtin_fmaf(val, val, t2[f]);
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int s = 4 * q + r;
+                    const bool ok = okg && s < k;
+                    const float val = v[r] + (kv[f][r] - qv[f]) + cw[f];
+                    t1[f] += ok ? val : 0.f;
+                    t2[f] = ok ? __builtin_fmaf(val, val, t2[f]) : t2[f];
+                    if (ok) W1[(pt * k + s) * G + g] = val;
                 }
             }
         }
