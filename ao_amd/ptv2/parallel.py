@@ -189,6 +189,12 @@ class GeometryPrefetcher:
         self.pending = "worker"
         self.worker.start()
 
+    def close(self):
+        """Wait for a build that is still running on the worker thread (call before the process winds down)."""
+        if self.pending == "worker" and self.worker is not None:
+            self.worker.join()
+            self.worker, self.pending = None, (self.result if not isinstance(self.result, BaseException) else None)
+
     def take(self):
         assert self.pending is not None, "GeometryPrefetcher.take() before start()"
         if self.pending == "worker":

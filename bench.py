@@ -410,10 +410,12 @@ def child_main(args):
 
     # geometry of batch i+1 (coordinates only) is built on a side stream during the backward of batch i, as a
     # loader would; every step still builds exactly one geometry (AO_AMD_PREFETCH=0: build it inline instead)
-    # AO_AMD_PREFETCH=1 (default): on the launching thread behind the backward; =thread: on a host thread of its own, started as
-    # soon as the current batch's geometry has been handed over (what a loader worker does; measured equal: 11.02-11.04 ms both
-    # ways on boxes with a host load average of 17-50)
-    prefetch, pf_mode = None, os.environ.get("AO_AMD_PREFETCH", "1")
+    # AO_AMD_PREFETCH=thread (default): built by a host thread of its own, started as soon as the current batch's geometry has
+    # been handed over -- what a loader worker does.  It takes 2.75 ms of the 7.5 ms per step off the launching thread, which
+    # otherwise runs only ~3.5 ms ahead of the GPU queue: on a quiet host both ways measure the same (10.93-11.06 ms, 24 paired
+    # runs), on a slow one the launching thread is what the step waits for ("Host side").
+    # =1: on the launching thread behind the backward (rounds 1-2); =0: in line
+    prefetch, pf_mode = None, os.environ.get("AO_AMD_PREFETCH", "thread")
     if pf_mode in ("1", "thread"):
         prefetch = parallel.GeometryPrefetcher(seg.backbone, device, threaded=pf_mode == "thread")
         prefetch.start(data["coord"], data["offset"])
@@ -477,6 +479,8 @@ def child_main(args):
             _lib.kernel_timer(True, only=dominant, stride=timed_stride)
     elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points,
                                                           finish=basket.flush if basket is not None else None)
+    if prefetch is not None:
+        prefetch.close()  # (thread mode: the geometry of the batch after the last one is still being built)
     if not args.no_roofline:
         _lib.lib().ptv2_profile_enable(0)
 
