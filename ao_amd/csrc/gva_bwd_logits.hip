@@ -777,14 +777,11 @@ int launch_logits_fwd_mfma(int n, int k, const float *kW, const float *qW, const
 
 int gva_logits_fwd_mfma_supported(int k, int c, int g) {
     if (k < 1 || k > 16) return 0;
-    // (6, 48): measured equal to the flat one-lane-per-slot kernel (58 vs 59 us at 120 k points: with 6 of 16 tile columns
-    // in use the epilogue stores 24-byte segments from 6 lanes); stays behind the knob
+    // (6, 48): measured equal to the flat one-lane-per-slot kernel (58 vs 59 us at 120 k points, 10.93 vs 10.95 ms per step after
+    // the load fixes of round 3: with 6 of 16 tile columns in use the epilogue stores 24-byte segments from 6 lanes); stays
+    // behind the knob
     static const bool narrow = [] { const char *e = getenv("AO_AMD_LOGITS_FWD6"); return e && e[0] == '1'; }();
     if (g == 6 && c == 48) return narrow ? 1 : 0;
-    if (g == 6 && c == 48) {  // (24-byte rows: float4 loads of a point's block need k = 16)
-        static const bool off = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6"); return e && e[0] == '0'; }();
-        return k == 16 && !off;
-    }
     return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
 }
 
