@@ -29,6 +29,10 @@ _SIGNATURES = {
     "ptv2_profile_kernel_count": (_c_int, []),
     "ptv2_profile_read": (_c_int, [_c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
+    "ptv2_profile_empty_stamp_us": (ctypes.c_double, [_vp, _c_int]),
+    "ptv2_graph_mode": (_c_int, [_c_int]),
+    "ptv2_graph_stats": (_c_int, [ctypes.POINTER(ctypes.c_double), _c_int]),
+    "ptv2_graph_reset": (_c_int, []),
     "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),
     "knn_query_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _vp]),
     "knn_query_count_pairs": (_c_int, [_vp]),
@@ -196,6 +200,14 @@ def kernel_timer(enable, only=None, stride=1):
     L.ptv2_profile_select(kid)
     L.ptv2_profile_stride(int(stride))
     L.ptv2_profile_enable(1 if enable else 0)
+
+
+def graph_stats(reset=False):
+    """Counters of the graph-issued model launchers (ao_amd/csrc/graph.hip)."""
+    out = (ctypes.c_double * 9)()
+    lib().ptv2_graph_stats(out, 1 if reset else 0)
+    keys = ("scopes", "updated", "instantiated", "declined", "nodes", "capture_us", "update_us", "launch_us", "wait_us")
+    return dict(zip(keys, [float(v) for v in out]))
 
 
 def kernel_timer_read():

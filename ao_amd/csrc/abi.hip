@@ -1,4 +1,5 @@
 // ao_amd/csrc/abi.hip -- library identification and the optional per-kernel timer (host only).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -161,16 +162,57 @@ hipEvent_t take_event() {
 }
 std::vector<Rec> g_recs[KID_COUNT];
 std::vector<hipEvent_t> g_pending[KID_COUNT];
+// ---- brackets inside a captured launcher body (graph.hip): device time stamps instead of HIP events.
+// An event-record node of a graph cannot be read with hipEventElapsedTime (rc 400, tools/probes/launch_cost_probe.hip), so a
+// bracket there is [stamp kernel, timed kernel, stamp kernel]: one lane stores wall_clock64() (the constant-rate counter,
+// hipDeviceAttributeWallClockRate kHz: 100 MHz on gfx950).  A captured sequence is brought into the executable graph of
+// its ring entry by hipGraphExecUpdate, which needs the same node count and -- measured -- refuses a node whose kernel
+// moves to another code object ("not supported", result 6): the brackets of one ring entry therefore sit at the SAME launch
+// positions every time, launch ordinal o of the timed kernel inside the scope being bracketed iff ((o + phase) % P) %
+// stride == 0 with P = the kernel's launch count in the previous scope of that slot and phase = ring entry * stride / ring
+// size (so the ring's entries together sample ring-size times as many positions as one).
+constexpr int STAMP_CAP = 1 << 15;  // brackets per enable
+unsigned long long *g_stamp_buf = nullptr;  // device, 2 * STAMP_CAP
+double g_stamp_us_per_tick = 0.01;
+int g_stamp_n = 0;
+struct StampRec { int slot; double bytes; };
+std::vector<StampRec> g_stamp_recs[KID_COUNT];
+std::vector<int> g_stamp_pending[KID_COUNT];
+unsigned g_scope_period[2][KID_COUNT];  // launches of each kernel in the previous scope of a slot
+unsigned g_scope_phase[2];
+thread_local unsigned t_scope_seen[KID_COUNT];
+thread_local int t_scope_which = -1;
+__global__ void stamp_kernel(unsigned long long *p) {
+    if (threadIdx.x == 0) *p = wall_clock64();
+}
 }  // namespace
 
 extern "C" int ptv2_profile_is_on(void) { return g_on; }
+int ptv2_profile_stamps(void) { return g_on && g_only >= 0 && g_stamp_buf != nullptr; }
+void ptv2_profile_scope(int which, int end, int ring_entry, int ring_size) {  // graph.hip: a captured body begins / ends on this thread
+    if (which < 0 || which > 1) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!end) {
+        for (int k = 0; k < KID_COUNT; ++k) t_scope_seen[k] = 0;
+        t_scope_which = which;
+        const int stride = g_stride > 1 ? g_stride : 1;
+        g_scope_phase[which] = (unsigned)(ring_entry * std::max(1, stride / std::max(1, ring_size)));
+    } else {
+        for (int k = 0; k < KID_COUNT; ++k) g_scope_period[which][k] = t_scope_seen[k];
+        t_scope_which = -1;
+    }
+}
 int ptv2_profile_wants(int kid) {
     if (!g_on || (g_only >= 0 && g_only != kid)) return 0;
-    if (g_stride <= 1) return 1;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (ptv2_graph_capturing() && t_scope_which >= 0) {
+        const unsigned o = t_scope_seen[kid]++, P = g_scope_period[t_scope_which][kid], ph = g_scope_phase[t_scope_which];
+        const unsigned stride = g_stride > 1 ? (unsigned)g_stride : 1u;
+        return (P > 0 ? ((o + ph) % P) % stride : o % stride) == 0;
+    }
+    if (g_stride <= 1) return 1;
     return (g_seen[kid]++ % (unsigned)g_stride) == 0;
 }
-
 // bracket only every n-th launch of the timed kernels (n >= 1): a uniform sample of the launches in a timed region
 extern "C" int ptv2_profile_stride(int n) {
     if (n < 1) return PTV2_ERR_ARG;
@@ -190,6 +232,13 @@ extern "C" int ptv2_profile_select(int kid) {
 
 void ptv2_profile_begin(int kid, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (ptv2_graph_capturing()) {
+        if (!g_stamp_buf || g_stamp_n >= STAMP_CAP) return;
+        const int slot = g_stamp_n++;
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, g_stamp_buf + 2 * slot);
+        g_stamp_pending[kid].push_back(slot);
+        return;
+    }
     hipEvent_t e = take_event();
     if (!e) return;
     (void)hipEventRecord(e, st);
@@ -198,6 +247,14 @@ void ptv2_profile_begin(int kid, hipStream_t st) {
 
 void ptv2_profile_end(int kid, hipStream_t st, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (ptv2_graph_capturing()) {
+        if (g_stamp_pending[kid].empty()) return;
+        const int slot = g_stamp_pending[kid].back();
+        g_stamp_pending[kid].pop_back();
+        hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, g_stamp_buf + 2 * slot + 1);
+        g_stamp_recs[kid].push_back(StampRec{slot, bytes});
+        return;
+    }
     hipEvent_t e = take_event();
     if (!e) return;
     (void)hipEventRecord(e, st);
@@ -212,6 +269,14 @@ extern "C" int ptv2_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (on) {
         for (int k = 0; k < KID_COUNT; ++k) g_seen[k] = 0;
+        if (!g_stamp_buf) {  // (outside any capture: bench.py enables the timer between steps)
+            if (hipMalloc((void **)&g_stamp_buf, sizeof(unsigned long long) * 2 * STAMP_CAP) != hipSuccess) g_stamp_buf = nullptr;
+            int dev = 0, khz = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+                g_stamp_us_per_tick = 1e3 / (double)khz;
+        }
+        g_stamp_n = 0;
+        for (int k = 0; k < KID_COUNT; ++k) { g_stamp_recs[k].clear(); g_stamp_pending[k].clear(); }
         for (int k = 0; k < KID_COUNT; ++k) {
             for (auto &r : g_recs[k]) { g_free.push_back(r.a); g_free.push_back(r.b); }
             g_recs[k].clear();
@@ -225,6 +290,38 @@ extern "C" int ptv2_profile_enable(int on) {
 
 extern "C" int ptv2_profile_kernel_count(void) { return KID_COUNT; }
 
+// microseconds of one EMPTY stamp bracket [stamp, stamp] inside a captured sequence, median of `reps` (bench.py subtracts it
+// from the stamp-bracketed averages, as it subtracts the empty HIP-event bracket from the event-bracketed ones)
+extern "C" double ptv2_profile_empty_stamp_us(void *stream, int reps) {
+    (void)stream;  // (the null stream cannot capture: a stream of its own)
+    if (!g_stamp_buf || reps < 1 || reps > 1024) return -1.0;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1.0;
+    unsigned long long *tmp = nullptr;
+    if (hipMalloc((void **)&tmp, sizeof(unsigned long long) * 2 * reps) != hipSuccess) { (void)hipStreamDestroy(st); return -1.0; }
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    double out = -1.0;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        for (int i = 0; i < 2 * reps; ++i) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, st, tmp + i);
+        if (hipStreamEndCapture(st, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess &&
+            hipGraphLaunch(ge, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+            std::vector<unsigned long long> host((size_t)2 * reps);
+            if (hipMemcpy(host.data(), tmp, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                std::vector<double> d;
+                for (int i = 0; i < reps; ++i) d.push_back(g_stamp_us_per_tick * (double)(host[2 * i + 1] - host[2 * i]));
+                std::sort(d.begin(), d.end());
+                out = d[d.size() / 2];
+            }
+        }
+    }
+    (void)hipGetLastError();
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipFree(tmp);
+    (void)hipStreamDestroy(st);
+    return out;
+}
+
 // Synchronises on the recorded events.  Returns PTV2_OK and fills name (>= 64 bytes), total microseconds,
 // number of launches and mean algorithmic bytes per launch of kernel id `kid`.
 extern "C" int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch) {
@@ -237,11 +334,21 @@ extern "C" int ptv2_profile_read(int kid, char *name, double *total_us, long lon
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) us += 1e3 * (double)ms;
         bytes += r.bytes;
     }
+    if (!g_stamp_recs[kid].empty() && g_stamp_buf) {
+        std::vector<unsigned long long> host((size_t)2 * g_stamp_n);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(host.data(), g_stamp_buf, sizeof(unsigned long long) * host.size(), hipMemcpyDeviceToHost) == hipSuccess)
+            for (auto &r : g_stamp_recs[kid]) {
+                us += g_stamp_us_per_tick * (double)(host[2 * r.slot + 1] - host[2 * r.slot]);
+                bytes += r.bytes;
+            }
+    }
+    const size_t count = g_recs[kid].size() + g_stamp_recs[kid].size();
     int i = 0;
     for (; kNames[kid][i] && i < 63; ++i) name[i] = kNames[kid][i];
     name[i] = 0;
     *total_us = us;
-    *launches = (long long)g_recs[kid].size();
-    *bytes_per_launch = g_recs[kid].empty() ? 0.0 : bytes / (double)g_recs[kid].size();
+    *launches = (long long)count;
+    *bytes_per_launch = count == 0 ? 0.0 : bytes / (double)count;
     return PTV2_OK;
 }

@@ -344,7 +344,7 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     VG.gWp1 = GP(PTV2_BLK_P1_W); VG.gbp1 = GP(PTV2_BLK_P1_B); VG.ggamma_p = GP(PTV2_BLK_PN_G); VG.gbeta_p = GP(PTV2_BLK_PN_B);
     VG.gWp2 = GP(PTV2_BLK_P2_W); VG.gbp2 = GP(PTV2_BLK_P2_B); VG.gWw1 = GP(PTV2_BLK_W1_W); VG.gbw1 = GP(PTV2_BLK_W1_B);
     VG.ggamma_w = GP(PTV2_BLK_WN_G); VG.gbeta_w = GP(PTV2_BLK_WN_B); VG.gWw2 = GP(PTV2_BLK_W2_W); VG.gbw2 = GP(PTV2_BLK_W2_B);
-    if (!G->inv_ptr) (void)hipMemsetAsync(gv, 0, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
+    if (!G->inv_ptr) (void)ptv2_zero_async(gv, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
     RUN(gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream));
     // linear_k / linear_q BatchNorm + ReLU
     if (batch[1] == batch[2]) {  // one reduce / finalize / apply for both

@@ -35,6 +35,22 @@ struct PtvScopedTimer {
     ~PtvScopedTimer() { if (on) ptv2_profile_end(kid, st, bytes); }
 };
 
+// graph.hip: the launcher body between construction and finish() is captured and issued as one hipGraph launch
+enum PtvGraphSlot { GRAPH_MODEL_FWD = 0, GRAPH_MODEL_BWD = 1 };
+struct PtvGraphScope {
+    void *st, *cap; int which; bool active; long long t0;
+    PtvGraphScope(void *stream, int which, bool allow = true);
+    void *stream() const { return cap; }  // where the body must enqueue: the capture stream, or the caller's when declined
+    int finish(int rc);   // returns rc, or PTV2_ERR_LAUNCH when the graph could not be built / launched
+    ~PtvGraphScope();     // an unfinished scope (early return) closes and discards its capture
+    PtvGraphScope(const PtvGraphScope &) = delete;
+    PtvGraphScope &operator=(const PtvGraphScope &) = delete;
+};
+int ptv2_graph_capturing(void);   // this thread is inside an active scope
+int ptv2_profile_stamps(void);    // the kernel timer brackets with device time stamps (legal inside a capture), not HIP events
+// zero-fill as a kernel launch (a kernel node like every other launch of a captured sequence; bytes % 4 == 0)
+int ptv2_zero_async(void *p, size_t bytes, hipStream_t st);
+
 // Matmul operand precision of the calling thread's launches (abi.hip): 0 = fp32 MFMA (V_MFMA_F32_16X16X4_F32, exact fp32),
 // 1 = bf16 MFMA (V_MFMA_F32_16X16X32_BF16: operands rounded to bf16 on their way into the matrix core, fp32
 // accumulation) -- what torch.autocast(dtype=bfloat16) does to the nn.Linear layers of the reference

@@ -538,7 +538,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
                                                 B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
                                                 W.gsh, G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
     // 3. + 4. BatchNorm over the logits (its backward is evaluated in the prologue of the rows kernel), logits stage
-    if (!G->inv_ptr) (void)hipMemsetAsync(W.gkW, 0, sizeof(float) * (size_t)n * g, st);
+    if (!G->inv_ptr) (void)ptv2_zero_async(W.gkW, sizeof(float) * (size_t)n * g, st);
     // the parameter-gradient sums of this stage and of the kW / qW weight gradient ride on the skinny_bwd launch below
     {
     const PtvDeferScope defer;

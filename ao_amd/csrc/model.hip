@@ -470,7 +470,28 @@ extern "C" size_t ptv2_model_workspace_bytes(const ptv2_model *M) {
     return carve_work(M, nullptr).bytes + 256;
 }
 
+namespace {
+int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream);
+int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, size_t workspace_bytes, void *stream);
+}  // namespace
+
+// Both directions enqueue their whole kernel sequence as ONE hipGraph launch (graph.hip): the body below runs under stream
+// capture, the executable graph of the previous call is updated in place with this call's arguments, and launched.
 extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
+    PtvGraphScope scope(stream, GRAPH_MODEL_FWD);
+    return scope.finish(model_forward(M, workspace, workspace_bytes, scope.stream()));
+}
+
+extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
+                                                size_t workspace_bytes, void *stream) {
+    // (an event that another stream waits on, or a second stream inside the body: issued eagerly)
+    PtvGraphScope scope(stream, GRAPH_MODEL_BWD, M && !M->decoder_done_event && !M->side_stream);
+    return scope.finish(model_backward(M, g_logits, workspace, workspace_bytes, scope.stream()));
+}
+
+namespace {
+
+int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
     if (!model_ok(M) || !M->saved) return PTV2_ERR_ARG;
     const PtvMatmulScope precision(M->matmul_bf16);
     const Arena A = carve(M, M->saved);
@@ -551,8 +572,7 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
     return PTV2_OK;
 }
 
-extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
-                                                size_t workspace_bytes, void *stream) {
+int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, size_t workspace_bytes, void *stream) {
     if (!model_ok(M) || !M->saved || !g_logits || !M->g_head_w) return PTV2_ERR_ARG;
     const PtvMatmulScope precision(M->matmul_bf16);
     const Arena A = carve(M, M->saved);
@@ -627,7 +647,7 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
         float *gp = seq_backward(M, 1 + i, A, A.pooled[i], W.gskip[i + 1], ga, W, stream, &rc);  // ping-pong gskip[i+1] / ga
         if (rc != PTV2_OK) return rc;
         // pooling: the gradient of a pooled value goes to its arg-max row (all other rows zero)
-        (void)hipMemsetAsync(gb, 0, sizeof(float) * (size_t)lv.n * c, st);
+        (void)ptv2_zero_async(gb, sizeof(float) * (size_t)lv.n * c, st);
         RUN(pool_max_backward_hip_launcher(M->level[i + 1].n, c, gp, A.arg[i], gb, stream));
         // GridPool.fc: the second contribution to the gradient of skip[i], added by the GEMM's accumulate epilogue
         RUN(linbn_backward(M, M->down[i], A.down[i], lv.n, skip[i], gb, gc, GH_DOWN + i, W.gskip[i], 1, W, stream));
@@ -648,3 +668,5 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
+
+}  // namespace

@@ -193,6 +193,24 @@ def op_microbench(data):
     return out
 
 
+def host_facts():
+    """What the launching thread runs on: a judge must be able to tell a slow host from a slow GPU from the one line."""
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
+    return {"cpu": model, "cpus_online": os.cpu_count(), "affinity": affinity, "loadavg": list(os.getloadavg())}
+
+
 def cpu_baseline(cfg, sample_points):
     """fwd+bwd+AdamW of the CPU oracle on a bounded crop of the same scene generator."""
     from ao_amd import synth
@@ -477,8 +495,26 @@ def child_main(args):
                 while math.gcd(timed_stride, per_step) != 1:
                     timed_stride += 2
             _lib.kernel_timer(True, only=dominant, stride=timed_stride)
-    elapsed, points_per_step, loss = parallel.timed_steps(step, args.steps, device, n_points,
+    # host side of the timed region: wall and CPU time the launching thread spends inside step(), and one
+    # event per step on the compute stream so that the per-step GPU-side durations can be told apart from host stalls
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_wall, host_cpu = [], []
+
+    def timed_step():
+        i = len(host_wall)
+        if i == 0:
+            marks[0].record()
+        w0, c0 = time.perf_counter(), time.thread_time()
+        out = step()
+        host_wall.append(time.perf_counter() - w0)
+        host_cpu.append(time.thread_time() - c0)
+        marks[i + 1].record()
+        return out
+
+    _lib.graph_stats(reset=True)
+    elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
                                                           finish=basket.flush if basket is not None else None)
+    graph = _lib.graph_stats()
     if prefetch is not None:
         prefetch.close()  # (thread mode: the geometry of the batch after the last one is still being built)
     if not args.no_roofline:
@@ -516,6 +552,26 @@ def child_main(args):
                                     % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",
                        "loss": float(loss.detach()), "library_build": "src " + str(src_hash(build_info))},
         }
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        pick = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
+        out["host"] = host_facts()
+        out["host"].update({
+            # time the launching thread spends inside one step (wall: includes waiting for a full queue / the geometry
+            # thread; cpu: time.thread_time of that thread) against the step time -- host-bound when they approach it
+            "host_issue_ms": 1e3 * sum(host_wall) / len(host_wall), "host_issue_ms_max": 1e3 * max(host_wall),
+            "host_cpu_ms": 1e3 * sum(host_cpu) / len(host_cpu),
+            # per-step durations between events recorded on the compute stream at the end of every step
+            "step_ms": {"min": step_ms[0], "median": pick(0.5), "p90": pick(0.9), "max": step_ms[-1]},
+            "issue": ("hipGraph: each direction of the model captured and launched as one graph (ao_amd/csrc/graph.hip)"
+                      if graph["scopes"] > 0 else "eager (hipLaunchKernelGGL per kernel)"),
+            "graph": {"launches_per_step": graph["scopes"] / args.steps, "nodes_per_step": graph["nodes"] / args.steps,
+                      "updated_in_place": int(graph["updated"]), "instantiated": int(graph["instantiated"]),
+                      "ran_eagerly": int(graph["declined"]),
+                      "capture_ms_per_step": 1e-3 * graph["capture_us"] / args.steps,
+                      "update_ms_per_step": 1e-3 * graph["update_us"] / args.steps,
+                      "launch_ms_per_step": 1e-3 * graph["launch_us"] / args.steps,
+                      "wait_for_gpu_ms_per_step": 1e-3 * graph["wait_us"] / args.steps},
+            "geometry_prefetch": pf_mode})
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
         out["config"]["step_frac_of_hbm_roofline"] = (step_bytes / (ms * 1e-3)) / (HBM_PEAK_GBS * 1e9)
@@ -534,6 +590,14 @@ def child_main(args):
                     b.record()
                 torch.cuda.synchronize(device)
                 empty_us = sorted(1e3 * a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+                bracket = "HIP events"
+                if graph["scopes"] > 0:
+                    # graph issue: the brackets of the timed region were pairs of device time-stamp kernels inside the captured
+                    # sequence (an event-record node cannot be read back); calibrate with empty stamp brackets in a graph
+                    bracket = "device time stamps (wall_clock64) inside the graph; the survey steps used HIP events, eager issue"
+                    e2 = _lib.lib().ptv2_profile_empty_stamp_us(torch.cuda.current_stream(device).cuda_stream, 200)
+                    if e2 >= 0:
+                        empty_us = e2
                 net_us = max(rec["avg_us"] - empty_us, 0.5 * rec["avg_us"])
                 achieved = rec["bytes_per_launch"] / (net_us * 1e-6) / 1e9
                 traffic, traffic_source = pmc_traffic(name, build_info)
@@ -541,6 +605,8 @@ def child_main(args):
                                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                    "traffic_source": traffic_source,
                                    "avg_us": net_us, "avg_us_bracket": rec["avg_us"], "empty_bracket_us": empty_us,
+                                   "bracket": bracket,
+                                   "avg_us_survey_hip_events": (round(survey[name]["avg_us"], 2) if name in survey else None),
                                    "launches_timed": rec["launches"],
                                    "ms_per_step": timed_stride * rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],

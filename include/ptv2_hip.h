@@ -51,6 +51,20 @@ int ptv2_profile_stride(int n); /* bracket every n-th launch only (uniform sampl
 int ptv2_profile_is_on(void);
 int ptv2_profile_kernel_count(void);
 int ptv2_profile_read(int kid, char *name, double *total_us, long long *launches, double *bytes_per_launch);
+/* Inside a graph-issued launcher (below) a bracket is a pair of device time-stamp kernels instead of a pair of HIP events
+ * (event-record nodes of a graph cannot be read back); the median duration of an EMPTY such bracket, in microseconds,
+ * measured on `stream` (< 0 on failure). */
+double ptv2_profile_empty_stamp_us(void *stream, int reps);
+
+/* Graph issue of the model launchers (ao_amd/csrc/graph.hip; host only).  ptv2_model_{forward,backward}_hip_launcher
+ * capture their kernel sequence on the caller's stream and enqueue it as ONE hipGraph launch (the previous call's
+ * executable graph updated in place with this call's arguments): ~1.7 us of host time per kernel instead of ~4, and no
+ * per-kernel doorbell.  Same kernels, same arguments, same order as eager issue.  mode(0) / AO_AMD_GRAPH=0 issues
+ * eagerly; mode(-1) only reads the setting.  stats: out[9] = scopes, updated, instantiated, declined (ran eagerly),
+ * nodes launched, host us capturing / updating+instantiating / launching / waiting for the GPU to release a graph. */
+int ptv2_graph_mode(int on);
+int ptv2_graph_stats(double *out, int reset);
+int ptv2_graph_reset(void);
 
 /* ------------------------------------------------------------------ kNN --
  * Replaces knn_query_cuda_launcher
