@@ -47,8 +47,10 @@ struct SlotKeyHash {
 // GPU: updating the one graph that the previous step's launch is still executing from would rewrite arguments under
 // running kernels.  So every slot holds a small ring of executable graphs, each fenced by an event recorded behind its
 // launch; a ring entry is only updated (or destroyed) once that event has completed -- which also bounds how far the
-// host can run ahead (RING steps).
-constexpr int RING = 3;
+// host can run ahead (RING steps).  Eight: the GPU boxes of this pool run under a cgroup CPU quota (cpu.max 16 CPUs per
+// 100 ms on a 256-thread host), and a throttled period stalls the issuing thread for up to ~90 ms; with eager issue the
+// host is only ~3 ms ahead of the GPU and every such stall is a GPU bubble, eight queued steps (~90 ms) ride it out.
+constexpr int RING = 8;
 struct Exec {
     hipGraphExec_t exec = nullptr;
     size_t nodes = 0;

@@ -65,7 +65,8 @@ def parse():
                     help="backbone config: the headline S3DIS one, or configs/scannet/semseg-pt-v2m2-0-base.py (BASELINE.json configs[4])")
     ap.add_argument("--segmentor", default="default", choices=["default", "sam_image"],
                     help="sam_image: DefaultSegmentorSAM_Image + the per-step logit basket of train_real (BASELINE.json configs[3])")
-    ap.add_argument("--cpu-sample-points", type=int, default=12000)
+    ap.add_argument("--cpu-sample-points", type=int, default=120000,
+                    help="points of the CPU-oracle scene (default: the metric's own 120 000; ~1-2 min on the box's 16-CPU quota)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the kNN / FPS us-per-query lines")
@@ -208,45 +209,81 @@ def host_facts():
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = None
-    return {"cpu": model, "cpus_online": os.cpu_count(), "affinity": affinity, "loadavg": list(os.getloadavg())}
+    return {"cpu": model, "cpus_online": os.cpu_count(), "affinity": affinity, "loadavg": list(os.getloadavg()),
+            "cgroup_cpu_max": cgroup_cpu()[0]}
 
 
-def cpu_baseline(cfg, sample_points):
-    """fwd+bwd+AdamW of the CPU oracle on a bounded crop of the same scene generator."""
+def cgroup_cpu():
+    """(cpu.max, {nr_periods, nr_throttled, throttled_usec}) of this process's cgroup (v2), or (None, {}).  The pool's GPU
+    boxes show 256 CPUs but run under a quota (1600000 100000 = 16 CPUs): a process that exceeds it inside a 100 ms
+    period is stopped -- every thread, the launching one included -- until the period ends."""
+    quota, stat = None, {}
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = line.split()
+            if k in ("nr_periods", "nr_throttled", "throttled_usec", "usage_usec"):
+                stat[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    return quota, stat
+
+
+def cpu_quota():
+    """CPUs this process may use: the cgroup quota when there is one, else the affinity mask."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = cgroup_cpu()[0]
+    if quota:
+        a, b = quota.split()
+        if a != "max":
+            n = min(n, max(1, int(a) // int(b)))
+    return n
+
+
+def cpu_baseline(cfg, sample_points, crop_points=12000):
+    """fwd+bwd+AdamW of the CPU oracle (oracle/ptv2_ref.py + the C kNN) on the metric's own workload -- one `sample_points`
+    scene of the same generator (default 120 000: the configuration `value` is quoted on), ONE step, timed after the code
+    paths were warmed on a `crop_points` crop (whose rate is reported beside it).  Threads = the CPUs this process may
+    actually use (the cgroup quota of the box, not the 256 it shows: with one thread per visible CPU the step is throttled)."""
     from ao_amd import synth
     from oracle import pointops_ref, ptv2_ref
 
     pointops_ref.build()
-    torch.manual_seed(0)
-    b = synth.scene_batch([0], point_max=sample_points, room=1)
-    data = {k: torch.from_numpy(v) for k, v in b.items()}
-    model = ptv2_ref.RefModule(dict(cfg, drop_path_rate=0.0)).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
-    times = []
-    for it in range(3):
-        t0 = time.perf_counter()
-        loss = torch.nn.functional.cross_entropy(model(data), data["segment"], ignore_index=-1)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    out = dict(value=sample_points / t, unit="points/s", cores=torch.get_num_threads(), kind="port",
-               sample="1 scene cropped to %d points, fwd+bwd+AdamW, median of 2 after 1 warm-up, %.1f s/step; "
-                      "torch-CPU restatement + C kNN (oracle/), drop_path 0" % (sample_points, t))
-    # the FULL 120 000-point scene costs ~2 min per step on the host: measured once with `--cpu-sample-points 120000` and
-    # committed; read from that record (never a literal here), null when the file is absent
-    full = None
-    path = os.path.join(ROOT, "profiles", "r02_cpu_baseline_120k.json")
-    if sample_points >= 120000:
-        full = dict(value=out["value"], cores=out["cores"], s_per_step=t, source="this run")
-    elif os.path.exists(path):
-        rec = json.load(open(path))
-        cb = rec["cpu_baseline"]
-        full = dict(value=cb["value"], cores=cb["cores"], s_per_step=120000 / cb["value"],
-                    source="profiles/r02_cpu_baseline_120k.json (%s; not re-measured in this run)" % rec.get("measured", "?"))
-    out["full_scene_120k"] = full
-    return out
+    threads = cpu_quota()
+    torch.set_num_threads(threads)
+
+    def run(points, reps):
+        torch.manual_seed(0)
+        b = synth.scene_batch([0], point_max=points, room=1)
+        data = {k: torch.from_numpy(v) for k, v in b.items()}
+        model = ptv2_ref.RefModule(dict(cfg, drop_path_rate=0.0)).train()
+        opt = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+        times = []
+        for it in range(reps):
+            t0 = time.perf_counter()
+            loss = torch.nn.functional.cross_entropy(model(data), data["segment"], ignore_index=-1)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            times.append(time.perf_counter() - t0)
+        return times, int(data["coord"].shape[0])
+
+    crop_times, crop_n = run(min(crop_points, sample_points), 3)
+    crop_t = float(np.median(crop_times[1:]))
+    crop = dict(value=crop_n / crop_t, points=crop_n, s_per_step=crop_t, sample="median of 2 steps after 1 warm-up")
+    if sample_points <= crop_points:
+        value, t, what = crop["value"], crop_t, "1 scene cropped to %d points, median of 2 steps after 1 warm-up" % crop_n
+    else:
+        full_times, full_n = run(sample_points, 1)
+        t = full_times[0]
+        value, what = full_n / t, "1 scene of %d points (the metric's workload), 1 step after a warm-up on a %d-point crop" % (full_n, crop_n)
+    return dict(value=value, unit="points/s", cores=threads, kind="port",
+                sample="%s, fwd+bwd+AdamW, %.1f s/step; torch-CPU restatement + C kNN (oracle/), drop_path 0; threads = "
+                       "cgroup CPU quota (%s)" % (what, t, cgroup_cpu()[0]),
+                s_per_step=t, crop=crop)
 
 
 def spawn_ranks(args):
@@ -365,6 +402,9 @@ def child_main(args):
             dist.destroy_process_group()
         return
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    # the GPU path needs no CPU worker threads; torch's default (one per visible CPU: 128 on the pool's hosts) overruns the
+    # boxes' cgroup quota (16 CPUs) whenever an intra-op pool spins up, and a throttled period stops the launching thread too
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota())))
     if os.environ.get("AO_AMD_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("AO_AMD_BENCH_BACKEND", "nccl")
@@ -512,9 +552,11 @@ def child_main(args):
         return out
 
     _lib.graph_stats(reset=True)
+    cg0 = cgroup_cpu()[1]
     elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
                                                           finish=basket.flush if basket is not None else None)
     graph = _lib.graph_stats()
+    cg1 = cgroup_cpu()[1]
     if prefetch is not None:
         prefetch.close()  # (thread mode: the geometry of the batch after the last one is still being built)
     if not args.no_roofline:
@@ -571,7 +613,10 @@ def child_main(args):
                       "update_ms_per_step": 1e-3 * graph["update_us"] / args.steps,
                       "launch_ms_per_step": 1e-3 * graph["launch_us"] / args.steps,
                       "wait_for_gpu_ms_per_step": 1e-3 * graph["wait_us"] / args.steps},
-            "geometry_prefetch": pf_mode})
+            "geometry_prefetch": pf_mode,
+            # the cgroup's CPU accounting across the timed region: a throttled period there is a stalled launching thread
+            "cgroup_timed_region": ({k: cg1[k] - cg0[k] for k in cg1 if k in cg0} if cg0 and cg1 else None),
+            "torch_cpu_threads": torch.get_num_threads()})
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
         out["config"]["step_frac_of_hbm_roofline"] = (step_bytes / (ms * 1e-3)) / (HBM_PEAK_GBS * 1e9)
