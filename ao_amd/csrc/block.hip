@@ -307,13 +307,6 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     // gradient tensors; g_h3, g_hq, g_hk, gv, g_h1 are also the gY operands of the five (c,c) weight gradients, which run
     // as ONE launch + one finalize at the end of the block instead of three launches spread along the chain
     float *g_h3 = W.t[0], *g_hq = W.t[1], *g_hk = W.t[2], *gv = W.t[3], *g_h1 = W.t[4], *ta = W.t[5], *tb = W.t[6];
-    const bool deferred = G->side_stream != nullptr;
-    if (deferred) {  // operands of the deferred weight gradients live in the caller's per-Block buffer
-        if (!G->keep || !G->side_event || !G->side_workspace || G->side_workspace_bytes < dense_workspace_bytes(n, 5 * c, c))
-            return PTV2_ERR_WORKSPACE;
-        const size_t nc = (size_t)n * c;
-        g_h3 = G->keep; g_hq = G->keep + nc; g_hk = G->keep + 2 * nc; gv = G->keep + 3 * nc; g_h1 = G->keep + 4 * nc;
-    }
 
     // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3, residual gradient straight into gx
     RUN(bn_backward_residual_hip_launcher(n, c, S.h3, G->gy, B->y, B->rowscale, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G],
@@ -382,14 +375,7 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
         const float *xsh[5] = {S.bsh[5], S.bsh[0], S.bsh[0], S.bsh[0], nullptr};
         float *dws[5] = {GP(PTV2_BLK_FC3_W), GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W), GP(PTV2_BLK_FC1_W)};
         float *dbs[5] = {nullptr, GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B), nullptr};
-        if (deferred) {
-            if (hipEventRecord((hipEvent_t)G->side_event, (hipStream_t)stream) != hipSuccess) return PTV2_ERR_LAUNCH;
-            if (hipStreamWaitEvent((hipStream_t)G->side_stream, (hipEvent_t)G->side_event, 0) != hipSuccess) return PTV2_ERR_LAUNCH;
-            RUN(linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, G->side_workspace, G->side_workspace_bytes,
-                                                G->side_stream));
-        } else {
-            RUN(linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
-        }
+        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

@@ -38,7 +38,7 @@ struct PtvScopedTimer {
 // graph.hip: the launcher body between construction and finish() is captured and issued as one hipGraph launch
 enum PtvGraphSlot { GRAPH_MODEL_FWD = 0, GRAPH_MODEL_BWD = 1 };
 struct PtvGraphScope {
-    void *st, *cap; int which; bool active; long long t0;
+    void *st, *cap; int which, ring_entry; bool active; long long t0;
     PtvGraphScope(void *stream, int which, bool allow = true);
     void *stream() const { return cap; }  // where the body must enqueue: the capture stream, or the caller's when declined
     int finish(int rc);   // returns rc, or PTV2_ERR_LAUNCH when the graph could not be built / launched

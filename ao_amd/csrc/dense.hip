@@ -235,6 +235,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_split_kernel(BnTileSet
         __hip_atomic_store(fold + ch, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(fold + c + ch, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fold stores are acknowledged before the arrival is published (gva_common.h: last_block_arrives)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -56,11 +56,26 @@ struct Exec {
     size_t nodes = 0;
     hipEvent_t done = nullptr;
     bool in_flight = false;
+    unsigned long long seq = 0;  // launch order, to find the oldest
 };
 struct Slot {
     Exec ring[RING];
-    int next = 0;
+    unsigned long long launches = 0;
 };
+// the entry the next launch of a slot uses: the first whose previous launch has completed (an entry is created -- one
+// instantiation -- only when every existing one is still in flight, i.e. only as far as the host actually runs ahead),
+// else the oldest, which finish() then waits for
+int pick_entry(Slot &slot) {
+    int oldest = 0;
+    for (int i = 0; i < RING; ++i) {
+        Exec &e = slot.ring[i];
+        if (e.in_flight && e.done && hipEventQuery(e.done) == hipSuccess) e.in_flight = false;
+        if (!e.in_flight) return i;
+        if (e.seq < slot.ring[oldest].seq) oldest = i;
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady of the queries)
+    return oldest;
+}
 struct StreamKey {
     int device;
     hipStream_t stream;
@@ -159,7 +174,8 @@ extern "C" int ptv2_graph_reset(void) {
     return PTV2_OK;
 }
 
-PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow) : st(stream), cap(stream), which(which_), active(false), t0(0) {
+PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow)
+    : st(stream), cap(stream), which(which_), ring_entry(0), active(false), t0(0) {
     hipStream_t s = (hipStream_t)stream;
     if (!allow || !mode() || g_inside) { g_stats.declined++; return; }
     // HIP-event brackets around every kernel (the survey of bench.py's roofline leg) cannot live in a graph
@@ -189,7 +205,7 @@ PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow) : st(stream),
     int entry = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        entry = g_slots[SlotKey{device, s, which}].next;  // the ring entry finish() will use (one issuing thread per stream)
+        entry = pick_entry(g_slots[SlotKey{device, s, which}]);  // (one issuing thread per stream: finish() uses this entry)
     }
     t0 = now_ns();
     if (hipStreamBeginCapture(c, hipStreamCaptureModeRelaxed) != hipSuccess) { g_stats.declined++; (void)hipGetLastError(); return; }
@@ -197,6 +213,7 @@ PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow) : st(stream),
     active = true;
     g_inside = 1;
     g_stats.scopes++;
+    ring_entry = entry;
     ptv2_profile_scope(which, 0, entry, RING);
 }
 
@@ -220,8 +237,8 @@ int PtvGraphScope::finish(int rc) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         Slot &ring = g_slots[SlotKey{device, s, which}];
-        Exec &slot = ring.ring[ring.next];
-        ring.next = (ring.next + 1) % RING;
+        Exec &slot = ring.ring[ring_entry];
+        slot.seq = ++ring.launches;
         if (!slot.done && hipEventCreateWithFlags(&slot.done, hipEventDisableTiming) != hipSuccess) slot.done = nullptr;
         if (slot.in_flight && slot.done) {
             const long long w0 = now_ns();

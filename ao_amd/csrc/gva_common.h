@@ -118,7 +118,15 @@ __device__ __forceinline__ float part_load(const float *p) { return *p; }
 // call after the block's part_store()s; true in exactly one block (the last to arrive), in all of its threads
 __device__ __forceinline__ bool last_block_arrives(unsigned *counter) {
     __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my stores have left the wavefront (waitcnt)
+    // EVERY thread's record stores must have been acknowledged by memory before thread 0 bumps the counter.  The records are
+    // agent-scope atomic stores (sc1: written through, no L2 write-back needed), so a drained store queue is all a release
+    // needs here -- but a workgroup-scope release fence does not emit it: the ISA of rounds 1-3 went `global_store ... sc1;
+    // s_barrier; global_atomic_add` with no s_waitcnt vmcnt(0) in between, i.e. the last-arriving block (on another XCD)
+    // could read a record that was still in flight: last launch's value of that slot, or on a fresh process whatever the
+    // workspace held (the once-in-67-runs NaN loss of the 2-rank test).  An agent-scope release fence
+    // would be correct too, but adds a buffer_wbl2 (a write-back of the whole L2) per block.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;

@@ -233,31 +233,9 @@ struct Work {
     char *dense; size_t dense_bytes;   // BatchNorm / weight-gradient partial records
     float *ga, *gb, *gc;               // gradient temporaries, max over levels of n * widest channel count
     float *gskip[PTV2_MAX_STAGES + 1]; // gradient of the encoder output at level i (two contributions)
-    // deferred weight gradients (M->side_stream != NULL): operands that must outlive the main chain's buffer reuse
-    float *keep_block[PTV2_MAX_BLOCKS];      // 5 (n,c) gradients per Block
-    float *keep_gh[3 * PTV2_MAX_STAGES + 2]; // gradient in front of each Linear+BatchNorm: embed, head, down/up/up_skip[i]
     float *fold_scratch[PTV2_MAX_BLOCKS];    // per-Block operands of the attention's parameter glue, run once at the end
-    char *side; size_t side_bytes;           // split-K records of everything enqueued on the side stream
     size_t bytes;
 };
-
-enum { GH_EMBED = 0, GH_HEAD = 1, GH_DOWN = 2, GH_UP = 2 + PTV2_MAX_STAGES, GH_SKIP = 2 + 2 * PTV2_MAX_STAGES };
-
-// Events that order the side stream behind the main one; created once, timing disabled, handed out round-robin (an
-// event may be re-recorded as soon as the wait on its previous record has been enqueued).
-hipEvent_t next_event() {
-    static std::mutex mu;
-    static std::vector<hipEvent_t> pool;
-    static size_t cursor = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    if (pool.size() < 128) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        pool.push_back(e);
-        return e;
-    }
-    return pool[cursor++ % pool.size()];
-}
 
 Work carve_work(const ptv2_model *M, void *base) {
     Work W;
@@ -302,27 +280,6 @@ Work carve_work(const ptv2_model *M, void *base) {
         for (int j = 0; j < s.depth; ++j)
             W.fold_scratch[s.first_block + j] = (float *)take(sizeof(float) * ptv2_gva_fold_scratch_floats(s.c, s.g));
     }
-    W.side = nullptr;
-    W.side_bytes = 0;
-    if (M->side_stream) {
-        W.side_bytes = W.dense_bytes;
-        for (int q = 0; q <= 2 * S; ++q) {
-            const ptv2_seq &s = M->seq[q];
-            const int n = M->level[s.level].n;
-            for (int j = 0; j < s.depth; ++j) {
-                W.keep_block[s.first_block + j] = (float *)take(sizeof(float) * 5 * (size_t)n * s.c);
-                W.side_bytes = std::max(W.side_bytes, dense_workspace_bytes(n, 5 * s.c, s.c));
-            }
-        }
-        W.keep_gh[GH_EMBED] = (float *)take(sizeof(float) * (size_t)M->level[0].n * M->embed.cout);
-        W.keep_gh[GH_HEAD] = (float *)take(sizeof(float) * (size_t)M->level[0].n * M->head.cout);
-        for (int i = 0; i < S; ++i) {
-            W.keep_gh[GH_DOWN + i] = (float *)take(sizeof(float) * (size_t)M->level[i].n * M->down[i].cout);
-            W.keep_gh[GH_UP + i] = (float *)take(sizeof(float) * (size_t)M->level[i + 1].n * M->up[i].cout);
-            W.keep_gh[GH_SKIP + i] = (float *)take(sizeof(float) * (size_t)M->level[i].n * M->up_skip[i].cout);
-        }
-        W.side = take(W.side_bytes);
-    }
     W.bytes = off;
     return W;
 }
@@ -362,33 +319,15 @@ int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S,
 
 // gy (n,cout) -> BatchNorm + ReLU backward -> gh (tmp); dgamma, dbeta; dW, db from (gh, x); gx (n,cin) = gh W (+)= when
 // `accumulate`; gx == NULL: the input needs no gradient (the patch embedding)
-// fork: everything enqueued on the side stream after this sees what the main stream has produced so far
-int fork_side(const ptv2_model *M, void *stream) {
-    hipEvent_t e = next_event();
-    if (!e || hipEventRecord(e, (hipStream_t)stream) != hipSuccess) return PTV2_ERR_LAUNCH;
-    return hipStreamWaitEvent((hipStream_t)M->side_stream, e, 0) == hipSuccess ? PTV2_OK : PTV2_ERR_LAUNCH;
-}
-
-// dW (cout,cin) = gY^T X (+ db): on the side stream when there is one (operands must persist), else in line
-int wgrad(const ptv2_model *M, int n, int cout, int cin, const float *gY, const float *X, float *dW, float *db, const Work &W,
-          void *stream) {
-    if (M->side_stream) {
-        RUN(fork_side(M, stream));
-        return linear_wgrad_hip_launcher(n, cout, cin, gY, X, dW, db, W.side, W.side_bytes, M->side_stream);
-    }
-    return linear_wgrad_hip_launcher(n, cout, cin, gY, X, dW, db, W.dense, W.dense_bytes, stream);
-}
-
 int linbn_backward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S, int n, const float *x, const float *gy, float *gh,
-                   int keep_slot, float *gx, int accumulate, const Work &W, void *stream) {
-    if (M->side_stream) gh = W.keep_gh[keep_slot];  // the weight gradient reads it later, on the side stream
+                   float *gx, int accumulate, const Work &W, void *stream) {
     RUN(bn_backward_hip_launcher(n, L.cout, S.h, gy, S.mean, S.rstd, L.gamma, L.beta, 1, use_batch(M, L) ? 1 : 0, gh, L.ggamma,
                                  L.gbeta, W.dense, W.dense_bytes, stream));
     if (gx) {
         if (L.cin % 4 != 0 || L.cout % 4 != 0) return PTV2_ERR_ARG;
         RUN(rows_gemm_hip_launcher(n, L.cin, L.cout, gh, L.w, 1, nullptr, gx, accumulate, stream));
     }
-    return wgrad(M, n, L.cout, L.cin, gh, x, L.gw, L.b ? L.gb : nullptr, W, stream);
+    return linear_wgrad_hip_launcher(n, L.cout, L.cin, gh, x, L.gw, L.b ? L.gb : nullptr, W.dense, W.dense_bytes, stream);
 }
 
 void fill_block(const ptv2_model *M, int q, int j, const Arena &A, const float *x, ptv2_block *B) {
@@ -442,10 +381,6 @@ float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_i
         ptv2_block_grads G{};
         G.gy = gy; G.inv_ptr = s.inv_ptr; G.inv_rows = s.inv_rows; G.gx = other; G.gparam = nullptr;
         for (int i = 0; i < PTV2_BLK_NPARAM; ++i) G.gp[i] = M->block[s.first_block + j].gparam[i];
-        if (M->side_stream) {
-            G.side_stream = M->side_stream; G.side_event = next_event(); G.keep = W.keep_block[s.first_block + j];
-            G.side_workspace = W.side; G.side_workspace_bytes = W.side_bytes;
-        }
         // the attention's parameter-sized glue is queued, not launched (its operands stay in this Block's scratch); not under
         // checkpointing, where the glue reads a saved vector that the next recomputation overwrites
         ptv2_gva_set_fold_scratch(M->checkpoint ? nullptr : W.fold_scratch[s.first_block + j]);
@@ -484,8 +419,8 @@ extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *worksp
 
 extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
-    // (an event that another stream waits on, or a second stream inside the body: issued eagerly)
-    PtvGraphScope scope(stream, GRAPH_MODEL_BWD, M && !M->decoder_done_event && !M->side_stream);
+    // (with an event that another stream waits on in the body: issued eagerly)
+    PtvGraphScope scope(stream, GRAPH_MODEL_BWD, M && !M->decoder_done_event);
     return scope.finish(model_backward(M, g_logits, workspace, workspace_bytes, scope.stream()));
 }
 
@@ -608,8 +543,8 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
         else
             hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(grid_for((long long)n0 * c0)), dim3(TPB), sizeof(float) * (size_t)nc * c0,
                                st, (long long)n0, c0, nc, g_logits, M->head_w, ga);
-        RUN(wgrad(M, n0, nc, c0, g_logits, A.head.y, M->g_head_w, M->head_b ? M->g_head_b : nullptr, W, stream));
-        RUN(linbn_backward(M, M->head, A.head, n0, dec_in[0], ga, gc, GH_HEAD, gb, 0, W, stream));
+        RUN(linear_wgrad_hip_launcher(n0, nc, c0, g_logits, A.head.y, M->g_head_w, M->head_b ? M->g_head_b : nullptr, W.dense, W.dense_bytes, stream));
+        RUN(linbn_backward(M, M->head, A.head, n0, dec_in[0], ga, gc, gb, 0, W, stream));
     }
     // decoder stages 0 .. S-1 (the forward ran them S-1 .. 0)
     float *g = gb, *o = ga;
@@ -620,7 +555,7 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
         if (rc != PTV2_OK) return rc;
         float *spare = gin == g ? o : g;
         // skip branch: first contribution to the gradient of skip[i]
-        RUN(linbn_backward(M, M->up_skip[i], A.up_skip[i], lv.n, skip[i], gin, gc, GH_SKIP + i, W.gskip[i], 0, W, stream));
+        RUN(linbn_backward(M, M->up_skip[i], A.up_skip[i], lv.n, skip[i], gin, gc, W.gskip[i], 0, W, stream));
         // unpooled rows: back to the coarse level
         if (M->interp) {
             if (!lv.up_inv_ptr || !lv.up_inv_rows) return PTV2_ERR_ARG;
@@ -631,7 +566,7 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
         // proj: gradient of the unpool's input = output of decoder stage i+1, or (i+1 == S) the deepest encoder output;
         // gin's rows are dead once both branches have read them
         float *dst = i + 1 == S ? W.gskip[S] : gin;
-        RUN(linbn_backward(M, M->up[i], A.up[i], n_coarse, dec_in[i + 1], spare, gc, GH_UP + i, dst, 0, W, stream));
+        RUN(linbn_backward(M, M->up[i], A.up[i], n_coarse, dec_in[i + 1], spare, gc, dst, 0, W, stream));
         g = dst;
         o = spare;
     }
@@ -650,21 +585,16 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
         (void)ptv2_zero_async(gb, sizeof(float) * (size_t)lv.n * c, st);
         RUN(pool_max_backward_hip_launcher(M->level[i + 1].n, c, gp, A.arg[i], gb, stream));
         // GridPool.fc: the second contribution to the gradient of skip[i], added by the GEMM's accumulate epilogue
-        RUN(linbn_backward(M, M->down[i], A.down[i], lv.n, skip[i], gb, gc, GH_DOWN + i, W.gskip[i], 1, W, stream));
+        RUN(linbn_backward(M, M->down[i], A.down[i], lv.n, skip[i], gb, gc, W.gskip[i], 1, W, stream));
     }
     // patch embedding (its input needs no gradient)
     {
         float *gp = seq_backward(M, 0, A, A.embed.y, W.gskip[0], ga, W, stream, &rc);
         if (rc != PTV2_OK) return rc;
-        RUN(linbn_backward(M, M->embed, A.embed, n0, M->feat, gp, gc, GH_EMBED, nullptr, 0, W, stream));
+        RUN(linbn_backward(M, M->embed, A.embed, n0, M->feat, gp, gc, nullptr, 0, W, stream));
     }
     RUN(ptv2_gva_flush_folds(stream));  // the queued parameter glue of all attention blocks: two launches
     drop_folds.armed = false;
-    if (M->side_stream) {  // join: whatever follows on the main stream (the optimizer) sees every weight gradient
-        hipEvent_t e = next_event();
-        if (!e || hipEventRecord(e, (hipStream_t)M->side_stream) != hipSuccess) return PTV2_ERR_LAUNCH;
-        if (hipStreamWaitEvent(st, e, 0) != hipSuccess) return PTV2_ERR_LAUNCH;
-    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

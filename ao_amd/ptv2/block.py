@@ -41,8 +41,7 @@ class _Blk(ctypes.Structure):  # mirrors ptv2_block
 
 
 class _BlkGrads(ctypes.Structure):  # mirrors ptv2_block_grads
-    _fields_ = ([(n_, _P) for n_ in ("gy", "inv_ptr", "inv_rows", "gx", "gparam")] + [("gp", _P * NPARAM)]
-                + [(n_, _P) for n_ in ("side_stream", "side_event", "keep", "side_workspace")] + [("side_workspace_bytes", ctypes.c_size_t)])
+    _fields_ = [(n_, _P) for n_ in ("gy", "inv_ptr", "inv_rows", "gx", "gparam")] + [("gp", _P * NPARAM)]
 
 
 _lib.check_struct(0, _Blk)

@@ -55,7 +55,7 @@ class _Model(ctypes.Structure):  # mirrors ptv2_model
                    ("num_blocks", _I), ("block", _MBlock * MAX_BLOCKS), ("embed", _LinBn), ("down", _LinBn * MAX_STAGES),
                    ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
                 + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
-                + [("saved_bytes", ctypes.c_size_t), ("side_stream", _P), ("matmul_bf16", _I), ("checkpoint", _I),
+                + [("saved_bytes", ctypes.c_size_t), ("matmul_bf16", _I), ("checkpoint", _I),
                    ("decoder_done_event", _P)])
 
 
@@ -254,12 +254,6 @@ class _Runtime:
             self._grad_buf, self._grad_views = flat, views
         return self._grad_buf, self._grad_views
 
-    def side_stream(self, device):
-        st = self.__dict__.get("_side")
-        if st is None or st.device != device:
-            st = self._side = torch.cuda.Stream(device)
-        return st
-
     def point_grads(self, flat):
         base = flat.data_ptr()
         offs = self.offsets
@@ -324,7 +318,7 @@ class _NativeModel(torch.autograd.Function):
         n0 = feat.shape[0]
         logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
         M.feat, M.logits = feat.data_ptr(), logits.data_ptr()
-        M.saved, M.saved_bytes, M.side_stream = None, 0, None
+        M.saved, M.saved_bytes = None, 0
         need = L.ptv2_model_saved_bytes(ctypes.addressof(M))
         if need == 0:
             raise RuntimeError("ao_amd: ptv2_model rejected by the native runtime (ptv2_model_saved_bytes == 0)")
@@ -351,10 +345,6 @@ class _NativeModel(torch.autograd.Function):
         M.feat, M.logits = feat.data_ptr(), None
         M.logits = g_logits.data_ptr()  # unused by the backward; keeps the struct valid
         M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
-        # AO_AMD_WGRAD_STREAM=1: weight gradients on a second stream, off the critical path of the backward chain (the
-        # launcher joins it).  Measured on MI355X at 120 k points: 14.92 ms/step against 14.62 ms in line -- the chain's
-        # kernels and the weight gradients compete for the same memory system, nothing is gained; kept as an option.
-        M.side_stream = rt.side_stream(dev).cuda_stream if os.environ.get("AO_AMD_WGRAD_STREAM", "0") == "1" else None
         # parallel.FlatGradSync(mode="flat2"): an event the launcher records once the head + decoder gradients are final
         owner = rt.model_ref()
         ev = owner.__dict__.get("native_decoder_done_event") if owner is not None else None
@@ -363,6 +353,8 @@ class _NativeModel(torch.autograd.Function):
             owner.__dict__["native_decoder_done_count"] = owner.__dict__.get("native_decoder_done_count", 0) + 1
         direct = ctx.mode == "direct"
         accumulate = direct and rt.params[0].grad is not None
+        if owner is not None:  # parallel.FlatGradSync: the early chunk may only leave from the launcher's own, unaccumulated buffer
+            owner.__dict__["native_last_backward_accumulated"] = bool(accumulate or not direct)
         flat, views = rt.grad_buffer(dev, fresh=accumulate or not direct)
         if flat is rt._grad_buf:
             flat.zero_()

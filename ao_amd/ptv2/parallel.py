@@ -85,6 +85,12 @@ class FlatGradSync:
             recorded = self.split is not None and self.backbone.__dict__.get("native_decoder_done_count", 0) != self.seen
             if recorded:
                 self.seen = self.backbone.__dict__["native_decoder_done_count"]
+                # ... and only when `flat` IS the buffer the launcher wrote, untouched since: with gradients delivered through
+                # autograd, accumulated over several backwards, or a segmentor with parameters of its own, flatten_grads()
+                # fills `flat` by a copy / add on the main stream AFTER the event, and the early chunk would go out stale
+                rt = self.backbone.__dict__.get("_ao_runtime")
+                direct = rt is not None and rt._grad_buf is not None and flat.data_ptr() == rt._grad_buf.data_ptr()
+                recorded = direct and not self.backbone.__dict__.get("native_last_backward_accumulated", True)
             if recorded and 0 < self.split < flat.numel():
                 main = torch.cuda.current_stream(flat.device)
                 self.comm.wait_event(self.event)  # the most recent record: enqueued by the backward that just returned

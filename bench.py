@@ -510,11 +510,14 @@ def child_main(args):
     # roofline leg: the last warm-up steps run with every hand-written kernel bracketed by HIP events to find the
     # dominant one; inside the timed region only every `timed_stride`-th launch of that kernel is bracketed (so the
     # step time the headline value comes from is not inflated by ~4000 event records)
+    # The warm-up: first the survey steps (eager issue: HIP events cannot be read back from a graph), then the remaining
+    # steps as the timed region will run them (graph issue, the dominant kernel sampled) so that the executable graphs exist
     survey_steps = 0 if args.no_roofline else min(2, args.warmup)
-    for _ in range(args.warmup - survey_steps):
-        step()
     survey, dominant, timed_stride = {}, None, 3
     if survey_steps:
+        pre = 1 if args.warmup > survey_steps else 0
+        for _ in range(pre):  # (one step before the survey when the warm-up allows: first-launch costs are not the kernels')
+            step()
         torch.cuda.synchronize(device)
         _lib.kernel_timer(True)
         for _ in range(survey_steps):
@@ -524,9 +527,9 @@ def child_main(args):
         survey = _lib.kernel_timer_read()
         if survey:
             dominant = max(survey.items(), key=lambda kv: kv[1]["total_us"])[0]
-            # every stride-th launch of it: a uniform sample over the timed region.  ~6 bracketed launches per step (two event
-            # records each cost ~3 us of queue time: bracketing all 52 weight-gradient launches of a step was 0.1 ms of it);
-            # the stride is co-prime with the launches per step so that every launch position of the step gets sampled
+            # every stride-th launch of it: a uniform sample over the timed region.  ~6 bracketed launches per step (a bracket
+            # costs ~3 us of queue time: bracketing all 52 weight-gradient launches of a step was 0.1 ms of it); the stride is
+            # co-prime with the launches per step so that the sampled positions spread over all Blocks
             import math
             per_step = max(1, round(survey[dominant]["launches"] / survey_steps))
             timed_stride = 3
@@ -535,6 +538,13 @@ def child_main(args):
                 while math.gcd(timed_stride, per_step) != 1:
                     timed_stride += 2
             _lib.kernel_timer(True, only=dominant, stride=timed_stride)
+        for _ in range(args.warmup - survey_steps - pre):
+            step()
+        if survey:  # the records of the warm-up are not the timed region's
+            _lib.kernel_timer(True, only=dominant, stride=timed_stride)
+    else:
+        for _ in range(args.warmup):
+            step()
     # host side of the timed region: wall and CPU time the launching thread spends inside step(), and one
     # event per step on the compute stream so that the per-step GPU-side durations can be told apart from host stalls
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]

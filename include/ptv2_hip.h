@@ -515,17 +515,6 @@ typedef struct ptv2_block_grads {
     float *gx;                     /* (n,c) */
     float *gparam;                 /* flat parameter gradients (layout: ptv2_block_param_layout), or NULL: */
     float *gp[PTV2_BLK_NPARAM];    /* ... one destination per parameter (float4-aligned; NULL for absent biases) */
-    /* Deferred weight gradients (optional, side_stream != NULL): the five (c,c) weight gradients of the Block are
-     * parameter-only work off the critical path of the backward; they are enqueued on `side_stream` behind an event
-     * recorded on the main stream, so that they fill the compute units the latency-bound chain leaves idle.  Their
-     * operands must then outlive this call: `keep` (5 n c floats, private to this Block until the caller has joined the
-     * side stream) replaces five workspace temporaries; `side_workspace` holds the split-K records (shared by everything
-     * enqueued on the side stream, which orders it).  The CALLER joins the streams before the gradients are read. */
-    void *side_stream;
-    void *side_event;              /* hipEvent_t (timing disabled), recorded on `stream`, waited for on side_stream */
-    float *keep;
-    void *side_workspace;
-    size_t side_workspace_bytes;
 } ptv2_block_grads;
 size_t ptv2_block_saved_bytes(int n, int k, int c, int g);
 size_t ptv2_block_workspace_bytes(int n, int k, int c, int g);
@@ -595,8 +584,6 @@ typedef struct ptv2_model {
     float *logits;                     /* (n0, num_classes) */
     void *saved;
     size_t saved_bytes;
-    void *side_stream;                 /* backward only, optional: weight gradients run here (see ptv2_block_grads);
-                                        * the launcher joins it into `stream` before it returns control of the queue */
     int matmul_bf16;                   /* as ptv2_block.matmul_bf16, for every Linear of the network */
     int checkpoint;                    /* != 0: activation checkpointing of the Blocks (enable_checkpoint of the reference,
                                         * point_transformer_v2m2_base.py:169-171): the forward keeps only every Block's

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "ptv2_hip.h")
 def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs))\s*\(", txt)))
+    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs|_stamp_us|_graph_mode|_graph_stats|_graph_reset))\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 6
+    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 7
     assert b"gfx950" in L.ptv2_build_info()
     a = L.knn_query_hip_workspace_bytes(80000, 80000, 1)
     b = L.knn_query_hip_workspace_bytes(240000, 240000, 3)

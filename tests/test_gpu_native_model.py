@@ -204,24 +204,6 @@ def test_training_loop_with_changing_scenes_matches_the_python_path(monkeypatch)
     assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
 
 
-def test_weight_gradient_side_stream_gives_the_same_bits(monkeypatch):
-    """AO_AMD_WGRAD_STREAM=1 (optional; measured slower): the weight gradients run on a second stream behind
-    one event per Block and are joined before the launcher returns the queue -- same kernels, same operands, so every
-    gradient must be bit-identical to the in-line run."""
-    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
-    data = _data([5, 6], 7000, cfg)
-    res = {}
-    for side in ("0", "1"):
-        monkeypatch.setenv("AO_AMD_WGRAD_STREAM", side)
-        model = _model(cfg, seed=4)
-        loss = F.cross_entropy(model(data), data["segment"], ignore_index=-1)
-        grads = torch.autograd.grad(loss, list(model.parameters()))
-        torch.cuda.synchronize()
-        res[side] = [g.clone() for g in grads]
-    for a, b in zip(res["0"], res["1"]):
-        assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("variant", ["two_stages_no_qkv_bias", "five_stages_map"])
 def test_native_model_on_other_architectures(monkeypatch, variant):
     """The runtime description is generic in the number of stages, depths, widths, neighbour counts, qkv bias and unpool
