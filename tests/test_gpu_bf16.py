@@ -75,14 +75,18 @@ def test_linear_wgrad_bf16_operands(bf16_matmul, n, cout, cin):
     assert 1e-4 < rel(dW, gy.double().t() @ x.double()) < 1e-2
 
 
-@pytest.mark.parametrize("tag,points", [("s3dis", 20000), ("scannet", 8000)])
+@pytest.mark.parametrize("tag,points", [("s3dis", 20000), ("scannet", 8000), ("s3dis_bench", 120000), ("scannet_bench", 100000)])
 def test_model_under_autocast_tracks_the_fp32_path(tag, points):
+    # (*_bench: the shapes profiles/*_bench_bf16.json / *_bench_scannet_bf16.json time -- 1 x 120 000 and 2 x 100 000 points)
+    bench = tag.endswith("_bench")
+    tag = tag.split("_")[0]
     import ao_amd.ptv2 as ptv2
     from ao_amd import synth
     from ao_amd.ptv2 import native_model
 
     cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.0)
-    b = synth.scene_batch([2, 3], point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"])
+    seeds = [0] if (bench and tag == "s3dis") else ([0, 1] if bench else [2, 3])
+    b = synth.scene_batch(seeds, point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"], room=1 if bench else 0)
     data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
     # labels that are a function of the input (height bands): a gradient with signal in it, not the noise of random labels
     data["segment"] = (data["coord"][:, 2] * 4).long().clamp(0, cfg["num_classes"] - 1)

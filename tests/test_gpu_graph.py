@@ -93,7 +93,9 @@ def test_graph_update_in_place_for_a_repeated_shape_and_on_a_side_stream(graph_m
     with torch.cuda.stream(side):
         got, _ = _run(_model(cfg, seed=8), scenes)
     st = _lib.graph_stats()
-    assert st["scopes"] == 14 and st["declined"] == 0 and st["instantiated"] == 6 and st["updated"] == 8, st
+    # an executable graph is created only when every existing one of the slot is still in flight: at least one per direction,
+    # at most the ring; every other call updates one in place (same shape, same node count)
+    assert st["scopes"] == 14 and st["declined"] == 0 and 2 <= st["instantiated"] <= 14 and st["updated"] == 14 - st["instantiated"], st
     # (running statistics differ between the 7 identical calls, the logits therefore too: compared call by call)
     for (lw, gw), (lg, gg) in zip(want, got):
         assert torch.equal(lw, lg)

@@ -115,12 +115,43 @@ def test_reference_run_step_statements_over_the_native_runtime(monkeypatch):
     assert optimizer._step == STEPS - 1
     assert log[-1]["loss"] < log[0]["loss"]  # it trains (same batch every step)
 
-    # the same statements over the stage-by-stage python path with torch.optim.AdamW: the trajectories agree
+    # the same statements over the stage-by-stage python path with torch.optim.AdamW: the trajectories agree.  (AdamW
+    # normalises every gradient element by its own running magnitude, so after 10 steps of lr 0.006 an element whose
+    # gradient is noise-level has moved +-0.06 either way in BOTH runs: the weights decorrelate at that scale -- 0.14 of
+    # their norm observed -- while the loss curves stay together; the gradients themselves are pinned below.)
     model_p, optimizer_p, log_p = _train(monkeypatch, "python")
     assert isinstance(optimizer_p, torch.optim.AdamW)
     assert [r["stepped"] for r in log_p] == [r["stepped"] for r in log]
     assert abs(log[0]["loss"] - log_p[0]["loss"]) < 2e-3  # one forward, bf16 products in both
     np.testing.assert_allclose([r["loss"] for r in log], [r["loss"] for r in log_p], rtol=0, atol=8e-2)
-    num = sum(float((a.double() - b.double()).pow(2).sum()) for a, b in zip(model.parameters(), model_p.parameters()))
-    den = sum(float(b.double().pow(2).sum()) for b in model_p.parameters())
-    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    num = sum(float((a.detach().double() - b.detach().double()).pow(2).sum()) for a, b in zip(model.parameters(), model_p.parameters()))
+    den = sum(float(b.detach().double().pow(2).sum()) for b in model_p.parameters())
+    assert (num / den) ** 0.5 < 0.3, (num / den) ** 0.5
+
+
+def test_gradients_after_unscale_are_the_unscaled_gradients(monkeypatch):
+    """What optimizer.step sees inside scaler.step: `scale(loss).backward()` then `unscale_` in place on the flat buffer's
+    views must give the gradients of `loss.backward()` -- the scale is a power of two and nothing overflows in fp32 storage,
+    so bit for bit -- for every parameter tensor (a mis-wired slot or a missed unscale would not show in AdamW's
+    scale-invariant update)."""
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    monkeypatch.setenv("AO_AMD_MODEL", "native")
+    got = {}
+    for use_scaler in (True, False):
+        model, optimizer, scheduler, scaler = _trainer(cfg, True)
+        model.backbone.native_param_grads = "direct"
+        batch = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in _batch(cfg).items()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with torch.cuda.amp.autocast(enabled=True):
+                loss = model(batch)["loss"]
+        optimizer.zero_grad()
+        if use_scaler:
+            scaler.scale(loss).backward()
+            scaler.unscale_(optimizer)
+        else:
+            loss.backward()
+        got[use_scaler] = [p.grad.detach().clone() for p in model.parameters()]
+    assert len(got[True]) == len(got[False]) > 400
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
