@@ -364,8 +364,12 @@ __global__ __launch_bounds__(256) void knn_grid_query_kernel(
                     const bool full = (R == 1) || (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
                     if (full) {
                         // cells x with gap(fx, x)^2 h^2 + base2 < bd[KC-1]: |x - fx| within r cells (r padded)
-                        const float r = fminf(sqrtf((bd[KC - 1] - base2) * inv_h2) * 1.0001f + 0.03f, 4096.f);
-                        const int xlo = max(xa, (int)floorf(fx - r)), xhi = min(xb, (int)floorf(fx + r));
+                        int xlo = xa, xhi = xb;
+                        if (bd[KC - 1] < 1e10f) {  // (no clip while the list is not full: the sentinel is not a distance)
+                            const float r = sqrtf((bd[KC - 1] - base2) * inv_h2) * 1.0001f + 0.03f;
+                            xlo = max(xa, (int)floorf(fmaxf(fx - r, -1.f)));
+                            xhi = min(xb, (int)floorf(fminf(fx + r, 1.0e6f)));
+                        }
                         if (xlo <= xhi)
                             scan_range<KC>(sorted, cell_start[row + xlo], cell_start[row + xhi + 1], qx, qy, qz, bd, bi, visited);
                     } else {
@@ -415,6 +419,248 @@ __global__ __launch_bounds__(256) void knn_grid_query_kernel(
                 orow[j] = bd[j] < 1e10f ? bi[j] : pad;
                 drow[j] = bd[j];
             }
+    }
+}
+
+// ---------------------------------------------------------- grid query, 16 lanes per query --
+// k <= 16 (every call of the PT-v2m2 path: k = 16 / 8 self queries, k = 3 interpolation, k = 1 label transfer).
+// A "row" = 16 consecutive lanes serves one query, four queries per wavefront:
+//   * the k best candidates live SORTED ACROSS the lanes of the row (lane j holds the j-th smallest distance and its point);
+//   * candidates are read 16 at a time (one float4 per lane: a 256-byte contiguous piece of the cell-sorted copy), every lane
+//     evaluates one distance, and a wave ballot against the row's current k-th best keeps the survivors;
+//   * a survivor is broadcast to its row and inserted by ONE compare + shift across the lanes (DPP row_shr:1), i.e. a
+//     constant handful of instructions for all four queries of the wave, instead of a k-long compare / select chain per
+//     lane and candidate in the one-lane-per-query form above (which spent most of its time there, and whose 64 lanes
+//     diverged over 64 different cell walks);
+//   * `e` tracks the smallest distance that is NOT in the list (rejected candidates and evicted entries), i.e. the
+//     (k+1)-th smallest: a tie between it and the k-th, or between neighbours of the list, sends the query to the exact
+//     re-run exactly as before.  Cells are pruned only when their lower bound EXCEEDS the k-th best (strictly), so a
+//     point at exactly that distance is always evaluated and the tie test sees it.
+// The result (k smallest by squared distance, ascending; ties re-run) is identical to the one-lane kernel's.
+__device__ __forceinline__ float row_shr1_f(float x, float fill) {  // lane j <- lane j-1 of its row; lane 0 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int row_shr1_i(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ float row_shl1_f(float x, float fill) {  // lane j <- lane j+1 of its row; lane 15 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x101, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_min16(float x) {  // minimum over the 16 lanes of the row, in every lane (row_ror 1, 2, 4, 8)
+    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)));
+    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)));
+    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)));
+    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)));
+    return x;
+}
+
+struct RowList {
+    float v;    // entry of this lane: the 16 lanes of a row hold an ascending list; lanes < k are the k best so far
+    int vi;
+    float tau;  // row-uniform: v of lane k-1, the k-th best so far
+    float e;    // PER LANE: smallest distance this lane saw leave or miss the 16-lane list (reduced over the row at the end)
+};
+// v of lane K - 1 in every lane of the row: DPP row_newbcast for the compile-time K of the hot call sites, ds_bpermute otherwise
+template <int K>
+__device__ __forceinline__ float row_kth(float v, int km1) {
+    if constexpr (K > 0) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + (K - 1), 0xf, 0xf, false));
+    else return __shfl(v, km1, 16);
+}
+
+// one compare-exchange stage of a bitonic network across the lanes of a row: partner = lane ^ STRIDE (ds_swizzle, no memory),
+// `up` = this lane keeps the smaller of the pair.  Equal keys: both lanes keep their own.
+template <int STRIDE>
+__device__ __forceinline__ void row_cmpx(float &d, int &id, bool up) {
+    const float od = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(d), (STRIDE << 10) | 0x1f));
+    const int oi = __builtin_amdgcn_ds_swizzle(id, (STRIDE << 10) | 0x1f);
+    const bool take = up ? (od < d) : (od > d);
+    d = take ? od : d;
+    id = take ? oi : id;
+}
+// ascending sort of 16 (d, id) pairs across the lanes of a row
+__device__ __forceinline__ void row_sort16(float &d, int &id, int r) {
+    row_cmpx<1>(d, id, ((r & 1) == 0) == ((r & 2) == 0));
+    row_cmpx<2>(d, id, ((r & 2) == 0) == ((r & 4) == 0));
+    row_cmpx<1>(d, id, ((r & 1) == 0) == ((r & 4) == 0));
+    row_cmpx<4>(d, id, ((r & 4) == 0) == ((r & 8) == 0));
+    row_cmpx<2>(d, id, ((r & 2) == 0) == ((r & 8) == 0));
+    row_cmpx<1>(d, id, ((r & 1) == 0) == ((r & 8) == 0));
+    row_cmpx<8>(d, id, (r & 8) == 0);
+    row_cmpx<4>(d, id, (r & 4) == 0);
+    row_cmpx<2>(d, id, (r & 2) == 0);
+    row_cmpx<1>(d, id, (r & 1) == 0);
+}
+
+// candidates [p0, p1) of the cell-sorted copy against the row's list
+template <int K>
+__device__ __forceinline__ void row_scan_range(const float4 *__restrict__ sorted, int p0, int p1, float qx, float qy, float qz,
+                                               int km1, int r, int lane, RowList &L, unsigned &visited) {
+    visited += (unsigned)(p1 - p0);
+    for (int p = p0; p < p1; p += 16) {
+        const bool have = p + r < p1;
+        const float4 c = ptv2_ld_or_zero(sorted + p + r, have);
+        float d2 = have ? ref_d2(qx, qy, qz, c.x, c.y, c.z) : 3.0e38f;
+        int id = __float_as_int(c.w);
+        const bool surv = d2 < L.tau;
+        unsigned my = (unsigned)((__ballot(surv) >> (lane & 48)) & 0xffffull);  // this row's survivors
+        if (__popc(my) >= 7) {
+            // many newcomers (the list is still filling up): sort the batch, then one bitonic merge with the list --
+            // min(list[j], batch[15 - j]) over the lanes is the 16 smallest of the 32, a bitonic sequence, four more stages
+            // sort it; what the merge drops (the larger of each pair) has left the list
+            row_sort16(d2, id, r);
+            const float rd = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d2), 0x140, 0xf, 0xf, false));  // row_mirror
+            const int ri = __builtin_amdgcn_update_dpp(0, id, 0x140, 0xf, 0xf, false);
+            const bool keep = L.v <= rd;
+            L.e = fminf(L.e, keep ? rd : L.v);
+            L.v = keep ? L.v : rd;
+            L.vi = keep ? L.vi : ri;
+            row_cmpx<8>(L.v, L.vi, (r & 8) == 0);
+            row_cmpx<4>(L.v, L.vi, (r & 4) == 0);
+            row_cmpx<2>(L.v, L.vi, (r & 2) == 0);
+            row_cmpx<1>(L.v, L.vi, (r & 1) == 0);
+            L.tau = row_kth<K>(L.v, km1);
+            continue;
+        }
+        // rejected candidates bound the (k+1)-th best from above
+        L.e = fminf(L.e, surv ? 3.0e38f : d2);
+        while (my) {
+            const int src = __builtin_ctz(my);
+            my &= my - 1;
+            const float cd = __shfl(d2, src, 16);
+            const int ci = __shfl(id, src, 16);
+            if (cd < L.tau) {  // (the k-th best may have dropped since the ballot)
+                const bool gt = L.v > cd;  // entries that move one lane up; equal ones stay in front of the newcomer
+                const float vp = row_shr1_f(L.v, cd);
+                const int ip = row_shr1_i(L.vi, ci);
+                const int gtp = row_shr1_i(gt ? 1 : 0, 0);
+                if (r == 15) L.e = fminf(L.e, L.v);  // what falls off the end of the 16-lane list
+                L.v = gt ? (gtp ? vp : cd) : L.v;
+                L.vi = gt ? (gtp ? ip : ci) : L.vi;
+                L.tau = row_kth<K>(L.v, km1);
+            } else {
+                L.e = fminf(L.e, cd);
+            }
+        }
+    }
+}
+
+// One slot of ring R around cell (cx, cy, cz) as a candidate range: slot u -> row of cells (z, y); rows on the shell of the
+// ring take their whole x run [cx - R, cx + R] (clipped by the k-th best), inner rows only their two end cells.  Returns
+// p0 >= p1 for an empty slot; lb2 = lower bound of the squared distance of every point of the range.
+struct RowRange { int p0, p1; float lb2; };
+__device__ __forceinline__ RowRange ring_slot(const SegGrid &g, const int *__restrict__ cell_start, int R, int u, int cx, int cy, int cz,
+                                              float fx, float fy, float fz, float tau) {
+    RowRange out{0, 0, 3.0e38f};
+    const int w = 2 * R + 1;
+    int t, side;
+    if (R == 1) { t = u; side = 0; } else { t = u >> 1; side = u & 1; }
+    if (t >= w * w) return out;
+    // nearest rows first inside a ring is not attempted: t enumerates z-major
+    const int dz = t / w - R, dy = t - (t / w) * w - R;
+    const int z = cz + dz, y = cy + dy;
+    if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) return out;
+    auto gap = [](float f, int c) { return fmaxf(fmaxf(fmaxf((float)c - f, f - (float)(c + 1)), 0.f) - 0.01f, 0.f); };
+    const float h2 = g.h * g.h;
+    const float gz_ = gap(fz, z), gy_ = gap(fy, y);
+    const float base2 = (gz_ * gz_ + gy_ * gy_) * h2;
+    if (base2 > tau) return out;
+    const int row = g.cell_base + (z * g.gy + y) * g.gx;
+    const bool shell = (R == 1) || (dz == R) || (dz == -R) || (dy == R) || (dy == -R);
+    if (shell) {
+        if (side) return out;
+        int xlo = max(cx - R, 0), xhi = min(cx + R, g.gx - 1);
+        if (tau < 1e10f) {  // cells x with gap(fx, x)^2 h^2 + base2 <= tau (no clip while the list is not full)
+            const float rr = sqrtf((tau - base2) * g.inv_h * g.inv_h) * 1.0001f + 0.03f;
+            xlo = max(xlo, (int)floorf(fmaxf(fx - rr, -1.f)));
+            xhi = min(xhi, (int)floorf(fminf(fx + rr, 1.0e6f)));
+        }
+        if (xlo > xhi) return out;
+        out.p0 = cell_start[row + xlo];
+        out.p1 = cell_start[row + xhi + 1];
+        out.lb2 = base2;
+    } else {
+        const int x = side ? cx + R : cx - R;
+        if (x < 0 || x >= g.gx) return out;
+        const float gx_ = gap(fx, x);
+        const float lb = gx_ * gx_ * h2 + base2;
+        if (lb > tau) return out;
+        out.p0 = cell_start[row + x];
+        out.p1 = cell_start[row + x + 1];
+        out.lb2 = lb;
+    }
+    return out;
+}
+
+template <int K, bool COUNT>
+__global__ __launch_bounds__(256) void knn_row_query_kernel(
+    int m, int k, const float4 *__restrict__ sorted, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int b,
+    const SegGrid *__restrict__ seg, const int *__restrict__ cell_start, int *__restrict__ idx,
+    float *__restrict__ dist2, int pad_with_start, int self_mode, int *tie_count, int *tie_list,
+    unsigned long long *pairs) {
+    const int lane = threadIdx.x & 63, r = lane & 15;
+    const int t = (int)(((long long)blockIdx.x * 256 + threadIdx.x) >> 4);  // query ordinal of this row
+    unsigned visited = 0;
+    if (t >= m) return;  // (whole rows leave together)
+    int qid, s;
+    float qx, qy, qz;
+    if (self_mode) {  // queries visited in cell order: the four rows of a wave walk neighbouring cells
+        const float4 p = sorted[t];
+        qx = p.x; qy = p.y; qz = p.z;
+        qid = __float_as_int(p.w);
+        s = seg_of(qid, offset, b);
+    } else {
+        qid = t;
+        qx = new_xyz[3 * (size_t)t]; qy = new_xyz[3 * (size_t)t + 1]; qz = new_xyz[3 * (size_t)t + 2];
+        s = seg_of(t, new_offset, b);
+    }
+    const SegGrid g = seg[s];
+    const int km1 = k - 1;
+    RowList L;
+    L.v = 1e10f; L.vi = -1; L.tau = 1e10f; L.e = 1e10f;
+
+    if (g.n_pts > 0) {
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.gx);
+        const int cy = cell_coord(qy, g.miny, g.inv_h, g.gy);
+        const int cz = cell_coord(qz, g.minz, g.inv_h, g.gz);
+        const int rmax = max(max(max(cx, g.gx - 1 - cx), max(cy, g.gy - 1 - cy)), max(cz, g.gz - 1 - cz));
+        // distances in cell units from the query's UNclamped fractional cell position, as in the one-lane kernel; culling against
+        // the k-th best and STRICT (see above)
+        const float fx = (qx - g.minx) * g.inv_h, fy = (qy - g.miny) * g.inv_h, fz = (qz - g.minz) * g.inv_h;
+        for (int R = 1;; ++R) {
+            const int w = 2 * R + 1;
+            const int slots = R == 1 ? w * w : 2 * w * w;
+            for (int u0 = 0; u0 < slots; u0 += 16) {
+                // the 16 lanes of the row set up 16 slots at once (their cell_start loads are in flight together) ...
+                const RowRange mine = ring_slot(g, cell_start, R, u0 + r, cx, cy, cz, fx, fy, fz, L.tau);
+                unsigned todo = (unsigned)((__ballot(mine.p0 < mine.p1) >> (lane & 48)) & 0xffffull);
+                // ... and walk the non-empty ones in turn
+                while (todo) {
+                    const int j = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const float lb2 = __shfl(mine.lb2, j, 16);
+                    if (lb2 > L.tau) continue;  // (the k-th best has dropped since the slot was set up)
+                    const int p0 = __shfl(mine.p0, j, 16), p1 = __shfl(mine.p1, j, 16);
+                    row_scan_range<K>(sorted, p0, p1, qx, qy, qz, km1, r, lane, L, visited);
+                }
+            }
+            if (R >= rmax) break;  // whole segment scanned
+            // every unvisited point is farther than (R - eps) cells along some axis (eps: rounding of cell_coord())
+            const float lim = ((float)R - 0.01f) * g.h;
+            if (L.tau < lim * lim) break;
+        }
+    }
+
+    if (COUNT && r == 0) atomicAdd(pairs, (unsigned long long)visited);  // a measurement build, not the timed one
+    // ties inside the k + 1 smallest distances: neighbours inside the list, or the k-th against the best outside it (lane k of
+    // the list when k < 16, and whatever left or missed the 16 lanes)
+    const float vn = row_shl1_f(L.v, 3.0e38f);
+    const float e = row_min16(fminf(L.e, r >= k ? L.v : 3.0e38f));
+    bool tie = (r + 1 < k && L.v == vn && vn < 1e10f) || (r == km1 && L.v == e && e < 1e10f);
+    const unsigned any = (unsigned)((__ballot(tie) >> (lane & 48)) & 0xffffull);
+    if (any && r == 0) tie_list[atomicAdd(tie_count, 1)] = qid;
+    if (r < k) {
+        const int pad = pad_with_start ? g.start : -1;
+        idx[(size_t)qid * k + r] = L.v < 1e10f ? L.vi : pad;
+        dist2[(size_t)qid * k + r] = L.v;
     }
 }
 
@@ -481,6 +727,136 @@ __global__ __launch_bounds__(EX_WAVES *WAVE) void knn_exact_kernel(
         for (int j = lane; j < k; j += WAVE) {
             idx[(size_t)q * k + j] = hi[j];
             dist2[(size_t)q * k + j] = hd[j];
+        }
+    }
+}
+
+// The same emulation for the LISTED queries (ties) with a whole workgroup per query: the heap's history is every
+// candidate that beat the root at its turn, in ascending index order -- a few hundred of a 120 000-point segment -- and
+// a single wavefront spends its 48 us streaming the other 119 800 past the root test (one dependent load round trip per
+// 64 points).  Here 16 wavefronts test a chunk of 4 096 points each trip against the root value at the chunk's start
+// (the root only decreases: a superset of what the sequential scan accepts), the survivors are compacted in index
+// order through LDS, and wavefront 0 replays them through the heap exactly as above.
+constexpr int EXW_WAVES = 16, EXW_PER_LANE = 4, EXW_CHUNK = EXW_WAVES * WAVE * EXW_PER_LANE, EXW_CAP = 1024;
+__global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
+    int k, const float *__restrict__ xyz, const float *__restrict__ new_xyz, const int *__restrict__ offset,
+    const int *__restrict__ new_offset, int b, int *__restrict__ idx, float *__restrict__ dist2, int pad_with_start,
+    const int *__restrict__ tie_count, const int *__restrict__ tie_list) {
+    __shared__ float s_d[128];
+    __shared__ int s_i[128];
+    __shared__ float s_cd[EXW_CAP];
+    __shared__ int s_ci[EXW_CAP];
+    __shared__ int s_cnt[EXW_WAVES * EXW_PER_LANE + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    volatile float *hd = s_d;
+    volatile int *hi = s_i;
+    const int total = *tie_count;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int q = tie_list[w];
+        const int s = seg_of(q, new_offset, b);
+        const int start = s == 0 ? 0 : offset[s - 1];
+        const int end = offset[s];
+        const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+        __syncthreads();  // (the previous query's heap has been written out)
+        for (int j = threadIdx.x; j < k; j += EXW_WAVES * WAVE) {
+            hd[j] = 1e10f;
+            hi[j] = pad_with_start ? start : -1;
+        }
+        __syncthreads();
+        // the distances of a chunk are formed one trip ahead: their loads are in flight while the previous chunk's survivors
+        // go through the barriers and the heap
+        float dn[EXW_PER_LANE];
+        auto fetch = [&](int cb) {
+#pragma unroll
+            for (int u = 0; u < EXW_PER_LANE; ++u) {
+                const int i = cb + (wid * EXW_PER_LANE + u) * WAVE + lane;
+                const bool ok = i < end;
+                const size_t ii = ok ? (size_t)i : (size_t)start;
+                const float d = ref_d2(qx, qy, qz, xyz[3 * ii], xyz[3 * ii + 1], xyz[3 * ii + 2]);
+                dn[u] = ok ? d : 3.0e38f;
+            }
+        };
+        fetch(start);
+        for (int cbase = start; cbase < end; cbase += EXW_CHUNK) {
+            const float root = hd[0];
+            // sub-batch u of wave wid covers points cbase + (wid * PER_LANE + u) * 64 + lane: ascending in (wid, u, lane)
+            float d2[EXW_PER_LANE];
+            unsigned long long mk[EXW_PER_LANE];
+#pragma unroll
+            for (int u = 0; u < EXW_PER_LANE; ++u) d2[u] = dn[u];
+            if (cbase + EXW_CHUNK < end) fetch(cbase + EXW_CHUNK);
+#pragma unroll
+            for (int u = 0; u < EXW_PER_LANE; ++u) {
+                mk[u] = __ballot(d2[u] < root);
+                if (lane == 0) s_cnt[wid * EXW_PER_LANE + u] = __popcll(mk[u]);
+            }
+            __syncthreads();
+            if (wid == 0) {  // exclusive scan of the 64 sub-batch counts: one per lane of wavefront 0
+                static_assert(EXW_WAVES * EXW_PER_LANE == WAVE, "one count per lane");
+                const int c = s_cnt[lane];
+                int inc = c;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int y = __shfl_up(inc, o, WAVE);
+                    if (lane >= o) inc += y;
+                }
+                s_cnt[lane] = inc - c;
+                if (lane == WAVE - 1) s_cnt[WAVE] = inc;
+            }
+            __syncthreads();
+            const int nsurv = s_cnt[EXW_WAVES * EXW_PER_LANE];
+            if (nsurv <= EXW_CAP) {
+#pragma unroll
+                for (int u = 0; u < EXW_PER_LANE; ++u)
+                    if ((mk[u] >> lane) & 1ull) {
+                        const int pos = s_cnt[wid * EXW_PER_LANE + u] + __popcll(mk[u] & ((1ull << lane) - 1ull));
+                        s_cd[pos] = d2[u];
+                        s_ci[pos] = cbase + (wid * EXW_PER_LANE + u) * WAVE + lane;
+                    }
+            }
+            __syncthreads();
+            if (wid == 0) {
+                if (nsurv <= EXW_CAP) {
+                    for (int j = 0; j < nsurv; ++j) {  // ascending index order
+                        const float cd = s_cd[j];
+                        if (cd < hd[0]) {  // knn_query_cuda_kernel.cu:93-97
+                            hd[0] = cd;
+                            hi[0] = s_ci[j];
+                            ex_reheap(hd, hi, k);
+                        }
+                    }
+                } else {  // (only the first chunks of a scan, while the heap still holds its 1e10 fillers: the one-wave walk)
+                    const int cend = min(cbase + EXW_CHUNK, end);
+                    for (int base = cbase; base < cend; base += WAVE) {
+                        const int i = base + lane;
+                        float d = 3.0e38f;
+                        if (i < cend) d = ref_d2(qx, qy, qz, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+                        unsigned long long mask = __ballot(d < hd[0]);
+                        while (mask) {
+                            const int l = __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            const float cd = __shfl(d, l, WAVE);
+                            if (cd < hd[0]) {
+                                hd[0] = cd;
+                                hi[0] = base + l;
+                                ex_reheap(hd, hi, k);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (wid == 0) {
+            for (int i = k - 1; i > 0; --i) {  // heap_sort (:33-42)
+                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
+                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
+                ex_reheap(hd, hi, i);
+            }
+            for (int j = lane; j < k; j += WAVE) {
+                idx[(size_t)q * k + j] = hi[j];
+                dist2[(size_t)q * k + j] = hd[j];
+            }
         }
     }
 }
@@ -553,14 +929,35 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        w.point_rank, w.sorted);
     {
     PtvScopedTimer qt(KID_KNN_QUERY, st, 12.0 * n + 12.0 * m + 8.0 * (double)m * k);
-    if (k <= 1) launch_query<2>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
+    static const bool lane_form = [] { const char *e = getenv("AO_AMD_KNN"); return e && e[0] == 'l'; }();  // A/B: one lane per query
+    if (k <= 16 && !lane_form) {
+        const dim3 grid(divup((long long)m * 16, 256)), blk(256);
+#define ROWQ(KK)                                                                                                                   \
+        do {                                                                                                                       \
+            if (g_pair_counter)                                                                                                    \
+                hipLaunchKernelGGL((knn_row_query_kernel<KK, true>), grid, blk, 0, st, m, k, w.sorted, new_xyz, offset, new_offset, b, \
+                                   w.seg, w.cell_start, idx, dist2, pad_with_start, self_mode, w.tie_count, w.tie_list,            \
+                                   g_pair_counter);                                                                                \
+            else                                                                                                                   \
+                hipLaunchKernelGGL((knn_row_query_kernel<KK, false>), grid, blk, 0, st, m, k, w.sorted, new_xyz, offset, new_offset, b, \
+                                   w.seg, w.cell_start, idx, dist2, pad_with_start, self_mode, w.tie_count, w.tie_list,            \
+                                   (unsigned long long *)nullptr);                                                                 \
+        } while (0)
+        if (k == 16) ROWQ(16);
+        else if (k == 8) ROWQ(8);
+        else if (k == 3) ROWQ(3);
+        else if (k == 1) ROWQ(1);
+        else ROWQ(0);
+#undef ROWQ
+    }
+    else if (k <= 1) launch_query<2>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 3) launch_query<4>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 8) launch_query<9>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else if (k <= 16) launch_query<17>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else launch_query<33>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     }
-    hipLaunchKernelGGL(knn_exact_kernel, dim3(512), dim3(EX_WAVES * WAVE), 0, st, m, k, xyz, new_xyz, offset,
-                       new_offset, b, idx, dist2, pad_with_start, (const int *)w.tie_count, (const int *)w.tie_list, 0);
+    hipLaunchKernelGGL(knn_exact_wide_kernel, dim3(128), dim3(EXW_WAVES * WAVE), 0, st, k, xyz, new_xyz, offset, new_offset, b, idx,
+                       dist2, pad_with_start, (const int *)w.tie_count, (const int *)w.tie_list);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }
