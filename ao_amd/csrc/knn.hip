@@ -20,6 +20,8 @@
 //      current heap root, survivors pushed in index order.  Bit-identical by construction.
 //
 // Squared distances use the pinned rounding sequence ref_d2() (common.h).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -45,6 +47,9 @@ struct Workspace {
     size_t bytes;
 };
 
+// cells per point the grid may use: a segment of cnt points gets at most CELLS_PER_POINT * cnt cells (surface clouds leave
+// most cells of their bounding volume empty: finer cells -> fewer candidates per query; the cell tables are 4 B per cell)
+constexpr int CELLS_PER_POINT = 4;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_THREADS;
@@ -53,7 +58,7 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 Workspace carve(void *base, int m, int n, int b) {
     Workspace w;
-    size_t ncell = (size_t)n + b + 1;
+    size_t ncell = (size_t)CELLS_PER_POINT * n + b + 1;
     size_t ncell_pad = (size_t)divup(ncell + 1, SCAN_TILE) * SCAN_TILE;
     char *p = (char *)base;
     size_t off = 0;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(int n, const float *__res
 }
 
 // One thread per segment: choose the cell size so that cells <= points (then the cell tables
-// of all segments fit n + b + 1 entries and segment s owns [start_s + s, ...)).
+// of all segments fit CELLS_PER_POINT * n + b + 1 entries and segment s owns [CELLS_PER_POINT * start_s + s, ...)).
 __global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, const int *bbox_lo,
                                       const int *bbox_hi, SegGrid *seg, float occupancy) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,7 +151,7 @@ __global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, con
     SegGrid g;
     g.start = start;
     g.n_pts = cnt > 0 ? cnt : 0;
-    g.cell_base = start + s;
+    g.cell_base = CELLS_PER_POINT * start + s;
     g.gx = g.gy = g.gz = 1;
     g.minx = g.miny = g.minz = 0.f;
     g.h = 1.f;
@@ -169,10 +174,10 @@ __global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, con
             gx = (int)fminf(floorf(ext[0] / h) + 1.f, 1024.f);
             gy = (int)fminf(floorf(ext[1] / h) + 1.f, 1024.f);
             gz = (int)fminf(floorf(ext[2] / h) + 1.f, 1024.f);
-            if ((long long)gx * gy * gz <= (long long)cnt) break;
+            if ((long long)gx * gy * gz <= (long long)cnt * CELLS_PER_POINT) break;
             h *= 1.08f;
         }
-        if ((long long)gx * gy * gz > (long long)cnt) { gx = gy = gz = 1; h = emax * 2.f + 1.f; }
+        if ((long long)gx * gy * gz > (long long)cnt * CELLS_PER_POINT) { gx = gy = gz = 1; h = emax * 2.f + 1.f; }
         g.gx = gx; g.gy = gy; g.gz = gz;
         g.h = h;
         g.inv_h = 1.f / h;
@@ -738,18 +743,42 @@ __global__ __launch_bounds__(EX_WAVES *WAVE) void knn_exact_kernel(
 // (the root only decreases: a superset of what the sequential scan accepts), the survivors are compacted in index
 // order through LDS, and wavefront 0 replays them through the heap exactly as above.
 constexpr int EXW_WAVES = 16, EXW_PER_LANE = 4, EXW_CHUNK = EXW_WAVES * WAVE * EXW_PER_LANE, EXW_CAP = 1024;
+
+// The heap of wavefront 0 lives ACROSS ITS LANES (node j in lane j of one register pair; k <= 32 here) and is walked with
+// v_readlane / a one-lane select on wave-uniform node numbers: a handful of cycles per access, where the LDS heap of the
+// one-wave kernel pays an LDS round trip for each (the replay of the ~150 accepted candidates was most of its 48 us).
+__device__ __forceinline__ float lane_get_f(float v, int node) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), node)); }
+__device__ __forceinline__ int lane_get_i(int v, int node) { return __builtin_amdgcn_readlane(v, node); }
+__device__ __forceinline__ void lane_set_f(float &v, int node, float x) { v = ((int)(threadIdx.x & 63) == node) ? x : v; }
+__device__ __forceinline__ void lane_set_i(int &v, int node, int x) { v = ((int)(threadIdx.x & 63) == node) ? x : v; }
+// reheap (knn_query_cuda_kernel.cu:15-30) with the root's (new) value handed in and written where it settles
+__device__ __forceinline__ void lanes_reheap(float &hd, int &hi, int k, float rd, int ri) {
+    int root = 0, child = 1;
+    while (child < k) {
+        float cd = lane_get_f(hd, child);
+        if (child + 1 < k) {
+            const float c1 = lane_get_f(hd, child + 1);
+            if (c1 > cd) { child++; cd = c1; }
+        }
+        if (rd > cd) break;
+        lane_set_f(hd, root, cd);
+        lane_set_i(hi, root, lane_get_i(hi, child));
+        root = child;
+        child = __builtin_amdgcn_readfirstlane(root * 2 + 1);
+    }
+    lane_set_f(hd, root, rd);
+    lane_set_i(hi, root, ri);
+}
+
 __global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
     int k, const float *__restrict__ xyz, const float *__restrict__ new_xyz, const int *__restrict__ offset,
     const int *__restrict__ new_offset, int b, int *__restrict__ idx, float *__restrict__ dist2, int pad_with_start,
     const int *__restrict__ tie_count, const int *__restrict__ tie_list) {
-    __shared__ float s_d[128];
-    __shared__ int s_i[128];
+    __shared__ float s_root;
     __shared__ float s_cd[EXW_CAP];
     __shared__ int s_ci[EXW_CAP];
     __shared__ int s_cnt[EXW_WAVES * EXW_PER_LANE + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    volatile float *hd = s_d;
-    volatile int *hi = s_i;
     const int total = *tie_count;
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         const int q = tie_list[w];
@@ -757,11 +786,10 @@ __global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
         const int start = s == 0 ? 0 : offset[s - 1];
         const int end = offset[s];
         const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
-        __syncthreads();  // (the previous query's heap has been written out)
-        for (int j = threadIdx.x; j < k; j += EXW_WAVES * WAVE) {
-            hd[j] = 1e10f;
-            hi[j] = pad_with_start ? start : -1;
-        }
+        float hd = 1e10f;                        // (wavefront 0) heap node `lane`
+        int hi = pad_with_start ? start : -1;
+        __syncthreads();  // (the previous query is done with s_root and the candidate buffers)
+        if (threadIdx.x == 0) s_root = 1e10f;
         __syncthreads();
         // the distances of a chunk are formed one trip ahead: their loads are in flight while the previous chunk's survivors
         // go through the barriers and the heap
@@ -778,7 +806,7 @@ __global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
         };
         fetch(start);
         for (int cbase = start; cbase < end; cbase += EXW_CHUNK) {
-            const float root = hd[0];
+            const float root = s_root;
             // sub-batch u of wave wid covers points cbase + (wid * PER_LANE + u) * 64 + lane: ascending in (wid, u, lane)
             float d2[EXW_PER_LANE];
             unsigned long long mk[EXW_PER_LANE];
@@ -816,13 +844,18 @@ __global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
             }
             __syncthreads();
             if (wid == 0) {
+                float rootv = lane_get_f(hd, 0);
                 if (nsurv <= EXW_CAP) {
-                    for (int j = 0; j < nsurv; ++j) {  // ascending index order
-                        const float cd = s_cd[j];
-                        if (cd < hd[0]) {  // knn_query_cuda_kernel.cu:93-97
-                            hd[0] = cd;
-                            hi[0] = s_ci[j];
-                            ex_reheap(hd, hi, k);
+                    for (int j0 = 0; j0 < nsurv; j0 += WAVE) {  // ascending index order, 64 survivors per read
+                        const float cdv = j0 + lane < nsurv ? s_cd[j0 + lane] : 3.0e38f;
+                        const int civ = j0 + lane < nsurv ? s_ci[j0 + lane] : 0;
+                        const int cnt = min(WAVE, nsurv - j0);
+                        for (int j = 0; j < cnt; ++j) {
+                            const float cd = lane_get_f(cdv, j);
+                            if (cd < rootv) {  // knn_query_cuda_kernel.cu:93-97
+                                lanes_reheap(hd, hi, k, cd, lane_get_i(civ, j));
+                                rootv = lane_get_f(hd, 0);
+                            }
                         }
                     }
                 } else {  // (only the first chunks of a scan, while the heap still holds its 1e10 fillers: the one-wave walk)
@@ -831,31 +864,33 @@ __global__ __launch_bounds__(EXW_WAVES *WAVE) void knn_exact_wide_kernel(
                         const int i = base + lane;
                         float d = 3.0e38f;
                         if (i < cend) d = ref_d2(qx, qy, qz, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
-                        unsigned long long mask = __ballot(d < hd[0]);
+                        unsigned long long mask = __ballot(d < rootv);
                         while (mask) {
                             const int l = __builtin_ctzll(mask);
                             mask &= mask - 1;
-                            const float cd = __shfl(d, l, WAVE);
-                            if (cd < hd[0]) {
-                                hd[0] = cd;
-                                hi[0] = base + l;
-                                ex_reheap(hd, hi, k);
+                            const float cd = lane_get_f(d, l);
+                            if (cd < rootv) {
+                                lanes_reheap(hd, hi, k, cd, base + l);
+                                rootv = lane_get_f(hd, 0);
                             }
                         }
                     }
                 }
+                if (lane == 0) s_root = rootv;
             }
             __syncthreads();
         }
         if (wid == 0) {
-            for (int i = k - 1; i > 0; --i) {  // heap_sort (:33-42)
-                float td = hd[0]; hd[0] = hd[i]; hd[i] = td;
-                int ti = hi[0]; hi[0] = hi[i]; hi[i] = ti;
-                ex_reheap(hd, hi, i);
+            for (int i = k - 1; i > 0; --i) {  // heap_sort (:33-42): swap root and node i, reheap the first i nodes
+                const float ld = lane_get_f(hd, i), rd = lane_get_f(hd, 0);
+                const int li = lane_get_i(hi, i), ri = lane_get_i(hi, 0);
+                lane_set_f(hd, i, rd);
+                lane_set_i(hi, i, ri);
+                lanes_reheap(hd, hi, i, ld, li);
             }
-            for (int j = lane; j < k; j += WAVE) {
-                idx[(size_t)q * k + j] = hi[j];
-                dist2[(size_t)q * k + j] = hd[j];
+            if (lane < k) {
+                idx[(size_t)q * k + lane] = hi;
+                dist2[(size_t)q * k + lane] = hd;
             }
         }
     }
@@ -909,7 +944,9 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
     }
     Workspace w = carve(workspace, m, n, b);
     if (!workspace || workspace_bytes < w.bytes) return PTV2_ERR_WORKSPACE;
-    const int ncell = n + b + 1;
+    const long long ncell_ll = (long long)CELLS_PER_POINT * n + b + 1;
+    if (ncell_ll + SCAN_TILE > 0x7fffffffLL) return PTV2_ERR_ARG;
+    const int ncell = (int)ncell_ll;
     const int ntiles = divup(ncell + 1, SCAN_TILE);
     const int ncell_pad = ntiles * SCAN_TILE;
     const int self_mode = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
@@ -918,8 +955,11 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        w.bbox_lo, w.bbox_hi, b, w.cell_count, ncell_pad);
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.bbox_lo,
                        w.bbox_hi);
+    // target points per cell of the bounding volume (surface clouds fill a fraction of their cells: several times as many per
+    // occupied one).  Swept at 120 k points with the 16-lane query: 2.0 -> 86 us, 1.0 -> 73, 0.5 -> 73, 0.25 -> 78 (k = 16)
+    static const float occupancy = [] { const char *e = getenv("AO_AMD_KNN_OCC"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 0.7f; }();
     hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(divup(b, 64)), dim3(64), 0, st, b, offset, w.bbox_lo, w.bbox_hi,
-                       w.seg, 2.0f);
+                       w.seg, occupancy);
     hipLaunchKernelGGL(knn_cell_count_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.seg,
                        w.cell_count, w.point_cell, w.point_rank);
     hipLaunchKernelGGL(knn_scan_reduce_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, w.cell_count, w.block_sums);
