@@ -117,11 +117,17 @@ def grid_pool_geometry(coord, offset, grid_size):
     n_out = torch.empty(1, dtype=torch.int32, device=dev)
     L = _lib.lib()
     ws = _lib.workspace(L.grid_pool_hip_workspace_bytes(n, b), dev)
-    rc = L.grid_pool_hip_launcher(n, b, coord.data_ptr(), off.data_ptr(), float(grid_size), cluster.data_ptr(),
-                                  order.data_ptr(), idx_ptr.data_ptr(), new_coord.data_ptr(), new_offset.data_ptr(),
-                                  n_out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-    _lib.check(rc, "grid_pool_hip_launcher")
-    m = int(n_out.item())  # the one host sync of the pooling: the output size is data dependent
+    def launch(sort_path):
+        rc = L.grid_pool_hip_launcher(n, b, coord.data_ptr(), off.data_ptr(), float(grid_size), cluster.data_ptr(),
+                                      order.data_ptr(), idx_ptr.data_ptr(), new_coord.data_ptr(), new_offset.data_ptr(),
+                                      n_out.data_ptr(), sort_path, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "grid_pool_hip_launcher")
+        return int(n_out.item())  # the one host sync of the pooling: the output size is data dependent
+
+    # the voxel grid is tabulated (no sort) when it is small enough -- which only the device knows: -2 asks for the sort path
+    m = launch(1 if os.environ.get("AO_AMD_GRIDPOOL") == "sort" else 0)
+    if m == -2:
+        m = launch(1)
     if m < 0:
         raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
     return new_coord[:m], new_offset, cluster, order, idx_ptr[: m + 1]

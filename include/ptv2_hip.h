@@ -330,11 +330,14 @@ int gva_block_backward_hip_launcher(const ptv2_gva_block *blk, const ptv2_gva_bl
 /*   grid_pool:     the whole coordinate half of GridPool.forward (:246-268): voxel ids (grid_cluster formula,
  *                  batch-major), stable sort, cluster ranks, pooled coordinates (mean in ascending point order),
  *                  new offsets.  cluster (n) int64, order (n), idx_ptr (n+1), new_coord (n,3), new_offset (b) are
- *                  sized for the worst case; *n_out (device int) = number of clusters (-1: voxel id overflow). */
+ *                  sized for the worst case; *n_out (device int) = number of clusters (-1: voxel id overflow).
+ *                  sort_path == 0 tabulates the voxel grid (no sort; grids up to 2^23 cells): *n_out == -2 then says the grid
+ *                  of this batch is larger and the call has to be repeated with sort_path != 0 (radix sort of the ids).
+ *                  Both paths give identical outputs. */
 size_t grid_pool_hip_workspace_bytes(int n, int b);
 int grid_pool_hip_launcher(int n, int b, const float *coord, const int *offset, float grid_size,
                            long long *cluster, int *order, int *idx_ptr, float *new_coord, int *new_offset,
-                           int *n_out, void *workspace, size_t workspace_bytes, void *stream);
+                           int *n_out, int sort_path, void *workspace, size_t workspace_bytes, void *stream);
 /*   inverse_table: CSR inverse of a neighbour table idx (n,k): for point j the slots r with idx[r] == j are
  *                  inv_rows[inv_ptr[j] .. inv_ptr[j+1]) in ascending r; inv_ptr (n+1), inv_rows (n*k). */
 size_t inverse_table_hip_workspace_bytes(int n, int k);

@@ -114,6 +114,25 @@ def test_geometry_matches_oracle(ptv2):
         c, o = nc, noff
 
 
+@pytest.mark.parametrize("points,grid", [(9000, 0.1), (60000, 0.06), (3000, 0.4), (20000, 0.0004)])
+def test_grid_pool_dense_table_equals_the_sort_path(monkeypatch, points, grid):
+    """GridPool's coordinate half two ways (ao_amd/csrc/gridpool.hip): the voxel grid tabulated (counts + scan, no sort) and
+    the radix sort of the voxel ids -- cluster map, member order, CSR, pooled coordinates and offsets identical.  The last
+    case (0.4 mm voxels: ~10^12 cells) is beyond the table: the dense call reports it and the wrapper repeats on the sort path."""
+    from ao_amd import synth
+    from ao_amd.ptv2.geometry import grid_pool_geometry
+
+    b = synth.scene_batch([7, 8, 9], point_max=points)
+    coord, offset = torch.from_numpy(b["coord"]).cuda(), torch.from_numpy(b["offset"]).cuda()
+    monkeypatch.setenv("AO_AMD_GRIDPOOL", "sort")
+    want = grid_pool_geometry(coord, offset, grid)
+    monkeypatch.setenv("AO_AMD_GRIDPOOL", "hip")
+    got = grid_pool_geometry(coord, offset, grid)
+    assert got[0].shape[0] == want[0].shape[0] > 0
+    for a, w, name in zip(got, want, ("new_coord", "new_offset", "cluster", "order", "idx_ptr")):
+        assert torch.equal(a, w), name
+
+
 def test_train_step_runs_and_reduces_loss(ptv2):
     from ao_amd import synth
 
