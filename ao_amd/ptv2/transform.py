@@ -70,8 +70,6 @@ class GridSample:
 
     def __call__(self, data_dict, generator=None, draws=None):
         assert "coord" in data_dict.keys()
-        if "sampled_index" in data_dict:
-            raise NotImplementedError("sampled_index (ScanNet data-efficient) is not handled on the device path")
         coord = _dev_f32(data_dict["coord"])
         idx_sort, start, count, cell, lo, _ = self.voxelise(coord)
         extras = self._extras(data_dict, coord, cell, lo)
@@ -81,6 +79,14 @@ class GridSample:
                 draws = torch.randint(0, int(count.max()), (count.numel(),), device=coord.device, generator=generator)
             draws = torch.as_tensor(draws, device=coord.device).long()
             idx_unique = idx_sort[start + draws % count]
+            if "sampled_index" in data_dict:
+                # transform.py:807-815 (ScanNet data-efficient): the labelled points are kept whatever the draw selected; the
+                # selection becomes the SORTED union (np.unique) and sampled_index is re-expressed in the new numbering
+                sampled = torch.as_tensor(data_dict["sampled_index"], device=coord.device).long()
+                idx_unique = torch.unique(torch.cat([idx_unique, sampled]))
+                mask = torch.zeros(coord.shape[0], dtype=torch.bool, device=coord.device)
+                mask[sampled] = True
+                data_dict["sampled_index"] = torch.nonzero(mask[idx_unique]).reshape(-1)
             if self.return_discrete_coord:
                 data_dict["discrete_coord"] = cell[idx_unique]
             if self.return_min_coord:
@@ -112,25 +118,66 @@ class SphereCrop:
 
     def __init__(self, point_max=80000, sample_rate=None, mode="random"):
         assert mode in ["random", "center", "all"]
-        if mode == "all":
-            raise NotImplementedError("SphereCrop(mode='all') (test-time tiling) stays on the host")
         self.point_max, self.sample_rate, self.mode = point_max, sample_rate, mode
 
     @staticmethod
-    def nearest(coord, centre, point_max):
-        """Indices of the point_max points nearest to `centre` (3 floats on the device), ascending distance."""
+    def dist2(coord, centre):
+        """Squared distances of every point to `centre` (3 floats on the device), rounded as numpy's
+        np.sum(np.square(coord - centre), 1) (ao_amd/csrc/dataops.hip)."""
         coord = _dev_f32(coord)
         n = coord.shape[0]
         d2 = torch.empty(n, dtype=torch.float32, device=coord.device)
         centre = centre.contiguous().float()
         rc = _lib.lib().center_dist2_hip_launcher(n, coord.data_ptr(), centre.data_ptr(), d2.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "center_dist2_hip_launcher")
-        return torch.sort(d2, stable=True)[1][:point_max]
+        return d2
 
-    def __call__(self, data_dict, generator=None, center_index=None):
+    @classmethod
+    def nearest(cls, coord, centre, point_max):
+        """Indices of the point_max points nearest to `centre`, ascending distance."""
+        return torch.sort(cls.dist2(coord, centre), stable=True)[1][:point_max]
+
+    PART_KEYS = ("coord", "discrete_coord", "normal", "color", "displacement", "strength")  # transform.py:933-948
+
+    def _all(self, data_dict, point_max, generator, priority):
+        """mode="all" (transform.py:914-968): overlapping crops of point_max points until every point is in one.  Each crop is
+        centred on the point of lowest priority; a crop raises the priority of its members by (1 - d2 / max d2)^2."""
+        coord = _dev_f32(data_dict["coord"])
+        n = coord.shape[0]
+        if "index" not in data_dict.keys():
+            data_dict["index"] = torch.arange(n, device=coord.device)
+        if n <= point_max:
+            part = dict(data_dict)
+            part["weight"] = torch.zeros(n, dtype=torch.float64, device=coord.device)
+            part["index"] = data_dict["index"]
+            return [part]
+        if priority is None:  # np.random.rand(n) * 1e-3
+            priority = torch.rand(n, dtype=torch.float64, device=coord.device, generator=generator) * 1e-3
+        coord_p = torch.as_tensor(priority, device=coord.device).double().clone()
+        covered = torch.zeros(n, dtype=torch.bool, device=coord.device)
+        parts = []
+        while not bool(covered.all()):
+            init_idx = torch.argmin(coord_p)
+            d2 = self.dist2(coord, coord[init_idx])
+            idx_crop = torch.sort(d2, stable=True)[1][:point_max]
+            part = {key: data_dict[key][idx_crop] for key in self.PART_KEYS if key in data_dict.keys()}
+            part["weight"] = d2[idx_crop]
+            part["index"] = data_dict["index"][idx_crop]
+            parts.append(part)
+            w = part["weight"]  # (fp32 arithmetic, as numpy's on the fp32 distances; the priorities are fp64)
+            coord_p[idx_crop] += torch.square(1 - w / w.max()).double()
+            covered[idx_crop] = True
+        return parts
+
+    def __call__(self, data_dict, generator=None, center_index=None, priority=None):
         assert "coord" in data_dict.keys()
         n = data_dict["coord"].shape[0]
         point_max = int(self.sample_rate * n) if self.sample_rate is not None else self.point_max
+        if self.mode == "all":
+            return self._all(data_dict, point_max, generator, priority)
+        return self._one(data_dict, n, point_max, generator, center_index)
+
+    def _one(self, data_dict, n, point_max, generator, center_index):
         if n <= point_max:
             return data_dict
         coord = _dev_f32(data_dict["coord"])

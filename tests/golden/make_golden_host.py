@@ -89,6 +89,21 @@ def gen_gridsample(T):
         parts = gt(dict(coord=coord.copy(), index=np.arange(coord.shape[0])))
         out[tag + "_test_index"] = np.concatenate([p["index"] for p in parts])
         out[tag + "_test_sizes"] = np.asarray([p["index"].shape[0] for p in parts])
+    # transform.py:807-815: the data-efficient branch (labelled points always kept).  It spells the mask dtype `np.bool`, an
+    # alias numpy removed in 1.24: restored for this call only, nothing else of the reference is touched
+    gs = T.GridSample(grid_size=np.float32(0.04), hash_type="fnv", mode="train", keys=("coord", "index", "segment"))
+    labelled = np.random.default_rng(23).choice(coord.shape[0], size=200, replace=False)
+    had = hasattr(np, "bool")
+    if not had:
+        np.bool = bool
+    np.random.seed(13)
+    d = gs(dict(coord=coord.copy(), index=np.arange(coord.shape[0]), segment=np.arange(coord.shape[0]) % 7,
+                sampled_index=labelled.copy()))
+    if not had:
+        del np.bool
+    out["sampled_in"] = labelled
+    out["sampled_train_index"] = d["index"]
+    out["sampled_out"] = d["sampled_index"]
     cells = np.random.default_rng(3).integers(0, 400, size=(500, 3))
     out["hash_cells"] = cells
     out["hash_fnv"] = T.GridSample.fnv_hash_vec(cells)
@@ -110,6 +125,15 @@ def gen_spherecrop(T):
     out["random_index"] = d["segment"]
     d = T.SphereCrop(point_max=10000, mode="random")(dict(coord=coord.copy(), segment=np.arange(coord.shape[0])))
     out["nocrop_index"] = d["segment"]
+    # mode="all" (test-time tiling, transform.py:914-968): every crop's members and weights, and the priorities it drew
+    np.random.seed(31)
+    out["all_priority"] = np.random.rand(coord.shape[0]) * 1e-3
+    np.random.seed(31)
+    parts = T.SphereCrop(point_max=2000, mode="all")(dict(coord=coord.copy(), color=coord.copy() * 2))
+    out["all_sizes"] = np.asarray([p["index"].shape[0] for p in parts])
+    out["all_index"] = np.concatenate([p["index"] for p in parts])
+    out["all_weight"] = np.concatenate([p["weight"] for p in parts])
+    out["all_color0"] = parts[0]["color"]
     save("host_spherecrop.npz", **out)
 
 

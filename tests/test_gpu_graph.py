@@ -118,7 +118,7 @@ def test_sampled_kernel_timer_brackets_inside_the_graph(graph_mode):
     assert _lib.graph_stats()["declined"] == 2  # HIP-event survey: eager
     _lib.kernel_timer(False)
     survey = _lib.kernel_timer_read()
-    name = "linear_wgrad_lds_kernel<0>"
+    name = "linear_wgrad_lds_kernel"
     assert name in survey and survey[name]["launches"] > 20
     per_step = survey[name]["launches"]
     _lib.kernel_timer(True, only=name, stride=5)

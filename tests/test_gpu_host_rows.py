@@ -115,6 +115,51 @@ def test_sphere_crop():
     assert r["coord"].shape[0] == n // 4
 
 
+def test_grid_sample_keeps_the_labelled_points():
+    """transform.py:807-815 (`sampled_index`, ScanNet data-efficient): fixture from the reference's own GridSample."""
+    from ao_amd.ptv2.transform import GridSample
+
+    g = load("host_gridsample.npz")
+    coord = g["coord"]
+    _, _, o_count, _, _ = H.grid_sample_sorted(coord, 0.04, "fnv")
+    np.random.seed(13)
+    draws = np.random.randint(0, o_count.max(), o_count.size)  # the reference's draw
+    gs = GridSample(grid_size=0.04, hash_type="fnv", mode="train", keys=("coord", "index", "segment"))
+    n = coord.shape[0]
+    d = gs(dict(coord=cuda(coord), index=torch.arange(n).cuda(), segment=(torch.arange(n) % 7).cuda(),
+                sampled_index=cuda(g["sampled_in"])), draws=draws)
+    sel = d["index"].cpu().numpy()
+    # which point of a multi-point voxel a draw selects depends on numpy's unstable argsort (module docstring), and with it how
+    # many labelled points the draw had already taken: against the reference's run the size may differ by those, so the
+    # statement itself is checked -- the SORTED union of this path's own selection with the labelled points -- and the
+    # reference's result for what does not depend on the sort: every labelled point kept, their new positions
+    base = gs(dict(coord=cuda(coord), index=torch.arange(n).cuda(), segment=(torch.arange(n) % 7).cuda()), draws=draws)["index"].cpu().numpy()
+    assert np.array_equal(sel, np.union1d(base, g["sampled_in"]))
+    assert abs(sel.shape[0] - g["sampled_train_index"].shape[0]) <= g["sampled_in"].shape[0]
+    assert np.isin(g["sampled_in"], g["sampled_train_index"]).all() and np.isin(g["sampled_in"], sel).all()
+    assert np.array_equal(sel[d["sampled_index"].cpu().numpy()], np.sort(g["sampled_in"]))
+    assert np.array_equal(g["sampled_train_index"][g["sampled_out"]], np.sort(g["sampled_in"]))  # (the reference: same statement)
+    assert np.array_equal(d["segment"].cpu().numpy(), sel % 7)
+
+
+def test_sphere_crop_all_tiles_the_cloud():
+    """SphereCrop(mode="all") (transform.py:914-968): every crop's members and weights as the reference produced them from
+    the same priorities."""
+    from ao_amd.ptv2.transform import SphereCrop
+
+    g = load("host_spherecrop.npz")
+    coord = g["coord"]
+    parts = SphereCrop(point_max=2000, mode="all")(dict(coord=cuda(coord), color=cuda(coord * 2)), priority=g["all_priority"])
+    assert [int(p["index"].shape[0]) for p in parts] == g["all_sizes"].tolist()
+    assert np.array_equal(torch.cat([p["index"] for p in parts]).cpu().numpy(), g["all_index"])
+    # (np.power(x, 2) and the kernel's x * x may differ in the last bit; the crops' members above are identical)
+    np.testing.assert_allclose(torch.cat([p["weight"] for p in parts]).cpu().numpy(), g["all_weight"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_array_equal(parts[0]["color"].cpu().numpy(), g["all_color0"])
+    assert np.unique(g["all_index"]).size == coord.shape[0]
+    small = SphereCrop(point_max=10000, mode="all")(dict(coord=cuda(coord)))
+    assert len(small) == 1 and int(small[0]["index"].shape[0]) == coord.shape[0] and float(small[0]["weight"].abs().max()) == 0.0
+
+
 def test_collect_and_collate():
     from ao_amd.ptv2.transform import Collect, point_collate
 
