@@ -315,7 +315,7 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     // fc3 input gradient -> g_f2 (ta); norm2 + ReLU -> g_attn (tb)
     // (at <= 512 row blocks the GEMM's epilogue leaves the reduce records of the BatchNorm backward that consumes its output)
     const int nrb = (n + 63) / 64;
-    const bool epi = nrb <= 512 && !getenv("AO_AMD_BN_BWD_SEPARATE");
+    const bool epi = nrb <= 512;
     if (epi) {
         const float *xs[1] = {g_h3}, *ws[1] = {P[PTV2_BLK_FC3_W]};
         RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G],

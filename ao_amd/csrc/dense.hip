@@ -959,8 +959,6 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
 
 // operands 16-byte aligned with row strides that keep them so: the LDS-staged form applies (fp32 products only)
 static bool wgrad_lds_ok(const void *a, long long ldy, long long sy, const void *b, long long ldx, long long sx) {
-    const char *e = getenv("AO_AMD_WGRAD");  // "direct": the fragment-from-global kernel (A/B switch of the tests)
-    if (e && e[0] == 'd') return false;
     return ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ldy % 4 == 0 && ldx % 4 == 0 && sy % 4 == 0 && sx % 4 == 0;
 }
 static bool wgrad_lds_shape_ok(int cout, int cin) { return cout % 4 == 0 && cin % 4 == 0; }
@@ -1091,10 +1089,7 @@ extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin
 // levels (n ~ 4 500, 80 tile-products) 256-row chunks made 1 440 workgroups = two full rounds of that fixed cost for 18
 // records to finalize.  Target ~3 workgroups per compute unit in ONE round; never fewer than 256 rows per workgroup.
 static int wg_chunk(int n, int tiles) {
-    static const int forced = [] { const char *e = getenv("AO_AMD_WG_CHUNK"); return e ? atoi(e) : 0; }();
-    if (forced >= WG_CHUNK_MIN) return forced;
-    static const int target = [] { const char *e = getenv("AO_AMD_WG_TARGET"); return e ? atoi(e) : 768; }();
-    if (target <= 0) return WG_CHUNK;
+    constexpr int target = 768;  // (swept in round 2: DESIGN.md / profiles/HISTORY.md)
     const int chunks = std::max(1, target / std::max(1, tiles));
     const long long rows = ((long long)n + chunks - 1) / chunks;
     long long chunk = std::max<long long>(WG_CHUNK, (rows + 127) / 128 * 128);
@@ -1226,7 +1221,7 @@ static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, floa
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
-    if (nrb_all >= 1024 && ((c + 15) / 16) * count <= 32 && !getenv("AO_AMD_BN_TILES_ONE")) {
+    if (nrb_all >= 1024 && ((c + 15) / 16) * count <= 32) {
         unsigned *cnt = ptv2_stream_counters((hipStream_t)stream);
         if (!cnt) return PTV2_ERR_LAUNCH;
         hipLaunchKernelGGL(bn_finalize_tiles_split_kernel, dim3((c + 15) / 16, BNT_NS, count), dim3(1024), 0, (hipStream_t)stream, A, B,

@@ -547,21 +547,17 @@ static void launch_one(dim3 grid, hipStream_t st, int m, int n, int k, const flo
 // workgroup count, so the wide block stays affordable there (4.5 k points x 192: 852 workgroups of 48 columns instead of
 // 2 556 of 16, each re-reading the X tile a third as often)
 static int column_block(int m, int n, int products = 1) {
-    static const int forced = [] { const char *e = getenv("AO_AMD_GEMM_BN"); return e ? atoi(e) : 0; }();
-    static const bool count_aware = [] { const char *e = getenv("AO_AMD_GEMM_COUNT_AWARE"); return !(e && e[0] == '0'); }();
     const bool n48 = n % 48 == 0;
     const int wide = n48 ? 48 : 64;
-    if (forced == 32 && n % 32 == 0) return 32;
-    if (forced == 16 || forced == 48 || forced == 64) return (forced == 16 && n % 16 == 0) ? 16 : wide;
-    const long long rbs = ((long long)m + gemm::BM - 1) / gemm::BM, prod = count_aware ? products : 1;
+    const long long rbs = ((long long)m + gemm::BM - 1) / gemm::BM, prod = products;
     const long long wgs = rbs * ((n + wide - 1) / wide) * prod;
-    static const int wide_min = [] { const char *e = getenv("AO_AMD_GEMM_WIDE"); return e ? atoi(e) : 768; }();
+    constexpr int wide_min = 768;
     if (wgs >= wide_min || n % 16 != 0) return wide;
     // in between: 32-column blocks when they still give a workgroup per compute unit -- every column block re-reads the X tile
     // from L2, 12 x with 16 columns at n = 192.  Measured at 120 k points (alternating runs on one box): 11.08 ms without
-    // (AO_AMD_GEMM_MID=0), 11.02 with the threshold at 512 workgroups, 10.98 at 256, 10.99 at 128
-    static const int mid = [] { const char *e = getenv("AO_AMD_GEMM_MID"); return e ? atoi(e) : 256; }();
-    if (mid > 0 && n % 32 == 0 && rbs * (n / 32) * prod >= mid) return 32;
+    // the 32-column form, 11.02 with the threshold at 512 workgroups, 10.98 at 256, 10.99 at 128
+    constexpr int mid = 256;
+    if (n % 32 == 0 && rbs * (n / 32) * prod >= mid) return 32;
     return 16;
 }
 

@@ -80,13 +80,23 @@ __global__ __launch_bounds__(TPB) void pool_scatter_kernel(int n, const int *__r
 
 // pooled coordinate = sequential fp32 sum over the members in sorted (= ascending point) order / count;
 // new_offset[s] = number of clusters whose cloud index is <= s
+// sort_members (dense path): the member slots came from atomics -- the cluster's thread first puts its handful of members
+// (one voxel) into ascending point order, in place, so that `order` is the stable sort by key and the sum below runs in it
 __global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ n_out, int b,
                                                         const float *__restrict__ coord, const int *__restrict__ offset,
-                                                        const int *__restrict__ order, const int *__restrict__ idx_ptr,
-                                                        float *__restrict__ new_coord, int *__restrict__ new_offset) {
+                                                        int *order, const int *__restrict__ idx_ptr,
+                                                        float *__restrict__ new_coord, int *__restrict__ new_offset, int sort_members) {
     const int m = *n_out;  // negative on key overflow: nothing to do
     for (int j = blockIdx.x * TPB + threadIdx.x; j < m; j += gridDim.x * TPB) {
         const int p0 = idx_ptr[j], p1 = idx_ptr[j + 1];
+        if (sort_members) {
+            for (int p = p0 + 1; p < p1; ++p) {
+                const int v = order[p];
+                int q = p - 1;
+                while (q >= p0 && order[q] > v) { order[q + 1] = order[q]; --q; }
+                order[q + 1] = v;
+            }
+        }
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int p = p0; p < p1; ++p) {
             const size_t r = (size_t)order[p];
@@ -97,6 +107,8 @@ __global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ 
         new_coord[3 * (size_t)j + 1] = sy / cnt;
         new_coord[3 * (size_t)j + 2] = sz / cnt;
         const int s0 = seg_of(order[p0], offset, b);
+        // (the next cluster's first slot, possibly while its own thread is still sorting it: every value ever stored in that range
+        // is one of its members, and any member lies in the cluster's cloud)
         const int s1 = (j + 1 < m) ? seg_of(order[idx_ptr[j + 1]], offset, b) : b;
         for (int s = s0; s < s1; ++s) new_offset[s] = j + 1;  // clouds s0 .. s1-1 end after cluster j
         if (j == 0)
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ 
 //   voxel its cluster number (occupied voxels before it, in key order = the order a sort + unique produces) and the start of
 //   its member list, the points are dropped into their slots, and each cluster orders its handful of members by point
 //   index (the slots came from atomics) before it takes their mean -- so `order` is exactly the stable sort by key.
-// Six launches instead of the ~16 of a 6-pass radix sort + scan, and 40 us instead of 250 at 120 k points.  The grid size
+// Six launches (the member sort rides in the mean kernel) instead of the ~16 of a 6-pass radix sort + scan, and 40 us instead of 250 at 120 k points.  The grid size
 // is only known on the device: a grid beyond DENSE_CAP sets *n_out = -2 and the caller repeats the call on the sort path.
 constexpr long long DENSE_CAP = 1ll << 23;
 constexpr int DSCAN_THREADS = 256, DSCAN_ITEMS = 8, DSCAN_TILE = DSCAN_THREADS * DSCAN_ITEMS;
@@ -227,22 +239,6 @@ __global__ __launch_bounds__(TPB) void dense_scatter_kernel(int n, const int *__
     if (slot[i] == 0) idx_ptr[bb.y] = bb.x;
 }
 
-// (dense path) members of a cluster into ascending point order before pool_mean_kernel reads them: the slots came from
-// atomics.  Clusters hold a handful of points (one voxel): insertion sort in place by the cluster's thread.
-__global__ __launch_bounds__(TPB) void dense_sort_members_kernel(const int *__restrict__ n_out, const int *__restrict__ idx_ptr,
-                                                                 int *__restrict__ order) {
-    const int m = *n_out;
-    for (int j = blockIdx.x * TPB + threadIdx.x; j < m; j += gridDim.x * TPB) {
-        const int p0 = idx_ptr[j], p1 = idx_ptr[j + 1];
-        for (int p = p0 + 1; p < p1; ++p) {
-            const int v = order[p];
-            int q = p - 1;
-            while (q >= p0 && order[q] > v) { order[q + 1] = order[q]; --q; }
-            order[q + 1] = v;
-        }
-    }
-}
-
 struct Ws {
     float *lo, *hi;
     PoolDims *dims;
@@ -327,10 +323,8 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
                            (const int *)w.d_count, (const int2 *)w.d_tiles, w.d_base, idx_ptr);
         hipLaunchKernelGGL(dense_scatter_kernel, dim3(nb), dim3(TPB), 0, st, n, (const int *)n_out, (const int *)w.d_key,
                            (const int *)w.d_slot, (const int2 *)w.d_base, cluster, order, idx_ptr);
-        hipLaunchKernelGGL(dense_sort_members_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out,
-                           (const int *)idx_ptr, order);
         hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out, b, coord, offset,
-                           (const int *)order, (const int *)idx_ptr, new_coord, new_offset);
+                           order, (const int *)idx_ptr, new_coord, new_offset, 1);
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
@@ -347,7 +341,7 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
     hipLaunchKernelGGL(pool_scatter_kernel, dim3(nb), dim3(TPB), 0, st, n, (const int *)w.rank, (const int *)w.flags,
                        (const int *)order, cluster, idx_ptr, n_out, (const PoolDims *)w.dims);
     hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out, b, coord, offset,
-                       (const int *)order, (const int *)idx_ptr, new_coord, new_offset);
+                       order, (const int *)idx_ptr, new_coord, new_offset, 0);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

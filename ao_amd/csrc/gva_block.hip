@@ -513,9 +513,8 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         // grad bp2 = sum_n g_out[n, ch] sw[n, group(ch)] as its weighted bias sums (it reads g_out anyway; that sum was a launch
         // of its own per Block, bp2_grad_kernel: 15 x 6 us); where the weight gradient cannot (bf16 operands), the kernel below
         const PtvDeferScope defer;
-        static const bool split = [] { const char *e = getenv("AO_AMD_BP2_GRAD"); return e && e[0] == 's'; }();  // A/B switch
-        RUN(linear_wgrad_strided_rowscale(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, split ? nullptr : G->gbp2,
-                                          split ? nullptr : B->sw, g, &bp2_done, W.wp2_part, W.wp2_bytes, stream));
+        RUN(linear_wgrad_strided_rowscale(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, G->gbp2, B->sw, g, &bp2_done,
+                                          W.wp2_part, W.wp2_bytes, stream));
     }
     if (!bp2_done) {
         const PtvDeferScope defer;  // (its record sum rides on the gv launch as well)

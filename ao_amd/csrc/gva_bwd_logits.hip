@@ -524,8 +524,7 @@ int launch_logits_bwd_fused6(int n, const float *a, const float *b, const float 
         int occ = 0, dev = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, 256, lds) != hipSuccess || occ < 1) occ = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        static const int cap = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6_WGS"); return e ? atoi(e) : 1024; }();
-        resident = std::max(64, std::min(occ * cus, cap));
+        resident = std::max(64, std::min(occ * cus, 1024));
     }
     const long long groups = ((long long)n + 3) / 4;
     long long cap = std::min<long long>(resident, (long long)(part_floats_avail / REC));
@@ -544,8 +543,7 @@ int gva_logits_bwd_fused_supported(int k, int c, int g) {
     // (64, 512) -- the ScanNet cfg's deepest level, a few dozen points -- would need 128 accumulator registers per lane and
     // spills: it stays on the staged kernels of gva_bwd.hip
     if (g == 6 && c == 48) {  // (24-byte rows: float4 loads of a point's block need k = 16)
-        static const bool off = [] { const char *e = getenv("AO_AMD_LOGITS_BWD6"); return e && e[0] == '0'; }();
-        return k == 16 && !off;
+        return k == 16;
     }
     return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
 }
@@ -777,11 +775,8 @@ int launch_logits_fwd_mfma(int n, int k, const float *kW, const float *qW, const
 
 int gva_logits_fwd_mfma_supported(int k, int c, int g) {
     if (k < 1 || k > 16) return 0;
-    // (6, 48): measured equal to the flat one-lane-per-slot kernel (58 vs 59 us at 120 k points, 10.93 vs 10.95 ms per step after
-    // the load fixes of round 3: with 6 of 16 tile columns in use the epilogue stores 24-byte segments from 6 lanes); stays
-    // behind the knob
-    static const bool narrow = [] { const char *e = getenv("AO_AMD_LOGITS_FWD6"); return e && e[0] == '1'; }();
-    if (g == 6 && c == 48) return narrow ? 1 : 0;
+    // (6, 48) stays on the flat one-lane-per-slot kernel: the MFMA form measured equal there (58 vs 59 us at 120 k points: with
+    // 6 of 16 tile columns in use the epilogue stores 24-byte segments from 6 lanes) and is not instantiated
     return (g == 12 && c == 96) || (g == 24 && c == 192) || (g == 48 && c == 384);
 }
 
@@ -791,7 +786,6 @@ int gva_logits_fwd_mfma_launch(int n, int k, int c, int g, const float *kW, cons
                                double *T1, double *T2, const gva::FoldWFwdArgs &F, hipStream_t st) {
     using namespace gva;
 #define ARGS n, k, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st
-    if (g == 6 && c == 48) return launch_logits_fwd_mfma<6, 48, 1>(ARGS);
     if (g == 12 && c == 96) return launch_logits_fwd_mfma<12, 96, 1>(ARGS);
     if (g == 24 && c == 192) return launch_logits_fwd_mfma<24, 192, 1>(ARGS);
     if (g == 48 && c == 384) return launch_logits_fwd_mfma<48, 384, 4>(ARGS);

@@ -1104,10 +1104,9 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
     using namespace gva;
     if (!g_A && !(Wp2 && bp2 && gva_bwd_point_local(k, c, g))) return PTV2_ERR_ARG;
 #define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st, Wp2, bp2
-    static const int nw_try = [] { const char *e = getenv("AO_AMD_ABP_NW"); return e ? atoi(e) : 0; }();  // sweep knob
     if (g == 6 && c == 48) return launch_bwd_point<6, 48, 1>(ARGS);
-    if (g == 12 && c == 96) return nw_try == 2 ? launch_bwd_point<12, 96, 2>(ARGS) : launch_bwd_point<12, 96, 1>(ARGS);
-    if (g == 24 && c == 192) return nw_try == 4 ? launch_bwd_point<24, 192, 4>(ARGS) : launch_bwd_point<24, 192, 2>(ARGS);
+    if (g == 12 && c == 96) return launch_bwd_point<12, 96, 1>(ARGS);
+    if (g == 24 && c == 192) return launch_bwd_point<24, 192, 2>(ARGS);
     if (g == 48 && c == 384) return launch_bwd_point<48, 384, 4>(ARGS);
     if (g == 64 && c == 512) return launch_bwd_point<64, 512, 4>(ARGS);
 #undef ARGS

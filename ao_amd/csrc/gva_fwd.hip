@@ -274,8 +274,7 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
     float *part = (float *)workspace;
     const long long rows = (long long)n * k;
     {
-        const char *lf = getenv("AO_AMD_LOGITS_FWD");  // "staged": round 2's kernels (A/B switch of the tests)
-        if (gva_logits_fwd_mfma_supported(k, c, g) && !(lf && lf[0] == 's') && !getenv("AO_AMD_BWD_STAGED")) {
+        if (gva_logits_fwd_mfma_supported(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) {
             PtvScopedTimer t(KID_LOGITS_FWD, st, 4.0 * ((double)n * k * (g + 1) + (double)n * (3 + 2 * g)));
             const int rc = gva_logits_fwd_mfma_launch(n, k, c, g, kW, qW, a, b, M, cW, coord, idx, W1, part, T1, T2, F, st);
             if (rc != PTV2_OK) return rc;

@@ -404,8 +404,7 @@ int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2,
     if (n < 0 || c < 4 || g < 1 || c % g != 0 || c % 4 != 0) return PTV2_ERR_ARG;
     if (stats_done) *stats_done = 0;
     if (n == 0) return PTV2_OK;
-    const char *form = getenv("AO_AMD_PEB");  // "flat": the one-lane-per-output kernel (A/B switch of the tests)
-    if (c / g == 8 && (c == 48 || c == 96 || c == 192 || c == 384 || c == 512) && !(form && form[0] == 'f')) {
+    if (c / g == 8 && (c == 48 || c == 96 || c == 192 || c == 384 || c == 512)) {
         hipStream_t st = (hipStream_t)stream;
         PtvScopedTimer t(KID_PEB_FWD, st, 4.0 * ((double)n * g * c + 2.0 * n * c + (double)n * g + (double)c * c));
         switch (c) {
@@ -422,8 +421,7 @@ int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2,
     // output channels per workgroup.  Wide C: 32 (not 64) -- the 64-channel stage of Wp2 rows is 99 KB of LDS at C = 384,
     // one workgroup per CU and the kernel parked on its A-row loads; 32 channels leave room for three (58 -> 37 us at
     // C = 384, 34 -> 21 us at C = 512, unchanged at C = 192)
-    static const int ct_wide = [] { const char *e = getenv("AO_AMD_PEB_CT"); return e ? atoi(e) : 32; }();
-    const int ct = c <= 128 ? c : ct_wide;
+    const int ct = c <= 128 ? c : 32;
     if (ct > TPB) return PTV2_ERR_ARG;
     const size_t lds = sizeof(float) * (size_t)ct * (c + 4);
     if (lds > 160 * 1024) return PTV2_ERR_ARG;

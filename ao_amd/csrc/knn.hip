@@ -969,8 +969,7 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        w.point_rank, w.sorted);
     {
     PtvScopedTimer qt(KID_KNN_QUERY, st, 12.0 * n + 12.0 * m + 8.0 * (double)m * k);
-    static const bool lane_form = [] { const char *e = getenv("AO_AMD_KNN"); return e && e[0] == 'l'; }();  // A/B: one lane per query
-    if (k <= 16 && !lane_form) {
+    if (k <= 16) {
         const dim3 grid(divup((long long)m * 16, 256)), blk(256);
 #define ROWQ(KK)                                                                                                                   \
         do {                                                                                                                       \
@@ -990,10 +989,6 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
         else ROWQ(0);
 #undef ROWQ
     }
-    else if (k <= 1) launch_query<2>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
-    else if (k <= 3) launch_query<4>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
-    else if (k <= 8) launch_query<9>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
-    else if (k <= 16) launch_query<17>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     else launch_query<33>(st, m, k, w, new_xyz, offset, new_offset, b, idx, dist2, pad_with_start, self_mode);
     }
     hipLaunchKernelGGL(knn_exact_wide_kernel, dim3(128), dim3(EXW_WAVES * WAVE), 0, st, k, xyz, new_xyz, offset, new_offset, b, idx,

@@ -5,7 +5,6 @@ python -m pytest tests/test_gpu_gva_stages.py tests/test_gpu_dense.py tests/test
 echo "pytest rc $?" >> $O/pytest.log
 tail -4 $O/pytest.log
 for i in 1 2 3; do python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; done
-AO_AMD_LOGITS_FWD6=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; print('fwd6', json.loads(sys.stdin.read())['ms_per_step'])"
 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline --dtype bf16 2>/dev/null | tail -1 | python -c "import json,sys; print('bf16', json.loads(sys.stdin.read())['ms_per_step'])"
 rocprofv3 --kernel-trace --stats -d $O/trace -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-ops --no-roofline --steps 6 --warmup 2 > $O/trace.log 2>&1
 python - $O/trace <<'PY' > $O/stats.txt
