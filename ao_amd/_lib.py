@@ -56,6 +56,8 @@ _SIGNATURES = {
     "grid_pool_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 2 + [ctypes.c_float] + [_vp] * 6 + [_c_int, _vp, _c_size, _vp]),
     "inverse_table_hip_workspace_bytes": (_c_size, [_c_int] * 2),
     "inverse_table_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 4 + [_c_size, _vp]),
+    "inverse_tables_hip_workspace_bytes": (_c_size, [_c_int, _vp]),
+    "inverse_tables_hip_launcher": (_c_int, [_c_int, _vp, _vp, _c_size, _vp]),
     "segment_minmax_hip_workspace_bytes": (_c_size, [_c_int]),
     "segment_minmax_hip_launcher": (_c_int, [_c_int] + [_vp] * 5 + [_c_size, _vp]),
     "pool_max_forward_hip_launcher": (_c_int, [_c_int] * 2 + [_vp] * 6),
@@ -98,7 +100,7 @@ _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace 
 _lib = None
 # bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
 # mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
-EXPECTED_ABI = 8
+EXPECTED_ABI = 9
 
 
 def build(verbose=False):

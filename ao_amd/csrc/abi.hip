@@ -8,7 +8,7 @@
 
 #include "gva_common.h"
 
-extern "C" int ptv2_abi_version(void) { return 8; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 9; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 // sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
 // layout drift between the header and a python mirror is an import error, not a misread pointer
@@ -17,6 +17,7 @@ extern "C" long long ptv2_struct_bytes(int which) {
         case 0: return (long long)sizeof(ptv2_block);
         case 1: return (long long)sizeof(ptv2_block_grads);
         case 2: return (long long)sizeof(ptv2_model);
+        case 3: return (long long)sizeof(ptv2_gva_block);
         default: return -1;
     }
 }
@@ -30,6 +31,22 @@ extern "C" int ptv2_matmul_precision(int bf16) {
     if (bf16 >= 0) g_matmul_bf16 = bf16 ? 1 : 0;
     return prev;
 }
+
+// ---- attention dropout of the gva_block call in progress on this thread (gva_common.h)
+namespace gva {
+namespace { thread_local PtvDrop g_drop{1.f, 0u, 0u}; }
+PtvDrop ptv2_attn_drop_current() { return g_drop; }
+void ptv2_attn_drop_set(float p, unsigned seed) {
+    if (!(p > 0.f)) { g_drop = PtvDrop{1.f, 0u, 0u}; return; }
+    const double pp = p < 1.f ? (double)p : 1.0;
+    const double t = pp * 4294967296.0;
+    g_drop.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    if (g_drop.thresh == 0u) g_drop.thresh = 1u;
+    g_drop.scale = pp < 1.0 ? (float)(1.0 / (1.0 - pp)) : 0.f;
+    g_drop.seed = seed;
+}
+PtvAttnDropScope::~PtvAttnDropScope() { g_drop = prev; }
+}  // namespace gva
 
 // ---- riders (gva_common.h): per-thread queue of finalizes that a later, independent launch carries
 namespace gva {

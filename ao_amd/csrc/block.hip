@@ -133,6 +133,7 @@ void fill_gva(const ptv2_block *B, const Saved &S, ptv2_gva_block *V) {
     V->out = S.attn;
     V->a = S.a; V->b = S.b; V->rstd_p = S.rstd_p; V->M = S.M; V->cW = S.cW; V->kW = S.kW; V->qW = S.qW; V->W1 = S.W1;
     V->w = S.w; V->A = S.A; V->sw = S.sw; V->sc = S.sc; V->sh = S.sh; V->mean_w = S.mean_w; V->rstd_w = S.rstd_w;
+    V->attn_drop_p = B->attn_drop_p; V->attn_drop_seed = B->attn_drop_seed;
 }
 
 }  // namespace

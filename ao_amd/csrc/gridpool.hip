@@ -347,61 +347,3 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
 }
 
 
-// ------------------------------------------------------------ inverse neighbour table --
-// For every point j the slots r = n*k + s with idx[r] == j, ascending r (CSR: inv_ptr (n+1), inv_rows (n*k)).
-// Stable radix sort of (idx + 1, r) over just the bits of n, then one binary search per point.  Used by the
-// fused-attention backward to turn scatter-adds into fixed-order gathers (gva_bwd.hip / gva_aggregate.hip).
-namespace {
-__global__ __launch_bounds__(TPB) void inv_keys_kernel(long long rows, const int *__restrict__ idx,
-                                                       unsigned *__restrict__ keys, int *__restrict__ vals) {
-    const long long r = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (r >= rows) return;
-    keys[r] = (unsigned)(idx[r] + 1);  // -1 placeholders sort first (key 0)
-    vals[r] = (int)r;
-}
-
-__global__ __launch_bounds__(TPB) void inv_ptr_kernel(int n, long long rows, const unsigned *__restrict__ sorted_keys,
-                                                      int *__restrict__ inv_ptr) {
-    const int j = blockIdx.x * TPB + threadIdx.x;
-    if (j > n) return;
-    const unsigned target = (unsigned)j + 1u;  // first position whose key >= j + 1
-    long long lo = 0, hi = rows;
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (sorted_keys[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    inv_ptr[j] = (int)lo;
-}
-}  // namespace
-
-extern "C" size_t inverse_table_hip_workspace_bytes(int n, int k) {
-    if (n < 1 || k < 1) return 0;
-    const size_t rows = (size_t)n * k;
-    size_t s1 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, s1, (const unsigned *)nullptr, (unsigned *)nullptr, (const int *)nullptr,
-                                             (int *)nullptr, (int)rows, 0, 32, (hipStream_t)0);
-    return al(sizeof(unsigned) * rows) * 2 + al(sizeof(int) * rows) + al(s1 + 256) + 1024;
-}
-
-extern "C" int inverse_table_hip_launcher(int n, int k, const int *idx, int *inv_ptr, int *inv_rows, void *workspace,
-                                          size_t workspace_bytes, void *stream) {
-    if (n < 1 || k < 1) return PTV2_ERR_ARG;
-    if (!workspace || workspace_bytes < inverse_table_hip_workspace_bytes(n, k)) return PTV2_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const long long rows = (long long)n * k;
-    char *p = (char *)workspace;
-    unsigned *keys_in = (unsigned *)p;  p += al(sizeof(unsigned) * rows);
-    unsigned *keys_out = (unsigned *)p; p += al(sizeof(unsigned) * rows);
-    int *vals_in = (int *)p;            p += al(sizeof(int) * rows);
-    void *cub = p;
-    size_t cb = workspace_bytes - (size_t)(p - (char *)workspace);
-    hipLaunchKernelGGL(inv_keys_kernel, dim3(divup(rows, TPB)), dim3(TPB), 0, st, rows, idx, keys_in, vals_in);
-    int bits = 1;
-    while ((1ll << bits) <= (long long)n + 1 && bits < 32) ++bits;  // keys are in [0, n]
-    if (hipcub::DeviceRadixSort::SortPairs(cub, cb, (const unsigned *)keys_in, keys_out, (const int *)vals_in, inv_rows,
-                                           (int)rows, 0, bits, st) != hipSuccess)
-        return PTV2_ERR_LAUNCH;
-    hipLaunchKernelGGL(inv_ptr_kernel, dim3(divup(n + 1, TPB)), dim3(TPB), 0, st, n, rows, (const unsigned *)keys_out, inv_ptr);
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}

@@ -86,12 +86,12 @@ __device__ __forceinline__ void logits_softmax(const float (&y)[G], const float 
 }
 
 // =================================================================== forward ==
-template <int G>
+template <int G, bool DROP>
 __global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k, const float *__restrict__ W1,
                                                            const float *__restrict__ sc, const float *__restrict__ sh,
                                                            const float *__restrict__ Ww2,
                                                            const float *__restrict__ bw2, const int *__restrict__ idx,
-                                                           float *__restrict__ w, float *__restrict__ sw) {
+                                                           float *__restrict__ w, float *__restrict__ sw, PtvDrop drop) {
     // wave-uniform operands from LDS (broadcast reads) instead of scalar loads: the G x G matrix does not fit the
     // scalar cache for G >= 24 and its miss latency dominated the deep-stage launches
     __shared__ float sWw2[G * G], sBw2[G], sSc[G], sSh[G];
@@ -110,6 +110,10 @@ __global__ __launch_bounds__(TPB) void softmax_rows_kernel(long long rows, int k
         const float valid = (act && idx[r] >= 0) ? 1.f : 0.f;
 #pragma unroll
         for (int g = 0; g < G; ++g) wt[g] *= valid;
+        if (DROP) {  // attention dropout on the softmax output (a template parameter: no registers for it when off)
+#pragma unroll
+            for (int g = 0; g < G; ++g) wt[g] *= ptv2_drop_factor(drop, (unsigned long long)r * G + g);
+        }
         if (act) store_row<G>(w + r * G, wt);
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -516,11 +520,11 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                          const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
-                         hipStream_t st, const float *Wp2, const float *bp2);
+                         hipStream_t st, const float *Wp2, const float *bp2, PtvDrop drop);
 int gva_bwd_point_local(int k, int c, int g);
 
 int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
-                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st);
+                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st, PtvDrop drop);
 
 static size_t agg_part_bytes(int c, int g) {
     return align_up(sizeof(float) * std::max({(size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g,
@@ -546,11 +550,17 @@ extern "C" int gva_aggregate_forward_hip_launcher(int n, int k, int c, int g, co
     {
         PtvScopedTimer t(KID_SOFTMAX_ROWS, st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * g));
         if (k <= 16 && (g == 12 || g == 24 || g == 48 || g == 64) && !getenv("AO_AMD_BWD_STAGED")) {  // g = 6: rows
-            const int rc = gva_softmax_point_launch(n, k, g, W1, sc, sh, Ww2, bw2, idx, w, sw, st);
+            const int rc = gva_softmax_point_launch(n, k, g, W1, sc, sh, Ww2, bw2, idx, w, sw, st, ptv2_attn_drop_current());
             if (rc != PTV2_OK) return rc;
         } else {
-#define CALL(GG) \
-    hipLaunchKernelGGL(softmax_rows_kernel<GG>, dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, w, sw)
+            const PtvDrop drop = ptv2_attn_drop_current();
+#define CALL(GG)                                                                                                                  \
+    if (drop.thresh)                                                                                                              \
+        hipLaunchKernelGGL((softmax_rows_kernel<GG, true>), dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, w, \
+                           sw, drop);                                                                                             \
+    else                                                                                                                          \
+        hipLaunchKernelGGL((softmax_rows_kernel<GG, false>), dim3(nb_rows), dim3(TPB), 0, st, rows, k, W1, sc, sh, Ww2, bw2, idx, \
+                           w, sw, drop)
             GVA_DISPATCH_G(g, CALL)
 #undef CALL
         }
@@ -594,7 +604,7 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
             const PtvDeferScope defer;  // its record sums ride on the gv launch below (which needs none of them)
             const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
                                                 gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st, g_fused_Wp2,
-                                                g_fused_bp2);
+                                                g_fused_bp2, ptv2_attn_drop_current());
             if (rc != PTV2_OK) return rc;
         }
         {
@@ -604,6 +614,7 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
+    if (ptv2_attn_drop_current().thresh) return PTV2_ERR_ARG;  // attention dropout: the fused point kernel only
     float *gw = (float *)(base + part_bytes);
     float *gz = (float *)(base + part_bytes + rows_bytes);
     float *yb = (float *)(base + part_bytes + 2 * rows_bytes);

@@ -452,6 +452,8 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
     if (!B) return PTV2_ERR_ARG;
     const int n = B->n, k = B->k, c = B->c, g = B->g;
     if (n < 0 || k < 1 || c < 4 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
+    if (B->attn_drop_p < 0.f || B->attn_drop_p > 1.f) return PTV2_ERR_ARG;
+    const gva::PtvAttnDropScope attn_drop(B->training ? B->attn_drop_p : 0.f, B->attn_drop_seed);
     if (n == 0) return PTV2_OK;
     BlockWs W = carve(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
@@ -485,6 +487,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     const int n = B->n, k = B->k, c = B->c, g = B->g;
     if (n < 0 || k < 1 || c < 4 || g < 1 || c % g != 0) return PTV2_ERR_ARG;
     if (n == 0) return PTV2_OK;
+    const gva::PtvAttnDropScope attn_drop(B->training ? B->attn_drop_p : 0.f, B->attn_drop_seed);
     BlockWs W = carve(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     if (g_fold_scratch) {  // the glue's operands in the caller's per-Block region: they outlive this call

@@ -69,14 +69,16 @@ struct BwdPointCfg {
 };
 
 // part[blockIdx.x][PF]: [4C] (ga.xyz, gb) per channel, [G] gsc, [G] gsh, [G*G] gWw2, [G] gbw2
-template <int G, int C, int NW, bool LOCAL>
+// DROP (attention dropout) is a template parameter: as a run-time branch the factor's registers cost every instance 18-24
+// VGPRs (the (24, 192) one went to 256 + scratch) and 8 % of its time with dropout OFF
+template <int G, int C, int NW, bool LOCAL, bool DROP>
 __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bwd_point_kernel(
     int n, int k, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
     const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
     const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ g_A,
     const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ part, const float *__restrict__ Wp2,
-    const float *__restrict__ bp2) {
+    const float *__restrict__ bp2, PtvDrop drop) {
     using K = BwdPointCfg<G, C, NW>;
     // Wp2 != NULL (narrow instances, one wavefront per point): g_A (g,ch) = sum_i g_out[gI+i] Wp2[gI+i,ch] and
     // g_sw = <g_out, bp2>_group -- the backward of the grouped projection -- are formed per point in LDS instead of
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 const float den = row16_sum(e);
                 sm[tg][r] = e * __builtin_amdgcn_rcpf(den);
                 wm[tg][r] = valid ? sm[tg][r] : 0.f;
+                if (DROP) wm[tg][r] *= ptv2_drop_factor(drop, (unsigned long long)row * G + (16 * tg + 4 * q + r));
             }
         }
         // ---- gw^T (g,s) partial over my channels: g_A P^T + Gm v[idx]^T
@@ -479,7 +482,9 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             const float gs[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gm = valid ? gw[tg][r] + gs[r] : 0.f;
+                float gm = valid ? gw[tg][r] + gs[r] : 0.f;
+                // (attention dropout: the weight that reached the aggregation was sm * D, so d loss / d sm = D * d loss / d w)
+                if (DROP) gm *= ptv2_drop_factor(drop, (unsigned long long)row * G + (16 * tg + 4 * q + r));
                 const float dot = row16_sum(sm[tg][r] * gm);
                 gz[tg][r] = rowok ? sm[tg][r] * (gm - dot) : 0.f;
             }
@@ -616,14 +621,14 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 // runs on the matrix cores (z^T = Ww2 y^T, slots as the 16 MFMA columns), the softmax over the 16 slots is a DPP
 // row reduction.  Replaces the per-thread G x G loop of softmax_rows_kernel, which took 100-430 us at the deep
 // stages (G = 24, 48) for 2-8 k points.
-template <int G>
+template <int G, bool DROP>
 __global__ __launch_bounds__(256) void attention_softmax_point_kernel(int n, int k, const float *__restrict__ W1,
                                                                       const float *__restrict__ sc,
                                                                       const float *__restrict__ sh,
                                                                       const float *__restrict__ Ww2,
                                                                       const float *__restrict__ bw2,
                                                                       const int *__restrict__ idx, float *__restrict__ w,
-                                                                      float *__restrict__ sw) {
+                                                                      float *__restrict__ sw, PtvDrop drop) {
     constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = ww_pitch(G);
     __shared__ __attribute__((aligned(16))) float sWw[G16 * GPW];
     __shared__ __attribute__((aligned(16))) float sBw[G16], sSc[G16], sSh[G16];
@@ -701,6 +706,7 @@ __global__ __launch_bounds__(256) void attention_softmax_point_kernel(int n, int
                 const float e = rowok ? expf(zz - mx) : 0.f;
                 const float den = row16_sum(e);
                 o[r] = valid ? e / den : 0.f;
+                if (DROP) o[r] *= ptv2_drop_factor(drop, ((unsigned long long)pt * k + l15) * G + (16 * tg + 4 * q + r));
                 so[r] = row16_sum(o[r]);
             }
             const int g0 = 16 * tg + 4 * q;
@@ -989,7 +995,7 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
                      const float *v, const float *a, const float *b, const float *coord, const int *idx, const float *g_out,
                      const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2,
                      float *ga, float *gb, float *part, size_t part_floats_avail, hipStream_t st, const float *Wp2,
-                     const float *bp2) {
+                     const float *bp2, PtvDrop drop) {
     using K = BwdPointCfg<G, C, NW>;
     constexpr bool HAS_LOCAL = G == 6 && C == 48 && NW == 1;  // the one instance where it pays (gva_bwd_point_local)
     const bool local = Wp2 != nullptr;
@@ -999,8 +1005,11 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
     // its weights once and then walks its points; any grid that is not co-resident runs a second, partly empty round
     // (measured at 120 k points, (6,48): 340 us at 512 workgroups, 406 at 1280, 468 at 640; (24,192) at 4.5 k
     // points: 92 / 116 / 111 us)
-    auto kern = (HAS_LOCAL && local) ? attention_bwd_point_kernel<G, C, NW, HAS_LOCAL> : attention_bwd_point_kernel<G, C, NW, false>;
-    static int resident[2] = {0, 0};
+    const bool dropping = drop.thresh != 0;
+    auto kern = (HAS_LOCAL && local) ? (dropping ? attention_bwd_point_kernel<G, C, NW, HAS_LOCAL, true> : attention_bwd_point_kernel<G, C, NW, HAS_LOCAL, false>)
+                                     : (dropping ? attention_bwd_point_kernel<G, C, NW, false, true> : attention_bwd_point_kernel<G, C, NW, false, false>);
+    static int resident_of[2][2] = {{0, 0}, {0, 0}};
+    int *resident = resident_of[dropping];
     if (!resident[local]) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int occ = 0, dev = 0, cus = 0;
@@ -1013,7 +1022,7 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
     const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
     if ((size_t)nblk * K::PF > part_floats_avail) return PTV2_ERR_WORKSPACE;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw,
-                       gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr);
+                       gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr, drop);
     launch_finalize(st, (const float *)part, nblk, K::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
     return PTV2_OK;
 }
@@ -1062,15 +1071,19 @@ int gva_logits_point_launch(int n, int k, int c, int g, const float *kW, const f
 
 // forward softmax stage on the matrix cores (k <= 16; g one of the instantiated group counts)
 int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
-                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st) {
+                             const float *bw2, const int *idx, float *w, float *sw, hipStream_t st, gva::PtvDrop drop) {
     using namespace gva;
     if (k < 1 || k > 16) return PTV2_ERR_ARG;
     const int nblk = (int)std::max<long long>(1, std::min<long long>(((long long)n + 3) / 4, 256 * 8));
     switch (g) {
 #define CASE(GG)                                                                                                          \
     case GG:                                                                                                              \
-        hipLaunchKernelGGL(attention_softmax_point_kernel<GG>, dim3(nblk), dim3(256), 0, st, n, k, W1, sc, sh, Ww2, bw2, idx, w, \
-                           sw);                                                                                           \
+        if (drop.thresh)                                                                                                  \
+            hipLaunchKernelGGL((attention_softmax_point_kernel<GG, true>), dim3(nblk), dim3(256), 0, st, n, k, W1, sc, sh, Ww2,  \
+                               bw2, idx, w, sw, drop);                                                                    \
+        else                                                                                                              \
+            hipLaunchKernelGGL((attention_softmax_point_kernel<GG, false>), dim3(nblk), dim3(256), 0, st, n, k, W1, sc, sh, Ww2, \
+                               bw2, idx, w, sw, drop);                                                                    \
         break;
         CASE(6) CASE(12) CASE(24) CASE(48) CASE(64)
 #undef CASE
@@ -1100,10 +1113,10 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                          const float *g_out, const float *g_A, const float *g_sw, float *gW1, float *gsc, float *gsh,
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
-                         hipStream_t st, const float *Wp2, const float *bp2) {
+                         hipStream_t st, const float *Wp2, const float *bp2, gva::PtvDrop drop) {
     using namespace gva;
     if (!g_A && !(Wp2 && bp2 && gva_bwd_point_local(k, c, g))) return PTV2_ERR_ARG;
-#define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st, Wp2, bp2
+#define ARGS n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, st, Wp2, bp2, drop
     if (g == 6 && c == 48) return launch_bwd_point<6, 48, 1>(ARGS);
     if (g == 12 && c == 96) return launch_bwd_point<12, 96, 1>(ARGS);
     if (g == 24 && c == 192) return launch_bwd_point<24, 192, 2>(ARGS);

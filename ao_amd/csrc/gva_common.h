@@ -208,6 +208,31 @@ struct PtvDeferScope {
     ~PtvDeferScope() { ptv2_rider_defer_depth(-1); }
 };
 
+// ---- attention dropout (GroupedVectorAttention.attn_drop, point_transformer_v2m2_base.py:101,122) inside the fused kernels.
+// nn.Dropout(p) on the softmax output multiplies every (point, slot, group) weight by Bernoulli(1 - p) / (1 - p).  The mask
+// is never stored: element e = (point * k + slot) * G + group of a Block's call gets the factor drop_factor(seed, e) -- a
+// 32-bit integer hash against a threshold -- which the forward softmax kernels and the backward point kernel evaluate
+// again (ao_amd/ptv2/gva.py::attn_drop_mask is the same function in torch, for the parity tests and the unfused path).
+// thresh == 0: no dropout (factor 1).
+struct PtvDrop { float scale; unsigned thresh, seed; };
+__device__ __forceinline__ float ptv2_drop_factor(const PtvDrop d, unsigned long long e) {
+    unsigned h = (unsigned)e ^ ((unsigned)(e >> 32) * 0x27D4EB2Fu);
+    h = h * 0x9E3779B1u + d.seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h >= d.thresh ? d.scale : 0.f;
+}
+// host side (abi.hip; per host thread): the setting of the gva_block call in progress, read by the launchers of the
+// softmax stage (forward) and of the point kernel (backward)
+PtvDrop ptv2_attn_drop_current();
+void ptv2_attn_drop_set(float p, unsigned seed);
+struct PtvAttnDropScope {
+    PtvDrop prev;
+    PtvAttnDropScope(float p, unsigned seed) : prev(ptv2_attn_drop_current()) { ptv2_attn_drop_set(p, seed); }
+    ~PtvAttnDropScope();
+};
+
 // few records, many columns (split-K weight gradients at the deep levels: 5-9 chunk records of 10^5 - 10^6 outputs):
 // one thread per column walks the records -- the sliced form above would launch 16 threads per column of which at most
 // nblk load anything (11 550 workgroups of 1 024 threads for 737 k columns: 24 us; this form: 2 880 of 256)

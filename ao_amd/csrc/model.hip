@@ -344,6 +344,7 @@ void fill_block(const ptv2_model *M, int q, int j, const Arena &A, const float *
     }
     B->y = A.block_y[b]; B->saved = A.block_saved[b]; B->saved_bytes = A.block_saved_bytes[b];
     B->matmul_bf16 = M->matmul_bf16;
+    B->attn_drop_p = M->training ? mb.attn_drop_p : 0.f; B->attn_drop_seed = mb.attn_drop_seed;
 }
 
 // input of block j of sequence q = output of block j-1, or the sequence's input
@@ -371,10 +372,13 @@ float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_i
         fill_block(M, q, j, A, x, &B);
         if (M->checkpoint) {
             // re-run this Block's forward into the shared region (same kernels, same inputs -> the same activations bit for
-            // bit); the running statistics were updated by the real forward and must not move again
+            // bit).  The reference checkpoints `self.attn` only (point_transformer_v2m2_base.py:169-171), and torch's
+            // recomputation runs its BatchNorm layers in training mode again: the running statistics of the four norms INSIDE
+            // the attention (q, k, positional bias, weight encoding: 1..4) take the momentum step a second time and their
+            // batch counters advance by two per step; norm1 / norm2 / norm3 (0, 5, 6) are outside and move once.
             ptv2_block R = B;
             for (int i = 0; i < PTV2_BLK_NBN; ++i)
-                if (M->training) { R.run_mean[i] = nullptr; R.run_var[i] = nullptr; R.batches[i] = nullptr; }
+                if (M->training && !(i >= 1 && i <= 4)) { R.run_mean[i] = nullptr; R.run_var[i] = nullptr; R.batches[i] = nullptr; }
             *rc = ptv2_block_forward_hip_launcher(&R, W.block, W.block_bytes, stream);
             if (*rc != PTV2_OK) return nullptr;
         }

@@ -37,7 +37,8 @@ class _Blk(ctypes.Structure):  # mirrors ptv2_block
                 + [("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
                 + [(n_, _P) for n_ in ("x", "coord", "idx", "mu", "cov", "rowscale")]
                 + [("param", _P * NPARAM), ("run_mean", _P * NBN), ("run_var", _P * NBN), ("batches", _P * NBN),
-                   ("y", _P), ("saved", _P), ("saved_bytes", ctypes.c_size_t), ("matmul_bf16", ctypes.c_int)])
+                   ("y", _P), ("saved", _P), ("saved_bytes", ctypes.c_size_t), ("matmul_bf16", ctypes.c_int),
+                   ("attn_drop_p", ctypes.c_float), ("attn_drop_seed", ctypes.c_uint)])
 
 
 class _BlkGrads(ctypes.Structure):  # mirrors ptv2_block_grads
@@ -173,14 +174,17 @@ def supported(blk, feat, idx):
             and feat.shape[0] >= 2):
         return False
     p = plan(blk)
-    if not p.static_ok or (blk.attn.attn_drop_rate != 0.0 and blk.training) or (not blk.training and not p.has_running):
+    if not p.static_ok or (not blk.training and not p.has_running):
+        return False
+    if blk.attn.attn_drop_rate != 0.0 and blk.training and not _gva.dropout_supported(p.c, p.g, idx.shape[1]):
         return False
     return _gva.supported(p.c, p.g, idx.shape[1])
 
 
-def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16=False):
+def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16=False, drop=(0.0, 0)):
     args = p.args
     args.matmul_bf16 = int(bf16)
+    args.attn_drop_p, args.attn_drop_seed = float(drop[0]), int(drop[1])
     args.n, args.k = idx.shape
     args.training = int(training)
     args.x, args.coord, args.idx = x.data_ptr(), coord.data_ptr(), idx.data_ptr()
@@ -191,19 +195,19 @@ def _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16=False):
 
 class _NativeBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, coord, idx, mu, cov, inv, rowscale, training, bf16, *params):
+    def forward(ctx, x, p, coord, idx, mu, cov, inv, rowscale, training, bf16, drop, *params):
         x = x.contiguous()
         n, k = idx.shape
         dev = x.device
         L = _lib.lib()
         y = torch.empty((n, p.c), dtype=torch.float32, device=dev)
         saved = torch.empty(L.ptv2_block_saved_bytes(n, k, p.c, p.g), dtype=torch.uint8, device=dev)
-        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16)
+        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, training, bf16, drop)
         ws = _lib.workspace(L.ptv2_block_workspace_bytes(n, k, p.c, p.g), dev)
         rc = L.ptv2_block_forward_hip_launcher(ctypes.addressof(args), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "ptv2_block_forward_hip_launcher")
         ctx.save_for_backward(x, coord, idx, mu, cov, rowscale, y, saved)
-        ctx.plan, ctx.inv, ctx.training, ctx.bf16 = p, inv, training, bf16
+        ctx.plan, ctx.inv, ctx.training, ctx.bf16, ctx.drop = p, inv, training, bf16, drop
         return y
 
     @staticmethod
@@ -214,7 +218,7 @@ class _NativeBlock(torch.autograd.Function):
         dev = x.device
         L = _lib.lib()
         gy = gy.contiguous()
-        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, ctx.training, ctx.bf16)
+        args = _fill(p, x, coord, idx, mu, cov, rowscale, y, saved, ctx.training, ctx.bf16, ctx.drop)  # (the forward's mask again)
         gx = torch.empty_like(x)
         gflat = torch.empty(p.off[NPARAM], dtype=torch.float32, device=dev)
         inv_ptr, inv_rows = ctx.inv if ctx.inv is not None else _gva.inverse_table(idx)
@@ -233,7 +237,7 @@ class _NativeBlock(torch.autograd.Function):
             if slot != prm.numel():
                 chunk = chunk[:prm.numel()]
             gp.append(chunk if prm.dim() == 1 else chunk.view(prm.shape))
-        return (gx, None, None, None, None, None, None, None, None, None, *gp)
+        return (gx, None, None, None, None, None, None, None, None, None, None, *gp)
 
 
 def block_forward(blk, feat, coord, idx, rowscale):
@@ -249,5 +253,7 @@ def block_forward(blk, feat, coord, idx, rowscale):
     from .native_model import matmul_bf16
 
     bf16 = matmul_bf16()
+    rate = blk.attn.attn_drop_rate
+    drop = (rate, _gva.next_drop_seed()) if (blk.training and rate > 0.0) else (0.0, 0)
     with torch.autocast("cuda", enabled=False):
-        return _NativeBlock.apply(feat.float(), p, coord, idx, mu, cov, inv, rowscale, training, bf16, *p.params)
+        return _NativeBlock.apply(feat.float(), p, coord, idx, mu, cov, inv, rowscale, training, bf16, drop, *p.params)

@@ -32,16 +32,18 @@ class Level:
     up_weight: Optional[torch.Tensor] = None  # (N,3) fp32
 
 
-    def neighbours(self, k):
+    def neighbours(self, k, inverse=True):
         """Self k-NN table of this level; one kNN launch per distinct K, shared by every BlockSequence
-        that works at this resolution (encoder and decoder)."""
+        that works at this resolution (encoder and decoder).  inverse=False: the caller builds the inverse tables of all
+        its levels in one call afterwards (gva.inverse_tables)."""
         if k not in self.knn:
             with torch.no_grad():
                 idx = knn_query_dist2(k, self.coord, self.offset)[0]  # (the table only: no sqrt of the distances)
                 # table-only quantities the fused attention needs (their host syncs belong to the geometry phase)
                 from . import gva
                 if gva.supported(8 * 6, 6, k):
-                    gva.inverse_table(idx)
+                    if inverse:
+                        gva.inverse_table(idx)
                     gva._pos_moments(gva._HipImpl, self.coord, idx)
                 self.knn[k] = idx
         return self.knn[k]
@@ -143,7 +145,7 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
     cur = Level(coord=coord, offset=offset)
     for i, ks in enumerate(neighbours):
         for k in ks:
-            cur.neighbours(k)
+            cur.neighbours(k, inverse=False)
         geo.levels.append(cur)
         if i == len(grid_sizes):
             break
@@ -151,7 +153,12 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
         cur.cluster, cur.order32, cur.idx_ptr32 = cluster, order, idx_ptr
         if interp:
             cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
-            from . import gva
-            gva.inverse_table(cur.up_idx)  # lets the unpool backward gather instead of scatter with float atomics
         cur = Level(coord=nc, offset=noff)
+    # inverse tables of every neighbour / interpolation table of the scene in one call (five launches: csrc/inverse.hip);
+    # they let the backward gather in a fixed order instead of scattering with float atomics
+    from . import gva
+    tables = [lv.up_idx for lv in geo.levels if lv.up_idx is not None]
+    tables += [idx for lv in geo.levels for k, idx in lv.knn.items() if gva.supported(8 * 6, 6, k)]
+    with torch.no_grad():
+        gva.inverse_tables(tables)
     return geo

@@ -114,13 +114,56 @@ def _f32c(t):
     return t.detach().float().contiguous()
 
 
+class _InverseJob(ctypes.Structure):  # mirrors ptv2_inverse_job (include/ptv2_hip.h)
+    _fields_ = [("n", ctypes.c_int), ("k", ctypes.c_int), ("idx", ctypes.c_void_p), ("inv_ptr", ctypes.c_void_p),
+                ("inv_rows", ctypes.c_void_p)]
+
+
+INVERSE_MAX_JOBS = 16  # PTV2_INVERSE_MAX_JOBS
+
+
+def _cached_inverse(idx):
+    cached = getattr(idx, "_ao_inverse", None)
+    if cached is not None and cached[0] == idx._version:
+        return cached[1], cached[2]
+    return None
+
+
+def inverse_tables(tables):
+    """inverse_table() of several tables of one device in ONE native call (five launches whatever the number of tables:
+    ao_amd/csrc/inverse.hip); results are cached on the tables, tables with a valid cache are skipped."""
+    todo = [t for t in tables if t is not None and t.is_cuda and _cached_inverse(t) is None]
+    todo = list({id(t): t for t in todo}.values())
+    L = _lib.lib()
+    for at in range(0, len(todo), INVERSE_MAX_JOBS):
+        part = todo[at:at + INVERSE_MAX_JOBS]
+        jobs = (_InverseJob * len(part))()
+        outs = []
+        for job, idx in zip(jobs, part):
+            assert idx.dtype == torch.int32 and idx.is_contiguous() and idx.dim() == 2
+            n, k = idx.shape
+            inv_ptr = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
+            inv_rows = torch.empty(n * k, dtype=torch.int32, device=idx.device)
+            job.n, job.k, job.idx, job.inv_ptr, job.inv_rows = n, k, idx.data_ptr(), inv_ptr.data_ptr(), inv_rows.data_ptr()
+            outs.append((inv_ptr, inv_rows))
+        ws = _lib.workspace(L.inverse_tables_hip_workspace_bytes(len(part), ctypes.addressof(jobs)), part[0].device)
+        rc = L.inverse_tables_hip_launcher(len(part), ctypes.addressof(jobs), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "inverse_tables_hip_launcher")
+        for idx, (inv_ptr, inv_rows) in zip(part, outs):
+            try:
+                idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
+            except AttributeError:
+                pass
+    return [inverse_table(t) if t is not None else None for t in tables]
+
+
 def inverse_table(idx):
     """CSR inverse of the neighbour table: for every point j the slots r = n*K + s with idx[r] == j, in
     ascending r (inv_ptr (N+1,) int32, inv_rows int32).  Depends on the table only -> cached on it; the
     backward kernels use it to turn scatter-adds into fixed-order gathers (no float atomics)."""
-    cached = getattr(idx, "_ao_inverse", None)
-    if cached is not None and cached[0] == idx._version:
-        return cached[1], cached[2]
+    cached = _cached_inverse(idx)
+    if cached is not None:
+        return cached
     n, k = idx.shape
     if idx.is_cuda:
         inv_ptr = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
@@ -257,6 +300,13 @@ def supported(channels, groups, k):
     i = channels // groups
     return (groups in (6, 12, 24, 48, 64) and channels % groups == 0 and i in (2, 4, 8) and channels % 4 == 0
             and k & (k - 1) == 0 and 2 <= k <= 64)
+
+
+def dropout_supported(channels, groups, k):
+    """Shapes for which attention dropout runs inside the fused kernels: the forward softmax kernels take it everywhere,
+    the backward needs the fused point kernel (ao_amd/csrc/gva_bwd_point.hip: the five (G, C) instances, k <= 16)."""
+    return ((groups, channels) in ((6, 48), (12, 96), (24, 192), (48, 384), (64, 512)) and k & (k - 1) == 0 and 2 <= k <= 16
+            and not os.environ.get("AO_AMD_BWD_STAGED"))
 
 
 def _track(bn, training):
@@ -399,7 +449,8 @@ class _BlockArgs(ctypes.Structure):  # mirrors ptv2_gva_block (include/ptv2_hip.
                     "Wp1", "bp1", "gamma_p", "beta_p", "Wp2", "bp2", "Ww1", "bw1", "gamma_w", "beta_w", "Ww2", "bw2",
                     "run_mean_p", "run_var_p", "run_mean_w", "run_var_w", "batches_p", "batches_w",
                     "out", "a", "b", "rstd_p", "M", "cW", "kW", "qW", "W1", "w", "A", "sw", "sc", "sh",
-                    "mean_w", "rstd_w", "q_sc", "q_sh", "k_sc", "k_sh")])
+                    "mean_w", "rstd_w", "q_sc", "q_sh", "k_sc", "k_sh")]
+                + [("attn_drop_p", ctypes.c_float), ("attn_drop_seed", ctypes.c_uint)])
 
 
 class _BlockGrads(ctypes.Structure):  # mirrors ptv2_gva_block_grads
@@ -420,7 +471,7 @@ class _GvaBlock(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, q, key, v, coord, idx, mu, cov, bn_p, bn_w, training, *params):
+    def forward(ctx, q, key, v, coord, idx, mu, cov, bn_p, bn_w, training, drop, *params):
         q, key, v = (_f32c(t) for t in (q, key, v))
         params = [p.contiguous() for p in params]
         n, k = idx.shape
@@ -451,6 +502,8 @@ class _GvaBlock(torch.autograd.Function):
             setattr(args, "batches_" + tag, bn.num_batches_tracked.data_ptr() if trk else 0)
         for name, t in sv.items():
             setattr(args, name, t.data_ptr())
+        args.attn_drop_p, args.attn_drop_seed = (float(drop[0]), int(drop[1])) if (drop and training) else (0.0, 0)
+        ctx.drop = (args.attn_drop_p, args.attn_drop_seed)
         L = _lib.lib()
         ws = _lib.workspace(L.gva_block_workspace_bytes(n, k, c, g), dev)
         rc = L.gva_block_forward_hip_launcher(ctypes.addressof(args), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
@@ -484,6 +537,7 @@ class _GvaBlock(torch.autograd.Function):
         args.run_mean_w = bn_w.running_mean.data_ptr() if bn_w.running_mean is not None else 0
         for name, t in sv.items():
             setattr(args, name, t.data_ptr())
+        args.attn_drop_p, args.attn_drop_seed = ctx.drop  # the forward's mask again
         grads = _BlockGrads()
         gq, gk = torch.empty_like(q), torch.empty_like(key)
         gv = torch.empty_like(v) if inv_ptr is not None else torch.zeros_like(v)
@@ -498,7 +552,7 @@ class _GvaBlock(torch.autograd.Function):
         rc = L.gva_block_backward_hip_launcher(ctypes.addressof(args), ctypes.addressof(grads), ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr())
         _lib.check(rc, "gva_block_backward_hip_launcher")
-        return (gq, gk, gv, None, None, None, None, None, None, None, *gp)
+        return (gq, gk, gv, None, None, None, None, None, None, None, None, *gp)
 
 
 def _block_call(mod, query, key, value, coord, idx):
@@ -508,9 +562,43 @@ def _block_call(mod, query, key, value, coord, idx):
     mu = cov = None
     if training:
         mu, cov = _pos_moments(_HipImpl, coord, idx)
-    return _GvaBlock.apply(query, key, value, coord, idx, mu, cov, bn_p, bn_w, training,
+    drop = (mod.attn_drop_rate, next_drop_seed()) if (mod.training and mod.attn_drop_rate > 0.0) else None
+    return _GvaBlock.apply(query, key, value, coord, idx, mu, cov, bn_p, bn_w, training, drop,
                            lin_p1.weight, lin_p1.bias, bn_p.weight, bn_p.bias, lin_p2.weight, lin_p2.bias,
                            lin_w1.weight, lin_w1.bias, bn_w.weight, bn_w.bias, lin_w2.weight, lin_w2.bias)
+
+
+# ---------------------------------------------------------------- attention dropout --
+_M32 = 0xFFFFFFFF
+
+
+def next_drop_seed():
+    """A fresh 32-bit seed for one Block's attention-dropout mask of one step, drawn on the HOST from torch's CPU generator
+    (reproducible under torch.manual_seed, no device synchronisation)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+def attn_drop_mask(seed, n, k, g, p, device):
+    """The dropout factor of every softmax weight, (n, k, g) fp32: 0 or 1 / (1 - p) -- the torch statement of
+    ptv2_drop_factor (ao_amd/csrc/gva_common.h), which the fused kernels evaluate in the forward and again in the backward
+    instead of storing a mask.  Element e = (point * k + slot) * g + group; a 32-bit integer hash of (e, seed) against
+    p * 2^32.  nn.Dropout(p) in the reference (point_transformer_v2m2_base.py:101,122) is the same distribution from
+    another generator."""
+    if not p > 0.0:
+        return torch.ones((n, k, g), dtype=torch.float32, device=device)
+    pp = min(float(p), 1.0)
+    thresh = min(int(pp * 4294967296.0), _M32)
+    thresh = max(thresh, 1)
+    scale = 1.0 / (1.0 - pp) if pp < 1.0 else 0.0
+    e = torch.arange(n * k * g, dtype=torch.int64, device=device)
+    h = (e & _M32) ^ (((e >> 32) * 0x27D4EB2F) & _M32)
+    h = (h * 0x9E3779B1 + int(seed)) & _M32
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & _M32
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & _M32
+    h = h ^ (h >> 16)
+    return ((h >= thresh).to(torch.float32) * scale).view(n, k, g)
 
 
 # -------------------------------------------------------------------- host logic --

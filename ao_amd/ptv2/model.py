@@ -102,7 +102,15 @@ class GroupedVectorAttention(nn.Module):
             relation_qk = relation_qk + peb
             value = value + peb
         weight = self.weight_encoding(relation_qk)
-        weight = self.attn_drop(self.softmax(weight))
+        weight = self.softmax(weight)
+        seed = self.__dict__.get("_ao_drop_seed")  # (tests: the fused kernels' mask instead of nn.Dropout's generator)
+        if seed is not None and self.training and self.attn_drop_rate > 0.0:
+            from . import gva
+
+            weight = weight * gva.attn_drop_mask(seed, weight.shape[0], weight.shape[1], weight.shape[2], self.attn_drop_rate,
+                                                 weight.device)
+        else:
+            weight = self.attn_drop(weight)
         mask = torch.sign(reference_index + 1).to(weight.dtype)
         weight = weight * mask.unsqueeze(-1)
         n, ns, c = value.shape
@@ -112,11 +120,15 @@ class GroupedVectorAttention(nn.Module):
     def forward(self, feat, coord, reference_index):
         query, key, value = self.linear_q(feat), self.linear_k(feat), self.linear_v(feat)
         mode = os.environ.get("AO_AMD_GVA", "fused")
-        fusable = self.pe_bias and not self.pe_multiplier and (self.attn_drop_rate == 0.0 or not self.training)
+        # attention dropout: inside the fused kernels (mode "fused": one native call per direction); the staged composition
+        # (one autograd node per stage) has no place for the mask and falls back to the literal op sequence
+        dropping = self.attn_drop_rate > 0.0 and self.training
+        fusable = self.pe_bias and not self.pe_multiplier and (not dropping or mode == "fused")
         if mode in ("fused", "staged") and fusable:
             from . import gva
 
-            if gva.supported(self.embed_channels, self.groups, reference_index.shape[1]):
+            if gva.supported(self.embed_channels, self.groups, reference_index.shape[1]) and (
+                    not dropping or gva.dropout_supported(self.embed_channels, self.groups, reference_index.shape[1])):
                 return gva.grouped_vector_attention(self, query, key, value, coord, reference_index)
         return self.gva_unfused(query, key, value, coord, reference_index)
 

@@ -46,7 +46,7 @@ class _Seq(ctypes.Structure):  # mirrors ptv2_seq
 
 class _MBlock(ctypes.Structure):  # mirrors ptv2_model_block
     _fields_ = [("param", _P * NPARAM), ("run_mean", _P * NBN), ("run_var", _P * NBN), ("batches", _P * NBN),
-                ("gparam", _P * NPARAM), ("rowscale", _P)]
+                ("gparam", _P * NPARAM), ("rowscale", _P), ("attn_drop_p", _F), ("attn_drop_seed", ctypes.c_uint)]
 
 
 class _Model(ctypes.Structure):  # mirrors ptv2_model
@@ -170,7 +170,10 @@ class _Runtime:
         self.has_running = b0.running_mean is not None
         self.static_ok = (self.uniform_bn and nb <= MAX_BLOCKS and S <= MAX_STAGES and len(self.grad_fields) == len(self.params)
                           and all(p.dtype == torch.float32 and p.is_cuda and p.is_contiguous() for p in self.params)
-                          and all(_block.plan(blk).static_core and (blk.attn.attn_drop_rate == 0.0) for blk in self.block_modules)
+                          and all(_block.plan(blk).static_core for blk in self.block_modules)
+                          and all(blk.attn.attn_drop_rate == 0.0
+                                  or _gva.dropout_supported(blk.attn.embed_channels, blk.attn.groups, seq.neighbours)
+                                  for seq in self.sequences for blk in seq.blocks)
                           and all(_gva.supported(blk.attn.embed_channels, blk.attn.groups, seq.neighbours)
                                   for seq in self.sequences for blk in seq.blocks)
                           and isinstance(model.seg_head, torch.nn.Sequential) and M.embed.cout % 4 == 0)
@@ -315,6 +318,11 @@ class _NativeModel(torch.autograd.Function):
         M.checkpoint = int(bool(rt.want_checkpoint))  # decided by forward() below (grad mode is off inside this function)
         ctx.checkpoint = M.checkpoint
         scales = rt.draw_droppath(geo, dev) if training else None
+        # attention dropout: one fresh mask seed per Block and step (the backward re-evaluates the mask from it)
+        for mb, blk in zip(M.block[: M.num_blocks], rt.block_modules):
+            rate = blk.attn.attn_drop_rate if training else 0.0
+            mb.attn_drop_p, mb.attn_drop_seed = (float(rate), _gva.next_drop_seed()) if rate > 0.0 else (0.0, 0)
+        ctx.attn_drop = [(mb.attn_drop_p, mb.attn_drop_seed) for mb in M.block[: M.num_blocks]]
         n0 = feat.shape[0]
         logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
         M.feat, M.logits = feat.data_ptr(), logits.data_ptr()
@@ -340,8 +348,9 @@ class _NativeModel(torch.autograd.Function):
         M = rt.M
         rt.fill_geometry(ctx.geo)  # the struct is shared between calls: restore this call's tables
         M.training, M.matmul_bf16, M.checkpoint = int(ctx.training), int(ctx.bf16), int(ctx.checkpoint)
-        for mb, rs in zip(M.block[: M.num_blocks], ctx.rowscale_ptrs):
+        for mb, rs, (dp, ds) in zip(M.block[: M.num_blocks], ctx.rowscale_ptrs, ctx.attn_drop):
             mb.rowscale = rs
+            mb.attn_drop_p, mb.attn_drop_seed = dp, ds
         M.feat, M.logits = feat.data_ptr(), None
         M.logits = g_logits.data_ptr()  # unused by the backward; keeps the struct valid
         M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()

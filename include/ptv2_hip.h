@@ -305,6 +305,11 @@ typedef struct ptv2_gva_block {
     /* optional (all four or none): q / key are the pre-BatchNorm outputs of linear_q[0] / linear_k[0] and the
      * BatchNorm + ReLU is applied as ReLU(x * sc + sh) on the operand load of the consumers (block.hip) */
     const float *q_sc, *q_sh, *k_sc, *k_sh;       /* (c) each */
+    /* attention dropout (attn_drop of the reference, :101,122), training only: every softmax weight (point, slot, group) is
+     * multiplied by Bernoulli(1 - p) / (1 - p); the mask is a counter-based hash of (attn_drop_seed, element index) that
+     * forward and backward kernels evaluate again (never stored).  The backward must be given the forward's seed.  p = 0: off */
+    float attn_drop_p;
+    unsigned attn_drop_seed;
 } ptv2_gva_block;
 
 typedef struct ptv2_gva_block_grads {
@@ -343,6 +348,19 @@ int grid_pool_hip_launcher(int n, int b, const float *coord, const int *offset, 
 size_t inverse_table_hip_workspace_bytes(int n, int k);
 int inverse_table_hip_launcher(int n, int k, const int *idx, int *inv_ptr, int *inv_rows, void *workspace,
                                size_t workspace_bytes, void *stream);
+/*   inverse_tables: the same for up to PTV2_INVERSE_MAX_JOBS tables at once (all neighbour / interpolation tables of a
+ *                  scene) in the same five launches (ao_amd/csrc/inverse.hip: counting sort, no library sort).
+ *                  `jobs` is a HOST array, read during the call. */
+#define PTV2_INVERSE_MAX_JOBS 16
+typedef struct ptv2_inverse_job {
+    int n, k;          /* table (n, k), entries in [-1, n) */
+    const int *idx;
+    int *inv_ptr;      /* (n + 1) */
+    int *inv_rows;     /* (n * k) */
+} ptv2_inverse_job;
+size_t inverse_tables_hip_workspace_bytes(int count, const ptv2_inverse_job *jobs);
+int inverse_tables_hip_launcher(int count, const ptv2_inverse_job *jobs, void *workspace, size_t workspace_bytes,
+                                void *stream);
 size_t segment_minmax_hip_workspace_bytes(int b);
 int segment_minmax_hip_launcher(int b, const float *xyz, const int *offset, float *lo, float *hi,
                                 void *workspace, size_t workspace_bytes, void *stream);
@@ -511,6 +529,8 @@ typedef struct ptv2_block {
     int matmul_bf16;           /* != 0: the Linear products (fc1, fc3, q/k/v and their input / weight gradients) run on the
                                 * bf16 matrix cores: operands rounded to bf16, fp32 accumulation, fp32 in memory -- the
                                 * arithmetic torch.autocast(bfloat16) gives nn.Linear in the reference trainer */
+    float attn_drop_p;         /* attention dropout of this Block's GroupedVectorAttention (see ptv2_gva_block), 0: off */
+    unsigned attn_drop_seed;   /* the same value in the forward and the backward call of a step */
 } ptv2_block;
 typedef struct ptv2_block_grads {
     const float *gy;               /* (n,c) */
@@ -572,6 +592,8 @@ typedef struct ptv2_model_block {
     long long *batches[PTV2_BLK_NBN];
     float *gparam[PTV2_BLK_NPARAM];    /* backward only */
     const float *rowscale;             /* (n) DropPath factors of this block or NULL */
+    float attn_drop_p;                 /* attention dropout of this block (ptv2_gva_block), 0: off */
+    unsigned attn_drop_seed;
 } ptv2_model_block;
 typedef struct ptv2_model {
     int num_stages, in_channels, num_classes, training, interp; /* interp != 0: "interp" unpool, else "map" */

@@ -130,6 +130,51 @@ def test_inverse_table_matches_host_statement():
     assert torch.equal(ptr.cpu(), hptr) and torch.equal(rows.cpu(), hrows)
 
 
+def _host_inverse(idx):
+    from ao_amd.ptv2.gva import inverse_table
+
+    return inverse_table(idx.cpu().clone())
+
+
+def test_inverse_tables_of_a_scene_in_one_call():
+    """gva.inverse_tables: tables of different shapes side by side in one native call (csrc/inverse.hip: counting sort in five
+    launches) -- self tables, interpolation tables (k = 3, targets in a coarser level: most buckets empty), placeholders, a
+    hub that many rows point at (buckets beyond the 16-lane path), single-row and single-column tables, more tables than one
+    call takes, and the bench's size; every list bit-equal to the stable sort of the host statement."""
+    from ao_amd.ptv2 import gva
+
+    g = torch.Generator().manual_seed(12)
+    tables = []
+    for n, k, hi in [(5000, 16, 5000), (5000, 8, 5000), (20000, 3, 4800), (1, 16, 1), (777, 1, 777), (120000, 16, 120000),
+                     (30000, 3, 7000), (257, 16, 257), (4097, 4, 4097)]:
+        idx = torch.randint(0, hi, (n, k), generator=g, dtype=torch.int32)
+        if n > 100:
+            idx[3::7, k - 1] = -1            # placeholders (bucket 0: n / 7 members)
+            idx[::5, 0] = min(hi, 42) - 1    # a hub: n / 5 rows point at one target
+            idx[1::50, 0] = hi - 1           # the last target
+        tables.append(idx.cuda())
+    small = [torch.randint(-1, 50, (50, 2), generator=g, dtype=torch.int32).cuda() for _ in range(20)]  # > 16 jobs: two calls
+    res = gva.inverse_tables(tables + small)
+    assert len(res) == len(tables) + len(small)
+    for idx, (ptr, rows) in zip(tables + small, res):
+        hptr, hrows = _host_inverse(idx)
+        assert torch.equal(ptr.cpu(), hptr), idx.shape
+        assert torch.equal(rows.cpu(), hrows), idx.shape
+        assert gva.inverse_table(idx)[0] is ptr  # cached on the table
+    # the single-table entry point and a second call on fresh copies give the same bits (arrival order does not show)
+    for idx, (ptr, rows) in zip(tables[:3], res[:3]):
+        p2, r2 = gva.inverse_table(idx.clone())
+        assert torch.equal(p2, ptr) and torch.equal(r2, rows)
+    # out-of-table entries are treated as placeholders, not written through
+    bad = tables[0].clone()
+    bad[7, 3], bad[9, 1] = 5000, -7
+    ptr, rows = gva.inverse_table(bad)
+    fixed = bad.clone()
+    fixed[7, 3], fixed[9, 1] = -1, -1
+    hptr, hrows = _host_inverse(fixed)
+    assert torch.equal(ptr.cpu(), hptr) and torch.equal(rows.cpu(), hrows)
+
+
 @pytest.mark.parametrize("n,c,g", [(3000, 48, 6), (500, 192, 24), (129, 384, 48), (40, 520, 65), (33, 40, 5), (1, 96, 12)])
 def test_grouped_projection_kernels(n, c, g):
     """out = out_v + A Wp2_g^T + bp2 * sw and its backward (g_A, g_sw) against torch, incl. shapes whose g * c / 4 does not

@@ -244,8 +244,9 @@ def test_native_model_on_other_architectures(monkeypatch, variant):
 def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
     """enable_checkpoint=True (reference :169-171) on the native runtime (ptv2_model.checkpoint): the forward keeps only the
     Blocks' outputs, the backward re-runs each Block's forward into ONE shared region right before its backward.  Same
-    kernels on the same inputs: logits, every gradient and the BatchNorm running statistics equal the non-checkpointed run
-    bit for bit (the recomputation must not advance the running statistics a second time); the saved arena shrinks."""
+    kernels on the same inputs: logits and every gradient equal the non-checkpointed run bit for bit; the saved arena shrinks.
+    Running statistics as under torch.utils.checkpoint in the reference: the norms inside the checkpointed attention take the
+    momentum step twice per training step (and count two batches), norm1 / norm2 / norm3 once."""
     import ctypes
 
     from ao_amd import _lib
@@ -267,6 +268,19 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
+    init = M.init_state(cfg, seed=23)
+    momentum, twice = 0.1, 0  # (nn.BatchNorm1d's default, what PointBatchNorm constructs)
     for k in res[False][2]:
-        assert torch.equal(res[True][2][k], res[False][2][k]), k
+        once, ck = res[False][2][k], res[True][2][k]
+        inside = ".attn." in k and ("running_" in k or "num_batches_tracked" in k)
+        if not inside:
+            assert torch.equal(ck, once), k
+        elif "num_batches_tracked" in k:
+            assert int(ck) == int(once) + 1 == 2, k
+        else:  # r2 = (1 - m) r1 + m b with m b = r1 - (1 - m) r0
+            r0 = torch.as_tensor(init[k]).cuda().float()
+            expect = (1 - momentum) * once + (once - (1 - momentum) * r0)
+            np.testing.assert_allclose(ck.cpu().numpy(), expect.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+            twice += 1
+    assert twice == 2 * 4 * 15  # mean and variance of four norms in each of the 15 Blocks
     assert saved[True] < 0.45 * saved[False], saved
