@@ -35,6 +35,8 @@ _SIGNATURES = {
     "ptv2_graph_reset": (_c_int, []),
     "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),
     "knn_query_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_size, _vp]),
+    "knn_query_grid_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                             _vp, _c_size, _vp]),
     "knn_query_count_pairs": (_c_int, [_vp]),
     "farthest_point_sampling_hip_workspace_bytes": (_c_size, [_c_int] * 2),
     "farthest_point_sampling_hip_launcher": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_size, _vp]),

@@ -82,7 +82,7 @@ Workspace carve(void *base, int m, int n, int b) {
 __global__ void knn_init_kernel(int *tie_count, int *bbox_lo, int *bbox_hi, int b, int *cell_count,
                                 int ncell_pad) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *tie_count = 0;
+    if (t < 4) tie_count[t] = 0;  // (one re-run list counter per query that shares this grid)
     if (t < 3 * b) {
         bbox_lo[t] = 0x7fffffff;
         bbox_hi[t] = (int)0x80000000;
@@ -926,11 +926,16 @@ extern "C" size_t knn_query_hip_workspace_bytes(int m, int n, int b) {
     return carve(nullptr, m, n, b).bytes;
 }
 
-extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
-                                      const int *offset, const int *new_offset, int *idx, float *dist2,
-                                      int n, int b, int pad_with_start, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
+// grid_mode 0: build the cell grid of (xyz, offset) in `workspace`, then query.  grid_mode 1: `workspace` still holds the grid
+// an earlier call (on the same stream, same xyz / offset / n / b) built there -- query only; `slot` (1 .. 3) numbers the queries
+// that share a grid (each has its own re-run counter).  A scene asks for up to three tables over the points of one level
+// (the interpolation table from the finer level and one or two self tables): one grid instead of three.
+extern "C" int knn_query_grid_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                                           const int *offset, const int *new_offset, int *idx, float *dist2,
+                                           int n, int b, int pad_with_start, int grid_mode, int slot, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
     if (nsample < 1 || nsample > 128 || m < 0 || n < 0 || b < 1) return PTV2_ERR_ARG;
+    if (grid_mode < 0 || grid_mode > 1 || slot < 0 || slot > 3 || (grid_mode == 0 && slot != 0)) return PTV2_ERR_ARG;
     if (m == 0) return PTV2_OK;
     if (!xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PTV2_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -951,6 +956,8 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
     const int ncell_pad = ntiles * SCAN_TILE;
     const int self_mode = (new_xyz == xyz && new_offset == offset && m == n) ? 1 : 0;
 
+    w.tie_count += slot;
+    if (grid_mode == 0) {
     hipLaunchKernelGGL(knn_init_kernel, dim3(min(divup(ncell_pad, 256), 1024)), dim3(256), 0, st, w.tie_count,
                        w.bbox_lo, w.bbox_hi, b, w.cell_count, ncell_pad);
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.bbox_lo,
@@ -967,6 +974,7 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        w.cell_start, ntiles);
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, w.cell_start, w.point_cell,
                        w.point_rank, w.sorted);
+    }
     {
     PtvScopedTimer qt(KID_KNN_QUERY, st, 12.0 * n + 12.0 * m + 8.0 * (double)m * k);
     if (k <= 16) {
@@ -995,4 +1003,12 @@ extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, cons
                        dist2, pad_with_start, (const int *)w.tie_count, (const int *)w.tie_list);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
+}
+
+extern "C" int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                                      const int *offset, const int *new_offset, int *idx, float *dist2,
+                                      int n, int b, int pad_with_start, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    return knn_query_grid_hip_launcher(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, n, b, pad_with_start, 0, 0,
+                                       workspace, workspace_bytes, stream);
 }

@@ -6,11 +6,11 @@ from .. import _lib
 from .query import knn_query, knn_query_dist2
 
 
-def interpolation_index_weight(xyz, new_xyz, offset, new_offset, k=3):
+def interpolation_index_weight(xyz, new_xyz, offset, new_offset, k=3, grid=None):
     """k-NN of every new_xyz row among xyz + normalised inverse-distance weights (:13-16).
     Index -1 (coarse segment shorter than k) wraps to the last row as torch indexing does (:21)."""
     if k <= 8:  # one launch (interpolation_weights_hip_launcher: the same arithmetic in the same order) instead of nine
-        idx, dist2 = knn_query_dist2(k, xyz, offset, new_xyz, new_offset)
+        idx, dist2 = knn_query_dist2(k, xyz, offset, new_xyz, new_offset, grid=grid)  # grid: the source points' KnnGrid
         weight = torch.empty_like(dist2)
         rc = _lib.lib().interpolation_weights_hip_launcher(idx.shape[0], k, xyz.shape[0], dist2.data_ptr(), idx.data_ptr(),
                                                            weight.data_ptr(), _lib.stream_ptr())

@@ -15,7 +15,7 @@ import torch
 
 from .. import _lib, pointops
 from ..pointops.interpolation import interpolation_index_weight
-from ..pointops.query import knn_query_dist2
+from ..pointops.query import KnnGrid, knn_query_dist2
 
 
 @dataclass
@@ -30,6 +30,7 @@ class Level:
     # link from the next coarser level back to this one ("interp" unpooling)
     up_idx: Optional[torch.Tensor] = None    # (N,3) int32 into the coarser level
     up_weight: Optional[torch.Tensor] = None  # (N,3) fp32
+    grid: Optional[object] = None            # pointops.query.KnnGrid while the scene is being built (one cell grid per level)
 
 
     def neighbours(self, k, inverse=True):
@@ -38,7 +39,7 @@ class Level:
         its levels in one call afterwards (gva.inverse_tables)."""
         if k not in self.knn:
             with torch.no_grad():
-                idx = knn_query_dist2(k, self.coord, self.offset)[0]  # (the table only: no sqrt of the distances)
+                idx = knn_query_dist2(k, self.coord, self.offset, grid=self.grid)[0]  # (the table only: no sqrt of the distances)
                 # table-only quantities the fused attention needs (their host syncs belong to the geometry phase)
                 from . import gva
                 if gva.supported(8 * 6, 6, k):
@@ -142,7 +143,9 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
     offset = offset.int().contiguous()
     coord = coord.contiguous()
     geo = SceneGeometry()
-    cur = Level(coord=coord, offset=offset)
+    # one cell grid per level, shared by the queries over its points: the interpolation table from the finer level (k = 3) and
+    # the level's self tables (csrc/knn.hip: knn_query_grid_hip_launcher)
+    cur = Level(coord=coord, offset=offset, grid=KnnGrid())
     for i, ks in enumerate(neighbours):
         for k in ks:
             cur.neighbours(k, inverse=False)
@@ -151,9 +154,10 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
             break
         nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, grid_sizes[i])
         cur.cluster, cur.order32, cur.idx_ptr32 = cluster, order, idx_ptr
+        nxt = Level(coord=nc, offset=noff, grid=KnnGrid())
         if interp:
-            cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3)
-        cur = Level(coord=nc, offset=noff)
+            cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3, grid=nxt.grid)
+        cur = nxt
     # inverse tables of every neighbour / interpolation table of the scene in one call (five launches: csrc/inverse.hip);
     # they let the backward gather in a fixed order instead of scattering with float atomics
     from . import gva
@@ -161,4 +165,6 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
     tables += [idx for lv in geo.levels for k, idx in lv.knn.items() if gva.supported(8 * 6, 6, k)]
     with torch.no_grad():
         gva.inverse_tables(tables)
+    for lv in geo.levels:
+        lv.grid = None  # (the grids' workspaces go back to the allocator; a table asked for later builds its own)
     return geo

@@ -85,6 +85,13 @@ int knn_query_hip_launcher(int m, int nsample, const float *xyz, const float *ne
                            const int *offset, const int *new_offset, int *idx, float *dist2,
                            int n, int b, int pad_with_start, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* The same query with the cell grid shared between calls: grid_mode 0 builds the grid of (xyz, offset) in `workspace` (slot 0),
+ * grid_mode 1 reuses the grid an earlier call on the same stream built there for the same xyz / offset / n / b (slot 1 .. 3,
+ * one per call that shares the grid); the workspace must be the caller's own, sized for the largest m of the calls. */
+int knn_query_grid_hip_launcher(int m, int nsample, const float *xyz, const float *new_xyz,
+                                const int *offset, const int *new_offset, int *idx, float *dist2,
+                                int n, int b, int pad_with_start, int grid_mode, int slot, void *workspace,
+                                size_t workspace_bytes, void *stream);
 /* Measurement hook (no reference counterpart; bench.py `ops`): while device_counter != NULL the calling thread's
  * knn_query_hip_launcher calls run the counting twin of the grid query kernel, which adds the number of candidate
  * distances it evaluates to *device_counter (64-bit, device memory, zeroed by the caller).  NULL switches it off. */

@@ -111,6 +111,41 @@ def test_knn_room_scene_full_size(hp):
     assert torch.equal(cidx.cpu()[sub], ridx) and torch.equal(cd2.cpu()[sub], rd2)
 
 
+def test_knn_queries_sharing_one_cell_grid(hp):
+    """KnnGrid: the interpolation table (k = 3, queries from a finer cloud), two self tables and a tie-heavy lattice over ONE
+    grid build give the bits of independent calls; a fifth query, other source points or a larger query set rebuild it."""
+    from ao_amd.pointops.query import KnnGrid
+
+    lat = synth.lattice_cloud(12, 10, 8, 0.125)  # ties everywhere: every query of the shared grid fills its own re-run list
+    src = np.concatenate([synth.random_cloud(6000, seed=21), lat]).astype(np.float32)
+    off = np.array([2500, 6000, src.shape[0]], np.int32)
+    fine = np.concatenate([synth.random_cloud(15000, seed=22, scale=1.1), lat + 0.0625]).astype(np.float32)
+    foff = np.array([7000, 15000, fine.shape[0]], np.int32)
+    x, o, q, qo = dev(src), dev(off), dev(fine), dev(foff)
+    grid = KnnGrid()
+    calls = [(3, q, qo), (16, None, None), (8, None, None), (1, q, qo), (16, None, None)]
+    modes = []
+    for k, nq, nqo in calls:
+        got = hp.knn_query_dist2(k, x, o, nq, nqo, grid=grid)
+        modes.append(grid.used)
+        ref = hp.knn_query_dist2(k, x, o, nq, nqo)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), k
+    assert modes == [1, 2, 3, 4, 1]  # the fifth query built the grid again
+    ridx, rd2 = P.knn_query_raw(16, cpu(src), cpu(off), cpu(src), cpu(off), mt=True)
+    got = hp.knn_query_dist2(16, x, o, grid=grid)
+    assert torch.equal(got[0].cpu(), ridx) and torch.equal(got[1].cpu(), rd2)
+    other = dev(src[::-1].copy())  # other points (another address): not the grid in the workspace
+    got = hp.knn_query_dist2(8, other, o, grid=grid)
+    assert grid.used == 1
+    ref = hp.knn_query_dist2(8, other, o)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    big = dev(np.concatenate([fine, fine + 0.01, fine - 0.01]).astype(np.float32))  # more queries than the workspace was sized for
+    bo = dev(np.array([3 * 7000, 3 * 15000, 3 * fine.shape[0]], np.int32))
+    got = hp.knn_query_dist2(3, other, o, big, bo, grid=grid)
+    ref = hp.knn_query_dist2(3, other, o, big, bo)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
 def test_knn_multi_scene_batch(hp):
     b = synth.scene_batch([1, 2, 3], point_max=20000)
     check_knn(hp, 16, b["coord"], b["offset"])
