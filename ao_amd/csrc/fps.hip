@@ -111,17 +111,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float *__restric
 
 
 // ------------------------------------------------------------- cooperative FPS --
-// W workgroups per cloud, every point of the cloud resident in VGPRs (RC = 2, 4 or 8 per lane), one exchange per
-// sample: each workgroup publishes its best candidate as ONE 8-byte granule
-//     [ float bits of tmp : 32 | tie key (bitrev(t) << 11 | j) inverted : 21 | sample number mod 2048 : 11 ]
-// with a device-scope (sc1) store into slots[cloud][parity][w]; lanes 0..W-1 of wave 0 poll the W granules of the
-// parity with relaxed device-scope loads until all carry the current sample number, reduce them with a wave max
-// and broadcast the winner through LDS.  A granule is data and flag in one naturally aligned store, so no fence
-// is needed (MI355X_MICROARCH.md, hand-off price list, row handoff-1to1); two parities suffice because a
-// workgroup can only publish sample i+2 after it has consumed every granule of sample i+1, which nobody
-// publishes before consuming sample i.  All b*W workgroups must be co-resident: the launcher keeps b*W <= 256
-// (one 1024-thread workgroup per CU) and bounds every spin.
+// W workgroups per cloud (W <= 32), every point of the cloud resident in VGPRs (RC = 2, 4, 8 or 16 per lane), one exchange
+// per sample.  A workgroup publishes its best candidate as four 8-byte granules, stored as two 16-byte pairs:
+//     key  [ float bits of tmp : 32 | tie key (bitrev(t) << 11 | j) inverted : 21 | sample number mod 2047 + 1 : 11 ]
+//     x, y, z of that candidate, each [ float bits : 32 | sample tag : 32 ]
+// -- the winner's COORDINATES travel with its key, so the next sample's distance update starts from registers instead of from
+// a dependent load of xyz[winner].  Wavefront 0 of every workgroup polls the 2 W pairs of the parity (one 16-byte load per
+// lane) until all carry the current sample number, reduces the keys with a wave max and broadcasts the winner through LDS.
+// A granule is data and flag in one naturally aligned store, so no fence is needed (MI355X_MICROARCH.md, hand-off price list,
+// row handoff-1to1); two parities suffice because a workgroup can only publish sample i+2 after it has consumed every granule
+// of sample i+1, which nobody publishes before consuming sample i.  All workgroups of a launch must be co-resident (the
+// launcher bounds the grid by the compute-unit count) and every spin is bounded.
+// Two exchanges (template LOCAL): through the L2 of ONE XCD that holds all W workgroups of the cloud (teams formed at run
+// time, see the kernel), or device scope through memory when the launch does not fit that way (AO_AMD_FPS_LOCAL=0 forces it).
+// Measured at 120 k points -> 30 k samples: 1.42-1.49 us per sample through the XCD's L2 (W = 30, 4 points per lane),
+// 2.37 through memory; round 3's form (branchy update, 8-byte granules polled by key only) 2.58.  What a sample costs now is
+// ~1.25 us of hand-offs that do not shrink with the cloud (two barriers, two wave reductions, the store's and the load's trip
+// to L2: 16 k .. 64 k points all take 1.27-1.33 us) plus ~0.05 us per point and lane.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int COOP_TAG_BITS = 11;
+constexpr int COOP_TEAMS = 32;       // teams per XCD the control block has room for (LOCAL exchange)
+constexpr int COOP_CTRL_INTS = 32 + 16 * COOP_TEAMS;  // tickets[16], next cloud, arrived, ..., cloud_of[16][COOP_TEAMS]
 constexpr unsigned COOP_TAG_MASK = (1u << COOP_TAG_BITS) - 1u;
 
 // tie part of the granule of point `rel` (21 bits, larger wins): fixed per point, formed once
@@ -152,22 +162,72 @@ __device__ __forceinline__ unsigned long long wave_max_pair(unsigned hi, unsigne
     return ((unsigned long long)mh << 32) | ml;
 }
 
-// The winner's COORDINATES travel with its key: a workgroup publishes four granules per sample -- key, and x / y / z each
-// as [float bits : 32 | sample tag : 32] -- and wavefront 0 polls the 4 W granules of the parity at once (W <= 16), so the
-// next sample's distance update starts from registers instead of from a dependent global load of xyz[winner] (an L2 round
-// trip on every sample's critical path).
-template <int RC>
+template <int RC, bool LOCAL>
 __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float *__restrict__ xyz,
                                                                const int *__restrict__ offset,
                                                                const int *__restrict__ new_offset, float *tmp,
                                                                int *__restrict__ idx, int B, int logB, int W,
-                                                               unsigned long long *slots, int *error_flag) {
+                                                               unsigned long long *slots, int *error_flag, int nclouds, int *ctrl) {
     __shared__ unsigned long long s_key[FPS_THREADS / WAVE];
     __shared__ float s_cand[FPS_THREADS / WAVE][3];
     __shared__ unsigned long long s_win;
     __shared__ float s_wxyz[3];
-    const int cloud = blockIdx.x / W, wg = blockIdx.x - cloud * W;
+    // LOCAL: all W workgroups of a cloud on ONE XCD, whose L2 then carries the exchange: a granule is stored at workgroup
+    // scope (sc0: through the CU's write-through L1 into the XCD's L2, no write-through to memory) and polled with a
+    // device-scope load (sc1: misses the reader's L1, hits that L2).  Device-scope stores -- what workgroups on different
+    // XCDs need -- go to memory before anyone can see them: 2.41 us per sample against 1.80 at 120 k points.
+    // Which XCD a workgroup lands on is the dispatcher's business (round-robin over the XCDs when they all have room:
+    // tools/probes/xcc_probe.hip -- but workgroup 112 of a 120-workgroup launch was seen on XCD 7), so the teams form at run
+    // time: a workgroup reads its XCC_ID, draws a ticket of that XCD (ticket / W = its team there, ticket % W = its rank), the
+    // one that completes a team claims the next cloud for it and tells the others.  Teams that never fill up (the launch has
+    // 8 (W - 1) + 1 - W workgroups more than the clouds need: one partial team per XCD cannot starve a cloud) leave once every workgroup of
+    // the launch has drawn its ticket.
+    int cloud, wg;
+    if (LOCAL) {
+        __shared__ int s_cloud, s_rank;
+        if (threadIdx.x == 0) {
+            int *tickets = ctrl, *next_cloud = ctrl + 16, *arrived = ctrl + 17, *cloud_of = ctrl + 32;  // cloud_of[16][COOP_TEAMS]
+            const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;  // HW_REG_XCC_ID[3:0]
+            const int t = __hip_atomic_fetch_add(tickets + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int team = t / W, rank = t - team * W;
+            int mine = -1;
+            if (team < COOP_TEAMS) {
+                int *slot = cloud_of + xcc * COOP_TEAMS + team;
+                if (rank == W - 1) {  // (tickets come in order: ranks 0 .. W-2 of this team are taken, the team is complete)
+                    mine = __hip_atomic_fetch_add(next_cloud, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(slot, mine + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int spins = 0;; ++spins) {
+                        if (spins > (1 << 22)) { *error_flag = 1; break; }  // (a launch that is not resident as a whole: fail loudly)
+                        int c = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (c == 0 && __hip_atomic_load(arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x)
+                            c = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);  // everybody is in: final answer
+                        else if (c == 0) { __builtin_amdgcn_s_sleep(8); continue; }
+                        mine = c - 1;  // (-1: the team never filled up)
+                        break;
+                    }
+                }
+            } else {
+                (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_cloud = mine;
+            s_rank = rank;
+        }
+        __syncthreads();
+        cloud = s_cloud;
+        wg = s_rank;
+        if (cloud < 0 || cloud >= nclouds) return;
+    } else {
+        cloud = blockIdx.x / W;
+        wg = blockIdx.x - cloud * W;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int STORE_SCOPE = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+    __shared__ int s_abort;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
     const int start_n = cloud == 0 ? 0 : offset[cloud - 1];
     const int end_n = offset[cloud];
     const int start_m = cloud == 0 ? 0 : new_offset[cloud - 1];
@@ -186,64 +246,89 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float *__re
         const bool ok = rel < cnt && tid + i * FPS_THREADS < chunk;
         const int k = start_n + (ok ? rel : 0);
         px[i] = xyz[3 * k]; py[i] = xyz[3 * k + 1]; pz[i] = xyz[3 * k + 2];
-        pt[i] = ok ? tmp[k] : -1.0f;
+        pt[i] = ok ? tmp[k] : 0.0f;  // (an unused slot: distance 0, tie 0 -- its key is 0)
         tie[i] = ok ? (coop_tie(rel, B, logB) << COOP_TAG_BITS) : 0u;
     }
     unsigned long long *my_slots = slots + (size_t)cloud * 2 * 4 * W;  // [parity][key, x, y, z][W]
     float x1 = xyz[3 * start_n], y1 = xyz[3 * start_n + 1], z1 = xyz[3 * start_n + 2];
     for (int j = start_m + 1; j < end_m; ++j) {
         const unsigned tag = (unsigned)((j - start_m) % (int)COOP_TAG_MASK) + 1u;  // 1..2047, never the memset value 0
-        unsigned bh = 0u, bl = 0u;  // "no candidate": dist bits 0, tie 0
-        float bx = 0.f, by = 0.f, bz = 0.f;
+        // branch-free: the candidate is ONE 64-bit key (distance bits : tie), the slot that holds it a small integer.  (The
+        // first form tracked (distance, tie, x, y, z) under per-point branches: the compiler turned every point into an
+        // exec-mask region -- ~14 scalar / mask instructions around 7 of arithmetic -- and the update, not the exchange,
+        // was most of a sample: 1.41 us per sample for ONE workgroup with 8 points per lane and nobody to talk to.)
+        unsigned long long best = 0ull;  // "no candidate": an unused slot has pt = 0, tie = 0 -> key 0, never taken
+        int bi = 0;
 #pragma unroll
         for (int i = 0; i < RC; ++i) {
-            if (pt[i] >= 0.0f) {
-                const float d = ref_d2(px[i], py[i], pz[i], x1, y1, z1);
-                const float d2 = fminf(d, pt[i]);
-                pt[i] = d2;
-                const unsigned h = __float_as_uint(d2);
-                const bool take = h > bh || (h == bh && tie[i] > bl);
-                bh = take ? h : bh;
-                bl = take ? tie[i] : bl;
-                bx = take ? px[i] : bx; by = take ? py[i] : by; bz = take ? pz[i] : bz;
-            }
+            const float d = ref_d2(px[i], py[i], pz[i], x1, y1, z1);
+            float d2;
+            asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(pt[i]));  // (fminf would canonicalise pt[i] first: one more op)
+            pt[i] = d2;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | tie[i];
+            const bool take = key > best;
+            best = take ? key : best;
+            bi = take ? i : bi;
         }
+        const unsigned bh = (unsigned)(best >> 32), bl = (unsigned)best;
         const unsigned long long wbest = wave_max_pair(bh, bl);
         // the holder: keys of real points are unique; among lanes without one (all-empty wavefront) the lowest
-        if (lane == __builtin_ctzll(__ballot((((unsigned long long)bh << 32) | bl) == wbest))) {
+        const int holder = __builtin_ctzll(__ballot(best == wbest));
+        const int hi_slot = __builtin_amdgcn_readlane(bi, holder);  // (wave-uniform: the selection below is scalar branches)
+        float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+        for (int i = 0; i < RC; ++i)
+            if (hi_slot == i) { bx = px[i]; by = py[i]; bz = pz[i]; }
+        if (lane == holder) {
             s_key[wid] = wbest | tag;
             s_cand[wid][0] = bx; s_cand[wid][1] = by; s_cand[wid][2] = bz;
         }
         __syncthreads();
         if (wid == 0) {
-            const unsigned long long mine = lane < FPS_THREADS / WAVE ? s_key[lane] : 0ull;
+            const bool has = lane < FPS_THREADS / WAVE;
+            const unsigned long long mine = has ? s_key[lane] : 0ull;
+            // (lane w also fetches wavefront w's candidate now: the winner's coordinates are then a register read away
+            // instead of an LDS round trip behind the reduction)
+            const float mx = has ? s_cand[lane][0] : 0.f, my = has ? s_cand[lane][1] : 0.f, mz = has ? s_cand[lane][2] : 0.f;
             const unsigned long long v = wave_max_pair((unsigned)(mine >> 32), (unsigned)mine);  // (all tags equal: the maximum keeps it)
             const int ww = __builtin_ctzll(__ballot(mine == v));  // the wavefront that holds the workgroup's best
-            unsigned long long *par = my_slots + (size_t)(j & 1) * 4 * W;
-            if (lane < 4) {
-                const unsigned long long g = lane == 0 ? v : (((unsigned long long)__float_as_uint(s_cand[ww][lane - 1]) << 32) | tag);
-                __hip_atomic_store(par + (size_t)lane * W + wg, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float vx = __uint_as_float((unsigned)__builtin_amdgcn_readlane(__float_as_int(mx), ww));
+            const float vy = __uint_as_float((unsigned)__builtin_amdgcn_readlane(__float_as_int(my), ww));
+            const float vz = __uint_as_float((unsigned)__builtin_amdgcn_readlane(__float_as_int(mz), ww));
+            // the parity's granules as 2 W pairs of 16 bytes: pair w = (key, x) of workgroup w, pair W + w = its (y, z).  One
+            // 16-byte store per pair (lanes 0, 1), one 16-byte load per lane and poll round (lanes 0 .. 2 W - 1, W <= 32); every
+            // 8-byte granule carries the sample tag, so it does not matter whether the two halves of a pair arrive together
+            u32x4 *par = (u32x4 *)(my_slots + (size_t)(j & 1) * 4 * W);
+            if (lane < 2) {
+                const float c0 = lane == 0 ? vx : vy, c1 = vz;
+                u32x4 g;
+                if (lane == 0) g = u32x4{(unsigned)v, (unsigned)(v >> 32), tag, __float_as_uint(c0)};
+                else g = u32x4{tag, __float_as_uint(c0), tag, __float_as_uint(c1)};
+                u32x4 *dst = par + (size_t)lane * W + wg;
+                if (LOCAL) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(dst), "v"(g) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(g) : "memory");
             }
-            unsigned long long got = (unsigned long long)tag;
-            if (lane < 4 * W) {
+            u32x4 got = u32x4{tag, 0u, tag, 0u};
+            if (lane < 2 * W) {
+                const u32x4 *src = par + lane;
                 int spins = 0;
                 for (;;) {
-                    got = __hip_atomic_load(par + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (((unsigned)got & COOP_TAG_MASK) == tag) break;
-                    if (++spins > (1 << 22)) { *error_flag = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(got) : "v"(src) : "memory");
+                    if ((got.x & COOP_TAG_MASK) == tag && (got.z & COOP_TAG_MASK) == tag) break;
+                    if (++spins > (1 << 20)) { *error_flag = 1; s_abort = 1; break; }
+                    if (!LOCAL) __builtin_amdgcn_s_sleep(1);  // (the XCD's L2 takes the tight loop; memory-side polling backs off)
                 }
             }
-            const unsigned long long keyv = lane < W ? got : 0ull;
+            const unsigned long long keyv = lane < W ? (((unsigned long long)got.y << 32) | got.x) : 0ull;
             const unsigned long long w = wave_max_pair((unsigned)(keyv >> 32), (unsigned)keyv);
             const int wl = __builtin_ctzll(__ballot(keyv == w));  // the workgroup that holds the cloud's best
-            const unsigned ghi = (unsigned)(got >> 32);
-            const float wx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ghi, W + wl));
-            const float wy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ghi, 2 * W + wl));
-            const float wz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ghi, 3 * W + wl));
+            const float wx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got.w, wl));
+            const float wy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got.y, W + wl));
+            const float wz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)got.w, W + wl));
             if (lane == 0) { s_win = w; s_wxyz[0] = wx; s_wxyz[1] = wy; s_wxyz[2] = wz; }
         }
         __syncthreads();
+        if (s_abort) return;  // (a granule never came: the launcher's caller raises; do not spin through the remaining samples)
         x1 = s_wxyz[0]; y1 = s_wxyz[1]; z1 = s_wxyz[2];
         if (wg == 0 && tid == 0) {
             const unsigned long long win = s_win;
@@ -261,11 +346,27 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float *__re
     }
 }
 
+// workgroups of the LOCAL kernel the device holds at once (occupancy x compute units), per RC
+int coop_capacity(int RC) {
+    static int cap[4] = {0, 0, 0, 0};
+    const int slot = RC == 2 ? 0 : RC == 4 ? 1 : RC == 8 ? 2 : 3;
+    if (!cap[slot]) {
+        const void *fn = RC == 2 ? (const void *)fps_coop_kernel<2, true> : RC == 4 ? (const void *)fps_coop_kernel<4, true>
+                       : RC == 8 ? (const void *)fps_coop_kernel<8, true> : (const void *)fps_coop_kernel<16, true>;
+        int occ = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, FPS_THREADS, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 0;
+        cap[slot] = std::max(1, occ * cus);
+    }
+    return cap[slot];
+}
+
 }  // namespace
 
 extern "C" size_t farthest_point_sampling_hip_workspace_bytes(int b, int n_total) {
     (void)n_total;
-    return sizeof(unsigned long long) * 2 * 4 * 256 * (size_t)(b > 0 ? b : 1) + 256;  // granule slots (key, x, y, z) + error flag
+    return sizeof(unsigned long long) * 2 * 4 * 256 * (size_t)(b > 0 ? b : 1) + sizeof(int) * (16 + COOP_CTRL_INTS) + 256;  // granule slots (key, x, y, z), error flag, team control block
 }
 
 extern "C" int farthest_point_sampling_hip_launcher(int b, int n_max, const float *xyz, const int *offset,
@@ -283,10 +384,10 @@ extern "C" int farthest_point_sampling_hip_launcher(int b, int n_max, const floa
     B = B > 1024 ? 1024 : (B < 1 ? 1 : B);
     int logB = 0;
     while ((1 << logB) < B) ++logB;
-    // cooperative variant: every cloud split over W <= 16 workgroups, all points in registers (2 .. 16 per lane).  (More
-    // workgroups with fewer points each measured no faster -- 40 x 2 points per lane: 2.58 us per sample against 2.46 with
-    // 10 x 8 -- the sample's critical path is the exchange and the hop of the winner's coordinates, not the distance update.)
-    const int Wcap = std::min(16, 256 / b);  // 4 W granules are polled by the 64 lanes of one wavefront
+    // cooperative variant: every cloud split over W <= 32 workgroups, all points in registers (2 .. 16 per lane): the fewest
+    // points per lane that W allows (with the exchange through one XCD's L2 the per-lane update is what is left to shrink:
+    // 120 k points as 30 x 4 per lane 1.42 us per sample, as 15 x 8 1.80, as 59 x 2 with two loads per poll 1.53)
+    const int Wcap = std::min(32, 256 / b);  // 2 W granule pairs are polled by the 64 lanes of one wavefront
     int RC = 2;
     while (RC < 16 && (n_max + RC * FPS_THREADS - 1) / (RC * FPS_THREADS) > Wcap) RC *= 2;
     const int W = (n_max + RC * FPS_THREADS - 1) / (RC * FPS_THREADS);
@@ -294,16 +395,28 @@ extern "C" int farthest_point_sampling_hip_launcher(int b, int n_max, const floa
                       workspace_bytes >= farthest_point_sampling_hip_workspace_bytes(b, n_total);
     if (coop) {
         unsigned long long *slots = (unsigned long long *)workspace;
+        // one XCD per cloud (see the kernel): the launch carries enough workgroups that W - 1 of them may be left over on every
+        // XCD, and all of it has to be resident at once; AO_AMD_FPS_LOCAL=0: the device-scope exchange (the tests' A/B switch)
+        const char *le = getenv("AO_AMD_FPS_LOCAL");
+        const int local_grid = (b - 1) * W + 8 * (W - 1) + 1;
+        const bool local = !(le && le[0] == '0') && local_grid <= coop_capacity(RC) && (b + 7) / 8 + 1 <= COOP_TEAMS;
         int *err = (int *)((char *)workspace + sizeof(unsigned long long) * 2 * 4 * 256 * (size_t)b);
-        (void)hipMemsetAsync(workspace, 0, sizeof(unsigned long long) * 2 * 4 * 256 * (size_t)b + sizeof(int), st);
-        if (RC == 2)
-            hipLaunchKernelGGL(fps_coop_kernel<2>, dim3(b * W), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset, tmp, idx, B, logB, W, slots, err);
-        else if (RC == 4)
-            hipLaunchKernelGGL(fps_coop_kernel<4>, dim3(b * W), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset, tmp, idx, B, logB, W, slots, err);
-        else if (RC == 16)
-            hipLaunchKernelGGL(fps_coop_kernel<16>, dim3(b * W), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset, tmp, idx, B, logB, W, slots, err);
-        else
-            hipLaunchKernelGGL(fps_coop_kernel<8>, dim3(b * W), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset, tmp, idx, B, logB, W, slots, err);
+        int *ctrl = err + 16;
+        (void)hipMemsetAsync(workspace, 0, sizeof(unsigned long long) * 2 * 4 * 256 * (size_t)b + sizeof(int) * (16 + COOP_CTRL_INTS), st);
+#define FPS_COOP(RCV)                                                                                                            \
+    do {                                                                                                                         \
+        if (local)                                                                                                               \
+            hipLaunchKernelGGL((fps_coop_kernel<RCV, true>), dim3(local_grid), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset,  \
+                               tmp, idx, B, logB, W, slots, err, b, ctrl);                                                       \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((fps_coop_kernel<RCV, false>), dim3(b * W), dim3(FPS_THREADS), 0, st, xyz, offset, new_offset, tmp, \
+                               idx, B, logB, W, slots, err, b, ctrl);                                                            \
+    } while (0)
+        if (RC == 2) FPS_COOP(2);
+        else if (RC == 4) FPS_COOP(4);
+        else if (RC == 16) FPS_COOP(16);
+        else FPS_COOP(8);
+#undef FPS_COOP
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }

@@ -26,13 +26,15 @@ class FarthestPointSampling(Function):
         # the multi-workgroup form exchanges its per-iteration arg-max between workgroups that must all be resident; its
         # spins are bounded and raise this flag instead of hanging (ao_amd/csrc/fps.hip: error_flag, behind the granule
         # slots).  FPS costs tens of milliseconds and the reference synchronises around it as well: read the flag back.
-        flag = ws[16 * 256 * b:16 * 256 * b + 4].view(torch.int32)
+        at = 8 * 2 * 4 * 256 * b  # behind the granule slots: [cloud][parity][key, x, y, z][256] of 8 bytes
+        flag = ws[at:at + 4].view(torch.int32)
         flag.zero_()
         rc = L.farthest_point_sampling_hip_launcher(
             b, n_max, xyz.data_ptr(), offset.int().contiguous().data_ptr(), new_offset.int().contiguous().data_ptr(),
             tmp.data_ptr(), idx.data_ptr(), n, m_total, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "farthest_point_sampling_hip_launcher")
-        if int(flag.item()) != 0:
+        code = int(flag.item())
+        if code != 0:
             raise RuntimeError("ao_amd: farthest_point_sampling: a workgroup gave up waiting for its peers (the cooperative "
                                "kernel needs all its workgroups resident; other work was holding the compute units)")
         ctx.mark_non_differentiable(idx)

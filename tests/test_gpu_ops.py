@@ -288,6 +288,37 @@ def test_fps_cooperative_multi_workgroup(hp):
     assert torch.equal(idx.cpu(), ref) and len(set(idx.cpu().tolist())) == 2300
 
 
+@pytest.mark.parametrize("local", ["1", "0"])
+def test_fps_exchange_through_one_xcd_and_through_memory(hp, local):
+    """The cooperative kernel's two exchanges -- all workgroups of a cloud on one XCD (granules through that XCD's L2) and the
+    device-scope one (AO_AMD_FPS_LOCAL=0) -- on 1, 3 and 11 clouds (more clouds than XCDs: two teams per XCD), sizes from one
+    workgroup's worth to the bench scene; bit-exact vs the oracle."""
+    import subprocess
+    import sys
+
+    code = r"""
+import numpy as np, torch
+from ao_amd import pointops
+from oracle import pointops_ref as P
+from tests import synth
+rng = np.random.default_rng(5)
+for sizes, frac in [([120000], 40), ([30000, 9000, 45000], 30), ([9000 + 1500 * i for i in range(11)], 25)]:
+    xyz = np.concatenate([synth.random_cloud(n, seed=100 + i) for i, n in enumerate(sizes)]).astype(np.float32)
+    off = np.cumsum(sizes).astype(np.int32)
+    noff = np.cumsum([max(2, n // frac // 10) for n in sizes]).astype(np.int32)
+    idx = pointops.farthest_point_sampling(torch.from_numpy(xyz).cuda(), torch.from_numpy(off).cuda(), torch.from_numpy(noff).cuda())
+    ref = P.farthest_point_sampling(torch.from_numpy(xyz), torch.from_numpy(off), torch.from_numpy(noff))
+    assert torch.equal(idx.cpu(), ref), sizes
+print("ok")
+"""
+    import os
+
+    env = dict(os.environ, AO_AMD_FPS_LOCAL=local)  # (the launcher reads the switch per call; a fresh process keeps it simple)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_empty_inputs(hp):
     """Zero queries / zero rows: every op returns an empty result of the right shape and dtype (the reference launches
     zero-size grids; here the launchers return before launching)."""
