@@ -412,7 +412,8 @@ def child_main(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     # the GPU path needs no CPU worker threads; torch's default (one per visible CPU: 128 on the pool's hosts) overruns the
     # boxes' cgroup quota (16 CPUs) whenever an intra-op pool spins up, and a throttled period stops the launching thread too
-    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota())))
+    # (N ranks share the quota: each takes its share, at least one)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), cpu_quota() // max(1, world))))
     if os.environ.get("AO_AMD_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("AO_AMD_BENCH_BACKEND", "nccl")
