@@ -31,6 +31,7 @@ _SIGNATURES = {
                                    ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double)]),
     "ptv2_profile_empty_stamp_us": (ctypes.c_double, [_vp, _c_int]),
     "ptv2_graph_mode": (_c_int, [_c_int]),
+    "ptv2_wgrad_defer_mode": (_c_int, [_c_int]),
     "ptv2_graph_stats": (_c_int, [ctypes.POINTER(ctypes.c_double), _c_int]),
     "ptv2_graph_reset": (_c_int, []),
     "knn_query_hip_workspace_bytes": (_c_size, [_c_int] * 3),

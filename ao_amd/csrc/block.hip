@@ -308,6 +308,13 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     // gradient tensors; g_h3, g_hq, g_hk, gv, g_h1 are also the gY operands of the five (c,c) weight gradients, which run
     // as ONE launch + one finalize at the end of the block instead of three launches spread along the chain
     float *g_h3 = W.t[0], *g_hq = W.t[1], *g_hk = W.t[2], *gv = W.t[3], *g_h1 = W.t[4], *ta = W.t[5], *tb = W.t[6];
+    // inside a model backward those five live in the deferral arena instead (the workspace is the next Block's too) and the
+    // launch at the end of this function is filed, to run with every other Block's at the end of the backward (dense.hip)
+    float *kept = ptv2_wgrad_defer_active() ? ptv2_wgrad_defer_alloc(5 * (size_t)n * c) : nullptr;
+    if (kept) {
+        const size_t nc = (size_t)n * c;
+        g_h3 = kept; g_hq = kept + nc; g_hk = kept + 2 * nc; gv = kept + 3 * nc; g_h1 = kept + 4 * nc;
+    }
 
     // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3, residual gradient straight into gx
     RUN(bn_backward_residual_hip_launcher(n, c, S.h3, G->gy, B->y, B->rowscale, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G],
@@ -376,7 +383,10 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
         const float *xsh[5] = {S.bsh[5], S.bsh[0], S.bsh[0], S.bsh[0], nullptr};
         float *dws[5] = {GP(PTV2_BLK_FC3_W), GP(PTV2_BLK_Q_W), GP(PTV2_BLK_K_W), GP(PTV2_BLK_V_W), GP(PTV2_BLK_FC1_W)};
         float *dbs[5] = {nullptr, GPB(PTV2_BLK_Q_B), GPB(PTV2_BLK_K_B), GPB(PTV2_BLK_V_B), nullptr};
-        RUN(linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream));
+        ptv2_wgrad_defer_arm(kept != nullptr);
+        const int wrc = linear_wgrad_multi_hip_launcher(n, c, c, 5, gys, xs, dws, dbs, xsc, xsh, W.dense, W.dense_bytes, stream);
+        ptv2_wgrad_defer_arm(false);
+        RUN(wrc);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

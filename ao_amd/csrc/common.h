@@ -51,6 +51,15 @@ int ptv2_profile_stamps(void);    // the kernel timer brackets with device time 
 // zero-fill as a kernel launch (a kernel node like every other launch of a captured sequence; bytes % 4 == 0)
 int ptv2_zero_async(void *p, size_t bytes, hipStream_t st);
 
+// dense.hip: the weight-gradient launches of a model backward, filed where they are called and run by one launch at its end
+void ptv2_wgrad_defer_begin(void *arena, size_t bytes);   // arena: job table + operands that must outlive their Block + records
+bool ptv2_wgrad_defer_active();
+float *ptv2_wgrad_defer_alloc(size_t floats);             // NULL: not deferring, or no room (the caller launches at once)
+void ptv2_wgrad_defer_arm(bool on);                       // the next weight-gradient call may be filed (its operands are kept)
+int ptv2_wgrad_defer_flush(void *stream);                 // run what has been filed
+void ptv2_wgrad_defer_end();
+size_t ptv2_wgrad_defer_table_bytes();
+
 // Matmul operand precision of the calling thread's launches (abi.hip): 0 = fp32 MFMA (V_MFMA_F32_16X16X4_F32, exact fp32),
 // 1 = bf16 MFMA (V_MFMA_F32_16X16X32_BF16: operands rounded to bf16 on their way into the matrix core, fp32
 // accumulation) -- what torch.autocast(dtype=bfloat16) does to the nn.Linear layers of the reference

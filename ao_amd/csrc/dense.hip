@@ -15,6 +15,7 @@
 //                                  staged through LDS, 3x3 register patch per lane), partial tiles
 //                                  summed in fixed order; the bias gradient falls out of the same pass
 #include <algorithm>
+#include <vector>
 #include <cstdlib>
 
 #include "gva_common.h"
@@ -816,22 +817,22 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
 constexpr int WL_ROWS = 64;  // rows per stage
 // RS != 0: the bias sums are WEIGHTED by a per-(row, product) scalar: db[b][o] = sum_n gY[n, b, o] * rowscale[n * lds_s + b]
 // (the grouped projection's bias gradient, sum_n g_out[n, ch] sw[n, group(ch)], which was a kernel of its own per Block)
+// (the body is a function of the workgroup's coordinates (bx: row chunk, by: output tile, bz: product) so that the same code
+// serves the one-launch-per-call kernel below and the batched kernel that runs the deferred launches of a whole backward)
 template <int RS>
-__global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, int cin, int tiles_i,
-                                                               const float *__restrict__ gY, long long ldy, long long sy,
-                                                               const float *__restrict__ X, long long ldx, long long sx,
-                                                               float *__restrict__ part, float *__restrict__ part_b,
-                                                               int batch, WgradMulti multi, int chunk,
-                                                               const float *__restrict__ rowscale, long long lds_s) {
+__device__ __forceinline__ void wgrad_lds_tile(const int n, const int cout, const int cin, const int tiles_i,
+                                               const float *__restrict__ A, const long long ldy,
+                                               const float *__restrict__ B, const long long ldx,
+                                               float *__restrict__ part, const bool part_b, const int batch,
+                                               const float *__restrict__ xs, const float *__restrict__ xh, const int chunk,
+                                               const float *__restrict__ rowscale, const long long lds_s, const int bx,
+                                               const int by, const int bz) {
     extern __shared__ float4 wl_lds4[];
     float *sA = (float *)wl_lds4;                    // [2][WL_ROWS][WG_TILE]
     float *sB = sA + 2 * WL_ROWS * WG_TILE;           // [2][WL_ROWS][WG_TILE]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int bz = blockIdx.z;
-    const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
-    const float *A = multi.count ? multi.gY[bz] : gY + (long long)bz * sy;
-    const float *B = multi.count ? multi.X[bz] : X + (long long)bz * sx;
-    const long long r0 = (long long)blockIdx.x * chunk;
+    const int to = (by / tiles_i) * WG_TILE, ti = (by % tiles_i) * WG_TILE;
+    const long long r0 = (long long)bx * chunk;
     const long long r1 = (r0 + chunk) < (long long)n ? (r0 + chunk) : (long long)n;
     const int lr = lane >> 4, lc = lane & 15;
     f32x4 acc[WG_MT][WG_MT];
@@ -842,7 +843,6 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
 #pragma unroll
         for (int t = 0; t < WG_MT; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const float *xs = multi.count ? multi.xsc[bz] : nullptr, *xh = multi.count ? multi.xsh[bz] : nullptr;
     float xsc_[WG_MT], xsh_[WG_MT];
 #pragma unroll
     for (int m = 0; m < WG_MT; ++m) {
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
     }
     __syncthreads();
     const size_t rec = (size_t)batch * cout * cin + (part_b ? (size_t)batch * cout : 0);
-    float *p = part + (size_t)blockIdx.x * rec + (size_t)bz * cout * cin;
+    float *p = part + (size_t)bx * rec + (size_t)bz * cout * cin;
     for (int e = threadIdx.x; e < WG_MT * WG_MT * 4 * WAVE; e += TPB) {
         const int q = e / WAVE, l = e - q * WAVE;
         const int mt = q / 4, r = q - mt * 4, m = mt / WG_MT, t = mt - m * WG_MT;
@@ -952,8 +952,96 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][WG_MT * WG_MT * 4 + m][l];
-            part[(size_t)blockIdx.x * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
+            part[(size_t)bx * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
         }
+    }
+}
+
+template <int RS>
+__global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, int cin, int tiles_i,
+                                                               const float *__restrict__ gY, long long ldy, long long sy,
+                                                               const float *__restrict__ X, long long ldx, long long sx,
+                                                               float *__restrict__ part, float *__restrict__ part_b,
+                                                               int batch, WgradMulti multi, int chunk,
+                                                               const float *__restrict__ rowscale, long long lds_s) {
+    const int bz = blockIdx.z;
+    wgrad_lds_tile<RS>(n, cout, cin, tiles_i, multi.count ? multi.gY[bz] : gY + (long long)bz * sy, ldy,
+                       multi.count ? multi.X[bz] : X + (long long)bz * sx, ldx, part, part_b != nullptr, batch,
+                       multi.count ? multi.xsc[bz] : nullptr, multi.count ? multi.xsh[bz] : nullptr, chunk, rowscale, lds_s,
+                       (int)blockIdx.x, (int)blockIdx.y, bz);
+}
+
+// ---- the deferred launches of a whole backward in one launch ------------------------------------------------------------
+// A Block's weight gradients are off its critical chain (nothing reads dW before the optimizer), and at the deep levels each
+// of their launches is a handful of latency-bound workgroups: 28-38 us for 3 MB of operands, a third of it spent alone on the
+// GPU.  Inside ptv2_model_backward the eligible launches (this LDS-staged kernel, fp32) are not issued where they are called:
+// the call files a job -- operands, shape, its slice of a record arena -- and ONE launch at the end of the backward runs them
+// all, workgroup -> (job, chunk, tile, product) through a job table in device memory, followed by ONE finalize over the
+// records of all jobs.  Chunking, record layout and the order of every sum are those of the per-call launch: the same bits.
+struct WgradJob {
+    int n, cout, cin, tiles_i, tiles, batch, chunk, chunks;
+    int wg0;          // first workgroup of the job in the batched launch
+    int has_pb, count;  // bias sums behind the weight records; > 0: the multi form (operand pairs per product)
+    int rec, fin0;    // floats per chunk record; first element of the job in the batched finalize
+    long long ldy, sy, ldx, sx, lds_s;
+    const float *gY, *X, *rowscale;
+    float *part;
+    const float *mgY[6], *mX[6], *mxsc[6], *mxsh[6];
+    float *dW, *db, *mdW[6], *mdb[6];  // finalize: strided form -> dW (batch * cout * cin) then db; multi form -> per product
+};
+constexpr int WGRAD_PACK = 8;  // jobs per table-writer launch (by value: the kernarg block holds 4 KB)
+struct WgradJobPack { WgradJob j[WGRAD_PACK]; };
+__global__ void wgrad_jobs_write_kernel(WgradJobPack pack, int count, WgradJob *table) {
+    if ((int)threadIdx.x < count) table[threadIdx.x] = pack.j[threadIdx.x];
+}
+
+template <int RS>
+__global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel_jobs(const WgradJob *__restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].wg0) ++j;  // (uniform: scalar loads)
+    const WgradJob &J = jobs[j];
+    const int local = (int)blockIdx.x - J.wg0;
+    const int bx = local % J.chunks, rest = local / J.chunks, by = rest % J.tiles, bz = rest / J.tiles;
+    const bool multi = J.count > 0;
+    wgrad_lds_tile<RS>(J.n, J.cout, J.cin, J.tiles_i, multi ? J.mgY[bz] : J.gY + (long long)bz * J.sy, J.ldy,
+                       multi ? J.mX[bz] : J.X + (long long)bz * J.sx, J.ldx, J.part, J.has_pb != 0, J.batch,
+                       multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, J.rowscale, J.lds_s, bx, by, bz);
+}
+
+// element e of the concatenated outputs of all jobs: the sum of its job's chunk records (double, four chains, as
+// gva::finalize_flat_kernel), written where the job's finalize would have written it
+__global__ __launch_bounds__(256) void wgrad_jobs_finalize_kernel(const WgradJob *__restrict__ jobs, int njobs, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int j = 0;
+    while (j + 1 < njobs && e >= jobs[j + 1].fin0) ++j;
+    const WgradJob &J = jobs[j];
+    const int col = e - J.fin0, nblk = J.chunks;
+    const size_t len = (size_t)J.rec;
+    const float *part = J.part;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        a0 += (double)part[(size_t)b * len + col];
+        a1 += (double)part[(size_t)(b + 1) * len + col];
+        a2 += (double)part[(size_t)(b + 2) * len + col];
+        a3 += (double)part[(size_t)(b + 3) * len + col];
+    }
+    for (; b < nblk; ++b) a0 += (double)part[(size_t)b * len + col];
+    const float v = (float)((a0 + a1) + (a2 + a3));
+    const int wlen = J.cout * J.cin, wtot = J.batch * wlen;
+    if (J.count > 0) {  // MapWgradMulti
+        if (col < wtot) {
+            const int p = col / wlen;
+            J.mdW[p][col - p * wlen] = v;
+        } else {
+            const int r = col - wtot, p = r / J.cout;
+            if (J.mdb[p]) J.mdb[p][r - p * J.cout] = v;
+        }
+    } else if (col < wtot) {
+        J.dW[col] = v;
+    } else if (J.db) {
+        J.db[col - wtot] = v;
     }
 }
 
@@ -1646,6 +1734,81 @@ template <> struct RiderOf<MapWgradMulti> {
 };
 }  // namespace gva
 
+// ---- deferred weight-gradient launches (see WgradJob) ----------------------------------------------------------------------
+namespace {
+struct WgradDefer {
+    bool active = false;
+    bool armed = false;          // the call in progress may be filed (set by the call sites whose operands outlive their Block)
+    char *arena = nullptr;       // [job tables | kept operands and chunk records]
+    size_t cap = 0, used = 0;
+    std::vector<WgradJob> jobs;  // filed since the last flush (RS = 0 form)
+    double bytes = 0.0;          // their algorithmic bytes (kernel timer)
+};
+thread_local WgradDefer g_wdefer;
+constexpr int WGRAD_MAX_JOBS = 64;
+constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) & ~(size_t)255;
+}  // namespace
+
+void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
+    WgradDefer &D = g_wdefer;
+    D.jobs.clear();
+    D.bytes = 0.0;
+    D.armed = false;
+    D.active = arena != nullptr && bytes > WGRAD_TABLE_BYTES;
+    D.arena = (char *)arena;
+    D.cap = bytes;
+    D.used = WGRAD_TABLE_BYTES;
+}
+bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
+void ptv2_wgrad_defer_end() { g_wdefer.active = false; g_wdefer.armed = false; g_wdefer.jobs.clear(); }
+void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
+size_t ptv2_wgrad_defer_table_bytes() { return WGRAD_TABLE_BYTES; }
+// a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
+float *ptv2_wgrad_defer_alloc(size_t floats) {
+    WgradDefer &D = g_wdefer;
+    const size_t bytes = (sizeof(float) * floats + 255) & ~(size_t)255;
+    if (!D.active || D.used + bytes > D.cap) return nullptr;
+    float *p = (float *)(D.arena + D.used);
+    D.used += bytes;
+    return p;
+}
+// runs the jobs filed so far: table writers, the batched kernel, the batched finalize
+int ptv2_wgrad_defer_flush(void *stream) {
+    WgradDefer &D = g_wdefer;
+    if (!D.active || D.jobs.empty()) return PTV2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    WgradJob *table = (WgradJob *)D.arena;
+    const int njobs = (int)D.jobs.size();
+    int wgs = 0, fin = 0;
+    for (WgradJob &J : D.jobs) {
+        J.wg0 = wgs; J.fin0 = fin;
+        wgs += J.chunks * J.tiles * J.batch;
+        fin += J.rec;
+    }
+    for (int at = 0; at < njobs; at += WGRAD_PACK) {
+        WgradJobPack pack;
+        const int cnt = std::min(WGRAD_PACK, njobs - at);
+        for (int i = 0; i < WGRAD_PACK; ++i) pack.j[i] = D.jobs[(size_t)std::min(at + i, njobs - 1)];
+        hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
+    }
+    static const bool once = [] {
+        return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel_jobs<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)WL_LDS_BYTES) == hipSuccess;
+    }();
+    if (!once) return PTV2_ERR_LAUNCH;
+    {
+        PtvScopedTimer t(KID_WGRAD_LDS, st, D.bytes);
+        hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st, (const WgradJob *)table,
+                           njobs);
+    }
+    hipLaunchKernelGGL(wgrad_jobs_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st, (const WgradJob *)table,
+                       njobs, fin);
+    D.jobs.clear();
+    D.bytes = 0.0;
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 // count (<= 6) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
 // shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))
 extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
@@ -1680,8 +1843,26 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         }
         bool lds_ok = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin);
         for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
-        PtvScopedTimer t(lds_ok ? KID_WGRAD_LDS : KID_WGRAD, st, 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin +
-                                                                       (double)count * cout * (cin + 1)));
+        const double algo_bytes = 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin + (double)count * cout * (cin + 1));
+        if (lds_ok && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs.size() < WGRAD_MAX_JOBS) {
+            // inside a model backward: filed, and run with all the others by ONE launch at the end (WgradJob); the records go
+            // to the arena (the caller's workspace is reused before that launch)
+            float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
+            if (keep) {
+                WgradJob J{};
+                J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = count;
+                J.chunk = chunk; J.chunks = chunks; J.has_pb = 1; J.count = count; J.rec = (int)rec;
+                J.ldy = cout; J.ldx = cin; J.part = keep;
+                for (int i = 0; i < count; ++i) {
+                    J.mgY[i] = m.gY[i]; J.mX[i] = m.X[i]; J.mxsc[i] = m.xsc[i]; J.mxsh[i] = m.xsh[i];
+                    J.mdW[i] = m.dW[i]; J.mdb[i] = m.db[i];
+                }
+                g_wdefer.jobs.push_back(J);
+                g_wdefer.bytes += algo_bytes;
+                return PTV2_OK;
+            }
+        }
+        PtvScopedTimer t(lds_ok ? KID_WGRAD_LDS : KID_WGRAD, st, algo_bytes);
         if (ptv2_matmul_bf16())
             hipLaunchKernelGGL(linear_wgrad_kernel<true>, grid, dim3(TPB), 0, st, n, cout, cin, tiles_i, (const float *)nullptr,
                                (long long)cout, 0LL, (const float *)nullptr, (long long)cin, 0LL, part, part, count, m, chunk);

@@ -17,6 +17,7 @@
 // the caller's workspace.  Parameter gradients go straight to the destinations named in the ptv2_model (slots of the
 // optimizer's flat gradient buffer in ao_amd/ptv2/native_model.py): no per-parameter tensors, no flatten copy.
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -234,6 +235,7 @@ struct Work {
     float *ga, *gb, *gc;               // gradient temporaries, max over levels of n * widest channel count
     float *gskip[PTV2_MAX_STAGES + 1]; // gradient of the encoder output at level i (two contributions)
     float *fold_scratch[PTV2_MAX_BLOCKS];    // per-Block operands of the attention's parameter glue, run once at the end
+    char *wdefer; size_t wdefer_bytes;       // deferred weight gradients (dense.hip): job table, kept operands, chunk records
     size_t bytes;
 };
 
@@ -280,6 +282,15 @@ Work carve_work(const ptv2_model *M, void *base) {
         for (int j = 0; j < s.depth; ++j)
             W.fold_scratch[s.first_block + j] = (float *)take(sizeof(float) * ptv2_gva_fold_scratch_floats(s.c, s.g));
     }
+    // per Block: its five (n, c) gradient operands + the records of the five-product weight gradient
+    W.wdefer_bytes = ptv2_wgrad_defer_table_bytes();
+    for (int q = 0; q <= 2 * S; ++q) {
+        const ptv2_seq &s = M->seq[q];
+        const int n = M->level[s.level].n;
+        for (int j = 0; j < s.depth; ++j)
+            W.wdefer_bytes += al(sizeof(float) * 5 * (size_t)n * s.c) + al(dense_workspace_bytes(n, 5 * s.c, s.c)) + 512;
+    }
+    W.wdefer = take(W.wdefer_bytes);
     W.bytes = off;
     return W;
 }
@@ -289,6 +300,17 @@ Work carve_work(const ptv2_model *M, void *base) {
         int rc_ = (call);                \
         if (rc_ != PTV2_OK) return rc_;  \
     } while (0)
+
+std::atomic<int> g_wgrad_defer_mode{-1};  // -1: read AO_AMD_WGRAD_DEFER on first use; 0 off; 1 on
+bool wgrad_defer_enabled() {
+    int m = g_wgrad_defer_mode.load();
+    if (m < 0) {
+        const char *e = getenv("AO_AMD_WGRAD_DEFER");
+        m = (e && e[0] == '0') ? 0 : 1;
+        g_wgrad_defer_mode.store(m);
+    }
+    return m != 0;
+}
 
 bool use_batch(const ptv2_model *M, const ptv2_linbn &L) { return M->training || !L.run_mean || !L.run_var; }
 
@@ -523,6 +545,12 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
     int rc = PTV2_OK;
     ptv2_gva_drop_folds();  // (a previous call that failed half-way may have left entries queued)
     struct DropFolds { bool armed = true; ~DropFolds() { if (armed) ptv2_gva_drop_folds(); } } drop_folds;
+    // the Blocks' five-product weight gradients are filed and run by one launch at the end (dense.hip: WgradJob).  Not under
+    // checkpointing (their X operands live in the one shared saved region); AO_AMD_WGRAD_DEFER=0: every launch where it is called
+    struct WgradDeferScope {
+        WgradDeferScope(void *arena, size_t bytes, bool on) { if (on) ptv2_wgrad_defer_begin(arena, bytes); }
+        ~WgradDeferScope() { ptv2_wgrad_defer_end(); }
+    } wgrad_defer(W.wdefer, W.wdefer_bytes, !M->checkpoint && wgrad_defer_enabled());
     // the sequences' inputs and outputs as the forward wired them
     auto seq_out = [&](int q, const float *in) {
         const ptv2_seq &s = M->seq[q];
@@ -576,6 +604,7 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
     }
     // head + decoder parameter gradients are final from here on (their finalizes were enqueued above)
     if (M->decoder_done_event) {
+        RUN(ptv2_wgrad_defer_flush(stream));
         RUN(ptv2_gva_flush_folds(stream));  // (the decoder Blocks' queued parameter glue belongs to that half)
         if (hipEventRecord((hipEvent_t)M->decoder_done_event, st) != hipSuccess) return PTV2_ERR_LAUNCH;
     }
@@ -597,6 +626,7 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
         if (rc != PTV2_OK) return rc;
         RUN(linbn_backward(M, M->embed, A.embed, n0, M->feat, gp, gc, nullptr, 0, W, stream));
     }
+    RUN(ptv2_wgrad_defer_flush(stream));  // the Blocks' filed weight gradients: table writers, one launch, one finalize
     RUN(ptv2_gva_flush_folds(stream));  // the queued parameter glue of all attention blocks: two launches
     drop_folds.armed = false;
     PTV2_CHECK_LAUNCH();
@@ -604,3 +634,11 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
 }
 
 }  // namespace
+
+// 1 / 0: file the Blocks' weight gradients and run them by one launch at the end of the backward / launch each where it is
+// called (the A/B switch of tests/test_gpu_native_model.py; also AO_AMD_WGRAD_DEFER=0).  Returns the previous setting; -1 asks.
+extern "C" int ptv2_wgrad_defer_mode(int on) {
+    const int prev = wgrad_defer_enabled() ? 1 : 0;
+    if (on >= 0) g_wgrad_defer_mode.store(on ? 1 : 0);
+    return prev;
+}

@@ -65,6 +65,11 @@ double ptv2_profile_empty_stamp_us(void *stream, int reps);
 int ptv2_graph_mode(int on);
 int ptv2_graph_stats(double *out, int reset);
 int ptv2_graph_reset(void);
+/* The weight gradients of the Blocks inside ptv2_model_backward_hip_launcher are filed where they are called and run by ONE
+ * launch at the end of the backward (ao_amd/csrc/dense.hip: WgradJob; same chunking and summation order, the same bits).
+ * on = 0: every launch where it is called; 1: deferred (default; AO_AMD_WGRAD_DEFER=0 sets 0); -1: query.  Returns the previous
+ * setting. */
+int ptv2_wgrad_defer_mode(int on);
 
 /* ------------------------------------------------------------------ kNN --
  * Replaces knn_query_cuda_launcher

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "ptv2_hip.h")
 def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs|_stamp_us|_graph_mode|_graph_stats|_graph_reset))\s*\(", txt)))
+    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs|_stamp_us|_graph_mode|_graph_stats|_graph_reset|_defer_mode))\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")

@@ -284,3 +284,36 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
             twice += 1
     assert twice == 2 * 4 * 15  # mean and variance of four norms in each of the 15 Blocks
     assert saved[True] < 0.45 * saved[False], saved
+
+
+@pytest.mark.parametrize("tag,points", [("s3dis", 9000), ("scannet", 7000)])
+def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points):
+    """ptv2_wgrad_defer_mode: the Blocks' weight gradients filed and run by ONE launch at the end of the backward (default)
+    against every launch where it is called -- the same chunking and summation order, so every gradient bit for bit, over two
+    steps with different scenes (the job table is rebuilt per call) and with drop_path on."""
+    from ao_amd import _lib
+
+    L = _lib.lib()
+    cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.3)
+    prev = L.ptv2_wgrad_defer_mode(-1)
+    res = {}
+    try:
+        for mode in (1, 0):
+            L.ptv2_wgrad_defer_mode(mode)
+            model = _model(cfg, seed=31)
+            torch.manual_seed(7)
+            steps = []
+            for seeds, pts in (([3, 4], points), ([5], points + 1500)):
+                data = _data(seeds, pts, cfg)
+                logits = model(data)
+                loss = F.cross_entropy(logits, data["segment"], ignore_index=-1)
+                grads = torch.autograd.grad(loss, list(model.parameters()))
+                steps.append((logits.detach().clone(), [g.clone() for g in grads]))
+            res[mode] = steps
+    finally:
+        L.ptv2_wgrad_defer_mode(prev)
+    names = [n for n, _ in model.named_parameters()]
+    for (la, ga), (lb, gb) in zip(res[1], res[0]):
+        assert torch.equal(la, lb)
+        for nm, a, b in zip(names, ga, gb):
+            assert torch.equal(a, b), (nm, float((a - b).abs().max()))
