@@ -310,10 +310,13 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     float *g_h3 = W.t[0], *g_hq = W.t[1], *g_hk = W.t[2], *gv = W.t[3], *g_h1 = W.t[4], *ta = W.t[5], *tb = W.t[6];
     // inside a model backward those five live in the deferral arena instead (the workspace is the next Block's too) and the
     // launch at the end of this function is filed, to run with every other Block's at the end of the backward (dense.hip)
-    float *kept = ptv2_wgrad_defer_active() ? ptv2_wgrad_defer_alloc(5 * (size_t)n * c) : nullptr;
+    // -- and so does g_attn, the gradient of the attention's output (norm2's backward writes it, the grouped projection's weight
+    // gradient reads it; tb, its place otherwise, is reused for g_f1 further down)
+    float *kept = ptv2_wgrad_defer_active() ? ptv2_wgrad_defer_alloc(6 * (size_t)n * c) : nullptr;
+    float *g_attn = tb;
     if (kept) {
         const size_t nc = (size_t)n * c;
-        g_h3 = kept; g_hq = kept + nc; g_hk = kept + 2 * nc; gv = kept + 3 * nc; g_h1 = kept + 4 * nc;
+        g_h3 = kept; g_hq = kept + nc; g_hk = kept + 2 * nc; gv = kept + 3 * nc; g_h1 = kept + 4 * nc; g_attn = kept + 5 * nc;
     }
 
     // tail: y = ReLU(x + rowscale * BN3(h3)) -> g_h3, residual gradient straight into gx
@@ -329,10 +332,10 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
         RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G],
                                          P[PTV2_BLK_N2_B], 1, W.stat[0], stream));
         RUN(bn_backward_records_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5],
-                                             tb, GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.stat[0], nrb, stream));
+                                             g_attn, GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.stat[0], nrb, stream));
     } else {
         RUN(rows_gemm_hip_launcher(n, c, c, g_h3, P[PTV2_BLK_FC3_W], 1, nullptr, ta, 0, stream));
-        RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], tb,
+        RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], g_attn,
                                      GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.dense, W.dense_bytes, stream));
     }
     // attention: gq (ta), gk (g_h1's buffer, free until the end of the chain), gv
@@ -340,13 +343,16 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     ptv2_gva_block V;
     fill_gva(B, S, &V);
     ptv2_gva_block_grads VG;
-    VG.g_out = tb; VG.inv_ptr = G->inv_ptr; VG.inv_rows = G->inv_rows;
+    VG.g_out = g_attn; VG.inv_ptr = G->inv_ptr; VG.inv_rows = G->inv_rows;
     VG.gq = gq; VG.gk = gk; VG.gv = gv;
     VG.gWp1 = GP(PTV2_BLK_P1_W); VG.gbp1 = GP(PTV2_BLK_P1_B); VG.ggamma_p = GP(PTV2_BLK_PN_G); VG.gbeta_p = GP(PTV2_BLK_PN_B);
     VG.gWp2 = GP(PTV2_BLK_P2_W); VG.gbp2 = GP(PTV2_BLK_P2_B); VG.gWw1 = GP(PTV2_BLK_W1_W); VG.gbw1 = GP(PTV2_BLK_W1_B);
     VG.ggamma_w = GP(PTV2_BLK_WN_G); VG.gbeta_w = GP(PTV2_BLK_WN_B); VG.gWw2 = GP(PTV2_BLK_W2_W); VG.gbw2 = GP(PTV2_BLK_W2_B);
     if (!G->inv_ptr) (void)ptv2_zero_async(gv, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
-    RUN(gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream));
+    ptv2_wgrad_defer_arm_rs(kept != nullptr);
+    const int grc = gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream);
+    ptv2_wgrad_defer_arm_rs(false);
+    RUN(grc);
     // linear_k / linear_q BatchNorm + ReLU
     if (batch[1] == batch[2]) {  // one reduce / finalize / apply for both
         const float *xs[2] = {S.hk, S.hq}, *gys[2] = {gk, gq}, *ms[2] = {S.mean[2], S.mean[1]}, *rs[2] = {S.rstd[2], S.rstd[1]};

@@ -1635,6 +1635,96 @@ int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy
     return PTV2_OK;
 }
 
+// ---- deferred weight-gradient launches (see WgradJob) ----------------------------------------------------------------------
+namespace {
+struct WgradDefer {
+    bool active = false;
+    bool armed = false;          // the call in progress may be filed (set by the call sites whose operands outlive their Block)
+    bool armed_rs = false;       // ... the row-scaled strided form (the grouped projection's weight gradient inside the attention)
+    char *arena = nullptr;       // [job table RS = 0 | job table RS = 1 | kept operands and chunk records]
+    size_t cap = 0, used = 0;
+    std::vector<WgradJob> jobs[2];  // filed since the last flush, per kernel form (RS = 0 / 1)
+    double bytes[2] = {0.0, 0.0};   // their algorithmic bytes (kernel timer)
+};
+thread_local WgradDefer g_wdefer;
+constexpr int WGRAD_MAX_JOBS = 64;
+constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) & ~(size_t)255;
+}  // namespace
+
+void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
+    WgradDefer &D = g_wdefer;
+    for (int f = 0; f < 2; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
+    D.armed = D.armed_rs = false;
+    D.active = arena != nullptr && bytes > 2 * WGRAD_TABLE_BYTES;
+    D.arena = (char *)arena;
+    D.cap = bytes;
+    D.used = 2 * WGRAD_TABLE_BYTES;
+}
+bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
+void ptv2_wgrad_defer_end() {
+    g_wdefer.active = g_wdefer.armed = g_wdefer.armed_rs = false;
+    g_wdefer.jobs[0].clear();
+    g_wdefer.jobs[1].clear();
+}
+void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
+void ptv2_wgrad_defer_arm_rs(bool on) { g_wdefer.armed_rs = on && g_wdefer.active; }
+size_t ptv2_wgrad_defer_table_bytes() { return 2 * WGRAD_TABLE_BYTES; }
+// a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
+float *ptv2_wgrad_defer_alloc(size_t floats) {
+    WgradDefer &D = g_wdefer;
+    const size_t bytes = (sizeof(float) * floats + 255) & ~(size_t)255;
+    if (!D.active || D.used + bytes > D.cap) return nullptr;
+    float *p = (float *)(D.arena + D.used);
+    D.used += bytes;
+    return p;
+}
+// runs the jobs filed so far: per kernel form the table writers, the batched kernel, the batched finalize
+int ptv2_wgrad_defer_flush(void *stream) {
+    WgradDefer &D = g_wdefer;
+    if (!D.active) return PTV2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool once = [] {
+        return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel_jobs<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)WL_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel_jobs<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)WL_LDS_BYTES) == hipSuccess;
+    }();
+    if (!once) return PTV2_ERR_LAUNCH;
+    for (int form = 0; form < 2; ++form) {
+        std::vector<WgradJob> &jobs = D.jobs[form];
+        if (jobs.empty()) continue;
+        WgradJob *table = (WgradJob *)(D.arena + (size_t)form * WGRAD_TABLE_BYTES);
+        const int njobs = (int)jobs.size();
+        int wgs = 0, fin = 0;
+        for (WgradJob &J : jobs) {
+            J.wg0 = wgs; J.fin0 = fin;
+            wgs += J.chunks * J.tiles * J.batch;
+            fin += J.rec;
+        }
+        for (int at = 0; at < njobs; at += WGRAD_PACK) {
+            WgradJobPack pack;
+            const int cnt = std::min(WGRAD_PACK, njobs - at);
+            for (int i = 0; i < WGRAD_PACK; ++i) pack.j[i] = jobs[(size_t)std::min(at + i, njobs - 1)];
+            hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
+        }
+        {
+            PtvScopedTimer t(KID_WGRAD_LDS, st, D.bytes[form]);
+            if (form == 0)
+                hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
+                                   (const WgradJob *)table, njobs);
+            else
+                hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<1>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
+                                   (const WgradJob *)table, njobs);
+        }
+        hipLaunchKernelGGL(wgrad_jobs_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st,
+                           (const WgradJob *)table, njobs, fin);
+        jobs.clear();
+        D.bytes[form] = 0.0;
+    }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 // internal (gva_block.hip): rowscale != NULL asks for db[b][o] = sum_n gY[n, b, o] * rowscale[n * lds_s + b] instead of the plain
 // column sums.  Only the LDS-staged fp32 kernel forms them: *weighted says whether it did (1) or whether the caller has to
 // compute db itself (0: db is then not written at all).
@@ -1672,6 +1762,21 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
         const bool rs = rowscale && db && use_lds;
         if (rowscale && !rs) db = nullptr;  // (the caller forms the weighted sums itself)
         if (rs && weighted) *weighted = 1;
+        if (rs && g_wdefer.active && g_wdefer.armed_rs && (int)g_wdefer.jobs[1].size() < WGRAD_MAX_JOBS) {
+            // inside a model backward (the caller keeps gY alive until its end): filed, run with the other Blocks' (WgradJob)
+            const size_t rec = (size_t)batch * ((size_t)cout * cin + cout);
+            float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
+            if (keep) {
+                WgradJob J{};
+                J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = batch;
+                J.chunk = chunk; J.chunks = chunks; J.has_pb = 1; J.count = 0; J.rec = (int)rec;
+                J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx; J.lds_s = lds_s;
+                J.gY = gY; J.X = X; J.rowscale = rowscale; J.part = keep; J.dW = dW; J.db = db;
+                g_wdefer.jobs[1].push_back(J);
+                g_wdefer.bytes[1] += 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + cout + (double)n);
+                return PTV2_OK;
+            }
+        }
         PtvScopedTimer t(use_lds ? KID_WGRAD_LDS : KID_WGRAD, st,
                          4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0) + (rs ? (double)n : 0.0)));
         if (ptv2_matmul_bf16())
@@ -1734,81 +1839,6 @@ template <> struct RiderOf<MapWgradMulti> {
 };
 }  // namespace gva
 
-// ---- deferred weight-gradient launches (see WgradJob) ----------------------------------------------------------------------
-namespace {
-struct WgradDefer {
-    bool active = false;
-    bool armed = false;          // the call in progress may be filed (set by the call sites whose operands outlive their Block)
-    char *arena = nullptr;       // [job tables | kept operands and chunk records]
-    size_t cap = 0, used = 0;
-    std::vector<WgradJob> jobs;  // filed since the last flush (RS = 0 form)
-    double bytes = 0.0;          // their algorithmic bytes (kernel timer)
-};
-thread_local WgradDefer g_wdefer;
-constexpr int WGRAD_MAX_JOBS = 64;
-constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) & ~(size_t)255;
-}  // namespace
-
-void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
-    WgradDefer &D = g_wdefer;
-    D.jobs.clear();
-    D.bytes = 0.0;
-    D.armed = false;
-    D.active = arena != nullptr && bytes > WGRAD_TABLE_BYTES;
-    D.arena = (char *)arena;
-    D.cap = bytes;
-    D.used = WGRAD_TABLE_BYTES;
-}
-bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
-void ptv2_wgrad_defer_end() { g_wdefer.active = false; g_wdefer.armed = false; g_wdefer.jobs.clear(); }
-void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
-size_t ptv2_wgrad_defer_table_bytes() { return WGRAD_TABLE_BYTES; }
-// a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
-float *ptv2_wgrad_defer_alloc(size_t floats) {
-    WgradDefer &D = g_wdefer;
-    const size_t bytes = (sizeof(float) * floats + 255) & ~(size_t)255;
-    if (!D.active || D.used + bytes > D.cap) return nullptr;
-    float *p = (float *)(D.arena + D.used);
-    D.used += bytes;
-    return p;
-}
-// runs the jobs filed so far: table writers, the batched kernel, the batched finalize
-int ptv2_wgrad_defer_flush(void *stream) {
-    WgradDefer &D = g_wdefer;
-    if (!D.active || D.jobs.empty()) return PTV2_OK;
-    hipStream_t st = (hipStream_t)stream;
-    WgradJob *table = (WgradJob *)D.arena;
-    const int njobs = (int)D.jobs.size();
-    int wgs = 0, fin = 0;
-    for (WgradJob &J : D.jobs) {
-        J.wg0 = wgs; J.fin0 = fin;
-        wgs += J.chunks * J.tiles * J.batch;
-        fin += J.rec;
-    }
-    for (int at = 0; at < njobs; at += WGRAD_PACK) {
-        WgradJobPack pack;
-        const int cnt = std::min(WGRAD_PACK, njobs - at);
-        for (int i = 0; i < WGRAD_PACK; ++i) pack.j[i] = D.jobs[(size_t)std::min(at + i, njobs - 1)];
-        hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
-    }
-    static const bool once = [] {
-        return hipFuncSetAttribute((const void *)linear_wgrad_lds_kernel_jobs<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)WL_LDS_BYTES) == hipSuccess;
-    }();
-    if (!once) return PTV2_ERR_LAUNCH;
-    {
-        PtvScopedTimer t(KID_WGRAD_LDS, st, D.bytes);
-        hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st, (const WgradJob *)table,
-                           njobs);
-    }
-    hipLaunchKernelGGL(wgrad_jobs_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st, (const WgradJob *)table,
-                       njobs, fin);
-    D.jobs.clear();
-    D.bytes = 0.0;
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-
 // count (<= 6) products dW[i] (cout,cin) = gY[i]^T X[i], db[i] = column sums of gY[i] (db[i] may be NULL), all of one
 // shape and row count, in one launch + one finalize (workspace: dense_workspace_bytes(n, count * cout, cin))
 extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int count, const float *const *gY,
@@ -1844,7 +1874,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         bool lds_ok = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin);
         for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
         const double algo_bytes = 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin + (double)count * cout * (cin + 1));
-        if (lds_ok && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs.size() < WGRAD_MAX_JOBS) {
+        if (lds_ok && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs[0].size() < WGRAD_MAX_JOBS) {
             // inside a model backward: filed, and run with all the others by ONE launch at the end (WgradJob); the records go
             // to the arena (the caller's workspace is reused before that launch)
             float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
@@ -1857,8 +1887,8 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                     J.mgY[i] = m.gY[i]; J.mX[i] = m.X[i]; J.mxsc[i] = m.xsc[i]; J.mxsh[i] = m.xsh[i];
                     J.mdW[i] = m.dW[i]; J.mdb[i] = m.db[i];
                 }
-                g_wdefer.jobs.push_back(J);
-                g_wdefer.bytes += algo_bytes;
+                g_wdefer.jobs[0].push_back(J);
+                g_wdefer.bytes[0] += algo_bytes;
                 return PTV2_OK;
             }
         }

@@ -282,13 +282,14 @@ Work carve_work(const ptv2_model *M, void *base) {
         for (int j = 0; j < s.depth; ++j)
             W.fold_scratch[s.first_block + j] = (float *)take(sizeof(float) * ptv2_gva_fold_scratch_floats(s.c, s.g));
     }
-    // per Block: its five (n, c) gradient operands + the records of the five-product weight gradient
+    // per Block: six (n, c) gradient operands + the records of the five-product and of the grouped-projection weight gradient
     W.wdefer_bytes = ptv2_wgrad_defer_table_bytes();
     for (int q = 0; q <= 2 * S; ++q) {
         const ptv2_seq &s = M->seq[q];
         const int n = M->level[s.level].n;
         for (int j = 0; j < s.depth; ++j)
-            W.wdefer_bytes += al(sizeof(float) * 5 * (size_t)n * s.c) + al(dense_workspace_bytes(n, 5 * s.c, s.c)) + 512;
+            W.wdefer_bytes += al(sizeof(float) * 6 * (size_t)n * s.c) + al(dense_workspace_bytes(n, 5 * s.c, s.c)) +
+                              al(dense_workspace_bytes(n, s.c, s.c)) + 1024;
     }
     W.wdefer = take(W.wdefer_bytes);
     W.bytes = off;
