@@ -57,6 +57,7 @@ bool ptv2_wgrad_defer_active();
 float *ptv2_wgrad_defer_alloc(size_t floats);             // NULL: not deferring, or no room (the caller launches at once)
 void ptv2_wgrad_defer_arm(bool on);                       // the next weight-gradient call may be filed (its operands are kept)
 void ptv2_wgrad_defer_arm_rs(bool on);                    // ... the row-scaled strided form inside the attention backward
+bool ptv2_wgrad_defer_armed_rs();
 int ptv2_wgrad_defer_flush(void *stream);                 // run what has been filed
 void ptv2_wgrad_defer_end();
 size_t ptv2_wgrad_defer_table_bytes();

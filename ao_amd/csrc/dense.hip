@@ -1668,6 +1668,7 @@ void ptv2_wgrad_defer_end() {
 }
 void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
 void ptv2_wgrad_defer_arm_rs(bool on) { g_wdefer.armed_rs = on && g_wdefer.active; }
+bool ptv2_wgrad_defer_armed_rs() { return g_wdefer.active && g_wdefer.armed_rs; }
 size_t ptv2_wgrad_defer_table_bytes() { return 2 * WGRAD_TABLE_BYTES; }
 // a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
 float *ptv2_wgrad_defer_alloc(size_t floats) {
@@ -1762,6 +1763,21 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
         const bool rs = rowscale && db && use_lds;
         if (rowscale && !rs) db = nullptr;  // (the caller forms the weighted sums itself)
         if (rs && weighted) *weighted = 1;
+        if (!rowscale && use_lds && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs[0].size() < WGRAD_MAX_JOBS) {
+            // (the plain strided form, armed by a caller that keeps gY alive: the Linear + BatchNorm layers between the stages)
+            const size_t rec = (size_t)batch * ((size_t)cout * cin + (db ? cout : 0));
+            float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
+            if (keep) {
+                WgradJob J{};
+                J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = batch;
+                J.chunk = chunk; J.chunks = chunks; J.has_pb = db ? 1 : 0; J.count = 0; J.rec = (int)rec;
+                J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx;
+                J.gY = gY; J.X = X; J.part = keep; J.dW = dW; J.db = db;
+                g_wdefer.jobs[0].push_back(J);
+                g_wdefer.bytes[0] += 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0));
+                return PTV2_OK;
+            }
+        }
         if (rs && g_wdefer.active && g_wdefer.armed_rs && (int)g_wdefer.jobs[1].size() < WGRAD_MAX_JOBS) {
             // inside a model backward (the caller keeps gY alive until its end): filed, run with the other Blocks' (WgradJob)
             const size_t rec = (size_t)batch * ((size_t)cout * cin + cout);

@@ -501,6 +501,13 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         W.ga2 = p; p += 3 * (size_t)c;
         W.gb2 = p;
     }
+    // inside a model backward that defers weight gradients (dense.hip: WgradJob; the caller kept g_out): gkW / gqW, the operands
+    // of the kW / qW weight gradient, go to the deferral arena too (its results already live in the per-Block glue region)
+    bool kq_kept = false;
+    if (g_fold_scratch && ptv2_wgrad_defer_armed_rs()) {
+        float *a = ptv2_wgrad_defer_alloc((size_t)n * g), *b2 = a ? ptv2_wgrad_defer_alloc((size_t)n * g) : nullptr;
+        if (a && b2) { W.gkW = a; W.gqW = b2; kq_kept = true; }
+    }
     hipStream_t st = (hipStream_t)stream;
     const double rows = (double)n * k;
     const int I = c / g;
@@ -554,7 +561,10 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         const float *gys[2] = {W.gkW, W.gqW}, *xs[2] = {B->key, B->q};
         float *dws[2] = {W.gWw1_k, W.gWw1_q};
         const float *xsc[2] = {B->k_sc, B->q_sc}, *xsh[2] = {B->k_sh, B->q_sh};
-        RUN(linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.kq_part, W.kq_bytes, stream));
+        ptv2_wgrad_defer_arm(kq_kept);
+        const int krc = linear_wgrad_multi_hip_launcher(n, g, c, 2, gys, xs, dws, nullptr, xsc, xsh, W.kq_part, W.kq_bytes, stream);
+        ptv2_wgrad_defer_arm(false);
+        RUN(krc);
     }
     }
     {

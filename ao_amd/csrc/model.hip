@@ -289,7 +289,20 @@ Work carve_work(const ptv2_model *M, void *base) {
         const int n = M->level[s.level].n;
         for (int j = 0; j < s.depth; ++j)
             W.wdefer_bytes += al(sizeof(float) * 6 * (size_t)n * s.c) + al(dense_workspace_bytes(n, 5 * s.c, s.c)) +
-                              al(dense_workspace_bytes(n, s.c, s.c)) + 1024;
+                              al(dense_workspace_bytes(n, s.c, s.c)) + 2 * al(sizeof(float) * (size_t)n * s.g) +
+                              al(dense_workspace_bytes(n, 2 * s.g, s.c)) + 2048;
+    }
+    {   // the Linear + BatchNorm layers between the stages: gh (n, cout) + records
+        auto layer = [&](const ptv2_linbn &L, int n) {
+            W.wdefer_bytes += al(sizeof(float) * (size_t)n * L.cout) + al(dense_workspace_bytes(n, L.cout, L.cin)) + 512;
+        };
+        layer(M->embed, M->level[0].n);
+        layer(M->head, M->level[0].n);
+        for (int i = 0; i < S; ++i) {
+            layer(M->down[i], M->level[i].n);
+            layer(M->up[i], M->level[i + 1].n);
+            layer(M->up_skip[i], M->level[i].n);
+        }
     }
     W.wdefer = take(W.wdefer_bytes);
     W.bytes = off;
@@ -344,13 +357,19 @@ int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S,
 // `accumulate`; gx == NULL: the input needs no gradient (the patch embedding)
 int linbn_backward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S, int n, const float *x, const float *gy, float *gh,
                    float *gx, int accumulate, const Work &W, void *stream) {
+    // (weight gradients deferred, dense.hip: gh, the operand of this layer's, lives in the deferral arena until the backward ends)
+    float *kept = ptv2_wgrad_defer_active() ? ptv2_wgrad_defer_alloc((size_t)n * L.cout) : nullptr;
+    if (kept) gh = kept;
     RUN(bn_backward_hip_launcher(n, L.cout, S.h, gy, S.mean, S.rstd, L.gamma, L.beta, 1, use_batch(M, L) ? 1 : 0, gh, L.ggamma,
                                  L.gbeta, W.dense, W.dense_bytes, stream));
     if (gx) {
         if (L.cin % 4 != 0 || L.cout % 4 != 0) return PTV2_ERR_ARG;
         RUN(rows_gemm_hip_launcher(n, L.cin, L.cout, gh, L.w, 1, nullptr, gx, accumulate, stream));
     }
-    return linear_wgrad_hip_launcher(n, L.cout, L.cin, gh, x, L.gw, L.b ? L.gb : nullptr, W.dense, W.dense_bytes, stream);
+    ptv2_wgrad_defer_arm(kept != nullptr);
+    const int rc = linear_wgrad_hip_launcher(n, L.cout, L.cin, gh, x, L.gw, L.b ? L.gb : nullptr, W.dense, W.dense_bytes, stream);
+    ptv2_wgrad_defer_arm(false);
+    return rc;
 }
 
 void fill_block(const ptv2_model *M, int q, int j, const Arena &A, const float *x, ptv2_block *B) {
