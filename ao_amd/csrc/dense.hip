@@ -682,19 +682,18 @@ struct WgradMulti {
 
 // BF16: the U = 8 k-steps of a trip (8 rows per lane and fragment) are exactly the 8-per-lane operand of
 // V_MFMA_F32_16X16X32_BF16: 8 fp32 MFMAs per tile pair become one instruction on bf16-rounded operands.
+// (a function of the workgroup's coordinates, like wgrad_lds_tile below: the per-call kernel and the batched kernel share it)
 template <bool BF16>
-__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
-                                                           const float *__restrict__ gY, long long ldy, long long sy,
-                                                           const float *__restrict__ X, long long ldx, long long sx,
-                                                           float *__restrict__ part, float *__restrict__ part_b,
-                                                           int batch, WgradMulti multi, int chunk) {
+__device__ __forceinline__ void wgrad_direct_tile(const int n, const int cout, const int cin, const int tiles_i,
+                                                  const float *__restrict__ A, const long long ldy,
+                                                  const float *__restrict__ B, const long long ldx, float *__restrict__ part,
+                                                  const bool part_b, const int batch, const float *__restrict__ xs,
+                                                  const float *__restrict__ xh, const int chunk, const int bx, const int by,
+                                                  const int bz) {
     __shared__ float sRed[TPB / WAVE][WG_MT * WG_MT * 4 + WG_MT][WAVE + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int bz = blockIdx.z;
-    const int to = (blockIdx.y / tiles_i) * WG_TILE, ti = (blockIdx.y % tiles_i) * WG_TILE;
-    const float *A = multi.count ? multi.gY[bz] : gY + (long long)bz * sy;
-    const float *B = multi.count ? multi.X[bz] : X + (long long)bz * sx;
-    const long long r0 = (long long)blockIdx.x * chunk;
+    const int to = (by / tiles_i) * WG_TILE, ti = (by % tiles_i) * WG_TILE;
+    const long long r0 = (long long)bx * chunk;
     const long long r1 = (r0 + chunk) < (long long)n ? (r0 + chunk) : (long long)n;
     const int lr = lane >> 4, lc = lane & 15;
     f32x4 acc[WG_MT][WG_MT];
@@ -709,7 +708,6 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
     // 12-byte load and a row is read as 192 contiguous bytes -- 16 instead of 48 vector-memory instructions per trip: slower at
     // every shape, 34 -> 38 us at 4.5 k x 192 x 5 products, 58 -> 71 us at 120 k x 48 x 5; three 64-byte segments stay)
     bool mo[WG_MT], mi[WG_MT];
-    const float *xs = multi.count ? multi.xsc[bz] : nullptr, *xh = multi.count ? multi.xsh[bz] : nullptr;
     float xsc_[WG_MT], xsh_[WG_MT];
 #pragma unroll
     for (int m = 0; m < WG_MT; ++m) {
@@ -781,7 +779,7 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
     }
     __syncthreads();
     const size_t rec = (size_t)batch * cout * cin + (part_b ? (size_t)batch * cout : 0);
-    float *p = part + (size_t)blockIdx.x * rec + (size_t)bz * cout * cin;
+    float *p = part + (size_t)bx * rec + (size_t)bz * cout * cin;
     for (int e = threadIdx.x; e < WG_MT * WG_MT * 4 * WAVE; e += TPB) {
         const int q = e / WAVE, l = e - q * WAVE;
         const int mt = q / 4, r = q - mt * 4, m = mt / WG_MT, t = mt - m * WG_MT;
@@ -799,9 +797,22 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int 
             float v = 0.f;
 #pragma unroll
             for (int wv = 0; wv < TPB / WAVE; ++wv) v += sRed[wv][WG_MT * WG_MT * 4 + m][l];
-            part[(size_t)blockIdx.x * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
+            part[(size_t)bx * rec + (size_t)batch * cout * cin + (size_t)bz * cout + o] = v;
         }
     }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(int n, int cout, int cin, int tiles_i,
+                                                           const float *__restrict__ gY, long long ldy, long long sy,
+                                                           const float *__restrict__ X, long long ldx, long long sx,
+                                                           float *__restrict__ part, float *__restrict__ part_b,
+                                                           int batch, WgradMulti multi, int chunk) {
+    const int bz = blockIdx.z;
+    wgrad_direct_tile<BF16>(n, cout, cin, tiles_i, multi.count ? multi.gY[bz] : gY + (long long)bz * sy, ldy,
+                            multi.count ? multi.X[bz] : X + (long long)bz * sx, ldx, part, part_b != nullptr, batch,
+                            multi.count ? multi.xsc[bz] : nullptr, multi.count ? multi.xsh[bz] : nullptr, chunk,
+                            (int)blockIdx.x, (int)blockIdx.y, bz);
 }
 
 // ---- the same reduction with the operands staged through LDS (fp32 matrix cores) ---------------------------------------
@@ -1006,6 +1017,19 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel_jobs(const WgradJ
     wgrad_lds_tile<RS>(J.n, J.cout, J.cin, J.tiles_i, multi ? J.mgY[bz] : J.gY + (long long)bz * J.sy, J.ldy,
                        multi ? J.mX[bz] : J.X + (long long)bz * J.sx, J.ldx, J.part, J.has_pb != 0, J.batch,
                        multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, J.rowscale, J.lds_s, bx, by, bz);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel_jobs(const WgradJob *__restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].wg0) ++j;
+    const WgradJob &J = jobs[j];
+    const int local = (int)blockIdx.x - J.wg0;
+    const int bx = local % J.chunks, rest = local / J.chunks, by = rest % J.tiles, bz = rest / J.tiles;
+    const bool multi = J.count > 0;
+    wgrad_direct_tile<BF16>(J.n, J.cout, J.cin, J.tiles_i, multi ? J.mgY[bz] : J.gY + (long long)bz * J.sy, J.ldy,
+                            multi ? J.mX[bz] : J.X + (long long)bz * J.sx, J.ldx, J.part, J.has_pb != 0, J.batch,
+                            multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, bx, by, bz);
 }
 
 // element e of the concatenated outputs of all jobs: the sum of its job's chunk records (double, four chains, as
@@ -1643,8 +1667,8 @@ struct WgradDefer {
     bool armed_rs = false;       // ... the row-scaled strided form (the grouped projection's weight gradient inside the attention)
     char *arena = nullptr;       // [job table RS = 0 | job table RS = 1 | kept operands and chunk records]
     size_t cap = 0, used = 0;
-    std::vector<WgradJob> jobs[2];  // filed since the last flush, per kernel form (RS = 0 / 1)
-    double bytes[2] = {0.0, 0.0};   // their algorithmic bytes (kernel timer)
+    std::vector<WgradJob> jobs[4];  // filed since the last flush, per kernel form: LDS-staged (RS = 0 / 1), direct fp32, direct bf16
+    double bytes[4] = {0.0, 0.0, 0.0, 0.0};  // their algorithmic bytes (kernel timer)
 };
 thread_local WgradDefer g_wdefer;
 constexpr int WGRAD_MAX_JOBS = 64;
@@ -1653,23 +1677,22 @@ constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) &
 
 void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
     WgradDefer &D = g_wdefer;
-    for (int f = 0; f < 2; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
+    for (int f = 0; f < 4; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
     D.armed = D.armed_rs = false;
-    D.active = arena != nullptr && bytes > 2 * WGRAD_TABLE_BYTES;
+    D.active = arena != nullptr && bytes > 4 * WGRAD_TABLE_BYTES;
     D.arena = (char *)arena;
     D.cap = bytes;
-    D.used = 2 * WGRAD_TABLE_BYTES;
+    D.used = 4 * WGRAD_TABLE_BYTES;
 }
 bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
 void ptv2_wgrad_defer_end() {
     g_wdefer.active = g_wdefer.armed = g_wdefer.armed_rs = false;
-    g_wdefer.jobs[0].clear();
-    g_wdefer.jobs[1].clear();
+    for (auto &j : g_wdefer.jobs) j.clear();
 }
 void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
 void ptv2_wgrad_defer_arm_rs(bool on) { g_wdefer.armed_rs = on && g_wdefer.active; }
 bool ptv2_wgrad_defer_armed_rs() { return g_wdefer.active && g_wdefer.armed_rs; }
-size_t ptv2_wgrad_defer_table_bytes() { return 2 * WGRAD_TABLE_BYTES; }
+size_t ptv2_wgrad_defer_table_bytes() { return 4 * WGRAD_TABLE_BYTES; }
 // a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
 float *ptv2_wgrad_defer_alloc(size_t floats) {
     WgradDefer &D = g_wdefer;
@@ -1691,7 +1714,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
                                    (int)WL_LDS_BYTES) == hipSuccess;
     }();
     if (!once) return PTV2_ERR_LAUNCH;
-    for (int form = 0; form < 2; ++form) {
+    for (int form = 0; form < 4; ++form) {
         std::vector<WgradJob> &jobs = D.jobs[form];
         if (jobs.empty()) continue;
         WgradJob *table = (WgradJob *)(D.arena + (size_t)form * WGRAD_TABLE_BYTES);
@@ -1709,13 +1732,19 @@ int ptv2_wgrad_defer_flush(void *stream) {
             hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
         }
         {
-            PtvScopedTimer t(KID_WGRAD_LDS, st, D.bytes[form]);
+            PtvScopedTimer t(form < 2 ? KID_WGRAD_LDS : KID_WGRAD, st, D.bytes[form]);
             if (form == 0)
                 hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
                                    (const WgradJob *)table, njobs);
-            else
+            else if (form == 1)
                 hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<1>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
                                    (const WgradJob *)table, njobs);
+            else if (form == 2)
+                hipLaunchKernelGGL(linear_wgrad_kernel_jobs<false>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
+                                   njobs);
+            else
+                hipLaunchKernelGGL(linear_wgrad_kernel_jobs<true>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
+                                   njobs);
         }
         hipLaunchKernelGGL(wgrad_jobs_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st,
                            (const WgradJob *)table, njobs, fin);
@@ -1763,7 +1792,11 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
         const bool rs = rowscale && db && use_lds;
         if (rowscale && !rs) db = nullptr;  // (the caller forms the weighted sums itself)
         if (rs && weighted) *weighted = 1;
-        if (!rowscale && use_lds && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs[0].size() < WGRAD_MAX_JOBS) {
+        const int form = ptv2_matmul_bf16() ? 3 : (use_lds ? 0 : 2);
+        // (also the row-scaled call whose weighted bias sums this path cannot form -- bf16 operands: the caller computes them
+        // itself and has kept gY for the deferral)
+        const bool plain = (!rowscale && g_wdefer.armed) || (rowscale && !rs && g_wdefer.armed_rs);
+        if (plain && g_wdefer.active && (int)g_wdefer.jobs[form].size() < WGRAD_MAX_JOBS) {
             // (the plain strided form, armed by a caller that keeps gY alive: the Linear + BatchNorm layers between the stages)
             const size_t rec = (size_t)batch * ((size_t)cout * cin + (db ? cout : 0));
             float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
@@ -1773,8 +1806,8 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
                 J.chunk = chunk; J.chunks = chunks; J.has_pb = db ? 1 : 0; J.count = 0; J.rec = (int)rec;
                 J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx;
                 J.gY = gY; J.X = X; J.part = keep; J.dW = dW; J.db = db;
-                g_wdefer.jobs[0].push_back(J);
-                g_wdefer.bytes[0] += 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0));
+                g_wdefer.jobs[form].push_back(J);
+                g_wdefer.bytes[form] += 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + (db ? cout : 0));
                 return PTV2_OK;
             }
         }
@@ -1890,7 +1923,8 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
         bool lds_ok = !ptv2_matmul_bf16() && wgrad_lds_shape_ok(cout, cin);
         for (int i = 0; i < count && lds_ok; ++i) lds_ok = wgrad_lds_ok(m.gY[i], cout, 0, m.X[i], cin, 0);
         const double algo_bytes = 4.0 * ((double)count * n * cout + (double)distinct_x * n * cin + (double)count * cout * (cin + 1));
-        if (lds_ok && g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs[0].size() < WGRAD_MAX_JOBS) {
+        const int form = ptv2_matmul_bf16() ? 3 : (lds_ok ? 0 : 2);
+        if (g_wdefer.active && g_wdefer.armed && (int)g_wdefer.jobs[form].size() < WGRAD_MAX_JOBS) {
             // inside a model backward: filed, and run with all the others by ONE launch at the end (WgradJob); the records go
             // to the arena (the caller's workspace is reused before that launch)
             float *keep = ptv2_wgrad_defer_alloc((size_t)chunks * rec);
@@ -1903,8 +1937,8 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                     J.mgY[i] = m.gY[i]; J.mX[i] = m.X[i]; J.mxsc[i] = m.xsc[i]; J.mxsh[i] = m.xsh[i];
                     J.mdW[i] = m.dW[i]; J.mdb[i] = m.db[i];
                 }
-                g_wdefer.jobs[0].push_back(J);
-                g_wdefer.bytes[0] += algo_bytes;
+                g_wdefer.jobs[form].push_back(J);
+                g_wdefer.bytes[form] += algo_bytes;
                 return PTV2_OK;
             }
         }

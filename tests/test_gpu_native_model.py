@@ -286,8 +286,8 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
     assert saved[True] < 0.45 * saved[False], saved
 
 
-@pytest.mark.parametrize("tag,points", [("s3dis", 9000), ("scannet", 7000)])
-def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points):
+@pytest.mark.parametrize("tag,points,bf16", [("s3dis", 9000, False), ("scannet", 7000, False), ("s3dis", 9000, True)])
+def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points, bf16):
     """ptv2_wgrad_defer_mode: the Blocks' weight gradients filed and run by ONE launch at the end of the backward (default)
     against every launch where it is called -- the same chunking and summation order, so every gradient bit for bit, over two
     steps with different scenes (the job table is rebuilt per call) and with drop_path on."""
@@ -305,8 +305,9 @@ def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points):
             steps = []
             for seeds, pts in (([3, 4], points), ([5], points + 1500)):
                 data = _data(seeds, pts, cfg)
-                logits = model(data)
-                loss = F.cross_entropy(logits, data["segment"], ignore_index=-1)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):  # (bf16: the direct-form kernels' jobs)
+                    logits = model(data)
+                    loss = F.cross_entropy(logits.float(), data["segment"], ignore_index=-1)
                 grads = torch.autograd.grad(loss, list(model.parameters()))
                 steps.append((logits.detach().clone(), [g.clone() for g in grads]))
             res[mode] = steps
