@@ -128,7 +128,8 @@ def pmc_traffic(kernel, build_info):
                 if name == "_build":
                     continue
                 short = name.split("::")[-1]
-                if short == kernel or (short.split("<")[0] == base and "<" not in kernel):
+                # (the batched form of a weight-gradient kernel, `<name>_jobs`, is timed under the kernel's name)
+                if short == kernel or (short.split("<")[0] in (base, base + "_jobs") and "<" not in kernel):
                     hits.append((short, v))
         if hits:
             launches = sum(v["launches"] for _, v in hits)
