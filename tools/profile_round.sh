@@ -24,7 +24,7 @@ python tools/trace_gaps.py "$O/trace" > "$O/trace_gaps.txt" 2>&1
 python tools/trace_grids.py "$O/trace" 25 > "$O/trace_grids.txt" 2>&1
 python tools/trace_step.py "$O/trace" 12 > "$O/step_sequence.txt" 2>&1
 # one S2 Block's backward (192 channels): the launches around the 4th-from-last attention_bwd_point_kernel<24, 192, 2> of a step
-python tools/trace_block.py "$O/trace" "attention_bwd_point_kernel<24, 192, 2" 60 13 9 > "$O/blockS2.txt" 2>&1
+python tools/trace_block.py "$O/trace" "attention_bwd_point_kernel<24, 192, 2" 60 7 12 > "$O/blockS2.txt" 2>&1
 rm -rf "$O/trace"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f" -- $B --steps 5 --warmup 2 > "$O/pmc_f.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w" -- $B --steps 5 --warmup 2 > "$O/pmc_w.log" 2>&1
