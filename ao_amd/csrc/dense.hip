@@ -994,6 +994,8 @@ struct WgradJob {
     int wg0;          // first workgroup of the job in the batched launch
     int has_pb, count;  // bias sums behind the weight records; > 0: the multi form (operand pairs per product)
     int rec, fin0;    // floats per chunk record; first element of the job in the batched finalize
+    int wgs, gw;      // workgroups of the job; (grouped form) groups per workgroup
+    int fin_lanes;    // threads per output element in the batched finalize (1 or 16)
     long long ldy, sy, ldx, sx, lds_s;
     const float *gY, *X, *rowscale;
     float *part;
@@ -1002,6 +1004,7 @@ struct WgradJob {
 };
 constexpr int WGRAD_PACK = 8;  // jobs per table-writer launch (by value: the kernarg block holds 4 KB)
 struct WgradJobPack { WgradJob j[WGRAD_PACK]; };
+static_assert(sizeof(WgradJobPack) + 16 <= 4096, "the table writer's argument block must fit the 4 KB kernarg segment");
 __global__ void wgrad_jobs_write_kernel(WgradJobPack pack, int count, WgradJob *table) {
     if ((int)threadIdx.x < count) table[threadIdx.x] = pack.j[threadIdx.x];
 }
@@ -1019,6 +1022,118 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel_jobs(const WgradJ
                        multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, J.rowscale, J.lds_s, bx, by, bz);
 }
 
+// ---- the grouped projection's weight gradient on the vector ALUs ---------------------------------------------------------------
+// dWp2[g][i][:] = sum_n g_out[n, 8 g + i] A[n, g, :] and db[g][i] = sum_n g_out[n, 8 g + i] sw[n, g] (eight output rows per group:
+// c / g = 8 in every PT-v2m2 configuration).  As a strided batch of (8, c) products on the matrix cores (linear_wgrad_lds_kernel
+// <1>) every workgroup streamed a 48-column piece of ONE group's rows of A -- 192 bytes every g c 4 = 18 KB -- and five sixths of
+// its 48 x 48 tile were padding: 2.5 TB/s over the 1.27 GB of A a step reads.  Here a workgroup takes a row chunk and a block
+// of `gw` consecutive groups, i.e. a contiguous gw c 4-byte piece of every row of A (3-4 KB), one float4 of it per thread and
+// row, eight float4 accumulators per thread; the row slots of the workgroup are added through LDS in slot order and the result
+// is one chunk record of the strided form's layout ([g][8][c] weights, then [g][8] bias sums): same finalize.
+constexpr int GRP_I = 8;
+__device__ __forceinline__ void grouped_wgrad_tile(const int n, const int c, const int g, const int gw, const int chunk,
+                                                   const float *__restrict__ gY, const float *__restrict__ X,
+                                                   const float *__restrict__ sw, float *__restrict__ part, const int rec,
+                                                   const int bx, const int bg) {
+    extern __shared__ float4 grp_lds4[];
+    const int q = c >> 2, units = gw * q, R = max(1, TPB / units);
+    const int tid = threadIdx.x, rs = tid / units, u = tid - rs * units;
+    const bool active = rs < R;
+    const int gl = u / q, qi = u - gl * q, grp = bg * gw + gl;
+    const bool live = active && grp < g;
+    float4 acc[GRP_I];
+    float bacc[GRP_I];
+#pragma unroll
+    for (int i = 0; i < GRP_I; ++i) { acc[i] = make_float4(0.f, 0.f, 0.f, 0.f); bacc[i] = 0.f; }
+    const long long r0 = (long long)bx * chunk, r1 = (r0 + chunk) < (long long)n ? (r0 + chunk) : (long long)n;
+    if (live) {
+        const float *xa = X + (size_t)grp * c + 4 * qi;  // + r * g * c
+        const float *ya = gY + (size_t)grp * GRP_I;       // + r * c
+        const float *sa = sw + grp;                       // + r * g
+        const size_t xs = (size_t)g * c;
+        constexpr int U = 4;  // rows in flight per thread
+        long long r = r0 + rs;
+        for (; r + (long long)(U - 1) * R < r1; r += (long long)U * R) {
+            float4 a[U], y0[U], y1[U];
+            float s[U];
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const size_t rr = (size_t)(r + (long long)t * R);
+                a[t] = *(const float4 *)(xa + rr * xs);
+                y0[t] = *(const float4 *)(ya + rr * c);
+                y1[t] = *(const float4 *)(ya + rr * c + 4);
+                s[t] = qi == 0 ? sa[rr * g] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const float y[GRP_I] = {y0[t].x, y0[t].y, y0[t].z, y0[t].w, y1[t].x, y1[t].y, y1[t].z, y1[t].w};
+#pragma unroll
+                for (int i = 0; i < GRP_I; ++i) {
+                    acc[i].x = __builtin_fmaf(y[i], a[t].x, acc[i].x); acc[i].y = __builtin_fmaf(y[i], a[t].y, acc[i].y);
+                    acc[i].z = __builtin_fmaf(y[i], a[t].z, acc[i].z); acc[i].w = __builtin_fmaf(y[i], a[t].w, acc[i].w);
+                    bacc[i] = __builtin_fmaf(y[i], s[t], bacc[i]);
+                }
+            }
+        }
+        for (; r < r1; r += R) {
+            const size_t rr = (size_t)r;
+            const float4 a = *(const float4 *)(xa + rr * xs), y0 = *(const float4 *)(ya + rr * c), y1 = *(const float4 *)(ya + rr * c + 4);
+            const float sv = qi == 0 ? sa[rr * g] : 0.f;
+            const float y[GRP_I] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int i = 0; i < GRP_I; ++i) {
+                acc[i].x = __builtin_fmaf(y[i], a.x, acc[i].x); acc[i].y = __builtin_fmaf(y[i], a.y, acc[i].y);
+                acc[i].z = __builtin_fmaf(y[i], a.z, acc[i].z); acc[i].w = __builtin_fmaf(y[i], a.w, acc[i].w);
+                bacc[i] = __builtin_fmaf(y[i], sv, bacc[i]);
+            }
+        }
+    }
+    // row slots 1 .. R-1 through LDS, added to slot 0 in slot order: [slot][i][unit] float4, then [slot][i][gl] floats
+    float4 *sAcc = grp_lds4;                                   // [R][GRP_I][units]
+    float *sB = (float *)(sAcc + (size_t)R * GRP_I * units);   // [R][GRP_I][gw]
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < GRP_I; ++i) {
+            sAcc[((size_t)rs * GRP_I + i) * units + u] = acc[i];
+            if (qi == 0) sB[((size_t)rs * GRP_I + i) * gw + gl] = bacc[i];
+        }
+    }
+    __syncthreads();
+    if (rs == 0 && grp < g) {
+        float *p = part + (size_t)bx * rec;
+#pragma unroll
+        for (int i = 0; i < GRP_I; ++i) {
+            float4 v = sAcc[(size_t)i * units + u];
+            for (int t = 1; t < R; ++t) {
+                const float4 w = sAcc[((size_t)t * GRP_I + i) * units + u];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            *(float4 *)(p + ((size_t)grp * GRP_I + i) * c + 4 * qi) = v;
+            if (qi == 0) {
+                float b = sB[(size_t)i * gw + gl];
+                for (int t = 1; t < R; ++t) b += sB[((size_t)t * GRP_I + i) * gw + gl];
+                p[(size_t)g * GRP_I * c + (size_t)grp * GRP_I + i] = b;
+            }
+        }
+    }
+}
+inline size_t grouped_lds_bytes(int c, int gw) {
+    const int units = gw * (c >> 2), R = std::max(1, TPB / units);
+    return sizeof(float4) * (size_t)R * GRP_I * units + sizeof(float) * (size_t)R * GRP_I * gw;
+}
+// one call: the job by value
+__global__ __launch_bounds__(TPB) void grouped_wgrad_kernel(WgradJob J) {
+    const int bx = (int)blockIdx.x % J.chunks, bg = (int)blockIdx.x / J.chunks;
+    grouped_wgrad_tile(J.n, J.cin, J.batch, J.gw, J.chunk, J.gY, J.X, J.rowscale, J.part, J.rec, bx, bg);
+}
+__global__ __launch_bounds__(TPB) void grouped_wgrad_kernel_jobs(const WgradJob *__restrict__ jobs, int njobs) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].wg0) ++j;
+    const WgradJob &J = jobs[j];
+    const int local = (int)blockIdx.x - J.wg0;
+    grouped_wgrad_tile(J.n, J.cin, J.batch, J.gw, J.chunk, J.gY, J.X, J.rowscale, J.part, J.rec, local % J.chunks, local / J.chunks);
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel_jobs(const WgradJob *__restrict__ jobs, int njobs) {
     int j = 0;
@@ -1032,27 +1147,41 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel_jobs(const WgradJob *
                             multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, bx, by, bz);
 }
 
-// element e of the concatenated outputs of all jobs: the sum of its job's chunk records (double, four chains, as
-// gva::finalize_flat_kernel), written where the job's finalize would have written it
+// the records of all jobs -> their outputs.  A job's output element is summed by `lanes` consecutive threads (1, or 16 when the
+// job has more than 32 chunk records: the full-resolution jobs have hundreds of records for a few thousand outputs, and one
+// thread per output walked them as a chain of dependent loads -- 75 us per launch); double accumulation, the lanes' sums added
+// in a fixed tree; written where the job's own finalize would have written it
 __global__ __launch_bounds__(256) void wgrad_jobs_finalize_kernel(const WgradJob *__restrict__ jobs, int njobs, int total) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+    const int sidx = blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= total) return;
     int j = 0;
-    while (j + 1 < njobs && e >= jobs[j + 1].fin0) ++j;
+    while (j + 1 < njobs && sidx >= jobs[j + 1].fin0) ++j;
     const WgradJob &J = jobs[j];
-    const int col = e - J.fin0, nblk = J.chunks;
+    const int lanes = J.fin_lanes, local = sidx - J.fin0;
+    const int col = local / lanes, l = local - col * lanes;
+    const int nblk = J.chunks;
     const size_t len = (size_t)J.rec;
     const float *part = J.part;
+    const bool ok = col < J.rec;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        a0 += (double)part[(size_t)b * len + col];
-        a1 += (double)part[(size_t)(b + 1) * len + col];
-        a2 += (double)part[(size_t)(b + 2) * len + col];
-        a3 += (double)part[(size_t)(b + 3) * len + col];
+    if (ok) {
+        int b = l;
+        for (; b + 3 * lanes < nblk; b += 4 * lanes) {
+            a0 += (double)part[(size_t)b * len + col];
+            a1 += (double)part[(size_t)(b + lanes) * len + col];
+            a2 += (double)part[(size_t)(b + 2 * lanes) * len + col];
+            a3 += (double)part[(size_t)(b + 3 * lanes) * len + col];
+        }
+        for (; b < nblk; b += lanes) a0 += (double)part[(size_t)b * len + col];
     }
-    for (; b < nblk; ++b) a0 += (double)part[(size_t)b * len + col];
-    const float v = (float)((a0 + a1) + (a2 + a3));
+    double acc = (a0 + a1) + (a2 + a3);
+    if (lanes == 16) {  // (a job's slots are a multiple of 64: the 16 lanes of an element sit in one wavefront, all of them here)
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 16);
+        if (l != 0) return;
+    }
+    if (!ok) return;
+    const float v = (float)acc;
     const int wlen = J.cout * J.cin, wtot = J.batch * wlen;
     if (J.count > 0) {  // MapWgradMulti
         if (col < wtot) {
@@ -1200,8 +1329,11 @@ extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin
 // 40 KB cross-wave reduction, its partial record) however few rows it sums, and three fit a compute unit: at the deep
 // levels (n ~ 4 500, 80 tile-products) 256-row chunks made 1 440 workgroups = two full rounds of that fixed cost for 18
 // records to finalize.  Target ~3 workgroups per compute unit in ONE round; never fewer than 256 rows per workgroup.
-static int wg_chunk(int n, int tiles) {
-    constexpr int target = 768;  // (swept in round 2: DESIGN.md / profiles/HISTORY.md)
+static int wg_chunk(int n, int tiles, bool filed = false) {
+    // filed: the launch will run inside the batched launch of a whole backward (WgradJob), where the OTHER jobs fill the GPU:
+    // longer chunks -- fewer records to write and to sum, the per-workgroup fixed cost paid less often
+    // (bench step at 768 / 384 / 192 / 96 workgroups per job: 10.51 / 10.42 / 10.42 / 10.47 ms)
+    const int target = filed ? 256 : 768;  // (768: swept in round 2, DESIGN.md / profiles/HISTORY.md)
     const int chunks = std::max(1, target / std::max(1, tiles));
     const long long rows = ((long long)n + chunks - 1) / chunks;
     long long chunk = std::max<long long>(WG_CHUNK, (rows + 127) / 128 * 128);
@@ -1667,8 +1799,8 @@ struct WgradDefer {
     bool armed_rs = false;       // ... the row-scaled strided form (the grouped projection's weight gradient inside the attention)
     char *arena = nullptr;       // [job table RS = 0 | job table RS = 1 | kept operands and chunk records]
     size_t cap = 0, used = 0;
-    std::vector<WgradJob> jobs[4];  // filed since the last flush, per kernel form: LDS-staged (RS = 0 / 1), direct fp32, direct bf16
-    double bytes[4] = {0.0, 0.0, 0.0, 0.0};  // their algorithmic bytes (kernel timer)
+    std::vector<WgradJob> jobs[5];  // filed since the last flush, per kernel form: LDS-staged (RS = 0 / 1), direct fp32, direct bf16, grouped
+    double bytes[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // their algorithmic bytes (kernel timer)
 };
 thread_local WgradDefer g_wdefer;
 constexpr int WGRAD_MAX_JOBS = 64;
@@ -1677,12 +1809,12 @@ constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) &
 
 void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
     WgradDefer &D = g_wdefer;
-    for (int f = 0; f < 4; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
+    for (int f = 0; f < 5; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
     D.armed = D.armed_rs = false;
-    D.active = arena != nullptr && bytes > 4 * WGRAD_TABLE_BYTES;
+    D.active = arena != nullptr && bytes > 5 * WGRAD_TABLE_BYTES;
     D.arena = (char *)arena;
     D.cap = bytes;
-    D.used = 4 * WGRAD_TABLE_BYTES;
+    D.used = 5 * WGRAD_TABLE_BYTES;
 }
 bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
 void ptv2_wgrad_defer_end() {
@@ -1692,7 +1824,7 @@ void ptv2_wgrad_defer_end() {
 void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
 void ptv2_wgrad_defer_arm_rs(bool on) { g_wdefer.armed_rs = on && g_wdefer.active; }
 bool ptv2_wgrad_defer_armed_rs() { return g_wdefer.active && g_wdefer.armed_rs; }
-size_t ptv2_wgrad_defer_table_bytes() { return 4 * WGRAD_TABLE_BYTES; }
+size_t ptv2_wgrad_defer_table_bytes() { return 5 * WGRAD_TABLE_BYTES; }
 // a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
 float *ptv2_wgrad_defer_alloc(size_t floats) {
     WgradDefer &D = g_wdefer;
@@ -1714,7 +1846,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
                                    (int)WL_LDS_BYTES) == hipSuccess;
     }();
     if (!once) return PTV2_ERR_LAUNCH;
-    for (int form = 0; form < 4; ++form) {
+    for (int form = 0; form < 5; ++form) {
         std::vector<WgradJob> &jobs = D.jobs[form];
         if (jobs.empty()) continue;
         WgradJob *table = (WgradJob *)(D.arena + (size_t)form * WGRAD_TABLE_BYTES);
@@ -1722,8 +1854,9 @@ int ptv2_wgrad_defer_flush(void *stream) {
         int wgs = 0, fin = 0;
         for (WgradJob &J : jobs) {
             J.wg0 = wgs; J.fin0 = fin;
-            wgs += J.chunks * J.tiles * J.batch;
-            fin += J.rec;
+            J.fin_lanes = J.chunks > 32 ? 16 : 1;
+            wgs += J.wgs;
+            fin += (J.rec * J.fin_lanes + 63) / 64 * 64;
         }
         for (int at = 0; at < njobs; at += WGRAD_PACK) {
             WgradJobPack pack;
@@ -1732,7 +1865,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
             hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
         }
         {
-            PtvScopedTimer t(form < 2 ? KID_WGRAD_LDS : KID_WGRAD, st, D.bytes[form]);
+            PtvScopedTimer t((form < 2 || form == 4) ? KID_WGRAD_LDS : KID_WGRAD, st, D.bytes[form]);
             if (form == 0)
                 hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
                                    (const WgradJob *)table, njobs);
@@ -1742,9 +1875,14 @@ int ptv2_wgrad_defer_flush(void *stream) {
             else if (form == 2)
                 hipLaunchKernelGGL(linear_wgrad_kernel_jobs<false>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
                                    njobs);
-            else
+            else if (form == 3)
                 hipLaunchKernelGGL(linear_wgrad_kernel_jobs<true>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
                                    njobs);
+            else {
+                size_t lds = 0;
+                for (const WgradJob &J : jobs) lds = std::max(lds, grouped_lds_bytes(J.cin, J.gw));
+                hipLaunchKernelGGL(grouped_wgrad_kernel_jobs, dim3((unsigned)wgs), dim3(TPB), lds, st, (const WgradJob *)table, njobs);
+            }
         }
         hipLaunchKernelGGL(wgrad_jobs_finalize_kernel, dim3((unsigned)((fin + 255) / 256)), dim3(256), 0, st,
                            (const WgradJob *)table, njobs, fin);
@@ -1776,8 +1914,53 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
                                              size_t workspace_bytes, void *stream) {
     if (weighted) *weighted = 0;
     if (n < 1 || cout < 1 || cin < 1 || batch < 1) return PTV2_ERR_ARG;
+    // the grouped projection's shape (eight output rows per group, operands as the attention backward passes them): the
+    // vector-ALU kernel that reads whole row pieces of X (grouped_wgrad_tile); AO_AMD_WP2_GROUPED=0: the strided matrix-core form
+    static const bool grouped_on = [] { const char *e = getenv("AO_AMD_WP2_GROUPED"); return !(e && e[0] == '0'); }();
+    if (grouped_on && rowscale && db && !ptv2_matmul_bf16() && cout == GRP_I && cin % 4 == 0 && cin / 4 <= TPB &&
+        ldy == (long long)batch * cout && sy == cout && ldx == (long long)batch * cin && sx == cin && lds_s == batch &&
+        wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
+        const int q = cin / 4;
+        int gw = 1;
+        for (int d = 1; d <= batch; ++d)
+            if (batch % d == 0 && d * q <= TPB) gw = d;
+        const int blocks_g = batch / gw;
+        const int chunks = (int)std::max<long long>(1, std::min<long long>(((long long)n + 127) / 128, std::max(1, 768 / blocks_g)));
+        const int chunk = (n + chunks - 1) / chunks;
+        const size_t rec = (size_t)batch * ((size_t)cout * cin + cout);
+        WgradJob J{};
+        J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = 1; J.tiles = blocks_g; J.batch = batch; J.chunk = chunk;
+        J.chunks = (n + chunk - 1) / chunk; J.has_pb = 1; J.count = 0; J.rec = (int)rec; J.gw = gw;
+        J.wgs = J.chunks * blocks_g;
+        J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx; J.lds_s = lds_s;
+        J.gY = gY; J.X = X; J.rowscale = rowscale; J.dW = dW; J.db = db;
+        const double algo = 4.0 * batch * ((double)n * (cout + cin) + (double)cout * cin + cout + (double)n);
+        if (g_wdefer.active && g_wdefer.armed_rs && (int)g_wdefer.jobs[4].size() < WGRAD_MAX_JOBS) {
+            float *keep = ptv2_wgrad_defer_alloc((size_t)J.chunks * rec);
+            if (keep) {
+                J.part = keep;
+                g_wdefer.jobs[4].push_back(J);
+                g_wdefer.bytes[4] += algo;
+                if (weighted) *weighted = 1;
+                return PTV2_OK;
+            }
+        }
+        if (workspace && workspace_bytes >= sizeof(float) * (size_t)J.chunks * rec) {
+            hipStream_t st = (hipStream_t)stream;
+            J.part = (float *)workspace;
+            const size_t lds = grouped_lds_bytes(cin, gw);
+            {
+                PtvScopedTimer t(KID_WGRAD_LDS, st, algo);
+                hipLaunchKernelGGL(grouped_wgrad_kernel, dim3((unsigned)J.wgs), dim3(TPB), lds, st, J);
+            }
+            launch_finalize(st, (const float *)J.part, J.chunks, (int)rec, gva::MapSplit2<float>{dW, db, batch * cout * cin});
+            if (weighted) *weighted = 1;
+            PTV2_CHECK_LAUNCH();
+            return PTV2_OK;
+        }
+    }
     const int tiles_o = (cout + WG_TILE - 1) / WG_TILE, tiles_i = (cin + WG_TILE - 1) / WG_TILE;
-    const int chunk = wg_chunk(n, tiles_o * tiles_i * batch);
+    const int chunk = wg_chunk(n, tiles_o * tiles_i * batch, g_wdefer.active && (rowscale ? g_wdefer.armed_rs : g_wdefer.armed));
     const int chunks = (n + chunk - 1) / chunk;
     const size_t need = sizeof(float) * (size_t)chunks * batch * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < need) return PTV2_ERR_WORKSPACE;
@@ -1804,6 +1987,7 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
                 WgradJob J{};
                 J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = batch;
                 J.chunk = chunk; J.chunks = chunks; J.has_pb = db ? 1 : 0; J.count = 0; J.rec = (int)rec;
+                J.wgs = chunks * J.tiles * J.batch;
                 J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx;
                 J.gY = gY; J.X = X; J.part = keep; J.dW = dW; J.db = db;
                 g_wdefer.jobs[form].push_back(J);
@@ -1819,6 +2003,7 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
                 WgradJob J{};
                 J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = batch;
                 J.chunk = chunk; J.chunks = chunks; J.has_pb = 1; J.count = 0; J.rec = (int)rec;
+                J.wgs = chunks * J.tiles * J.batch;
                 J.ldy = ldy; J.sy = sy; J.ldx = ldx; J.sx = sx; J.lds_s = lds_s;
                 J.gY = gY; J.X = X; J.rowscale = rowscale; J.part = keep; J.dW = dW; J.db = db;
                 g_wdefer.jobs[1].push_back(J);
@@ -1895,7 +2080,8 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                                                const float *const *xsc, const float *const *xsh, void *workspace,
                                                size_t workspace_bytes, void *stream) {
     if (n < 1 || cout < 1 || cin < 1 || count < 1 || count > 6 || !gY || !X || !dW) return PTV2_ERR_ARG;
-    const int chunk = wg_chunk(n, ((cout + WG_TILE - 1) / WG_TILE) * ((cin + WG_TILE - 1) / WG_TILE) * count);
+    const int chunk = wg_chunk(n, ((cout + WG_TILE - 1) / WG_TILE) * ((cin + WG_TILE - 1) / WG_TILE) * count,
+                               g_wdefer.active && g_wdefer.armed);
     const int chunks = (n + chunk - 1) / chunk;
     const size_t rec = (size_t)count * ((size_t)cout * cin + cout);
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)chunks * rec) return PTV2_ERR_WORKSPACE;
@@ -1932,6 +2118,7 @@ extern "C" int linear_wgrad_multi_hip_launcher(int n, int cout, int cin, int cou
                 WgradJob J{};
                 J.n = n; J.cout = cout; J.cin = cin; J.tiles_i = tiles_i; J.tiles = tiles_o * tiles_i; J.batch = count;
                 J.chunk = chunk; J.chunks = chunks; J.has_pb = 1; J.count = count; J.rec = (int)rec;
+                J.wgs = chunks * J.tiles * J.batch;
                 J.ldy = cout; J.ldx = cin; J.part = keep;
                 for (int i = 0; i < count; ++i) {
                     J.mgY[i] = m.gY[i]; J.mX[i] = m.X[i]; J.mxsc[i] = m.xsc[i]; J.mxsh[i] = m.xsh[i];

@@ -288,9 +288,10 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
 
 @pytest.mark.parametrize("tag,points,bf16", [("s3dis", 9000, False), ("scannet", 7000, False), ("s3dis", 9000, True)])
 def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points, bf16):
-    """ptv2_wgrad_defer_mode: the Blocks' weight gradients filed and run by ONE launch at the end of the backward (default)
-    against every launch where it is called -- the same chunking and summation order, so every gradient bit for bit, over two
-    steps with different scenes (the job table is rebuilt per call) and with drop_path on."""
+    """ptv2_wgrad_defer_mode: the weight gradients filed and run by a few batched launches at the end of the backward (default)
+    against every launch where it is called, over two steps with different scenes (the job table is rebuilt per call) and with
+    drop_path on.  Same kernels and tile order; a filed job sums over longer row chunks (fewer records), so a weight gradient
+    may differ in its last bits: logits and every other gradient bit for bit, the weight gradients to 2e-6 of their norm."""
     from ao_amd import _lib
 
     L = _lib.lib()
@@ -316,5 +317,10 @@ def test_deferred_weight_gradients_equal_the_per_block_launches(tag, points, bf1
     names = [n for n, _ in model.named_parameters()]
     for (la, ga), (lb, gb) in zip(res[1], res[0]):
         assert torch.equal(la, lb)
+        differ = 0
         for nm, a, b in zip(names, ga, gb):
-            assert torch.equal(a, b), (nm, float((a - b).abs().max()))
+            if not torch.equal(a, b):
+                differ += 1
+                # (a bias in front of a training-mode BatchNorm has an exactly zero gradient: both sides hold summation noise)
+                assert rel(a, b) < (2e-3 if bf16 else 2e-6) or float((a - b).abs().max()) < 1e-8, (nm, rel(a, b), float((a - b).abs().max()))
+        assert differ < len(names) // 2  # (BatchNorm parameters, input-side gradients, the attention's folded parameters: untouched)
