@@ -1865,7 +1865,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
             hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
         }
         {
-            PtvScopedTimer t((form < 2 || form == 4) ? KID_WGRAD_LDS : KID_WGRAD, st, D.bytes[form]);
+            PtvScopedTimer t(form == 4 ? KID_WGRAD_GROUPED : (form < 2 ? KID_WGRAD_LDS : KID_WGRAD), st, D.bytes[form]);
             if (form == 0)
                 hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
                                    (const WgradJob *)table, njobs);
@@ -1917,7 +1917,8 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
     // the grouped projection's shape (eight output rows per group, operands as the attention backward passes them): the
     // vector-ALU kernel that reads whole row pieces of X (grouped_wgrad_tile); AO_AMD_WP2_GROUPED=0: the strided matrix-core form
     static const bool grouped_on = [] { const char *e = getenv("AO_AMD_WP2_GROUPED"); return !(e && e[0] == '0'); }();
-    if (grouped_on && rowscale && db && !ptv2_matmul_bf16() && cout == GRP_I && cin % 4 == 0 && cin / 4 <= TPB &&
+    // (also when the matrix products run on bf16 operands: this one is a vector-ALU kernel, exact fp32 either way)
+    if (grouped_on && rowscale && db && cout == GRP_I && cin % 4 == 0 && cin / 4 <= TPB &&
         ldy == (long long)batch * cout && sy == cout && ldx == (long long)batch * cin && sx == cin && lds_s == batch &&
         wgrad_lds_ok(gY, ldy, sy, X, ldx, sx)) {
         const int q = cin / 4;
@@ -1950,7 +1951,7 @@ extern "C" int linear_wgrad_strided_rowscale(int n, int cout, int cin, int batch
             J.part = (float *)workspace;
             const size_t lds = grouped_lds_bytes(cin, gw);
             {
-                PtvScopedTimer t(KID_WGRAD_LDS, st, algo);
+                PtvScopedTimer t(KID_WGRAD_GROUPED, st, algo);
                 hipLaunchKernelGGL(grouped_wgrad_kernel, dim3((unsigned)J.wgs), dim3(TPB), lds, st, J);
             }
             launch_finalize(st, (const float *)J.part, J.chunks, (int)rec, gva::MapSplit2<float>{dW, db, batch * cout * cin});
