@@ -128,8 +128,10 @@ def pmc_traffic(kernel, build_info):
                 if name == "_build":
                     continue
                 short = name.split("::")[-1]
-                # (the batched form of a weight-gradient kernel, `<name>_jobs`, is timed under the kernel's name)
-                if short == kernel or (short.split("<")[0] in (base, base + "_jobs") and "<" not in kernel):
+                # (the batched form of a weight-gradient kernel, `<name>_jobs`, is timed under the kernel's name; a timer name
+                # with template arguments stands for the instances that extend its argument list -- the dropout flag)
+                if short == kernel or (short.split("<")[0] in (base, base + "_jobs") and "<" not in kernel) or (
+                        "<" in kernel and short.startswith(kernel[:-1] + ",")):
                     hits.append((short, v))
         if hits:
             launches = sum(v["launches"] for _, v in hits)
@@ -676,6 +678,12 @@ def child_main(args):
                                    "ms_per_step": timed_stride * rec["total_us"] / 1e3 / args.steps,
                                    "algorithmic_bytes_per_launch": rec["bytes_per_launch"],
                                    "survey_steps": survey_steps, "timed_launch_stride": timed_stride,
+                                   # the next families by time, from the survey steps (HIP events, eager issue), same definitions
+                                   "next": [dict(kernel=k, achieved=round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1),
+                                                 frac=round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                                                 avg_us=round(v["avg_us"], 1), launches_per_step=v["launches"] / max(survey_steps, 1),
+                                                 traffic=pmc_traffic(k, build_info)[0])
+                                            for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])[1:4]],
                                    "all_kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                                                        "ms_per_step": round(v["total_us"] / 1e3 / max(survey_steps, 1), 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
