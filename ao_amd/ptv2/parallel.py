@@ -148,26 +148,32 @@ def _geometry_tensors(geo):
 
 
 class GeometryPrefetcher:
-    """Builds the scene geometry of the NEXT batch (kNN tables, grid pooling, interpolation tables: functions of
-    the coordinates only) on a side HIP stream while the current batch's backward runs, the way a data loader
+    """Builds the scene geometry of the NEXT batches (kNN tables, grid pooling, interpolation tables: functions of
+    the coordinates only) on a side HIP stream while the current batch trains, the way a data loader
     overlaps host-side preparation.  The pooling has data-dependent output sizes, i.e. 4-byte read-backs; on the
     compute stream each of them drains the whole queue and leaves the GPU idle while the host catches up
     (profiles/r01: 3.7 ms of a 30 ms step).  On the side stream the read-backs wait for the geometry kernels only.
 
-      pre.start(coord, offset)      enqueue geometry of the next batch (side stream)
-      geo = pre.take()              make the compute stream wait for it, hand it over
+      pre.start(coord, offset)      enqueue the geometry of a coming batch (side stream); may be called several times ahead
+      geo = pre.take()              the oldest one not yet taken: make the compute stream wait for it, hand it over
     """
 
     def __init__(self, backbone, device, threaded=False):
         self.backbone, self.device = backbone, device
         self.stream = torch.cuda.Stream(device)
-        self.pending = None
-        # threaded: the geometry is built by a host thread of its own, as a loader worker would.  Building it is ~2 ms of host
-        # time per 120 k-point scene, most of it blocked in the 4-byte read-backs; on the launching thread those 2 ms come out
-        # of the ~3.7 ms the host is ahead of the GPU queue (tools/host_bound.py: 7.5 ms of host issue for an 11.2 ms step),
-        # which a busy host (other tenants on the box) eats first.  The launchers release the GIL (ctypes), so the two threads
-        # overlap where it matters.
-        self.threaded, self.worker, self.result = threaded, None, None
+        # threaded: the geometry is built by ONE host thread of its own, as a loader worker would, request after request (the
+        # builds share the side stream and its scratch, so they must not interleave).  Building it is ~2 ms of host time per
+        # 120 k-point scene, most of it blocked in the 4-byte read-backs; on the launching thread those come out of the time the
+        # host is ahead of the GPU queue, which a busy host (other tenants on the box) eats first.  The launchers release the GIL
+        # (ctypes), so the two threads overlap where it matters.  With two builds requested ahead (bench.py) the launching
+        # thread finds the next geometry finished instead of waiting for the worker's read-backs.
+        self.threaded, self.worker = threaded, None
+        import collections
+        self.done = collections.deque()  # (geo, event) or an exception, oldest first (not threaded)
+        self.outstanding = 0
+        if threaded:
+            import queue
+            self.requests, self.results = queue.Queue(), queue.Queue()
 
     def _build(self, coord, offset, ready):
         if ready is not None:  # event after which coord/offset are valid (e.g. the H2D copy of the loader)
@@ -178,39 +184,50 @@ class GeometryPrefetcher:
             done.record(self.stream)
         return geo, done
 
-    def start(self, coord, offset, ready=None):
-        if not self.threaded:
-            self.pending = self._build(coord, offset, ready)
-            return
-        import threading
-
-        def run():
+    def _loop(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            req = self.requests.get()
+            if req is None:
+                return
             try:
-                torch.cuda.set_device(self.device)
-                self.result = self._build(coord, offset, ready)
+                self.results.put(self._build(*req))
             except BaseException as e:  # re-raised by take()
-                self.result = e
+                self.results.put(e)
 
-        self.worker = threading.Thread(target=run, name="ao_amd-geometry", daemon=True)
-        self.pending = "worker"
-        self.worker.start()
+    def start(self, coord, offset, ready=None):
+        self.outstanding += 1
+        if not self.threaded:
+            self.done.append(self._build(coord, offset, ready))
+            return
+        if self.worker is None:
+            import threading
+            self.worker = threading.Thread(target=self._loop, name="ao_amd-geometry", daemon=True)
+            self.worker.start()
+        self.requests.put((coord, offset, ready))
+
+    @property
+    def pending(self):
+        return self.outstanding if self.outstanding else None
 
     def close(self):
-        """Wait for a build that is still running on the worker thread (call before the process winds down)."""
-        if self.pending == "worker" and self.worker is not None:
+        """Wait for the builds that are still running and stop the worker thread (call before the process winds down)."""
+        if self.threaded and self.worker is not None:
+            self.requests.put(None)
             self.worker.join()
-            self.worker, self.pending = None, (self.result if not isinstance(self.result, BaseException) else None)
+            self.worker = None
+            while not self.results.empty():
+                self.results.get()
+        self.done.clear()
+        self.outstanding = 0
 
     def take(self):
-        assert self.pending is not None, "GeometryPrefetcher.take() before start()"
-        if self.pending == "worker":
-            self.worker.join()
-            self.worker, self.pending = None, self.result
-            if isinstance(self.pending, BaseException):
-                err, self.pending = self.pending, None
-                raise err
-        geo, done = self.pending
-        self.pending = None
+        assert self.outstanding > 0, "GeometryPrefetcher.take() before start()"
+        self.outstanding -= 1
+        res = self.results.get() if self.threaded else self.done.popleft()
+        if isinstance(res, BaseException):
+            raise res
+        geo, done = res
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
         for t in _geometry_tensors(geo):  # allocated on the side stream, consumed on the compute stream

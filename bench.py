@@ -488,7 +488,10 @@ def child_main(args):
     prefetch, pf_mode = None, os.environ.get("AO_AMD_PREFETCH", "thread")
     if pf_mode in ("1", "thread"):
         prefetch = parallel.GeometryPrefetcher(seg.backbone, device, threaded=pf_mode == "thread")
-        prefetch.start(data["coord"], data["offset"])
+        # thread mode: two geometries requested ahead -- the launching thread then finds the next one built instead of waiting for
+        # the worker's read-backs, and a stall of either thread is absorbed by the other's lead.  Every step still builds one.
+        for _ in range(2 if pf_mode == "thread" else 1):
+            prefetch.start(data["coord"], data["offset"])
 
     def step():
         batch = data if prefetch is None else dict(data, geometry=prefetch.take())
