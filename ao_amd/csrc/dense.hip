@@ -1851,6 +1851,13 @@ int ptv2_wgrad_defer_flush(void *stream) {
         if (jobs.empty()) continue;
         WgradJob *table = (WgradJob *)(D.arena + (size_t)form * WGRAD_TABLE_BYTES);
         const int njobs = (int)jobs.size();
+        // the jobs whose workgroups run longest first (rows per workgroup x the row piece it reads): the backward files the
+        // full-resolution patch-embedding Block LAST, and its 150 us workgroups starting at the end of the launch were its tail
+        // (bench step 10.53 -> 10.49 ms)
+        std::stable_sort(jobs.begin(), jobs.end(), [form](const WgradJob &a, const WgradJob &b) {
+            const long long wa = (long long)a.chunk * (form == 4 ? a.gw * a.cin : 1), wb = (long long)b.chunk * (form == 4 ? b.gw * b.cin : 1);
+            return wa > wb;
+        });
         int wgs = 0, fin = 0;
         for (WgradJob &J : jobs) {
             J.wg0 = wgs; J.fin0 = fin;
