@@ -28,16 +28,21 @@ struct PoolDims {
 constexpr int KEY_BITS = 48;  // radix-sorted key width (6 passes); 2^48 voxels = (65536 per axis)^3
 
 // per-axis max over clouds of (hi - lo), then trunc(/size) + 1   (grid_cluster: (end - start) / size + 1)
-__global__ void pool_dims_kernel(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size,
-                                 PoolDims *dims) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ PoolDims pool_dims_of(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size) {
     float e[3] = {0.f, 0.f, 0.f};
     for (int s = 0; s < b; ++s)
         for (int a = 0; a < 3; ++a) e[a] = fmaxf(e[a], hi[3 * s + a] - lo[3 * s + a]);
-    dims->nx = (long long)(e[0] / size) + 1;
-    dims->ny = (long long)(e[1] / size) + 1;
-    dims->nz = (long long)(e[2] / size) + 1;
-    dims->total = dims->nx * dims->ny * dims->nz * (long long)b;
+    PoolDims d;
+    d.nx = (long long)(e[0] / size) + 1;
+    d.ny = (long long)(e[1] / size) + 1;
+    d.nz = (long long)(e[2] / size) + 1;
+    d.total = d.nx * d.ny * d.nz * (long long)b;
+    return d;
+}
+__global__ void pool_dims_kernel(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size,
+                                 PoolDims *dims) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *dims = pool_dims_of(b, lo, hi, size);
 }
 
 __global__ __launch_bounds__(TPB) void pool_keys_kernel(int n, int b, const float *__restrict__ coord,
@@ -128,8 +133,13 @@ __global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ 
 constexpr long long DENSE_CAP = 1ll << 23;
 constexpr int DSCAN_THREADS = 256, DSCAN_ITEMS = 8, DSCAN_TILE = DSCAN_THREADS * DSCAN_ITEMS;
 
-__global__ __launch_bounds__(TPB) void dense_zero_kernel(const PoolDims *__restrict__ dims, int *__restrict__ count, int *n_out) {
-    const long long total = dims->total;
+// (the grid's dimensions are derived here by every workgroup -- a loop over the b clouds' extents -- and stored by the first:
+// what was a one-thread launch of its own in front of this one)
+__global__ __launch_bounds__(TPB) void dense_zero_kernel(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size,
+                                                         PoolDims *__restrict__ dims, int *__restrict__ count, int *n_out) {
+    const PoolDims d = pool_dims_of(b, lo, hi, size);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dims = d;
+    const long long total = d.total;
     if (total <= 0 || total > DENSE_CAP) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = (total > 0 && total < (1ll << KEY_BITS)) ? -2 : -1;
         return;
@@ -309,12 +319,14 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
     hipStream_t st = (hipStream_t)stream;
     int rc = segment_minmax_hip_launcher(b, coord, offset, w.lo, w.hi, w.mm, w.mm_bytes, stream);
     if (rc != PTV2_OK) return rc;
-    hipLaunchKernelGGL(pool_dims_kernel, dim3(1), dim3(64), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
-                       w.dims);
     const int nb = divup(n, TPB);
+    if (sort_path)
+        hipLaunchKernelGGL(pool_dims_kernel, dim3(1), dim3(64), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
+                           w.dims);
     if (!sort_path) {
         const int ztiles = (int)((DENSE_CAP + DSCAN_TILE) / DSCAN_TILE);
-        hipLaunchKernelGGL(dense_zero_kernel, dim3(1024), dim3(TPB), 0, st, (const PoolDims *)w.dims, w.d_count, n_out);
+        hipLaunchKernelGGL(dense_zero_kernel, dim3(1024), dim3(TPB), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
+                           w.dims, w.d_count, n_out);
         hipLaunchKernelGGL(dense_keys_kernel, dim3(nb), dim3(TPB), 0, st, n, b, coord, offset, (const float *)w.lo, grid_size,
                            (const PoolDims *)w.dims, (const int *)n_out, w.d_count, w.d_key, w.d_slot);
         hipLaunchKernelGGL(dense_scan_reduce_kernel, dim3(ztiles), dim3(DSCAN_THREADS), 0, st, (const PoolDims *)w.dims,

@@ -80,8 +80,9 @@ Workspace carve(void *base, int m, int n, int b) {
 
 // ---------------------------------------------------------------- grid build --
 __global__ void knn_init_kernel(int *tie_count, int *bbox_lo, int *bbox_hi, int b, int *cell_count,
-                                int ncell_pad) {
+                                int ncell_pad, int *block_sums, int ntiles) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = t; i < ntiles; i += gridDim.x * blockDim.x) block_sums[i] = 0;  // (the scan's hand-off words)
     if (t < 4) tie_count[t] = 0;  // (one re-run list counter per query that shares this grid)
     if (t < 3 * b) {
         bbox_lo[t] = 0x7fffffff;
@@ -209,33 +210,38 @@ __global__ __launch_bounds__(256) void knn_cell_count_kernel(int n, const float 
     point_rank[t] = atomicAdd(&cell_count[cell], 1);
 }
 
-// exclusive scan over ncell_pad ints, phase 1: per-tile sums
-__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_reduce_kernel(const int *__restrict__ in,
-                                                                       int *block_sums) {
-    __shared__ int s_w[SCAN_THREADS / WAVE];
-    const int4 *p = (const int4 *)(in + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
-    int4 a = p[0], c = p[1];
-    int v = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < SCAN_THREADS / WAVE; ++i) t += s_w[i];
-        block_sums[blockIdx.x] = t;
-    }
-}
-
-// phase 2: every tile re-derives its base from the tile sums before it, then scans itself
-__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_apply_kernel(const int *__restrict__ in,
-                                                                      const int *__restrict__ block_sums,
-                                                                      int *out, int ntiles) {
+// exclusive scan over ncell_pad ints.
+// One pass: a tile sums itself, publishes the sum (bit 31 = "there"; the counts stay below 2^31), adds the sums of the tiles in
+// front of it as they appear (tiles start in index order: the ones waited for are running or done) and scans itself.  The
+// hand-off words are zeroed by knn_init_kernel.  (Two launches before -- a reduce and an apply that re-read the tile.)
+__global__ __launch_bounds__(SCAN_THREADS) void knn_scan_kernel(const int *__restrict__ in, int *block_sums, int *out, int ntiles) {
     __shared__ int s_w[SCAN_THREADS / WAVE];
     __shared__ int s_base;
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    {
+        const int4 *p = (const int4 *)(in + (size_t)blockIdx.x * SCAN_TILE) + threadIdx.x * 2;
+        const int4 a = p[0], c = p[1];
+        int v = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+        if (lane == 0) s_w[wid] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int i = 0; i < SCAN_THREADS / WAVE; ++i) t += s_w[i];
+            __hip_atomic_store(block_sums + blockIdx.x, (int)(0x80000000u | (unsigned)t), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     int part = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) part += block_sums[i];
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) {
+        int w;
+        do {
+            w = __hip_atomic_load(block_sums + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (w >= 0) __builtin_amdgcn_s_sleep(1);
+        } while (w >= 0);
+        part += w & 0x7fffffff;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, WAVE);
     if (lane == 0) s_w[wid] = part;
@@ -959,7 +965,7 @@ extern "C" int knn_query_grid_hip_launcher(int m, int nsample, const float *xyz,
     w.tie_count += slot;
     if (grid_mode == 0) {
     hipLaunchKernelGGL(knn_init_kernel, dim3(min(divup(ncell_pad, 256), 1024)), dim3(256), 0, st, w.tie_count,
-                       w.bbox_lo, w.bbox_hi, b, w.cell_count, ncell_pad);
+                       w.bbox_lo, w.bbox_hi, b, w.cell_count, ncell_pad, w.block_sums, ntiles);
     hipLaunchKernelGGL(knn_bbox_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.bbox_lo,
                        w.bbox_hi);
     // target points per cell of the bounding volume (surface clouds fill a fraction of their cells: several times as many per
@@ -969,8 +975,7 @@ extern "C" int knn_query_grid_hip_launcher(int m, int nsample, const float *xyz,
                        w.seg, occupancy);
     hipLaunchKernelGGL(knn_cell_count_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.seg,
                        w.cell_count, w.point_cell, w.point_rank);
-    hipLaunchKernelGGL(knn_scan_reduce_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, w.cell_count, w.block_sums);
-    hipLaunchKernelGGL(knn_scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, w.cell_count, w.block_sums,
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, (const int *)w.cell_count, w.block_sums,
                        w.cell_start, ntiles);
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, w.cell_start, w.point_cell,
                        w.point_rank, w.sorted);
