@@ -988,7 +988,8 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
 // GPU.  Inside ptv2_model_backward the eligible launches (this LDS-staged kernel, fp32) are not issued where they are called:
 // the call files a job -- operands, shape, its slice of a record arena -- and ONE launch at the end of the backward runs them
 // all, workgroup -> (job, chunk, tile, product) through a job table in device memory, followed by ONE finalize over the
-// records of all jobs.  Chunking, record layout and the order of every sum are those of the per-call launch: the same bits.
+// records of all jobs.  Kernels, tile order and record layout are those of the per-call launch; a filed job's row chunks are
+// longer (wg_chunk: the other jobs fill the GPU), so its sums agree with the per-call launch's to ~2e-6 of the gradient's norm.
 struct WgradJob {
     int n, cout, cin, tiles_i, tiles, batch, chunk, chunks;
     int wg0;          // first workgroup of the job in the batched launch

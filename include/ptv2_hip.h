@@ -66,7 +66,8 @@ int ptv2_graph_mode(int on);
 int ptv2_graph_stats(double *out, int reset);
 int ptv2_graph_reset(void);
 /* The weight gradients of the Blocks inside ptv2_model_backward_hip_launcher are filed where they are called and run by ONE
- * launch at the end of the backward (ao_amd/csrc/dense.hip: WgradJob; same chunking and summation order, the same bits).
+ * launch per kernel form at the end of the backward (ao_amd/csrc/dense.hip: WgradJob; same kernels over longer row chunks: equal
+ * to ~2e-6 of a gradient's norm).
  * on = 0: every launch where it is called; 1: deferred (default; AO_AMD_WGRAD_DEFER=0 sets 0); -1: query.  Returns the previous
  * setting. */
 int ptv2_wgrad_defer_mode(int on);
@@ -625,8 +626,10 @@ typedef struct ptv2_model {
     int checkpoint;                    /* != 0: activation checkpointing of the Blocks (enable_checkpoint of the reference,
                                         * point_transformer_v2m2_base.py:169-171): the forward keeps only every Block's
                                         * output; all Blocks share ONE saved-activation region, and the backward re-runs a
-                                        * Block's forward (without touching the running statistics) right before its
-                                        * backward.  Same results bit for bit, ptv2_model_saved_bytes() shrinks. */
+                                        * Block's forward right before its
+                                        * backward.  Logits and gradients bit for bit, ptv2_model_saved_bytes() shrinks; the running
+                                        * statistics of the norms inside the attention advance twice per step, as under
+                                        * torch.utils.checkpoint in the reference. */
     void *decoder_done_event;          /* backward only, optional hipEvent_t: recorded on `stream` once the head and every
                                         * decoder stage have written their parameter gradients (the tail of the flat
                                         * gradient buffer in module.parameters() order) -- a data-parallel caller starts
