@@ -527,6 +527,19 @@ def child_main(args):
     # step time the headline value comes from is not inflated by ~4000 event records)
     # The warm-up: first the survey steps (eager issue: HIP events cannot be read back from a graph), then the remaining
     # steps as the timed region will run them (graph issue, the dominant kernel sampled) so that the executable graphs exist
+    if prefetch is not None and args.warmup > 0:
+        # The timed region lets the host run up to eight steps ahead of the GPU (the graph ring), the warm-up at most `warmup`
+        # steps: the geometries of the steps in flight are memory the caching allocator cannot hand out again yet, and the first
+        # time the host gets that far ahead it has to ask the driver for more (hipMalloc: a 70-130 ms stall of the launching
+        # thread, seen as ONE long step in three of ~60 runs).  Untimed: hold eight geometries at once on the prefetch stream,
+        # then let them go -- the allocator's pool of that stream is then as large as the run-ahead can make it.
+        held = []
+        for _ in range(8):
+            prefetch.start(data["coord"], data["offset"])
+        for _ in range(8):
+            held.append(prefetch.take())
+        torch.cuda.synchronize(device)
+        del held
     survey_steps = 0 if args.no_roofline else min(2, args.warmup)
     survey, dominant, timed_stride = {}, None, 3
     if survey_steps:
