@@ -342,6 +342,9 @@ class _NativeModel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_logits):
         rt = ctx.rt
+        if ctx.keep is None:
+            raise RuntimeError("ao_amd: the native PT-v2m2 runtime releases its saved activations at the end of the backward "
+                               "(retain_graph / a second backward through the same forward is not supported)")
         keep, scales, feat, saved = ctx.keep
         dev = feat.device
         L = _lib.lib()
@@ -372,6 +375,10 @@ class _NativeModel(torch.autograd.Function):
         ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
         rc = L.ptv2_model_backward_hip_launcher(ctypes.addressof(M), g_logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "ptv2_model_backward_hip_launcher")
+        # the activation arena (≈3 GB at 120 k points) goes back to the allocator now, not when the loss tensor that holds this
+        # graph is dropped -- a training loop keeps the previous step's loss / output dict alive into the next forward, which
+        # then needed a SECOND arena (and the allocator a multi-gigabyte hipMalloc in the middle of the second step)
+        ctx.keep = ctx.geo = None
         if direct:
             if accumulate:
                 torch._foreach_add_([p.grad for p in rt.params], views)

@@ -527,7 +527,7 @@ def child_main(args):
     # step time the headline value comes from is not inflated by ~4000 event records)
     # The warm-up: first the survey steps (eager issue: HIP events cannot be read back from a graph), then the remaining
     # steps as the timed region will run them (graph issue, the dominant kernel sampled) so that the executable graphs exist
-    if prefetch is not None and args.warmup > 0:
+    if prefetch is not None and args.warmup > 0 and os.environ.get("AO_AMD_BENCH_POOL_WARM", "1") != "0":
         # The timed region lets the host run up to eight steps ahead of the GPU (the graph ring), the warm-up at most `warmup`
         # steps: the geometries of the steps in flight are memory the caching allocator cannot hand out again yet, and the first
         # time the host gets that far ahead it has to ask the driver for more (hipMalloc: a 70-130 ms stall of the launching
@@ -579,7 +579,7 @@ def child_main(args):
     # host side of the timed region: wall and CPU time the launching thread spends inside step(), and one
     # event per step on the compute stream so that the per-step GPU-side durations can be told apart from host stalls
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    host_wall, host_cpu = [], []
+    host_wall, host_cpu, reserved_trace = [], [], []
 
     def timed_step():
         i = len(host_wall)
@@ -589,6 +589,7 @@ def child_main(args):
         out = step()
         host_wall.append(time.perf_counter() - w0)
         host_cpu.append(time.thread_time() - c0)
+        reserved_trace.append(torch.cuda.memory_reserved(device))
         marks[i + 1].record()
         return out
 
@@ -599,11 +600,13 @@ def child_main(args):
     import gc
     gc.collect()
     gc.disable()
+    reserved0 = torch.cuda.memory_reserved(device)
     try:
         elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
                                                               finish=basket.flush if basket is not None else None)
     finally:
         gc.enable()
+    reserved_growth = torch.cuda.memory_reserved(device) - reserved0  # > 0: the caching allocator went to the driver while timed
     graph = _lib.graph_stats()
     cg1 = cgroup_cpu()[1]
     if prefetch is not None:
@@ -665,6 +668,10 @@ def child_main(args):
             "geometry_prefetch": pf_mode,
             # the cgroup's CPU accounting across the timed region: a throttled period there is a stalled launching thread
             "cgroup_timed_region": ({k: cg1[k] - cg0[k] for k in cg1 if k in cg0} if cg0 and cg1 else None),
+            # bytes torch's caching allocator obtained from the driver inside the timed region (hipMalloc blocks the launching thread)
+            "allocator_reserved_growth_MB": round(reserved_growth / 2 ** 20, 1),
+            "allocator_reserved_MB_after_step": [round(r / 2 ** 20) for r in reserved_trace[:12]],
+            "allocator_reserved_MB_before": round(reserved0 / 2 ** 20),
             "torch_cpu_threads": torch.get_num_threads()})
         step_bytes = algorithmic_step_bytes(levels, cfg)
         out["config"]["algorithmic_step_GB"] = step_bytes / 1e9
