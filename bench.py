@@ -532,16 +532,30 @@ def child_main(args):
         # steps: the geometries of the steps in flight are memory the caching allocator cannot hand out again yet, and the first
         # time the host gets that far ahead it has to ask the driver for more (hipMalloc: a 70-130 ms stall of the launching
         # thread, seen as ONE long step in three of ~60 runs).  Untimed: hold eight geometries at once on the prefetch stream,
-        # then let them go -- the allocator's pool of that stream is then as large as the run-ahead can make it.
+        # then let them go -- the allocator's pool of that stream is then as large as the run-ahead can make it.  (Twelve: the
+        # eight steps of the graph ring, the two geometries the prefetcher keeps ahead, the one in use and one being freed; with
+        # eight held the pool still grew by 74 MB in steps 8-11 of every timed region.)
         held = []
-        for _ in range(8):
+        for _ in range(12):
             prefetch.start(data["coord"], data["offset"])
-        for _ in range(8):
+        for _ in range(12):
             held.append(prefetch.take())
         torch.cuda.synchronize(device)
         del held
     survey_steps = 0 if args.no_roofline else min(2, args.warmup)
     survey, dominant, timed_stride = {}, None, 3
+    # (no cyclic-garbage collection inside the timed region: a full collection of the interpreter's objects is tens of
+    # milliseconds on the launching thread, which no training loop would let happen in the middle of a step either.  The
+    # collection itself runs BEFORE the last warm-up steps, not between them and the timed region: tens of milliseconds of an
+    # idle GPU there sent the first timed step off at idle clocks -- it took 1.25-1.3 x the median step at every size, 0.13-0.33
+    # ms on the mean of 20.)
+    import gc
+
+    def gc_off():
+        if gc.isenabled():
+            gc.collect()
+            gc.disable()
+
     if survey_steps:
         pre = 1 if args.warmup > survey_steps else 0
         for _ in range(pre):  # (one step before the survey when the warm-up allows: first-launch costs are not the kernels')
@@ -569,11 +583,13 @@ def child_main(args):
                 while math.gcd(timed_stride, per_step) != 1:
                     timed_stride += 2
             _lib.kernel_timer(True, only=dominant, stride=timed_stride)
+        gc_off()
         for _ in range(args.warmup - survey_steps - pre):
             step()
         if survey:  # the records of the warm-up are not the timed region's
             _lib.kernel_timer(True, only=dominant, stride=timed_stride)
     else:
+        gc_off()
         for _ in range(args.warmup):
             step()
     # host side of the timed region: wall and CPU time the launching thread spends inside step(), and one
@@ -595,11 +611,7 @@ def child_main(args):
 
     _lib.graph_stats(reset=True)
     cg0 = cgroup_cpu()[1]
-    # (no cyclic-garbage collection inside the timed region: a full collection of the interpreter's objects is tens of
-    # milliseconds on the launching thread, which no training loop would let happen in the middle of a step either)
-    import gc
-    gc.collect()
-    gc.disable()
+    gc_off()
     reserved0 = torch.cuda.memory_reserved(device)
     try:
         elapsed, points_per_step, loss = parallel.timed_steps(timed_step, args.steps, device, n_points,
@@ -646,6 +658,7 @@ def child_main(args):
                                     % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",
                        "loss": float(loss.detach()), "library_build": "src " + str(src_hash(build_info))},
         }
+        first_step_ms = marks[0].elapsed_time(marks[1])
         step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         pick = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
         out["host"] = host_facts()
@@ -655,7 +668,9 @@ def child_main(args):
             "host_issue_ms": 1e3 * sum(host_wall) / len(host_wall), "host_issue_ms_max": 1e3 * max(host_wall),
             "host_cpu_ms": 1e3 * sum(host_cpu) / len(host_cpu),
             # per-step durations between events recorded on the compute stream at the end of every step
-            "step_ms": {"min": step_ms[0], "median": pick(0.5), "p90": pick(0.9), "max": step_ms[-1]},
+            # (`first`: the step behind the synchronisation that opens the timed region -- the GPU idles while the host captures,
+            # updates and launches the forward's graph, and runs the step's first milliseconds from a cold start)
+            "step_ms": {"min": step_ms[0], "median": pick(0.5), "p90": pick(0.9), "max": step_ms[-1], "first": first_step_ms},
             "issue": ("hipGraph: each direction of the model captured and launched as one graph (ao_amd/csrc/graph.hip)"
                       if graph["scopes"] > 0 else "eager (hipLaunchKernelGGL per kernel)"),
             "graph": {"launches_per_step": graph["scopes"] / args.steps, "nodes_per_step": graph["nodes"] / args.steps,
