@@ -996,7 +996,7 @@ struct WgradJob {
     int has_pb, count;  // bias sums behind the weight records; > 0: the multi form (operand pairs per product)
     int rec, fin0;    // floats per chunk record; first element of the job in the batched finalize
     int wgs, gw;      // workgroups of the job; (grouped form) groups per workgroup
-    int fin_lanes;    // threads per output element in the batched finalize (1 or 16)
+    int fin_lanes;    // record groups per output element in the batched finalize (1, or 4: the wavefronts of a workgroup)
     long long ldy, sy, ldx, sx, lds_s;
     const float *gY, *X, *rowscale;
     float *part;
@@ -1148,25 +1148,28 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel_jobs(const WgradJob *
                             multi ? J.mxsc[bz] : nullptr, multi ? J.mxsh[bz] : nullptr, J.chunk, bx, by, bz);
 }
 
-// the records of all jobs -> their outputs.  A job's output element is summed by `lanes` consecutive threads (1, or 16 when the
-// job has more than 32 chunk records: the full-resolution jobs have hundreds of records for a few thousand outputs, and one
-// thread per output walked them as a chain of dependent loads -- 75 us per launch); double accumulation, the lanes' sums added
-// in a fixed tree; written where the job's own finalize would have written it
+// the records of all jobs -> their outputs.  A job's slots are whole workgroups.  With up to 32 chunk records a thread sums one
+// output element; with more (the full-resolution jobs have hundreds of records for a few thousand outputs: one thread per output
+// walked them as a chain of dependent loads, 75 us per launch) the four wavefronts of a workgroup take every fourth record of the
+// same 64 consecutive elements -- every load instruction reads 256 contiguous bytes of one record (16 lanes per element, each on
+// a record of its own, touched 16 lines per instruction for 16 bytes of each: 43 us per launch on average) -- and their sums
+// meet in LDS, added in wavefront order.  Double accumulation; written where the job's own finalize would have written it.
 __global__ __launch_bounds__(256) void wgrad_jobs_finalize_kernel(const WgradJob *__restrict__ jobs, int njobs, int total) {
-    const int sidx = blockIdx.x * 256 + threadIdx.x;
-    if (sidx >= total) return;
+    __shared__ double s_sum[3][64];
+    const int sidx = blockIdx.x * 256 + threadIdx.x;  // (total is a multiple of 256, and so is every job's fin0)
     int j = 0;
-    while (j + 1 < njobs && sidx >= jobs[j + 1].fin0) ++j;
+    while (j + 1 < njobs && (int)blockIdx.x * 256 >= jobs[j + 1].fin0) ++j;  // (uniform)
     const WgradJob &J = jobs[j];
     const int lanes = J.fin_lanes, local = sidx - J.fin0;
-    const int col = local / lanes, l = local - col * lanes;
+    const int rg = lanes == 1 ? 0 : (int)threadIdx.x >> 6;
+    const int col = lanes == 1 ? local : (local >> 8) * 64 + ((int)threadIdx.x & 63);
     const int nblk = J.chunks;
     const size_t len = (size_t)J.rec;
     const float *part = J.part;
     const bool ok = col < J.rec;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (ok) {
-        int b = l;
+        int b = rg;
         for (; b + 3 * lanes < nblk; b += 4 * lanes) {
             a0 += (double)part[(size_t)b * len + col];
             a1 += (double)part[(size_t)(b + lanes) * len + col];
@@ -1176,10 +1179,11 @@ __global__ __launch_bounds__(256) void wgrad_jobs_finalize_kernel(const WgradJob
         for (; b < nblk; b += lanes) a0 += (double)part[(size_t)b * len + col];
     }
     double acc = (a0 + a1) + (a2 + a3);
-    if (lanes == 16) {  // (a job's slots are a multiple of 64: the 16 lanes of an element sit in one wavefront, all of them here)
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 16);
-        if (l != 0) return;
+    if (lanes != 1) {  // (uniform over the workgroup)
+        if (rg > 0) s_sum[rg - 1][threadIdx.x & 63] = acc;
+        __syncthreads();
+        if (rg > 0) return;
+        acc = (acc + s_sum[0][threadIdx.x]) + (s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x]);
     }
     if (!ok) return;
     const float v = (float)acc;
@@ -1862,9 +1866,9 @@ int ptv2_wgrad_defer_flush(void *stream) {
         int wgs = 0, fin = 0;
         for (WgradJob &J : jobs) {
             J.wg0 = wgs; J.fin0 = fin;
-            J.fin_lanes = J.chunks > 32 ? 16 : 1;
+            J.fin_lanes = J.chunks > 32 ? 4 : 1;
             wgs += J.wgs;
-            fin += (J.rec * J.fin_lanes + 63) / 64 * 64;
+            fin += J.fin_lanes == 1 ? (J.rec + 255) / 256 * 256 : (J.rec + 63) / 64 * 256;  // whole workgroups
         }
         for (int at = 0; at < njobs; at += WGRAD_PACK) {
             WgradJobPack pack;
