@@ -1,5 +1,5 @@
 // tools/probes/graph_branch_probe.hip -- do parallel branches of a hipGraph run beside each other, and what does an edge between
-// branches cost?  (the weight-gradient kernels of a Block's backward are off its critical chain.)
+// branches cost?  (DESIGN.md section 4.5 / profiles/HISTORY.md: the weight-gradient kernels of a Block's backward are off its critical chain.)
 //
 // A chain of CHAIN dependent small kernels (a few workgroups, a few microseconds each: the deep-level Block backward) and SIDE
 // longer low-occupancy kernels (the split-K weight gradients), each of which needs the output of one chain kernel and is needed
