@@ -234,11 +234,19 @@ int PtvGraphScope::finish(int rc) {
     size_t nodes = 0;
     (void)hipGraphGetNodes(g, nullptr, &nodes);
     int out = PTV2_OK;
+    // g_mu protects the slot TABLE only: the ring entry is looked up under it, the wait for its previous launch, the update and
+    // the launch run outside (they can take a whole GPU step; a second issuing thread -- another model, an evaluation pass on its
+    // own stream -- must not queue behind them).  One issuing thread per (device, stream, direction) is the contract of the
+    // scope (the entry was picked by the constructor of THIS scope); entries of a std::unordered_map stay where they are.
+    Exec *slot_p = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         Slot &ring = g_slots[SlotKey{device, s, which}];
-        Exec &slot = ring.ring[ring_entry];
-        slot.seq = ++ring.launches;
+        slot_p = &ring.ring[ring_entry];
+        slot_p->seq = ++ring.launches;
+    }
+    {
+        Exec &slot = *slot_p;
         if (!slot.done && hipEventCreateWithFlags(&slot.done, hipEventDisableTiming) != hipSuccess) slot.done = nullptr;
         if (slot.in_flight && slot.done) {
             const long long w0 = now_ns();
@@ -291,6 +299,7 @@ int PtvGraphScope::finish(int rc) {
 PtvGraphScope::~PtvGraphScope() {
     if (!active) return;  // finished, or never started
     // an early return of the launcher body: close the capture and discard it
+    ptv2_profile_scope(which, 1, 0, RING);  // (the kernel timer's per-scope state must not outlive the aborted scope)
     g_inside = 0;
     hipGraph_t g = nullptr;
     (void)hipStreamEndCapture((hipStream_t)cap, &g);
