@@ -15,7 +15,7 @@
 // caller's grow-only workspace.
 #include <algorithm>
 
-#include "arrive.h"
+#include "common.h"
 
 namespace {
 
@@ -169,13 +169,6 @@ extern "C" int ptv2_block_param_layout(int c, int g, long long *offsets) {
 
 static bool use_batch(const ptv2_block *B, int i) { return B->training || !B->run_mean[i] || !B->run_var[i]; }
 
-// where the statistics of BatchNorm `i` go when the producing launch finishes them itself
-static bnfin::Emit emit_of(const ptv2_block *B, int i, const float *gamma, const float *beta, const Saved &S) {
-    const bool track = B->training && B->run_mean[i] && B->run_var[i];
-    return bnfin::Emit{S.mean[i], S.rstd[i], S.bsc[i], S.bsh[i], track ? B->run_mean[i] : nullptr, track ? B->run_var[i] : nullptr,
-                       track ? B->batches[i] : nullptr, gamma, beta};
-}
-
 // statistics of BatchNorm `i` (input h, (n,c)) -> S.mean / S.rstd / S.sc / S.sh: from the producing GEMM's epilogue
 // records (`part` != NULL), from a pass over h (`part` == NULL, batch statistics), or from the running buffers (eval)
 int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
@@ -202,23 +195,11 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
 }
 
 int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream);
-// gemm.hip: rows_gemm_fused whose statistics records are merged inside the launch (arrive.h); *finished = 0: the caller finalizes
-int rows_gemm_fused_bn(int m, int n, int k, int count, int sum, const float *const *X, const float *const *W, int w_kmajor,
-                       const float *const *bias, float *const *Y, int accumulate, const float *xsc, const float *xsh,
-                       float *const *stats, const bnfin::Emit *emit, float eps, float momentum, int *finished, void *stream);
-int rows_gemm_bnbwd_fin(int m, int n, int k, int count, const float *const *X, const float *const *W, int w_kmajor, float *Y,
-                        const float *bn_x, const float *bn_mean, const float *bn_rstd, const float *bn_gamma, const float *bn_beta,
-                        int relu, float *records, float *dbeta, float *dgamma, int *finished, void *stream);
-// AO_AMD_BN_INKERNEL=0: every record sum in a launch of its own (the A/B switch of tests/test_gpu_block.py)
-bool ptv2_bn_inkernel();
-// dense.hip: the apply pass of a BatchNorm backward whose column sums (dbeta, dgamma) are final
-int bn_backward_apply(int n, int c, const float *x, const float *gy, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, int relu, int training, float *gx, const float *dbeta, const float *dgamma, void *stream);
 int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
                             float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
                             float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream);
-int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                            float momentum, void *workspace, size_t workspace_bytes, void *stream);
+int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 // internal to the library (model.hip): the parameter-only folds of `count` Blocks in one launch per 8 Blocks, ahead of the
 // forward; the Blocks are then run inside ptv2_gva_set_prefolded(1)
@@ -246,29 +227,21 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     const float *const *P = B->param;
     float *st_h1 = use_batch(B, 0) ? W.stat[0] : nullptr, *st_hq = use_batch(B, 1) ? W.stat[1] : nullptr;
     float *st_hk = use_batch(B, 2) ? W.stat[2] : nullptr, *st_h3 = use_batch(B, 6) ? W.stat[3] : nullptr;
-    const bool inker = ptv2_bn_inkernel();
-    int fin = 0;
     // fc1 (+ statistics of h1) -> norm1
     {
         const float *xs[1] = {B->x}, *ws[1] = {P[PTV2_BLK_FC1_W]};
         float *ys[1] = {S.h1}, *sts[1] = {st_h1};
-        const bnfin::Emit em[1] = {emit_of(B, 0, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S)};
-        RUN(rows_gemm_fused_bn(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, nullptr, nullptr, sts, inker ? em : nullptr, B->eps, B->momentum,
-                               &fin, stream));
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, nullptr, nullptr, sts, stream));
     }
-    if (!fin) RUN(bn_prepare(B, 0, S.h1, st_h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S, W, stream));
+    RUN(bn_prepare(B, 0, S.h1, st_h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S, W, stream));
     // linear_q / linear_k / linear_v on f1 = ReLU(BN1(h1)) (applied on the operand load), statistics of hq, hk
     {
         const float *xs[3] = {S.h1, S.h1, S.h1}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
         const float *bs[3] = {P[PTV2_BLK_Q_B], P[PTV2_BLK_K_B], P[PTV2_BLK_V_B]};
         float *ys[3] = {S.hq, S.hk, S.v}, *sts[3] = {st_hq, st_hk, nullptr};
-        const bnfin::Emit em[3] = {emit_of(B, 1, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S), emit_of(B, 2, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S),
-                                   bnfin::Emit{}};
-        RUN(rows_gemm_fused_bn(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, S.bsc[0], S.bsh[0], sts, inker && st_hq && st_hk ? em : nullptr, B->eps,
-                               B->momentum, &fin, stream));
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 3, 0, xs, ws, 0, bs, ys, 0, S.bsc[0], S.bsh[0], sts, stream));
     }
-    if (fin) {
-    } else if (st_hq && st_hk) {  // both from their GEMM records: one launch finishes the two BatchNorms
+    if (st_hq && st_hk) {  // both from their GEMM records: one launch finishes the two BatchNorms
         const bool tq = B->training && B->run_mean[1] && B->run_var[1], tk = B->training && B->run_mean[2] && B->run_var[2];
         float *parts[2] = {st_hq, st_hk}, *means[2] = {S.mean[1], S.mean[2]}, *rstds[2] = {S.rstd[1], S.rstd[2]};
         float *scs[2] = {S.bsc[1], S.bsc[2]}, *shs[2] = {S.bsh[1], S.bsh[2]};
@@ -287,34 +260,25 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     // (the attention's last stage leaves the tile statistics of its output where the matrix-core form of it runs: h1's
     // record buffer is free by now)
     int attn_stats = 0;
-    {
-        const bnfin::Emit em = emit_of(B, 5, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S);
-        RUN(gva_block_forward_stats(&V, use_batch(B, 5) ? W.stat[0] : nullptr, &attn_stats, inker ? &em : nullptr, B->eps, B->momentum,
-                                    W.gva, W.gva_bytes, stream));
-    }
-    // norm2 (statistics merged inside the attention's last launch, else from its records, else by a pass over attn) -> fc3 on
-    // f2 = ReLU(BN2(attn)) (+ statistics of h3) -> norm3 -> tail
-    if (attn_stats != 2)
-        RUN(bn_prepare(B, 5, S.attn, attn_stats ? W.stat[0] : nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
-    fin = 0;
+    RUN(gva_block_forward_stats(&V, use_batch(B, 5) ? W.stat[0] : nullptr, &attn_stats, W.gva, W.gva_bytes, stream));
+    // norm2 (statistics from those records, else by a pass over attn) -> fc3 on f2 = ReLU(BN2(attn)) (+ statistics of h3)
+    // -> norm3 -> tail
+    RUN(bn_prepare(B, 5, S.attn, attn_stats ? W.stat[0] : nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
     {
         const float *xs[1] = {S.attn}, *ws[1] = {P[PTV2_BLK_FC3_W]};
         float *ys[1] = {S.h3}, *sts[1] = {st_h3};
-        const bnfin::Emit em[1] = {emit_of(B, 6, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S)};
-        RUN(rows_gemm_fused_bn(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, S.bsc[5], S.bsh[5], sts, inker ? em : nullptr, B->eps, B->momentum,
-                               &fin, stream));
+        RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, S.bsc[5], S.bsh[5], sts, stream));
     }
-    // norm3 + tail: with the records still unmerged, the apply kernel of the deep levels merges them itself (one launch
-    // instead of two)
+    // norm3 + tail: at the deep levels the apply kernel merges the tile records itself (one launch instead of two)
     int tail_done = 0;
-    if (st_h3 && !fin) {
+    if (st_h3) {
         const bool track = B->training && B->run_mean[6] && B->run_var[6];
         tail_done = bn_tiles_apply_residual(n, c, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S.mean[6], S.rstd[6], S.bsc[6], S.bsh[6],
                                             track ? B->run_mean[6] : nullptr, track ? B->run_var[6] : nullptr,
                                             track ? B->batches[6] : nullptr, B->eps, B->momentum, S.h3, B->x, B->rowscale, B->y, stream);
     }
     if (!tail_done) {
-        if (!fin) RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
+        RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
         RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
                                            B->y, stream));
     }
@@ -361,21 +325,14 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                           stream));
     // fc3 input gradient -> g_f2 (ta); norm2 + ReLU -> g_attn (tb)
     // (at <= 512 row blocks the GEMM's epilogue leaves the reduce records of the BatchNorm backward that consumes its output)
-    // (with the records merged inside the GEMM -- arrive.h -- at every level, and the BatchNorm backward is the apply pass alone)
     const int nrb = (n + 63) / 64;
-    const bool inker = ptv2_bn_inkernel();
-    const bool epi = nrb <= 512 || inker;
-    int fin = 0;
+    const bool epi = nrb <= 512;
     if (epi) {
         const float *xs[1] = {g_h3}, *ws[1] = {P[PTV2_BLK_FC3_W]};
-        RUN(rows_gemm_bnbwd_fin(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, W.stat[0],
-                                inker ? GP(PTV2_BLK_N2_B) : nullptr, inker ? GP(PTV2_BLK_N2_G) : nullptr, &fin, stream));
-        if (fin)
-            RUN(bn_backward_apply(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], g_attn,
-                                  GP(PTV2_BLK_N2_B), GP(PTV2_BLK_N2_G), stream));
-        else
-            RUN(bn_backward_records_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5],
-                                                 g_attn, GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.stat[0], nrb, stream));
+        RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G],
+                                         P[PTV2_BLK_N2_B], 1, W.stat[0], stream));
+        RUN(bn_backward_records_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5],
+                                             g_attn, GP(PTV2_BLK_N2_G), GP(PTV2_BLK_N2_B), W.stat[0], nrb, stream));
     } else {
         RUN(rows_gemm_hip_launcher(n, c, c, g_h3, P[PTV2_BLK_FC3_W], 1, nullptr, ta, 0, stream));
         RUN(bn_backward_hip_launcher(n, c, S.attn, ta, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], 1, batch[5], g_attn,
@@ -413,14 +370,10 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     {
         const float *xs[3] = {g_hq, g_hk, gv}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
         if (epi) {
-            RUN(rows_gemm_bnbwd_fin(n, c, c, 3, xs, ws, 1, tb, S.h1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, W.stat[0],
-                                    inker ? GP(PTV2_BLK_N1_B) : nullptr, inker ? GP(PTV2_BLK_N1_G) : nullptr, &fin, stream));
-            if (fin)
-                RUN(bn_backward_apply(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1, batch[0], g_h1,
-                                      GP(PTV2_BLK_N1_B), GP(PTV2_BLK_N1_G), stream));
-            else
-                RUN(bn_backward_records_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1,
-                                                     batch[0], g_h1, GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.stat[0], nrb, stream));
+            RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 3, xs, ws, 1, tb, S.h1, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G],
+                                             P[PTV2_BLK_N1_B], 1, W.stat[0], stream));
+            RUN(bn_backward_records_hip_launcher(n, c, S.h1, tb, S.mean[0], S.rstd[0], P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], 1,
+                                                 batch[0], g_h1, GP(PTV2_BLK_N1_G), GP(PTV2_BLK_N1_B), W.stat[0], nrb, stream));
         } else {
             float *ys[3] = {tb, nullptr, nullptr};
             RUN(rows_gemm_multi_hip_launcher(n, c, c, 3, 1, xs, ws, 1, nullptr, ys, 0, stream));

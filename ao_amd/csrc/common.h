@@ -95,10 +95,8 @@ __device__ __forceinline__ T ptv2_ld_or_zero(const T *p, bool ok) {
 }
 
 // Zeroed per-stream device counters for kernels that reduce their own per-block partial sums (abi.hip).
-// [CNT_ARRIVE, + ARRIVE_COUNTERS): the region of arrive.h's two-level in-kernel sums (every launch leaves it zeroed)
-#define PTV2_NUM_COUNTERS 16384
-#define ARRIVE_COUNTERS (PTV2_NUM_COUNTERS - 64)
-enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE, CNT_BN_TILES = 16 /* .. + 31 */, CNT_ARRIVE = 64 };
+#define PTV2_NUM_COUNTERS 64
+enum PtvCounterSlot { CNT_LOGITS_FWD = 0, CNT_BP2, CNT_LOGITS_BWD_ROWS, CNT_CE, CNT_BN_TILES = 16 /* .. + 31 */ };
 unsigned *ptv2_stream_counters(hipStream_t st);
 
 // Squared distance with the rounding sequence pinned (see oracle/pointops_oracle.c REF_D2):

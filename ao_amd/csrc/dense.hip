@@ -19,9 +19,6 @@
 #include <cstdlib>
 
 #include "gva_common.h"
-#include "arrive.h"
-
-bool ptv2_bn_inkernel();  // AO_AMD_BN_INKERNEL=0: every record sum in a launch of its own
 
 namespace dense {
 
@@ -32,18 +29,9 @@ constexpr int MAX_BLK = 512;
 
 // ------------------------------------------------------------------ BN: stats --
 // lanes: (row lane, float4 column quad); requires c % 4 == 0
-// fin.on: the block records are merged inside the launch by the blocks that arrive last (arrive.h) and the statistics emitted
-struct BnStatsFin {
-    int on;
-    arrive::Args arr;
-    bnfin::Emit emit;
-    bnfin::Norm norm;
-    float eps, momentum;
-};
 __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float *__restrict__ x,
-                                                       float *__restrict__ part, BnStatsFin fin) {
+                                                       float *__restrict__ part) {
     extern __shared__ float4 lds4[];
-    __shared__ int s_flag;
     const int cq = c >> 2;
     const int rl = TPB / cq;                 // row lanes per block (>= 1 for c <= 1024)
     const int q = threadIdx.x % cq, r = threadIdx.x / cq;
@@ -72,17 +60,8 @@ __global__ __launch_bounds__(TPB) void bn_stats_kernel(int n, int c, const float
             b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
         }
         float *p = part + (size_t)blockIdx.x * 2 * c;
-        arrive::store_f4(p + 4 * threadIdx.x, a);
-        arrive::store_f4(p + c + 4 * threadIdx.x, b);
-    }
-    if (fin.on) {
-        const bnfin::Emit E = fin.emit;
-        const bnfin::Norm N = fin.norm;
-        const float eps = fin.eps, momentum = fin.momentum;
-        // sums of (x - x0) and (x - x0)^2: mean = x0 + t1 / n, var = t2 / n - (t1 / n)^2 -- as emit_stats sees them with t1' = t1,
-        // t2' = t2 and the mean shifted afterwards
-        arrive::finish(fin.arr, (int)blockIdx.x, 0, 0, c, (double *)lds4, &s_flag, bnfin::SumRec{part, 2 * c, 0, c},
-                       [=](int col, double a, double b) { bnfin::emit_stats_shifted(E, col, a, b, (double)x[col], N, eps, momentum); });
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b;
     }
 }
 
@@ -324,14 +303,6 @@ __global__ __launch_bounds__(TPB) void bn_apply_residual_kernel(long long total4
     }
 }
 
-// fin.on: the block records of a backward reduce pass are merged inside the launch (arrive.h) into dbeta / dgamma of set
-// blockIdx.y -- the BatchNorm's parameter gradients, and the two column sums its input gradient needs
-struct BnBwdFin {
-    int on;
-    arrive::Args arr;
-    float *dbeta[2], *dgamma[2];
-};
-
 // backward of the fused tail: d = gy * (y > 0) is the gradient of the residual; d * rowscale[n] enters the BN backward
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_residual_kernel(int n, int c, const float *__restrict__ x,
                                                                      const float *__restrict__ gy,
@@ -339,9 +310,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_residual_kernel(int n, int 
                                                                      const float *__restrict__ rowscale,
                                                                      const float *__restrict__ mean,
                                                                      const float *__restrict__ rstd,
-                                                                     float *__restrict__ part, BnBwdFin fin) {
+                                                                     float *__restrict__ part) {
     extern __shared__ float4 lds4[];
-    __shared__ int s_flag;
     const int cq = c >> 2;
     const int rl = TPB / cq;
     const int q = threadIdx.x % cq, r = threadIdx.x / cq;
@@ -372,13 +342,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_residual_kernel(int n, int 
             b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
         }
         float *p = part + (size_t)blockIdx.x * 2 * c;
-        arrive::store_f4(p + 4 * threadIdx.x, a);
-        arrive::store_f4(p + c + 4 * threadIdx.x, b2);
-    }
-    if (fin.on) {
-        float *db = fin.dbeta[0], *dg = fin.dgamma[0];
-        arrive::finish(fin.arr, (int)blockIdx.x, 0, 0, c, (double *)lds4, &s_flag, bnfin::SumRec{part, 2 * c, 0, c},
-                       [=](int col, double a_, double b_) { db[col] = (float)a_; dg[col] = (float)b_; });
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b2;
     }
 }
 
@@ -422,9 +387,8 @@ struct BnSecond {
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const float *x, const float *gy,
                                                             const float *mean, const float *rstd, const float *gamma,
                                                             const float *beta, int relu, float *__restrict__ part,
-                                                            BnSecond second, BnBwdFin fin) {
+                                                            BnSecond second) {
     extern __shared__ float4 lds4[];
-    __shared__ int s_flag;
     if (blockIdx.y) { x = second.x; gy = second.gy; mean = second.mean; rstd = second.rstd; gamma = second.gamma; beta = second.beta; }
     const int cq = c >> 2;
     const int rl = TPB / cq;
@@ -462,17 +426,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const 
             b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
         }
         float *p = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * c;  // record of a block: [set 0 | set 1]
-        arrive::store_f4(p + 4 * threadIdx.x, a);
-        arrive::store_f4(p + c + 4 * threadIdx.x, b2);
-    }
-    if (fin.on) {
-        const int set = blockIdx.y;
-        float *db = set ? fin.dbeta[1] : fin.dbeta[0], *dg = set ? fin.dgamma[1] : fin.dgamma[0];
-        arrive::Args A = fin.arr;
-        A.fold += (size_t)set * arrive::fold_doubles(c);
-        arrive::finish(A, (int)blockIdx.x, set, 0, c, (double *)lds4, &s_flag,
-                       bnfin::SumRec{part, 2 * c * (int)gridDim.y, 2 * c * set, c},
-                       [=](int col, double a_, double b_) { db[col] = (float)a_; dg[col] = (float)b_; });
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b2;
     }
 }
 
@@ -1370,9 +1325,7 @@ using namespace dense;
 extern "C" size_t dense_workspace_bytes(int n, int cout, int cin) {  // cout*cin = total outputs over all batches
     const size_t chunks = (size_t)(n + WG_CHUNK_MIN - 1) / WG_CHUNK_MIN + 1;
     const size_t wg = sizeof(float) * chunks * ((size_t)cout * cin + cout);
-    // BatchNorm reduce records (up to two sets side by side) + the level-1 partials of their in-kernel sums (arrive.h)
-    const size_t cm = (size_t)std::max(cout, cin);
-    const size_t bn = sizeof(float) * (size_t)MAX_BLK * 2 * cm + sizeof(double) * arrive::fold_doubles((int)cm);
+    const size_t bn = sizeof(float) * (size_t)MAX_BLK * 2 * (size_t)std::max(cout, cin);
     return align_up(std::max(wg, bn)) + 1024;
 }
 
@@ -1419,21 +1372,8 @@ static int bn_stats_impl(int n, int c, const float *x, float *mean, float *rstd,
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
     {
-        BnStatsFin fin{};
-        // (the level-1 partials behind the records: dense_workspace_bytes reserves them)
-        if (ptv2_bn_inkernel() && arrive::make(&fin.arr, st, nblk, 1, (double *)(part + (size_t)MAX_BLK * 2 * c), c)) {
-            fin.on = 1;
-            fin.emit = bnfin::Emit{mean, rstd, sc, sh, running_mean, running_var, num_batches_tracked, gamma, beta};
-            fin.norm = bnfin::norm_of(n);
-            fin.eps = eps;
-            fin.momentum = momentum;
-        }
         PtvScopedTimer t(KID_BN_STATS, st, 4.0 * n * c);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part, fin);
-        if (fin.on) {
-            PTV2_CHECK_LAUNCH();
-            return PTV2_OK;
-        }
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, part);
     }
     if (nblk >= 64)
         hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((c + 15) / 16), dim3(1024), 0, st, (const float *)part, nblk, c, n, x, eps,
@@ -1507,13 +1447,7 @@ __global__ void bn_finalize_folded_kernel(BnTileSet A, BnTileSet B, int nrec, in
 
 // statistics of a (n,c) tensor from the records its producing rows_gemm_fused launch left in `part`
 extern "C" size_t bn_tiles_floats(int n, int c) {  // floats of a statistics record buffer (incl. the folding scratch)
-    return (size_t)((n + 63) / 64) * 2 * c + 2 + 2 * arrive::fold_doubles(c);  // (arrive.h: up to 128 level-1 partials of [2][c] float64)
-}
-
-// AO_AMD_BN_INKERNEL=0: every record sum of the BatchNorms in a launch of its own (rounds 1-4; the A/B switch of the tests)
-bool ptv2_bn_inkernel() {
-    static const bool on = [] { const char *e = getenv("AO_AMD_BN_INKERNEL"); return !(e && e[0] == '0'); }();
-    return on;
+    return (size_t)((n + 63) / 64) * 2 * c + 2 + 2 * (size_t)16 * 2 * c;
 }
 
 // count (1 or 2) tensors of one shape in one launch (two for > 512 records: fold, then finish)
@@ -1649,23 +1583,19 @@ extern "C" int bn_backward_residual_hip_launcher(int n, int c, const float *x, c
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
-    BnBwdFin fin{};
-    if (ptv2_bn_inkernel() && arrive::make(&fin.arr, st, nblk, 1, (double *)(part + (size_t)MAX_BLK * 2 * c), c)) {
-        fin.on = 1; fin.dbeta[0] = dbeta; fin.dgamma[0] = dgamma;
-    }
     {
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 12.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_residual_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, y,
-                           rowscale, mean, rstd, part, fin);
+                           rowscale, mean, rstd, part);
     }
-    if (!fin.on && finapply_ok(n, nblk)) {
+    if (finapply_ok(n, nblk)) {
         PtvScopedTimer t(KID_BN_BWD_APPLY, st, 20.0 * n * c);
         const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, nullptr, gx, dbeta, dgamma, y, rowscale, g_residual};
         launch_finapply(st, n, c, 1, training, true, 1, A, A);
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
-    if (!fin.on) launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
+    launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
     {
@@ -1686,45 +1616,25 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
     hipStream_t st = (hipStream_t)stream;
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
-    BnBwdFin fin{};
-    if (ptv2_bn_inkernel() && arrive::make(&fin.arr, st, nblk, 1, (double *)(part + (size_t)MAX_BLK * 2 * c), c)) {
-        fin.on = 1; fin.dbeta[0] = dbeta; fin.dgamma[0] = dgamma;
-    }
     {
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 8.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x, gy, mean,
-                           rstd, gamma, beta, relu, part, BnSecond{}, fin);
+                           rstd, gamma, beta, relu, part, BnSecond{});
     }
-    if (!fin.on && finapply_ok(n, nblk)) {
+    if (finapply_ok(n, nblk)) {
         PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
         const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, beta, gx, dbeta, dgamma, nullptr, nullptr, nullptr};
         launch_finapply(st, n, c, relu, training, false, 1, A, A);
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
-    if (!fin.on) launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
+    launch_finalize(st, (const float *)part, nblk, 2 * c, gva::MapSplit2<float>{dbeta, dgamma, c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
     {
         PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean,
                            rstd, gamma, beta, relu, (const float *)dbeta, (const float *)dgamma, training, gx, BnSecond{});
-    }
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-
-// the apply pass alone: dbeta / dgamma are final (the producing launch merged its records itself, arrive.h)
-int bn_backward_apply(int n, int c, const float *x, const float *gy, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, int relu, int training, float *gx, const float *dbeta, const float *dgamma, void *stream) {
-    if (n < 1 || c < 4 || c % 4 != 0 || c > 1024) return PTV2_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const long long total4 = (long long)n * (c >> 2);
-    const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
-    {
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, mean, rstd,
-                           gamma, beta, relu, dbeta, dgamma, training, gx, BnSecond{});
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -1780,16 +1690,12 @@ extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x
     const int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
     const BnSecond sec{x[1], gy[1], mean[1], rstd[1], gamma[1], beta[1], gx[1], dgamma[1], dbeta[1]};
-    BnBwdFin fin{};
-    if (ptv2_bn_inkernel() && arrive::make(&fin.arr, st, nblk, 2, (double *)(part + (size_t)MAX_BLK * 4 * c), c)) {
-        fin.on = 1; fin.dbeta[0] = dbeta[0]; fin.dgamma[0] = dgamma[0]; fin.dbeta[1] = dbeta[1]; fin.dgamma[1] = dgamma[1];
-    }
     {
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 16.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, 2), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x[0], gy[0], mean[0],
-                           rstd[0], gamma[0], beta[0], relu, part, sec, fin);
+                           rstd[0], gamma[0], beta[0], relu, part, sec);
     }
-    if (!fin.on && finapply_ok(n, nblk)) {  // record of a block: [set 0: dbeta c | dgamma c][set 1: ...]
+    if (finapply_ok(n, nblk)) {  // record of a block: [set 0: dbeta c | dgamma c][set 1: ...]
         PtvScopedTimer t(KID_BN_BWD_APPLY, st, 24.0 * n * c);
         const BnFinApply A0{part, nblk, 4 * c, 0, x[0], gy[0], mean[0], rstd[0], gamma[0], beta[0], gx[0], dbeta[0], dgamma[0], nullptr,
                             nullptr, nullptr};
@@ -1799,7 +1705,7 @@ extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
-    if (!fin.on) launch_finalize(st, (const float *)part, nblk, 4 * c, MapBnPair{dbeta[0], dgamma[0], dbeta[1], dgamma[1], c});
+    launch_finalize(st, (const float *)part, nblk, 4 * c, MapBnPair{dbeta[0], dgamma[0], dbeta[1], dgamma[1], c});
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
     {

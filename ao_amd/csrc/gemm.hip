@@ -14,7 +14,7 @@
 //   * epilogue: + bias[n], optional accumulate onto Y (sums of several products, residual gradients).
 #include <algorithm>
 
-#include "arrive.h"
+#include "common.h"
 
 namespace gemm {
 
@@ -57,17 +57,6 @@ struct GemmMulti {
     const float *bnx, *bnm, *bnr, *bng, *bnb;
     int bnrelu;
     float *brec;
-    // fin != 0: the records are merged INSIDE this launch by the workgroups that arrive last (arrive.h) -- 1: the forward
-    // statistics of stats[z] -> emit[z] (mean, rstd, folded affine, running buffers: what bn_tiles_finalize did in a launch of
-    // its own); 2: the backward records brec -> bdbeta / bdgamma (the BatchNorm's parameter gradients, which are also the two
-    // column sums its input gradient needs).  arr: plan + counters of set 0 (set z: + z * ncb * (ngroups + 1)), fold[z]
-    int fin;
-    arrive::Args arr;
-    double *fold[3];
-    bnfin::Emit emit[3];
-    float *bdbeta, *bdgamma;
-    float eps, momentum;
-    bnfin::Norm norm;
 };
 
 template <int CTRL>
@@ -88,8 +77,7 @@ __device__ __forceinline__ float row16_sum(float v) {  // all-reduce over the 16
 template <int BN>
 __device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long long row0, const int rb, const int n0, const int z,
                                               const bool indep, const int m, const int n, const float *__restrict__ bias,
-                                              float *__restrict__ Y, const int accumulate, const GemmMulti &multi, float *sS_,
-                                              const int ncb, int *s_flag) {
+                                              float *__restrict__ Y, const int accumulate, const GemmMulti &multi, float *sS_) {
     constexpr int NT = BN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     float *sX = sS_;
@@ -152,16 +140,8 @@ __device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long lo
                 float a = sS[which * BN + cc];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) a += sS[(w * 2 + which) * BN + cc];
-                arrive::store_f(multi.brec + (size_t)rb * 2 * n + (size_t)which * n + n0 + cc, a);
+                multi.brec[(size_t)rb * 2 * n + (size_t)which * n + n0 + cc] = a;
             }
-        }
-        if (multi.fin == 2) {  // the last workgroups of this column block finish dbeta / dgamma (arrive.h)
-            const int ncols = (n - n0) < BN ? (n - n0) : BN;
-            float *db = multi.bdbeta, *dg = multi.bdgamma;
-            arrive::Args A = multi.arr;
-            A.fold = multi.fold[0];
-            arrive::finish(A, rb, n0 / BN, n0, ncols, (double *)sS, s_flag, bnfin::SumRec{multi.brec, 2 * n, 0, n},
-                           [=](int col, double a, double b) { db[col] = (float)a; dg[col] = (float)b; });
         }
     }
     float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
@@ -196,7 +176,7 @@ __device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long lo
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int col = n0 + t * 16 + cl;
-            if (wid == 0 && (lane & 15) == 0 && col < n) arrive::store_f4(stats + (size_t)rb * 2 * n + col, mean[t]);
+            if (wid == 0 && (lane & 15) == 0 && col < n) *(float4 *)(stats + (size_t)rb * 2 * n + col) = mean[t];
             const float dx = rv ? val[t].x - mean[t].x * inv : 0.f, dy = rv ? val[t].y - mean[t].y * inv : 0.f;
             const float dz = rv ? val[t].z - mean[t].z * inv : 0.f, dw = rv ? val[t].w - mean[t].w * inv : 0.f;
             const float qx = row16_sum(dx * dx), qy = row16_sum(dy * dy), qz = row16_sum(dz * dz), qw = row16_sum(dw * dw);
@@ -214,21 +194,9 @@ __device__ __forceinline__ void gemm_epilogue(v4f (&acc)[BN / 16], const long lo
                         const float4 o = *(const float4 *)(sS + w * BN + t * 16 + cl);
                         a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
                     }
-                    arrive::store_f4(stats + (size_t)rb * 2 * n + n + col, a);
+                    *(float4 *)(stats + (size_t)rb * 2 * n + n + col) = a;
                 }
             }
-        }
-        if (multi.fin == 1) {  // the last workgroups of this column block merge the records and emit the statistics (arrive.h)
-            const int zz = indep ? z : 0;
-            const int ncols = (n - n0) < BN ? (n - n0) : BN;
-            arrive::Args A = multi.arr;
-            A.counters += (size_t)zz * ncb * (A.ngroups + 1);
-            A.fold = multi.fold[zz];
-            const bnfin::Emit E = multi.emit[zz];
-            const float eps = multi.eps, momentum = multi.momentum;
-            const bnfin::Norm N = multi.norm;
-            arrive::finish(A, rb, n0 / BN, n0, ncols, (double *)sS, s_flag, bnfin::TileRec{stats, n, m, N.last, N.inv_last},
-                           [=](int col, double a, double b) { bnfin::emit_stats(E, col, a, b, N, eps, momentum); });
         }
     }
 }
@@ -244,7 +212,6 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
     constexpr int PITCH = KC + 8;
     __shared__ __attribute__((aligned(16))) float sX[BM * PITCH];
     __shared__ __attribute__((aligned(16))) float sW[BN * PITCH];
-    __shared__ int s_flag;
     constexpr int NT = BN / 16;            // MFMA column tiles per wavefront
     constexpr int KQ = KC / 4;             // float4 per row of a chunk
     constexpr int XLOADS = BM * KQ / THREADS;
@@ -381,7 +348,7 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
             }
         }
     }
-    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sX, ncb, &s_flag);
+    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sX);
 }
 
 // ---- the same product with X read straight into the MFMA operand registers ("direct" form, round 3) -----------------
@@ -395,15 +362,12 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_kernel(int m, int n, int k,
 // only barrier before the epilogue; (k,n)-major weights are transposed on the way in) with row pitch K + 8 floats: the
 // ds_read_b128 operand reads of a lane group fall on 16 distinct slots for every K in use.  Contraction index of lane
 // quarter q in step (j, e): k = 16 j + 4 q + e, identically for both operands.
-// (K = 48, the full-resolution level: the launch is ONE round of resident wavefronts at 6 per SIMD (8 for 16-column blocks);
-// the bound keeps the in-kernel record sums of the epilogue, a path one workgroup in dozens takes, from costing that)
 template <int BN, bool W_KMAJOR, int K, bool BF16>
-__global__ __launch_bounds__(THREADS, (K == 48 ? (BN == 48 ? 6 : 8) : 1)) void rows_gemm_direct_kernel(int m, int n, const float *__restrict__ X0,
+__global__ __launch_bounds__(THREADS) void rows_gemm_direct_kernel(int m, int n, const float *__restrict__ X0,
                                                                    const float *__restrict__ W0, const float *__restrict__ bias0,
                                                                    float *__restrict__ Y0, int accumulate, int ncb, GemmMulti multi) {
     constexpr int NT = BN / 16, QF = K / 16, LDW = K + 8, KQ = K / 4;
     extern __shared__ float4 gd_lds4[];
-    __shared__ int s_flag;
     float *sW = (float *)gd_lds4;            // [BN][K + 8]
     float *sSc = sW + (size_t)BN * LDW;       // [K] scale, [K] shift of the fused BatchNorm + ReLU on X (when present)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -521,7 +485,7 @@ __global__ __launch_bounds__(THREADS, (K == 48 ? (BN == 48 ? 6 : 8) : 1)) void r
         }
     }
     __syncthreads();  // the weight block is dead: its LDS is the epilogue's scratch
-    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sW, ncb, &s_flag);
+    gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sW);
 }
 
 }  // namespace gemm
@@ -529,7 +493,7 @@ __global__ __launch_bounds__(THREADS, (K == 48 ? (BN == 48 ? 6 : 8) : 1)) void r
 template <int BN, bool KM, int K>
 static void launch_direct(dim3 grid, hipStream_t st, int m, int n, const float *X, const float *W, const float *bias, float *Y,
                           int accumulate, int ncb, const gemm::GemmMulti &gm) {
-    const size_t lds = std::max(sizeof(float) * ((size_t)BN * (K + 8) + 2 * K), sizeof(double) * 2 * gemm::THREADS);  // (arrive.h scratch)
+    const size_t lds = sizeof(float) * ((size_t)BN * (K + 8) + 2 * K);
     if (ptv2_matmul_bf16()) {
         auto kern = gemm::rows_gemm_direct_kernel<BN, KM, K, true>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -645,13 +609,11 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
 // as rows_gemm_multi, with BatchNorm fused on either side: xsc / xsh (k) != NULL: the X operand is ReLU(x * xsc + xsh);
 // stats != NULL: stats[i] != NULL receives the per-row-block column statistics of Y[i] (ceil(m / 64) records of
 // [2][n] floats: sum, centred sum of squares), to be merged by bn_tiles_finalize_hip_launcher
-// stats[i] + emit != NULL: the statistics records are merged inside the launch (GemmMulti::fin = 1) and *finished = 1; when the
-// launch does not fit the counter region the records are left for the caller's finalize launch (*finished = 0)
-int rows_gemm_fused_bn(int m, int n, int k, int count, int sum, const float *const *X, const float *const *W, int w_kmajor,
-                       const float *const *bias, float *const *Y, int accumulate, const float *xsc, const float *xsh,
-                       float *const *stats, const bnfin::Emit *emit, float eps, float momentum, int *finished, void *stream) {
+extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
+                                            const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
+                                            int accumulate, const float *xsc, const float *xsh, float *const *stats,
+                                            void *stream) {
     using namespace gemm;
-    if (finished) *finished = 0;
     if (m < 0 || n < 4 || k < 4 || n % 4 != 0 || k % 4 != 0 || count < 1 || count > 3 || !X || !W || !Y) return PTV2_ERR_ARG;
     if (m == 0) return PTV2_OK;
     GemmMulti gm{};
@@ -671,23 +633,6 @@ int rows_gemm_fused_bn(int m, int n, int k, int count, int sum, const float *con
     const int ncb = (n + bn - 1) / bn;
     const long long nrb = ((long long)m + BM - 1) / BM;
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
-    if (emit && stats && finished && nrb < (1 << 24)) {
-        bool any = false, all = true;
-        for (int i = 0; i < (sum ? 1 : count); ++i)
-            if (gm.stats[i]) { any = true; if (!emit[i].mean || !emit[i].rstd) all = false; }
-        if (any && all && arrive::make(&gm.arr, st, (int)nrb, (long long)ncb * (sum ? 1 : count), nullptr, n)) {
-            gm.fin = 1;
-            gm.eps = eps;
-            gm.momentum = momentum;
-            gm.norm = bnfin::norm_of(m);
-            for (int i = 0; i < (sum ? 1 : count); ++i) {
-                gm.emit[i] = emit[i];
-                // the level-1 partials live behind the tile records (bn_tiles_floats reserves them)
-                gm.fold[i] = gm.stats[i] ? (double *)(gm.stats[i] + (((size_t)nrb * 2 * n + 1) & ~(size_t)1)) : nullptr;
-            }
-            *finished = 1;
-        }
-    }
     const dim3 grid((unsigned)(nrb * ncb), sum ? 1 : count);
     const float *b0 = sum ? gm.bias[0] : nullptr;
     {
@@ -697,14 +642,6 @@ int rows_gemm_fused_bn(int m, int n, int k, int count, int sum, const float *con
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
-}
-
-extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
-                                            const float *const *W, int w_kmajor, const float *const *bias, float *const *Y,
-                                            int accumulate, const float *xsc, const float *xsh, float *const *stats,
-                                            void *stream) {
-    return rows_gemm_fused_bn(m, n, k, count, sum, X, W, w_kmajor, bias, Y, accumulate, xsc, xsh, stats, nullptr, 0.f, 0.f, nullptr,
-                              stream);
 }
 
 extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int sum, const float *const *X,
@@ -717,12 +654,10 @@ extern "C" int rows_gemm_multi_hip_launcher(int m, int n, int k, int count, int 
 // rows_gemm_multi (sum or single) whose output Y[0] is the gradient entering a BatchNorm (+ ReLU) with input bn_x: also
 // leaves that BatchNorm's backward-reduce records (ceil(m / 64) records of [2][n]: sum g', sum g' xhat) in `records`,
 // to be finished by bn_backward_records_hip_launcher
-// dbeta / dgamma != NULL: the records are merged inside the launch (GemmMulti::fin = 2) and *finished = 1
-int rows_gemm_bnbwd_fin(int m, int n, int k, int count, const float *const *X, const float *const *W, int w_kmajor, float *Y,
-                        const float *bn_x, const float *bn_mean, const float *bn_rstd, const float *bn_gamma, const float *bn_beta,
-                        int relu, float *records, float *dbeta, float *dgamma, int *finished, void *stream) {
+extern "C" int rows_gemm_bnbwd_hip_launcher(int m, int n, int k, int count, const float *const *X, const float *const *W,
+                                            int w_kmajor, float *Y, const float *bn_x, const float *bn_mean, const float *bn_rstd,
+                                            const float *bn_gamma, const float *bn_beta, int relu, float *records, void *stream) {
     using namespace gemm;
-    if (finished) *finished = 0;
     if (m < 0 || n < 4 || k < 4 || n % 4 != 0 || k % 4 != 0 || count < 1 || count > 3 || !X || !W || !Y) return PTV2_ERR_ARG;
     if (!bn_x || !bn_mean || !bn_rstd || !records || (relu && (!bn_gamma || !bn_beta))) return PTV2_ERR_ARG;
     if (m == 0) return PTV2_OK;
@@ -741,14 +676,6 @@ int rows_gemm_bnbwd_fin(int m, int n, int k, int count, const float *const *X, c
     const int ncb = (n + bn - 1) / bn;
     const long long nrb = ((long long)m + BM - 1) / BM;
     if (nrb * ncb > 2147483647LL) return PTV2_ERR_ARG;
-    if (dbeta && dgamma && finished && nrb < (1 << 24) &&
-        arrive::make(&gm.arr, st, (int)nrb, ncb, (double *)(records + (((size_t)nrb * 2 * n + 1) & ~(size_t)1)), n)) {
-        gm.fin = 2;
-        gm.fold[0] = gm.arr.fold;
-        gm.bdbeta = dbeta;
-        gm.bdgamma = dgamma;
-        *finished = 1;
-    }
     const dim3 grid((unsigned)(nrb * ncb), 1);
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
@@ -757,11 +684,4 @@ int rows_gemm_bnbwd_fin(int m, int n, int k, int count, const float *const *X, c
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
-}
-
-extern "C" int rows_gemm_bnbwd_hip_launcher(int m, int n, int k, int count, const float *const *X, const float *const *W,
-                                            int w_kmajor, float *Y, const float *bn_x, const float *bn_mean, const float *bn_rstd,
-                                            const float *bn_gamma, const float *bn_beta, int relu, float *records, void *stream) {
-    return rows_gemm_bnbwd_fin(m, n, k, count, X, W, w_kmajor, Y, bn_x, bn_mean, bn_rstd, bn_gamma, bn_beta, relu, records, nullptr,
-                               nullptr, nullptr, stream);
 }

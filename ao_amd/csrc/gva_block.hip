@@ -10,7 +10,6 @@
 #include <vector>
 
 #include "gva_common.h"
-#include "arrive.h"
 #include "gva_fold_p.h"
 
 namespace gva {
@@ -436,21 +435,19 @@ int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stre
 }
 
 int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,
-                          const float *out_v, float *out, float *stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                          float momentum, void *stream);
-int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                            float momentum, void *workspace, size_t workspace_bytes, void *stream);
+                          const float *out_v, float *out, float *stats, int *stats_done, void *stream);
+int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
+                            void *stream);
 
 extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *workspace, size_t workspace_bytes,
                                               void *stream) {
-    return gva_block_forward_stats(B, nullptr, nullptr, nullptr, 0.f, 0.f, workspace, workspace_bytes, stream);
+    return gva_block_forward_stats(B, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 // internal (block.hip): out_stats != NULL asks the last stage for the per-64-row-block column statistics of `out` (the
-// BatchNorm behind the attention then needs no statistics pass); *stats_done says whether they were produced (1), or produced
-// and -- emit != NULL -- merged into that BatchNorm's statistics inside the same launch (2)
-int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                            float momentum, void *workspace, size_t workspace_bytes, void *stream) {
+// BatchNorm behind the attention then needs no statistics pass); *stats_done says whether they were produced
+int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
+                            void *stream) {
     if (stats_done) *stats_done = 0;
     if (!B) return PTV2_ERR_ARG;
     const int n = B->n, k = B->k, c = B->c, g = B->g;
@@ -479,7 +476,7 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
                                 W.stage, W.stage_bytes, stream));
     RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
                                            B->idx, W.out_v, B->A, B->sw, B->w, stream));
-    RUN(gva_peb_forward_stats(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, out_stats, stats_done, emit, eps, momentum, stream));
+    RUN(gva_peb_forward_stats(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, out_stats, stats_done, stream));
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

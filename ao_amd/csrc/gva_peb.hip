@@ -11,7 +11,6 @@
 #include <cstdlib>
 
 #include "gva_common.h"
-#include "arrive.h"
 
 namespace gva {
 
@@ -107,22 +106,11 @@ __device__ __forceinline__ float peb_row16_sum(float v) {  // all-reduce over th
     return v;
 }
 
-// fin.on: the statistics records are merged inside this launch by the workgroups that arrive last (arrive.h) and emitted as
-// mean / rstd / folded affine / running buffers -- what bn_tiles_finalize did in a launch of its own
-struct PebFin {
-    int on;
-    arrive::Args arr;
-    bnfin::Emit emit;
-    bnfin::Norm norm;
-    float eps, momentum;
-};
-
 template <int C, int PEB_MAX_GPW>  // PEB_MAX_GPW: groups per workgroup (compile-time: per-group registers are arrays of it)
 __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const float *__restrict__ A,
                                                            const float *__restrict__ Wp2, const float *__restrict__ bp2,
                                                            const float *__restrict__ sw, const float *__restrict__ out_v,
-                                                           float *__restrict__ out, float *__restrict__ stats, PebFin fin) {
-    __shared__ int s_flag;
+                                                           float *__restrict__ out, float *__restrict__ stats) {
     constexpr int QF = C / 16;                      // float4 per lane and group (a lane owns C / 4 of the c')
     constexpr int CH = QF <= 6 ? QF : (QF % 6 == 0 ? 6 : 4);  // float4 per lane and item
     constexpr int NCH = QF / CH;                    // items per group
@@ -260,7 +248,7 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
 #pragma unroll
     for (int t = 0; t < PEB_MAX_GPW; ++t)
         if (t < ng) {
-            if (wid == 0 && l15 == 0 && q < 2) arrive::store_f4(rec + t * 8 + 4 * q, mean[t]);
+            if (wid == 0 && l15 == 0 && q < 2) *(float4 *)(rec + t * 8 + 4 * q) = mean[t];
             const bool ok = rv && q < 2;
             const float dx = ok ? val[t].x - mean[t].x * inv : 0.f, dy = ok ? val[t].y - mean[t].y * inv : 0.f;
             const float dz = ok ? val[t].z - mean[t].z * inv : 0.f, dw = ok ? val[t].w - mean[t].w * inv : 0.f;
@@ -278,17 +266,8 @@ __global__ __launch_bounds__(TPB) void peb_fwd_mfma_kernel(int n, int g, const f
                     const float4 o = *(const float4 *)(sS + w * ncol + t * 8 + 4 * q);
                     a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
                 }
-                arrive::store_f4(rec + C + t * 8 + 4 * q, a);
+                *(float4 *)(rec + C + t * 8 + 4 * q) = a;
             }
-    }
-    if (fin.on) {
-        const bnfin::Emit E = fin.emit;
-        const bnfin::Norm N = fin.norm;
-        const float eps = fin.eps, momentum = fin.momentum;
-        // (the Wp2 rows in LDS are dead: every wavefront passed the barriers above after its last product)
-        arrive::finish(fin.arr, (int)blockIdx.x, (int)blockIdx.y, g0 * 8, ncol, (double *)sW, &s_flag,
-                       bnfin::TileRec{stats, C, n, N.last, N.inv_last},
-                       [=](int col, double a, double b) { bnfin::emit_stats(E, col, a, b, N, eps, momentum); });
     }
 }
 
@@ -385,36 +364,27 @@ using namespace gva;
 
 // internal (gva_block.hip): stats != NULL asks for the per-64-row-block column statistics of `out` (bn_tiles_floats(n, c)
 // floats; see peb_fwd_mfma_kernel); *stats_done tells whether this call produced them (the matrix-core form only)
-// emit != NULL: the records are merged inside the launch and the statistics emitted (*stats_done = 2)
 int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,
-                          const float *out_v, float *out, float *stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                          float momentum, void *stream);
+                          const float *out_v, float *out, float *stats, int *stats_done, void *stream);
 
 extern "C" int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const float *Wp2, const float *bp2,
                                             const float *sw, const float *out_v, float *out, void *stream) {
-    return gva_peb_forward_stats(n, c, g, A, Wp2, bp2, sw, out_v, out, nullptr, nullptr, nullptr, 0.f, 0.f, stream);
+    return gva_peb_forward_stats(n, c, g, A, Wp2, bp2, sw, out_v, out, nullptr, nullptr, stream);
 }
-
-static thread_local int g_peb_fin_done = 0;  // whether the last matrix-core launch of this thread merges its records itself
 
 template <int C, int GPW>
 static void launch_peb_mfma_g(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
-                              float *out, float *stats, PebFin fin, hipStream_t st) {
+                              float *out, float *stats, hipStream_t st) {
     const int nrb = (n + 63) / 64;
-    if (fin.on) {  // the plan: one column block per grid row of groups
-        fin.on = 0;
-        if (arrive::make(&fin.arr, st, nrb, (g + GPW - 1) / GPW, (double *)(stats + (((size_t)nrb * 2 * C + 1) & ~(size_t)1)), C)) fin.on = 1;
-    }
-    g_peb_fin_done = fin.on;
-    const size_t lds = std::max(sizeof(float) * ((size_t)GPW * 8 * (C + 8) + 4 * GPW * 8), sizeof(double) * 2 * TPB);
+    const size_t lds = sizeof(float) * ((size_t)GPW * 8 * (C + 8) + 4 * GPW * 8);
     auto kern = peb_fwd_mfma_kernel<C, GPW>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(nrb, (g + GPW - 1) / GPW), dim3(TPB), lds, st, n, g, A, Wp2, bp2, sw, out_v, out, stats, fin);
+    hipLaunchKernelGGL(kern, dim3(nrb, (g + GPW - 1) / GPW), dim3(TPB), lds, st, n, g, A, Wp2, bp2, sw, out_v, out, stats);
 }
 
 template <int C>
 static void launch_peb_mfma(int n, int g, const float *A, const float *Wp2, const float *bp2, const float *sw, const float *out_v,
-                            float *out, float *stats, const PebFin &fin, hipStream_t st) {
+                            float *out, float *stats, hipStream_t st) {
     const int nrb = (n + 63) / 64;
     // groups per workgroup: as many (of 6, 3, 2, 1) as keep >= ~512 workgroups in the launch (each stages its Wp2 rows once)
     const int opts[4] = {6, 3, 2, 1};
@@ -422,34 +392,29 @@ static void launch_peb_mfma(int n, int g, const float *A, const float *Wp2, cons
     for (int i = 0; i < 4; ++i)
         if ((long long)nrb * ((g + opts[i] - 1) / opts[i]) >= 512 || opts[i] == 1) { gpw = opts[i]; break; }
     switch (gpw) {
-        case 6: launch_peb_mfma_g<C, 6>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-        case 3: launch_peb_mfma_g<C, 3>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-        case 2: launch_peb_mfma_g<C, 2>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-        default: launch_peb_mfma_g<C, 1>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
+        case 6: launch_peb_mfma_g<C, 6>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        case 3: launch_peb_mfma_g<C, 3>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        case 2: launch_peb_mfma_g<C, 2>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+        default: launch_peb_mfma_g<C, 1>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
     }
 }
 
 int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2, const float *bp2, const float *sw,
-                          const float *out_v, float *out, float *stats, int *stats_done, const bnfin::Emit *emit, float eps,
-                          float momentum, void *stream) {
+                          const float *out_v, float *out, float *stats, int *stats_done, void *stream) {
     if (n < 0 || c < 4 || g < 1 || c % g != 0 || c % 4 != 0) return PTV2_ERR_ARG;
     if (stats_done) *stats_done = 0;
     if (n == 0) return PTV2_OK;
     if (c / g == 8 && (c == 48 || c == 96 || c == 192 || c == 384 || c == 512)) {
         hipStream_t st = (hipStream_t)stream;
         PtvScopedTimer t(KID_PEB_FWD, st, 4.0 * ((double)n * g * c + 2.0 * n * c + (double)n * g + (double)c * c));
-        PebFin fin{};
-        if (stats && stats_done && emit && emit->mean && emit->rstd) {
-            fin.on = 1; fin.emit = *emit; fin.norm = bnfin::norm_of(n); fin.eps = eps; fin.momentum = momentum;
-        }
         switch (c) {
-            case 48: launch_peb_mfma<48>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-            case 96: launch_peb_mfma<96>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-            case 192: launch_peb_mfma<192>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-            case 384: launch_peb_mfma<384>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
-            default: launch_peb_mfma<512>(n, g, A, Wp2, bp2, sw, out_v, out, stats, fin, st); break;
+            case 48: launch_peb_mfma<48>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 96: launch_peb_mfma<96>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 192: launch_peb_mfma<192>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            case 384: launch_peb_mfma<384>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
+            default: launch_peb_mfma<512>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
         }
-        if (stats && stats_done) *stats_done = g_peb_fin_done ? 2 : 1;
+        if (stats && stats_done) *stats_done = 1;
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }

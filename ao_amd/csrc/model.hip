@@ -21,7 +21,7 @@
 #include <mutex>
 #include <vector>
 
-#include "arrive.h"
+#include "common.h"
 
 int ptv2_blocks_fold_forward(int count, const ptv2_block *blocks, void *stream);  // block.hip
 void ptv2_gva_set_prefolded(int on);                                                // gva_block.hip
@@ -29,10 +29,6 @@ size_t ptv2_gva_fold_scratch_floats(int c, int g);  // deferred M / cW glue of t
 void ptv2_gva_set_fold_scratch(float *p);
 int ptv2_gva_flush_folds(void *stream);
 void ptv2_gva_drop_folds();
-int rows_gemm_fused_bn(int m, int n, int k, int count, int sum, const float *const *X, const float *const *W, int w_kmajor,
-                       const float *const *bias, float *const *Y, int accumulate, const float *xsc, const float *xsh,
-                       float *const *stats, const bnfin::Emit *emit, float eps, float momentum, int *finished, void *stream);  // gemm.hip
-bool ptv2_bn_inkernel();  // dense.hip
 
 namespace {
 
@@ -236,7 +232,6 @@ Arena carve(const ptv2_model *M, void *base) {
 struct Work {
     char *block; size_t block_bytes;   // workspace of the Block runtime
     char *dense; size_t dense_bytes;   // BatchNorm / weight-gradient partial records
-    float *stat;                       // tile statistics records of a Linear + BatchNorm layer's GEMM (bn_tiles_floats)
     float *ga, *gb, *gc;               // gradient temporaries, max over levels of n * widest channel count
     float *gskip[PTV2_MAX_STAGES + 1]; // gradient of the encoder output at level i (two contributions)
     float *fold_scratch[PTV2_MAX_BLOCKS];    // per-Block operands of the attention's parameter glue, run once at the end
@@ -260,9 +255,7 @@ Work carve_work(const ptv2_model *M, void *base) {
         W.block_bytes = std::max(W.block_bytes, ptv2_block_workspace_bytes(n, s.k, s.c, s.g));
         widest = std::max(widest, (size_t)n * s.c);
     }
-    size_t stat_floats = 0;
     auto note = [&](const ptv2_linbn &L, int n) {
-        stat_floats = std::max(stat_floats, bn_tiles_floats(n, L.cout));
         widest = std::max(widest, (size_t)n * std::max(L.cin, L.cout));
         W.dense_bytes = std::max(W.dense_bytes, dense_workspace_bytes(n, std::max(L.cin, L.cout), std::max(L.cin, L.cout)));
     };
@@ -277,7 +270,6 @@ Work carve_work(const ptv2_model *M, void *base) {
                                                                   std::max(M->in_channels, M->head.cout)));
     W.block = take(W.block_bytes);
     W.dense = take(W.dense_bytes);
-    W.stat = (float *)take(sizeof(float) * stat_floats);
     W.ga = (float *)take(sizeof(float) * widest);
     W.gb = (float *)take(sizeof(float) * widest);
     W.gc = (float *)take(sizeof(float) * widest);
@@ -342,22 +334,7 @@ int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S,
                   void *stream) {
     hipStream_t st = (hipStream_t)stream;
     if (L.cin % 4 == 0 && L.cout % 4 == 0) {
-        // training: the GEMM's epilogue leaves the tile statistics of h and the workgroups that arrive last merge them
-        // (arrive.h) -- Linear -> BatchNorm is GEMM + apply instead of GEMM + statistics pass + finalize + apply
-        if (use_batch(M, L) && ptv2_bn_inkernel() && W.stat) {
-            const bool track = M->training && L.run_mean && L.run_var;
-            const float *xs[1] = {x}, *ws[1] = {L.w}, *bs[1] = {L.b};
-            float *ys[1] = {S.h}, *sts[1] = {W.stat};
-            const bnfin::Emit em[1] = {bnfin::Emit{S.mean, S.rstd, nullptr, nullptr, track ? L.run_mean : nullptr,
-                                                   track ? L.run_var : nullptr, track ? L.batches : nullptr, L.gamma, L.beta}};
-            int fin = 0;
-            RUN(rows_gemm_fused_bn(n, L.cout, L.cin, 1, 0, xs, ws, 0, bs, ys, 0, nullptr, nullptr, sts, em, M->eps, M->momentum, &fin,
-                                   stream));
-            if (fin) return bn_apply_hip_launcher(n, L.cout, S.h, S.mean, S.rstd, L.gamma, L.beta, 1, y, stream);
-            // (the records stay unused: the statistics pass below does the same work)
-        } else {
-            RUN(rows_gemm_hip_launcher(n, L.cout, L.cin, x, L.w, 0, L.b, S.h, 0, stream));
-        }
+        RUN(rows_gemm_hip_launcher(n, L.cout, L.cin, x, L.w, 0, L.b, S.h, 0, stream));
     } else {
         const size_t lds = sizeof(float) * ((size_t)L.cout * L.cin + L.cout);
         hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(grid_for((long long)n * L.cout)), dim3(TPB), lds, st, (long long)n, L.cin,
