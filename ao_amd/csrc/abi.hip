@@ -8,7 +8,7 @@
 
 #include "gva_common.h"
 
-extern "C" int ptv2_abi_version(void) { return 9; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 10; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 // sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
 // layout drift between the header and a python mirror is an import error, not a misread pointer
@@ -18,6 +18,7 @@ extern "C" long long ptv2_struct_bytes(int which) {
         case 1: return (long long)sizeof(ptv2_block_grads);
         case 2: return (long long)sizeof(ptv2_model);
         case 3: return (long long)sizeof(ptv2_gva_block);
+        case 4: return (long long)sizeof(ptv2_scene_geo);
         default: return -1;
     }
 }
@@ -196,8 +197,8 @@ int g_stamp_n = 0;
 struct StampRec { int slot; double bytes; };
 std::vector<StampRec> g_stamp_recs[KID_COUNT];
 std::vector<int> g_stamp_pending[KID_COUNT];
-unsigned g_scope_period[2][KID_COUNT];  // launches of each kernel in the previous scope of a slot
-unsigned g_scope_phase[2];
+unsigned g_scope_period[GRAPH_SLOTS][KID_COUNT];  // launches of each kernel in the previous scope of a slot
+unsigned g_scope_phase[GRAPH_SLOTS];
 thread_local unsigned t_scope_seen[KID_COUNT];
 thread_local int t_scope_which = -1;
 __global__ void stamp_kernel(unsigned long long *p) {

@@ -37,7 +37,7 @@ struct PtvScopedTimer {
 };
 
 // graph.hip: the launcher body between construction and finish() is captured and issued as one hipGraph launch
-enum PtvGraphSlot { GRAPH_MODEL_FWD = 0, GRAPH_MODEL_BWD = 1 };
+enum PtvGraphSlot { GRAPH_MODEL_FWD = 0, GRAPH_MODEL_BWD = 1, GRAPH_MODEL_FWD_PREFIX = 2, GRAPH_MODEL_FWD_REST = 3, GRAPH_SLOTS = 4 };
 struct PtvGraphScope {
     void *st, *cap; int which, ring_entry; bool active; long long t0;
     PtvGraphScope(void *stream, int which, bool allow = true);

@@ -191,14 +191,23 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float *__re
             const int t = __hip_atomic_fetch_add(tickets + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int team = t / W, rank = t - team * W;
             int mine = -1;
+            // every workgroup reports in exactly once; the LAST one knows how many clouds found a team.  Fewer than nclouds
+            // (the dispatcher spread the workgroups so unevenly that complete teams were over the cap, or partial teams ate the
+            // slack) would leave those clouds' indices unwritten without any spin timing out: fail loudly instead
+            auto report_in = [&]() {
+                const int before = __hip_atomic_fetch_add(arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1 == (int)gridDim.x &&
+                    __hip_atomic_load(next_cloud, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nclouds)
+                    *error_flag = 1;
+            };
             if (team < COOP_TEAMS) {
                 int *slot = cloud_of + xcc * COOP_TEAMS + team;
                 if (rank == W - 1) {  // (tickets come in order: ranks 0 .. W-2 of this team are taken, the team is complete)
                     mine = __hip_atomic_fetch_add(next_cloud, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(slot, mine + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    report_in();
                 } else {
-                    (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    report_in();
                     for (int spins = 0;; ++spins) {
                         if (spins > (1 << 22)) { *error_flag = 1; break; }  // (a launch that is not resident as a whole: fail loudly)
                         int c = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_coop_kernel(const float *__re
                     }
                 }
             } else {
-                (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                report_in();
             }
             s_cloud = mine;
             s_rank = rank;

@@ -87,10 +87,20 @@ __global__ __launch_bounds__(TPB) void pool_scatter_kernel(int n, const int *__r
 // new_offset[s] = number of clusters whose cloud index is <= s
 // sort_members (dense path): the member slots came from atomics -- the cluster's thread first puts its handful of members
 // (one voxel) into ascending point order, in place, so that `order` is the stable sort by key and the sum below runs in it
-__global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ n_out, int b,
+// `over` (dense path): set by the scan when some voxel holds more than DENSE_MAX_MEMBERS points -- the one-thread insertion
+// sort below is quadratic in a voxel's members (a coarse grid, a duplicate-heavy cloud, a scene inside ONE voxel: 10^5 members
+// = 10^10 serial global read-modify-writes), so such a call is handed back (*n_out = -2) and repeated on the radix-sort path,
+// whose cost does not depend on the occupancy
+__global__ __launch_bounds__(TPB) void pool_mean_kernel(int *n_out, int b,
                                                         const float *__restrict__ coord, const int *__restrict__ offset,
                                                         int *order, const int *__restrict__ idx_ptr,
-                                                        float *__restrict__ new_coord, int *__restrict__ new_offset, int sort_members) {
+                                                        float *__restrict__ new_coord, int *__restrict__ new_offset, int sort_members,
+                                                        const int *__restrict__ over) {
+    if (over && *over) {
+        // (every thread leaves before anyone reads *n_out below: the store cannot race with a read of this launch)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && *n_out >= 0) *n_out = -2;
+        return;
+    }
     const int m = *n_out;  // negative on key overflow: nothing to do
     for (int j = blockIdx.x * TPB + threadIdx.x; j < m; j += gridDim.x * TPB) {
         const int p0 = idx_ptr[j], p1 = idx_ptr[j + 1];
@@ -131,16 +141,18 @@ __global__ __launch_bounds__(TPB) void pool_mean_kernel(const int *__restrict__ 
 // Six launches (the member sort rides in the mean kernel) instead of the ~16 of a 6-pass radix sort + scan, and 40 us instead of 250 at 120 k points.  The grid size
 // is only known on the device: a grid beyond DENSE_CAP sets *n_out = -2 and the caller repeats the call on the sort path.
 constexpr long long DENSE_CAP = 1ll << 23;
+constexpr int DENSE_MAX_MEMBERS = 64;  // members of one voxel the dense path sorts with one thread (PT-v2 levels: 5-15)
 constexpr int DSCAN_THREADS = 256, DSCAN_ITEMS = 8, DSCAN_TILE = DSCAN_THREADS * DSCAN_ITEMS;
 
 // (the grid's dimensions are derived here by every workgroup -- a loop over the b clouds' extents -- and stored by the first:
 // what was a one-thread launch of its own in front of this one)
 __global__ __launch_bounds__(TPB) void dense_zero_kernel(int b, const float *__restrict__ lo, const float *__restrict__ hi, float size,
-                                                         PoolDims *__restrict__ dims, int *__restrict__ count, int *n_out) {
+                                                         PoolDims *__restrict__ dims, int *__restrict__ count, int *n_out,
+                                                         long long cells_cap, int *__restrict__ over) {
     const PoolDims d = pool_dims_of(b, lo, hi, size);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *dims = d;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *dims = d; *over = 0; }
     const long long total = d.total;
-    if (total <= 0 || total > DENSE_CAP) {
+    if (total <= 0 || total > cells_cap) {  // (beyond the table carved for this n: the sort path)
         if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = (total > 0 && total < (1ll << KEY_BITS)) ? -2 : -1;
         return;
     }
@@ -189,7 +201,8 @@ __global__ __launch_bounds__(DSCAN_THREADS) void dense_scan_reduce_kernel(const 
 // base[cell] = (members before the cell, occupied cells before it); the last tile also publishes the cluster count
 __global__ __launch_bounds__(DSCAN_THREADS) void dense_scan_apply_kernel(const PoolDims *__restrict__ dims, int *n_out, int n,
                                                                          const int *__restrict__ count, const int2 *__restrict__ tile_sums,
-                                                                         int2 *__restrict__ base, int *__restrict__ idx_ptr) {
+                                                                         int2 *__restrict__ base, int *__restrict__ idx_ptr,
+                                                                         int *__restrict__ over) {
     const long long total = dims->total;
     if (*n_out < 0 || (long long)blockIdx.x * DSCAN_TILE >= total) return;
     __shared__ int2 s_w[DSCAN_THREADS / WAVE];
@@ -212,9 +225,10 @@ __global__ __launch_bounds__(DSCAN_THREADS) void dense_scan_apply_kernel(const P
     const int4 *p = (const int4 *)(count + (size_t)blockIdx.x * DSCAN_TILE) + threadIdx.x * 2;
     const int4 a = p[0], c = p[1];
     const int v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-    int ex[8], eo[8], tot = 0, occ = 0;
+    int ex[8], eo[8], tot = 0, occ = 0, big = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ex[i] = tot; eo[i] = occ; tot += v[i]; occ += v[i] > 0; }
+    for (int i = 0; i < 8; ++i) { ex[i] = tot; eo[i] = occ; tot += v[i]; occ += v[i] > 0; big |= v[i] > DENSE_MAX_MEMBERS; }
+    if (big) *over = 1;  // (benign race: every writer stores the same value)
     int inc = tot, inco = occ;  // inclusive wave scans of the per-thread totals
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -257,8 +271,9 @@ struct Ws {
     void *mm, *cub;
     size_t mm_bytes, cub_bytes, bytes;
     // dense path
-    int *d_count, *d_key, *d_slot;
+    int *d_count, *d_key, *d_slot, *d_over;
     int2 *d_tiles, *d_base;
+    long long d_cells;  // cells the dense tables were carved for
 };
 
 }  // namespace
@@ -288,14 +303,17 @@ static Ws carve(void *base, int n, int b) {
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, s2, (const int *)nullptr, (int *)nullptr, n, (hipStream_t)0);
     w.cub_bytes = std::max(s1, s2) + 256;
     w.cub = take(w.cub_bytes);
-    // dense path: the cell table cannot be larger than min(DENSE_CAP, what the key space of n points ... ) -- the grid size is
-    // data dependent, so the table is sized for the cap
-    const size_t cells = (size_t)DENSE_CAP + DSCAN_TILE;
+    // dense path: the grid size is data dependent, so the table is sized from n -- 64 cells per point (PT-v2 levels have 3-12:
+    // a 0.06 m grid over a 120 k-point scan is 1.4 M cells), at most DENSE_CAP -- and a grid beyond it takes the sort path.
+    // (Sized for the cap whatever n, the tables were 100 MB of every stream's retained workspace, also for a 2 k-point call.)
+    w.d_cells = std::min<long long>(DENSE_CAP, std::max<long long>(64ll * n, 1 << 16));
+    const size_t cells = (size_t)w.d_cells + DSCAN_TILE;
     w.d_count = (int *)take(sizeof(int) * cells);
     w.d_base = (int2 *)take(sizeof(int2) * cells);
     w.d_tiles = (int2 *)take(sizeof(int2) * (cells / DSCAN_TILE + 1));
     w.d_key = (int *)take(sizeof(int) * n);
     w.d_slot = (int *)take(sizeof(int) * n);
+    w.d_over = (int *)take(sizeof(int) * 4);
     w.bytes = off;
     return w;
 }
@@ -324,19 +342,19 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
         hipLaunchKernelGGL(pool_dims_kernel, dim3(1), dim3(64), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
                            w.dims);
     if (!sort_path) {
-        const int ztiles = (int)((DENSE_CAP + DSCAN_TILE) / DSCAN_TILE);
+        const int ztiles = (int)((w.d_cells + DSCAN_TILE) / DSCAN_TILE);
         hipLaunchKernelGGL(dense_zero_kernel, dim3(1024), dim3(TPB), 0, st, b, (const float *)w.lo, (const float *)w.hi, grid_size,
-                           w.dims, w.d_count, n_out);
+                           w.dims, w.d_count, n_out, w.d_cells, w.d_over);
         hipLaunchKernelGGL(dense_keys_kernel, dim3(nb), dim3(TPB), 0, st, n, b, coord, offset, (const float *)w.lo, grid_size,
                            (const PoolDims *)w.dims, (const int *)n_out, w.d_count, w.d_key, w.d_slot);
         hipLaunchKernelGGL(dense_scan_reduce_kernel, dim3(ztiles), dim3(DSCAN_THREADS), 0, st, (const PoolDims *)w.dims,
                            (const int *)n_out, (const int *)w.d_count, w.d_tiles);
         hipLaunchKernelGGL(dense_scan_apply_kernel, dim3(ztiles), dim3(DSCAN_THREADS), 0, st, (const PoolDims *)w.dims, n_out, n,
-                           (const int *)w.d_count, (const int2 *)w.d_tiles, w.d_base, idx_ptr);
+                           (const int *)w.d_count, (const int2 *)w.d_tiles, w.d_base, idx_ptr, w.d_over);
         hipLaunchKernelGGL(dense_scatter_kernel, dim3(nb), dim3(TPB), 0, st, n, (const int *)n_out, (const int *)w.d_key,
                            (const int *)w.d_slot, (const int2 *)w.d_base, cluster, order, idx_ptr);
-        hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out, b, coord, offset,
-                           order, (const int *)idx_ptr, new_coord, new_offset, 1);
+        hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, n_out, b, coord, offset,
+                           order, (const int *)idx_ptr, new_coord, new_offset, 1, (const int *)w.d_over);
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }
@@ -352,8 +370,8 @@ extern "C" int grid_pool_hip_launcher(int n, int b, const float *coord, const in
     if (hipcub::DeviceScan::InclusiveSum(w.cub, cb, (const int *)w.flags, w.rank, n, st) != hipSuccess) return PTV2_ERR_LAUNCH;
     hipLaunchKernelGGL(pool_scatter_kernel, dim3(nb), dim3(TPB), 0, st, n, (const int *)w.rank, (const int *)w.flags,
                        (const int *)order, cluster, idx_ptr, n_out, (const PoolDims *)w.dims);
-    hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, (const int *)n_out, b, coord, offset,
-                       order, (const int *)idx_ptr, new_coord, new_offset, 0);
+    hipLaunchKernelGGL(pool_mean_kernel, dim3(std::min(nb, 2048)), dim3(TPB), 0, st, n_out, b, coord, offset,
+                       order, (const int *)idx_ptr, new_coord, new_offset, 0, (const int *)nullptr);
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

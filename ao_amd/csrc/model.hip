@@ -167,7 +167,7 @@ struct Arena {  // the `saved` buffer of one forward
     float *block_y[PTV2_MAX_BLOCKS];
     char *block_saved[PTV2_MAX_BLOCKS];
     size_t block_saved_bytes[PTV2_MAX_BLOCKS];
-    size_t bytes;
+    size_t bytes, bytes0;  // of `saved`; of `saved0` (0 when the prefix lives at the head of `saved`)
 };
 
 bool model_ok(const ptv2_model *M) {
@@ -186,11 +186,31 @@ bool model_ok(const ptv2_model *M) {
     return M->feat && M->logits && M->head_w;
 }
 
-Arena carve(const ptv2_model *M, void *base) {
-    Arena A;
-    char *p = (char *)base;
-    size_t off = 0;
+// what the prefix (patch embedding + seq 0) reads of the struct
+bool prefix_ok(const ptv2_model *M) {
+    if (!M || M->num_blocks < 1 || M->num_blocks > PTV2_MAX_BLOCKS || M->in_channels < 1 || M->in_channels > 64) return false;
+    if (M->level[0].n < 2 || !M->level[0].coord) return false;
+    const ptv2_seq &s = M->seq[0];
+    if (s.depth < 0 || s.first_block != 0 || s.depth > M->num_blocks || s.level != 0) return false;
+    if (s.depth > 0 && (!s.idx || s.c < 4 || s.g < 1 || s.k < 1)) return false;
+    if (M->embed.cin != M->in_channels || (s.depth > 0 && M->embed.cout != s.c)) return false;
+    return M->feat != nullptr && !M->checkpoint;
+}
+
+// base0 != NULL (or split): the prefix's items -- the patch embedding's rows, the outputs and saved regions of seq 0's Blocks --
+// are carved from a region of their own, whose layout depends on level 0 alone; prefix_only: nothing else is looked at
+Arena carve(const ptv2_model *M, void *base, void *base0 = nullptr, bool split = false, bool prefix_only = false) {
+    Arena A{};
+    split = split || base0 != nullptr;
+    char *p = (char *)base, *p0 = (char *)base0;
+    size_t off = 0, off0 = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
+    auto take0 = [&](size_t bytes) {
+        if (!split) return take(bytes);
+        char *r = p0 ? p0 + off0 : nullptr;
+        off0 += al(bytes);
+        return r;
+    };
     auto linbn = [&](const ptv2_linbn &L, int n, bool keep_y) {
         LinBnSaved s;
         s.h = (float *)take(sizeof(float) * (size_t)n * L.cout);
@@ -200,7 +220,27 @@ Arena carve(const ptv2_model *M, void *base) {
         return s;
     };
     const int S = M->num_stages;
-    A.embed = linbn(M->embed, M->level[0].n, true);
+    {   // the prefix first
+        const ptv2_linbn &L = M->embed;
+        const int n = M->level[0].n;
+        A.embed.h = (float *)take0(sizeof(float) * (size_t)n * L.cout);
+        A.embed.y = (float *)take0(sizeof(float) * (size_t)n * L.cout);
+        A.embed.mean = (float *)take0(sizeof(float) * L.cout);
+        A.embed.rstd = (float *)take0(sizeof(float) * L.cout);
+        const ptv2_seq &s = M->seq[0];
+        if (!M->checkpoint)
+            for (int j = 0; j < s.depth; ++j) {
+                const int b = s.first_block + j;
+                A.block_y[b] = (float *)take0(sizeof(float) * (size_t)n * s.c);
+                A.block_saved_bytes[b] = ptv2_block_saved_bytes(n, s.k, s.c, s.g);
+                A.block_saved[b] = take0(A.block_saved_bytes[b]);
+            }
+    }
+    if (prefix_only) {
+        A.bytes = off;
+        A.bytes0 = off0;
+        return A;
+    }
     for (int i = 0; i < S; ++i) {
         A.down[i] = linbn(M->down[i], M->level[i].n, true);
         A.pooled[i] = (float *)take(sizeof(float) * (size_t)M->level[i + 1].n * M->down[i].cout);
@@ -210,7 +250,7 @@ Arena carve(const ptv2_model *M, void *base) {
     }
     A.head = linbn(M->head, M->level[0].n, true);
     size_t shared_saved = 0;  // checkpointing: one region, sized for the largest Block, shared by all of them
-    for (int q = 0; q <= 2 * S; ++q) {
+    for (int q = (M->checkpoint ? 0 : 1); q <= 2 * S; ++q) {  // (seq 0: above, unless its Blocks share the checkpoint region)
         const ptv2_seq &s = M->seq[q];
         const int n = M->level[s.level].n;
         for (int j = 0; j < s.depth; ++j) {
@@ -226,6 +266,7 @@ Arena carve(const ptv2_model *M, void *base) {
         for (int b = 0; b < M->num_blocks; ++b) A.block_saved[b] = region;
     }
     A.bytes = off;
+    A.bytes0 = off0;
     return A;
 }
 
@@ -239,8 +280,9 @@ struct Work {
     size_t bytes;
 };
 
-Work carve_work(const ptv2_model *M, void *base) {
-    Work W;
+// prefix_only: the workspace of the forward's prefix (patch embedding + seq 0) -- a function of level 0 alone
+Work carve_work(const ptv2_model *M, void *base, bool prefix_only = false) {
+    Work W{};
     char *p = (char *)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += al(bytes); return r; };
@@ -248,7 +290,7 @@ Work carve_work(const ptv2_model *M, void *base) {
     W.block_bytes = 0;
     size_t widest = 0;
     W.dense_bytes = 0;
-    for (int q = 0; q <= 2 * S; ++q) {
+    for (int q = 0; q <= (prefix_only ? 0 : 2 * S); ++q) {
         const ptv2_seq &s = M->seq[q];
         if (s.depth < 1) continue;
         const int n = M->level[s.level].n;
@@ -260,6 +302,12 @@ Work carve_work(const ptv2_model *M, void *base) {
         W.dense_bytes = std::max(W.dense_bytes, dense_workspace_bytes(n, std::max(L.cin, L.cout), std::max(L.cin, L.cout)));
     };
     note(M->embed, M->level[0].n);
+    if (prefix_only) {
+        W.block = take(W.block_bytes);
+        W.dense = take(W.dense_bytes);
+        W.bytes = off;
+        return W;
+    }
     note(M->head, M->level[0].n);
     for (int i = 0; i < S; ++i) {
         note(M->down[i], M->level[i].n);
@@ -442,8 +490,18 @@ float *seq_backward(const ptv2_model *M, int q, const Arena &A, const float *x_i
 }  // namespace
 
 extern "C" size_t ptv2_model_saved_bytes(const ptv2_model *M) {
-    if (!model_ok(M)) return 0;
-    return carve(M, nullptr).bytes + 256;
+    if (!model_ok(M) || (M->saved0 && M->checkpoint)) return 0;
+    return carve(M, nullptr, nullptr, M->saved0 != nullptr).bytes + 256;  // (saved0 set: the rest alone)
+}
+
+extern "C" size_t ptv2_model_prefix_saved_bytes(const ptv2_model *M) {
+    if (!prefix_ok(M)) return 0;
+    return carve(M, nullptr, nullptr, true, true).bytes0 + 256;
+}
+
+extern "C" size_t ptv2_model_prefix_workspace_bytes(const ptv2_model *M) {
+    if (!prefix_ok(M)) return 0;
+    return carve_work(M, nullptr, true).bytes + 256;
 }
 
 extern "C" size_t ptv2_model_workspace_bytes(const ptv2_model *M) {
@@ -452,7 +510,8 @@ extern "C" size_t ptv2_model_workspace_bytes(const ptv2_model *M) {
 }
 
 namespace {
-int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream);
+enum { PHASE_ALL = 0, PHASE_PREFIX = 1, PHASE_REST = 2 };
+int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream, int phase);
 int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, size_t workspace_bytes, void *stream);
 }  // namespace
 
@@ -460,7 +519,18 @@ int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, 
 // capture, the executable graph of the previous call is updated in place with this call's arguments, and launched.
 extern "C" int ptv2_model_forward_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
     PtvGraphScope scope(stream, GRAPH_MODEL_FWD);
-    return scope.finish(model_forward(M, workspace, workspace_bytes, scope.stream()));
+    return scope.finish(model_forward(M, workspace, workspace_bytes, scope.stream(), PHASE_ALL));
+}
+
+// the same forward as two graphs: what needs level 0 only, and the rest (include/ptv2_hip.h)
+extern "C" int ptv2_model_forward_prefix_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
+    PtvGraphScope scope(stream, GRAPH_MODEL_FWD_PREFIX);
+    return scope.finish(model_forward(M, workspace, workspace_bytes, scope.stream(), PHASE_PREFIX));
+}
+
+extern "C" int ptv2_model_forward_rest_hip_launcher(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
+    PtvGraphScope scope(stream, GRAPH_MODEL_FWD_REST);
+    return scope.finish(model_forward(M, workspace, workspace_bytes, scope.stream(), PHASE_REST));
 }
 
 extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float *g_logits, void *workspace,
@@ -472,12 +542,14 @@ extern "C" int ptv2_model_backward_hip_launcher(const ptv2_model *M, const float
 
 namespace {
 
-int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!model_ok(M) || !M->saved) return PTV2_ERR_ARG;
+int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, void *stream, int phase) {
+    const bool pre = phase == PHASE_PREFIX;
+    if (pre ? (!prefix_ok(M) || !M->saved0) : (!model_ok(M) || !M->saved)) return PTV2_ERR_ARG;
+    if (phase == PHASE_REST && (!M->saved0 || M->checkpoint)) return PTV2_ERR_ARG;
     const PtvMatmulScope precision(M->matmul_bf16);
-    const Arena A = carve(M, M->saved);
-    if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
-    const Work W = carve_work(M, workspace);
+    const Arena A = carve(M, M->saved, M->saved0, pre, pre);
+    if ((!pre && M->saved_bytes < A.bytes) || (M->saved0 && M->saved0_bytes < A.bytes0)) return PTV2_ERR_WORKSPACE;
+    const Work W = carve_work(M, workspace, pre);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int S = M->num_stages;
@@ -486,9 +558,11 @@ int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, 
     // each Block)
     // (not under checkpointing: the folds live in the Blocks' saved regions, which then are one shared region -- every Block
     // folds for itself, in its forward and again in its recomputation)
+    // (prefix / rest: each folds for the Blocks it runs)
     if (!M->checkpoint) {
         std::vector<ptv2_block> blocks;
-        for (int q = 0; q <= 2 * S; ++q)
+        const int q0 = phase == PHASE_REST ? 1 : 0, q1 = pre ? 0 : 2 * S;
+        for (int q = q0; q <= q1; ++q)
             for (int j = 0; j < M->seq[q].depth; ++j) {
                 ptv2_block B;
                 fill_block(M, q, j, A, M->feat /* unused by the folds */, &B);
@@ -500,9 +574,19 @@ int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, 
         explicit Prefolded(int on) { ptv2_gva_set_prefolded(on); }
         ~Prefolded() { ptv2_gva_set_prefolded(0); }
     } prefolded(M->checkpoint ? 0 : 1);
-    RUN(linbn_forward(M, M->embed, A.embed, M->level[0].n, M->feat, A.embed.y, W, stream));
-    const float *x = seq_forward(M, 0, A, A.embed.y, W, stream, &rc);
-    if (rc != PTV2_OK) return rc;
+    const float *x = nullptr;
+    if (phase != PHASE_REST) {
+        RUN(linbn_forward(M, M->embed, A.embed, M->level[0].n, M->feat, A.embed.y, W, stream));
+        x = seq_forward(M, 0, A, A.embed.y, W, stream, &rc);
+        if (rc != PTV2_OK) return rc;
+        if (pre) {
+            PTV2_CHECK_LAUNCH();
+            return PTV2_OK;
+        }
+    } else {  // the prefix's output, where seq_forward left it
+        const ptv2_seq &s0 = M->seq[0];
+        x = s0.depth > 0 ? A.block_y[s0.first_block + s0.depth - 1] : A.embed.y;
+    }
     const float *skip[PTV2_MAX_STAGES + 1];
     skip[0] = x;
     for (int i = 0; i < S; ++i) {
@@ -556,8 +640,9 @@ int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, 
 int model_backward(const ptv2_model *M, const float *g_logits, void *workspace, size_t workspace_bytes, void *stream) {
     if (!model_ok(M) || !M->saved || !g_logits || !M->g_head_w) return PTV2_ERR_ARG;
     const PtvMatmulScope precision(M->matmul_bf16);
-    const Arena A = carve(M, M->saved);
-    if (M->saved_bytes < A.bytes) return PTV2_ERR_WORKSPACE;
+    if (M->saved0 && M->checkpoint) return PTV2_ERR_ARG;
+    const Arena A = carve(M, M->saved, M->saved0);
+    if (M->saved_bytes < A.bytes || (M->saved0 && M->saved0_bytes < A.bytes0)) return PTV2_ERR_WORKSPACE;
     const Work W = carve_work(M, workspace);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;

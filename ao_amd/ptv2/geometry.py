@@ -7,6 +7,7 @@ every GridPool voxelises + sorts (:244-269, with a host-sync python loop in offs
 computed ONCE per batch, up front, under no_grad: 1 + S self-kNNs, S grid poolings, S cross-kNNs
 for an S-stage model -- and handed to the layers as a `SceneGeometry`.
 """
+import ctypes
 import os
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -140,22 +141,51 @@ def grid_pool_geometry(coord, offset, grid_size):
 def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
     """neighbours[i] = iterable of K values needed at level i (level 0 = input resolution,
     level i+1 = after grid_sizes[i])."""
-    offset = offset.int().contiguous()
-    coord = coord.contiguous()
-    geo = SceneGeometry()
+    state = begin_geometry(coord, offset, grid_sizes, neighbours, interp)
+    if native_finish_supported(state):  # one native call for everything behind the first pooling (csrc/scene.hip)
+        return finish_geometry_native(state)
+    return finish_geometry(state)
+
+
+class _GeometryState:
+    __slots__ = ("geo", "cur", "grid_sizes", "neighbours", "interp")
+
+
+@torch.no_grad()
+def begin_geometry(coord, offset, grid_sizes, neighbours, interp=True):
+    """First half of build_geometry: the level-0 neighbour tables (+ their position moments) -- everything the network's
+    level-0 prefix (patch embedding) needs, and nothing whose size is data dependent.  Returns the state finish_geometry
+    continues from; `state.geo.levels[0]` is usable at once (on the stream this ran on)."""
+    st = _GeometryState()
+    st.geo = SceneGeometry()
     # one cell grid per level, shared by the queries over its points: the interpolation table from the finer level (k = 3) and
     # the level's self tables (csrc/knn.hip: knn_query_grid_hip_launcher)
-    cur = Level(coord=coord, offset=offset, grid=KnnGrid())
-    for i, ks in enumerate(neighbours):
-        for k in ks:
-            cur.neighbours(k, inverse=False)
-        geo.levels.append(cur)
-        if i == len(grid_sizes):
+    st.cur = Level(coord=coord.contiguous(), offset=offset.int().contiguous(), grid=KnnGrid())
+    st.grid_sizes, st.neighbours, st.interp = list(grid_sizes), [list(ks) for ks in neighbours], interp
+    for k in st.neighbours[0]:
+        st.cur.neighbours(k, inverse=False)
+    st.geo.levels.append(st.cur)
+    return st
+
+
+@torch.no_grad()
+def finish_geometry(st, before_inverse=None):
+    """Second half: the grid poolings (one 4-byte read-back each: the next level's size), the deeper levels' tables, the
+    interpolation tables and the inverse tables of the whole scene.  May run on another stream than begin_geometry did
+    (native_model's pipelined forward: a side stream, while the level-0 prefix computes); `before_inverse()` is called in
+    front of the one launch that reads the level-0 tables (the caller's cross-stream wait)."""
+    geo, cur = st.geo, st.cur
+    for i, ks in enumerate(st.neighbours):
+        if i > 0:
+            for k in ks:
+                cur.neighbours(k, inverse=False)
+            geo.levels.append(cur)
+        if i == len(st.grid_sizes):
             break
-        nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, grid_sizes[i])
+        nc, noff, cluster, order, idx_ptr = grid_pool_geometry(cur.coord, cur.offset, st.grid_sizes[i])
         cur.cluster, cur.order32, cur.idx_ptr32 = cluster, order, idx_ptr
         nxt = Level(coord=nc, offset=noff, grid=KnnGrid())
-        if interp:
+        if st.interp:
             cur.up_idx, cur.up_weight = interpolation_index_weight(nc, cur.coord, noff, cur.offset, 3, grid=nxt.grid)
         cur = nxt
     # inverse tables of every neighbour / interpolation table of the scene in one call (five launches: csrc/inverse.hip);
@@ -163,8 +193,121 @@ def build_geometry(coord, offset, grid_sizes, neighbours, interp=True):
     from . import gva
     tables = [lv.up_idx for lv in geo.levels if lv.up_idx is not None]
     tables += [idx for lv in geo.levels for k, idx in lv.knn.items() if gva.supported(8 * 6, 6, k)]
+    if before_inverse is not None:
+        before_inverse()
     with torch.no_grad():
         gva.inverse_tables(tables)
     for lv in geo.levels:
         lv.grid = None  # (the grids' workspaces go back to the allocator; a table asked for later builds its own)
+    return geo
+
+
+# ---- the second half as ONE native call (ao_amd/csrc/scene.hip) --------------------------------------------------------------
+_MAX_STAGES, _GEO_MAX_K = 5, 2
+_LL = ctypes.c_longlong
+
+
+class _GeoTable(ctypes.Structure):  # mirrors ptv2_geo_table
+    _fields_ = [("k", ctypes.c_int)] + [(n, _LL) for n in ("idx", "mu", "cov", "inv_ptr", "inv_rows")]
+
+
+class _GeoLevel(ctypes.Structure):  # mirrors ptv2_geo_level
+    _fields_ = ([("n", ctypes.c_int), ("nk", ctypes.c_int), ("knn", _GeoTable * _GEO_MAX_K)]
+                + [(n, _LL) for n in ("coord", "offset", "cluster", "order", "idx_ptr", "up_idx", "up_w", "up_inv_ptr", "up_inv_rows")])
+
+
+class _SceneGeo(ctypes.Structure):  # mirrors ptv2_scene_geo
+    _fields_ = [("num_stages", ctypes.c_int), ("b", ctypes.c_int), ("interp", ctypes.c_int), ("grid_size", ctypes.c_float * _MAX_STAGES),
+                ("coord0", ctypes.c_void_p), ("offset0", ctypes.c_void_p), ("knn0", ctypes.c_void_p * _GEO_MAX_K),
+                ("fwd_ready_event", ctypes.c_void_p), ("knn0_event", ctypes.c_void_p), ("level", _GeoLevel * (_MAX_STAGES + 1))]
+
+
+_lib.register({
+    "ptv2_scene_geometry_arena_bytes": (_lib._c_size, [ctypes.c_void_p]),
+    "ptv2_scene_geometry_workspace_bytes": (_lib._c_size, [ctypes.c_void_p]),
+    "ptv2_scene_geometry_hip_launcher": (_lib._c_int, [ctypes.c_void_p, ctypes.c_void_p, _lib._c_size, ctypes.c_void_p, _lib._c_size,
+                                                       ctypes.c_void_p]),
+})
+_lib.check_struct(4, _SceneGeo)
+
+
+def native_finish_supported(st):
+    return (len(st.grid_sizes) <= _MAX_STAGES and all(1 <= len(ks) <= _GEO_MAX_K and all(1 <= k <= 32 for k in ks) for ks in st.neighbours)
+            and len(st.neighbours) == len(st.grid_sizes) + 1 and os.environ.get("AO_AMD_GEOMETRY", "native") == "native"
+            and os.environ.get("AO_AMD_GRIDPOOL", "hip") == "hip")
+
+
+@torch.no_grad()
+def finish_geometry_native(st, fwd_ready_event=None, knn0_event=None):
+    """finish_geometry as one native call (ptv2_scene_geometry_hip_launcher): the same launchers in the same order, enqueued
+    from native code; the tables of levels 1.. are views of ONE arena tensor, carved as the poolings' sizes are read back.
+    Runs on the current stream (and synchronises it once per stage).  The events are torch.cuda.Event objects that have been
+    recorded at least once (their handle exists): `fwd_ready_event` is recorded once everything the forward needs is enqueued,
+    `knn0_event` is waited for in front of the inverse tables."""
+    from . import gva
+
+    geo, lv0 = st.geo, st.cur
+    dev = lv0.coord.device
+    S = len(st.grid_sizes)
+    G = _SceneGeo()
+    G.num_stages, G.b, G.interp = S, lv0.offset.numel(), 1 if st.interp else 0
+    for i, g in enumerate(st.grid_sizes):
+        G.grid_size[i] = float(g)
+    G.coord0, G.offset0 = lv0.coord.data_ptr(), lv0.offset.data_ptr()
+    G.level[0].n = lv0.coord.shape[0]
+    for i, ks in enumerate(st.neighbours):
+        G.level[i].nk = len(ks)
+        for j, k in enumerate(ks):
+            G.level[i].knn[j].k = int(k)
+    for j, k in enumerate(st.neighbours[0]):
+        G.knn0[j] = lv0.knn[k].data_ptr()
+    G.fwd_ready_event = fwd_ready_event.cuda_event if fwd_ready_event is not None else None
+    G.knn0_event = knn0_event.cuda_event if knn0_event is not None else None
+    L = _lib.lib()
+    addr = ctypes.addressof(G)
+    arena = torch.empty(L.ptv2_scene_geometry_arena_bytes(addr), dtype=torch.uint8, device=dev)
+    ws = _lib.workspace(L.ptv2_scene_geometry_workspace_bytes(addr), dev)
+    rc = L.ptv2_scene_geometry_hip_launcher(addr, arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    if rc == 1 and any(G.level[i + 1].n < 1 for i in range(S)):
+        raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
+    _lib.check(rc, "ptv2_scene_geometry_hip_launcher")
+
+    def view(off, dtype, *shape):
+        if off < 0:
+            return None
+        count = 1
+        for d in shape:
+            count *= d
+        nbytes = count * torch.empty((), dtype=dtype).element_size()
+        return arena[off:off + nbytes].view(dtype).view(*shape)
+
+    def attach(idx, coord, T):
+        inv_ptr, inv_rows = view(T.inv_ptr, torch.int32, idx.shape[0] + 1), view(T.inv_rows, torch.int32, idx.numel())
+        idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
+        if T.mu >= 0:
+            idx._ao_pos_moments = ((coord.data_ptr(), idx._version), view(T.mu, torch.float64, 3), view(T.cov, torch.float64, 3, 3))
+
+    b = G.b
+    levels = [lv0]
+    for i in range(1, S + 1):
+        Li = G.level[i]
+        lv = Level(coord=view(Li.coord, torch.float32, Li.n, 3), offset=view(Li.offset, torch.int32, b))
+        for j, k in enumerate(st.neighbours[i]):
+            lv.knn[k] = view(Li.knn[j].idx, torch.int32, Li.n, k)
+            attach(lv.knn[k], lv.coord, Li.knn[j])
+        levels.append(lv)
+    for j, k in enumerate(st.neighbours[0]):
+        attach(lv0.knn[k], lv0.coord, G.level[0].knn[j])
+    for i in range(S):
+        Li, lv = G.level[i], levels[i]
+        n, m = Li.n, G.level[i + 1].n
+        lv.cluster, lv.order32 = view(Li.cluster, torch.int64, n), view(Li.order, torch.int32, n)
+        lv.idx_ptr32 = view(Li.idx_ptr, torch.int32, m + 1)
+        if st.interp:
+            lv.up_idx, lv.up_weight = view(Li.up_idx, torch.int32, n, 3), view(Li.up_w, torch.float32, n, 3)
+            lv.up_idx._ao_inverse = (lv.up_idx._version, view(Li.up_inv_ptr, torch.int32, n + 1), view(Li.up_inv_rows, torch.int32, 3 * n))
+    for lv in levels:
+        lv.grid = None
+    geo.levels = levels
+    geo.arena = arena  # (the views keep it alive as well)
     return geo

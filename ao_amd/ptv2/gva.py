@@ -453,6 +453,9 @@ class _BlockArgs(ctypes.Structure):  # mirrors ptv2_gva_block (include/ptv2_hip.
                 + [("attn_drop_p", ctypes.c_float), ("attn_drop_seed", ctypes.c_uint)])
 
 
+_lib.check_struct(3, _BlockArgs)  # (the mirror must have the size the library was compiled with)
+
+
 class _BlockGrads(ctypes.Structure):  # mirrors ptv2_gva_block_grads
     _fields_ = [(n_, _P) for n_ in (
         "g_out", "inv_ptr", "inv_rows", "gq", "gk", "gv", "gWp1", "gbp1", "ggamma_p", "gbeta_p", "gWp2", "gbp2",

@@ -430,22 +430,32 @@ class PointTransformerV2(nn.Module):
                                        nn.ReLU(inplace=True), RowLinear(dec_channels[0], num_classes))
                          if num_classes > 0 else nn.Identity())
 
-    def geometry(self, coord, offset):
+    def geometry_neighbours(self):
+        """K values needed per level (level 0: patch embedding + last decoder stage; level i + 1: encoder stage i + decoder
+        stage i + 1)."""
         ks = [{self.patch_embed.blocks.neighbours, self.dec_stages[0].blocks.neighbours}]
         for i in range(self.num_stages):
             here = {self.enc_stages[i].blocks.neighbours}
             if i + 1 < self.num_stages:
                 here.add(self.dec_stages[i + 1].blocks.neighbours)
             ks.append(here)
-        return build_geometry(coord, offset, self.grid_sizes, ks, interp=self.unpool_backend == "interp")
+        return [sorted(k) for k in ks]
+
+    def geometry(self, coord, offset):
+        return build_geometry(coord, offset, self.grid_sizes, self.geometry_neighbours(), interp=self.unpool_backend == "interp")
 
     def forward(self, data_dict, geometry=None):
         coord, feat = data_dict["coord"], data_dict["feat"]
         offset = data_dict["offset"].int()
-        if geometry is None:
-            geometry = data_dict.get("geometry")  # prebuilt SceneGeometry (parallel.GeometryPrefetcher)
-        geo = geometry if geometry is not None else self.geometry(coord, offset)
         from . import native_model
+
+        if geometry is None:
+            geometry = data_dict.get("geometry")  # prebuilt SceneGeometry (parallel.GeometryPrefetcher: an optional acceleration)
+        if geometry is None and native_model.supported(self, feat) and native_model.pipelined_ok(self):
+            # the default: geometry built inside the native forward, its size-dependent half on a side stream behind the
+            # level-0 prefix of the network (native_model._NativeModel.forward)
+            return native_model.forward(self, data_dict, None)
+        geo = geometry if geometry is not None else self.geometry(coord, offset)
 
         if native_model.supported(self, feat) and native_model.geometry_supported(geo):  # the whole network behind one native call per direction
             return native_model.forward(self, data_dict, geo)

@@ -56,7 +56,7 @@ class _Model(ctypes.Structure):  # mirrors ptv2_model
                    ("up", _LinBn * MAX_STAGES), ("up_skip", _LinBn * MAX_STAGES), ("head", _LinBn)]
                 + [(n, _P) for n in ("head_w", "head_b", "g_head_w", "g_head_b", "feat", "logits", "saved")]
                 + [("saved_bytes", ctypes.c_size_t), ("matmul_bf16", _I), ("checkpoint", _I),
-                   ("decoder_done_event", _P)])
+                   ("decoder_done_event", _P), ("saved0", _P), ("saved0_bytes", ctypes.c_size_t)])
 
 
 _lib.register({
@@ -64,6 +64,10 @@ _lib.register({
     "ptv2_model_workspace_bytes": (_lib._c_size, [_P]),
     "ptv2_model_forward_hip_launcher": (_lib._c_int, [_P, _P, _lib._c_size, _P]),
     "ptv2_model_backward_hip_launcher": (_lib._c_int, [_P, _P, _P, _lib._c_size, _P]),
+    "ptv2_model_prefix_saved_bytes": (_lib._c_size, [_P]),
+    "ptv2_model_prefix_workspace_bytes": (_lib._c_size, [_P]),
+    "ptv2_model_forward_prefix_hip_launcher": (_lib._c_int, [_P, _P, _lib._c_size, _P]),
+    "ptv2_model_forward_rest_hip_launcher": (_lib._c_int, [_P, _P, _lib._c_size, _P]),
 })
 
 
@@ -186,6 +190,27 @@ class _Runtime:
         self._keep_cache = {}
 
     # -- per step ------------------------------------------------------------------------------------------------
+    def fill_prefix(self, lv):
+        """Level 0 and seq 0 alone: what ptv2_model_forward_prefix_hip_launcher reads (the other levels are not known yet)."""
+        M = self.M
+        L = M.level[0]
+        L.n, L.b = lv.coord.shape[0], lv.offset.numel()
+        L.coord, L.offset = lv.coord.data_ptr(), lv.offset.data_ptr()
+        L.order = L.idx_ptr = L.cluster = L.up_idx = L.up_w = L.up_inv_ptr = L.up_inv_rows = None
+        sq = M.seq[0]
+        idx = lv.neighbours(sq.k)
+        mu, cov = _gva._pos_moments(_gva._HipImpl, lv.coord, idx)
+        sq.idx, sq.mu, sq.cov, sq.inv_ptr, sq.inv_rows = idx.data_ptr(), mu.data_ptr(), cov.data_ptr(), None, None
+        return [idx, mu, cov]
+
+    def side_stream(self, device):
+        """The stream the pipelined forward builds the deeper levels' geometry on (one per runtime and device)."""
+        st = self.__dict__.get("_side")
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device)
+            self.__dict__["_side"] = st
+        return st
+
     def fill_geometry(self, geo):
         M, S = self.M, self.S
         for i, lv in enumerate(geo.levels):
@@ -213,16 +238,21 @@ class _Runtime:
             keep += [idx, mu, cov, inv_ptr, inv_rows]
         return keep
 
-    def draw_droppath(self, geo, device):
+    def draw_droppath(self, geo, device, q_from=0, q_to=None):
         """Per-point DropPath factors (timm DropPath on an (N,C) tensor, point_transformer_v2m2_base.py:160-162,175) of
-        every block in ONE draw: Bernoulli(keep_b) / keep_b for the rows of block b, 0-rate blocks skipped."""
+        every block of the sequences q_from .. q_to in ONE draw: Bernoulli(keep_b) / keep_b for the rows of block b, 0-rate
+        blocks skipped.  (The pipelined forward draws for seq 0 first and for the others once their levels' sizes are known.)"""
+        if q_to is None:
+            q_to = len(self.droppath) - 1
         sizes = tuple(lv.coord.shape[0] for lv in geo.levels)
-        entry = self._keep_cache.get(sizes)
+        key = (sizes[: 1 + max(self.M.seq[q].level for q in range(q_from, q_to + 1))], q_from, q_to)
+        entry = self._keep_cache.get(key)
         if entry is None:
-            spans, probs, off, nb = [], [], 0, 0
-            for q, rates in enumerate(self.droppath):
+            spans, probs, off = [], [], 0
+            for q in range(q_from, q_to + 1):
                 n = sizes[self.M.seq[q].level]
-                for r in rates:
+                nb = self.M.seq[q].first_block
+                for r in self.droppath[q]:
                     if r > 0.0:
                         spans.append((nb, off, n))
                         probs.append(torch.full((n,), 1.0 - r, dtype=torch.float32))
@@ -230,10 +260,14 @@ class _Runtime:
                     nb += 1
             keep = torch.cat(probs).to(device) if probs else None
             entry = (spans, keep)
-            self._keep_cache = {sizes: entry}  # scenes change size every batch: keep the latest layout only
+            # scenes change size every batch: keep the latest layout of each range only
+            self._keep_cache = {k: v for k, v in self._keep_cache.items() if k[1:] != key[1:]}
+            self._keep_cache[key] = entry
         spans, keep = entry
-        for mb in self.M.block[: self.M.num_blocks]:
-            mb.rowscale = None
+        for q in range(q_from, q_to + 1):
+            sq = self.M.seq[q]
+            for mb in self.M.block[sq.first_block: sq.first_block + sq.depth]:
+                mb.rowscale = None
         if keep is None:
             return None
         scales = torch.bernoulli(keep).div_(keep)
@@ -305,6 +339,18 @@ def geometry_supported(geo):
     return all(int(lv.coord.shape[0]) >= 2 for lv in geo.levels)
 
 
+class _Pipelined:
+    """Stands in for the SceneGeometry of a forward that builds it itself, pipelined with the level-0 prefix."""
+
+    def __init__(self, model, coord, offset):
+        self.model, self.coord, self.offset = model, coord, offset
+
+
+def _side_tensors(geo):
+    from .parallel import _geometry_tensors
+    return _geometry_tensors(geo)
+
+
 class _NativeModel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, anchor, rt, geo, training, mode, bf16, *params):
@@ -312,30 +358,91 @@ class _NativeModel(torch.autograd.Function):
         dev = feat.device
         L = _lib.lib()
         M = rt.M
-        keep = rt.fill_geometry(geo)
         M.training, M.matmul_bf16 = int(training), int(bf16)
         # activation checkpointing (reference :169-171: only while training with gradients enabled)
         M.checkpoint = int(bool(rt.want_checkpoint))  # decided by forward() below (grad mode is off inside this function)
         ctx.checkpoint = M.checkpoint
-        scales = rt.draw_droppath(geo, dev) if training else None
         # attention dropout: one fresh mask seed per Block and step (the backward re-evaluates the mask from it)
         for mb, blk in zip(M.block[: M.num_blocks], rt.block_modules):
             rate = blk.attn.attn_drop_rate if training else 0.0
             mb.attn_drop_p, mb.attn_drop_seed = (float(rate), _gva.next_drop_seed()) if rate > 0.0 else (0.0, 0)
         ctx.attn_drop = [(mb.attn_drop_p, mb.attn_drop_seed) for mb in M.block[: M.num_blocks]]
         n0 = feat.shape[0]
+        M.feat, M.logits = feat.data_ptr(), None
+        M.saved, M.saved_bytes, M.saved0, M.saved0_bytes = None, 0, None, 0
+        saved0, scales0, ev_all = None, None, None
+        if isinstance(geo, _Pipelined):
+            # The geometry is built HERE, pipelined with the network (no prefetcher thread, no `geometry=` batch key: the
+            # reference trainer's `model(input_dict)`, pointcept/engines/train_sam_pp2s.py:181).  Only the grid poolings have
+            # data-dependent sizes (one 4-byte read-back each); nothing at level 0 depends on them.  So: the level-0 tables and
+            # the level-0 PREFIX of the network (patch embedding: ~1.5 ms of GPU work at 120 k points) are enqueued first, on the
+            # caller's stream; the poolings, the deeper levels' tables and the inverse tables follow on a side stream, where
+            # their read-backs wait for the geometry kernels only -- the host blocks there while the GPU is busy with the
+            # prefix; then the rest of the network is enqueued behind an event.
+            from .geometry import begin_geometry, finish_geometry, finish_geometry_native, native_finish_supported
+            req, model = geo, geo.model
+            main = torch.cuda.current_stream(dev)
+            side = rt.side_stream(dev)
+            ev_in = torch.cuda.Event()
+            ev_in.record(main)  # coord / offset may have been produced on this stream (the trainer's H2D copies)
+            st = begin_geometry(req.coord, req.offset, model.grid_sizes, model.geometry_neighbours(),
+                                interp=model.unpool_backend == "interp")
+            ev_l0 = torch.cuda.Event()
+            ev_l0.record(main)  # the level-0 tables exist (the inverse tables on the side stream read them)
+            lv0 = st.geo.levels[0]
+            keep0 = rt.fill_prefix(lv0)
+            scales0 = rt.draw_droppath(st.geo, dev, 0, 0) if training else None
+            need0 = L.ptv2_model_prefix_saved_bytes(ctypes.addressof(M))
+            if need0 == 0:
+                raise RuntimeError("ao_amd: ptv2_model prefix rejected by the native runtime")
+            saved0 = torch.empty(need0, dtype=torch.uint8, device=dev)
+            M.saved0, M.saved0_bytes = saved0.data_ptr(), saved0.numel()
+            ws = _lib.workspace(L.ptv2_model_prefix_workspace_bytes(ctypes.addressof(M)), dev)
+            rc = L.ptv2_model_forward_prefix_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "ptv2_model_forward_prefix_hip_launcher")
+            ev_fwd, ev_all = torch.cuda.Event(), torch.cuda.Event()
+
+            def before_inverse():
+                ev_fwd.record(side)      # everything the forward's rest needs is enqueued
+                side.wait_event(ev_l0)
+
+            for t in (lv0.coord, lv0.offset, *lv0.knn.values(), *keep0):  # made on the caller's stream, read on the side stream
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_in)
+                if native_finish_supported(st):  # one native call (csrc/scene.hip): ~0.3 ms of host time instead of ~2
+                    ev_fwd.record(side)  # (creates the handle the launcher re-records)
+                    geo = finish_geometry_native(st, fwd_ready_event=ev_fwd, knn0_event=ev_l0)
+                else:
+                    geo = finish_geometry(st, before_inverse=before_inverse)
+                ev_all.record(side)
+            main.wait_event(ev_fwd)
+            for t in _side_tensors(geo):  # allocated on the side stream, consumed on the caller's
+                t.record_stream(main)
+            if not geometry_supported(geo):
+                raise RuntimeError("ao_amd: a level of this batch has fewer than 2 points; training-mode BatchNorm needs 2 "
+                                   "(the reference's nn.BatchNorm1d raises here as well)")
+            keep = rt.fill_geometry(geo)
+            scales = rt.draw_droppath(geo, dev, 1) if (training and len(rt.droppath) > 1) else None
+        else:
+            keep = rt.fill_geometry(geo)
+            scales = rt.draw_droppath(geo, dev) if training else None
         logits = torch.empty((n0, M.num_classes), dtype=torch.float32, device=dev)
-        M.feat, M.logits = feat.data_ptr(), logits.data_ptr()
-        M.saved, M.saved_bytes = None, 0
+        M.logits = logits.data_ptr()
         need = L.ptv2_model_saved_bytes(ctypes.addressof(M))
         if need == 0:
             raise RuntimeError("ao_amd: ptv2_model rejected by the native runtime (ptv2_model_saved_bytes == 0)")
         saved = torch.empty(need, dtype=torch.uint8, device=dev)
         M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
         ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
-        rc = L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "ptv2_model_forward_hip_launcher")
-        ctx.rt, ctx.geo, ctx.keep, ctx.mode, ctx.training, ctx.bf16 = rt, geo, (keep, scales, feat, saved), mode, training, bf16
+        if saved0 is not None:
+            rc = L.ptv2_model_forward_rest_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "ptv2_model_forward_rest_hip_launcher")
+        else:
+            rc = L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "ptv2_model_forward_hip_launcher")
+        ctx.rt, ctx.geo, ctx.keep, ctx.mode, ctx.training, ctx.bf16 = rt, geo, (keep, (scales, scales0), feat, saved, saved0), mode, training, bf16
+        ctx.ev_all = ev_all  # (the backward waits for the inverse tables; without one, their inputs carry record_stream marks)
         ctx.rowscale_ptrs = [mb.rowscale for mb in M.block[: M.num_blocks]]
         return logits
 
@@ -345,8 +452,10 @@ class _NativeModel(torch.autograd.Function):
         if ctx.keep is None:
             raise RuntimeError("ao_amd: the native PT-v2m2 runtime releases its saved activations at the end of the backward "
                                "(retain_graph / a second backward through the same forward is not supported)")
-        keep, scales, feat, saved = ctx.keep
+        keep, scales, feat, saved, saved0 = ctx.keep
         dev = feat.device
+        if ctx.ev_all is not None:  # pipelined forward: the inverse tables were built on the side stream
+            torch.cuda.current_stream(dev).wait_event(ctx.ev_all)
         L = _lib.lib()
         M = rt.M
         rt.fill_geometry(ctx.geo)  # the struct is shared between calls: restore this call's tables
@@ -357,6 +466,7 @@ class _NativeModel(torch.autograd.Function):
         M.feat, M.logits = feat.data_ptr(), None
         M.logits = g_logits.data_ptr()  # unused by the backward; keeps the struct valid
         M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
+        M.saved0, M.saved0_bytes = (saved0.data_ptr(), saved0.numel()) if saved0 is not None else (None, 0)
         # parallel.FlatGradSync(mode="flat2"): an event the launcher records once the head + decoder gradients are final
         owner = rt.model_ref()
         ev = owner.__dict__.get("native_decoder_done_event") if owner is not None else None
@@ -389,10 +499,23 @@ class _NativeModel(torch.autograd.Function):
         return (None,) * 7 + tuple(views)
 
 
+def pipelined_ok(model):
+    """Whether forward(model, data, None) may build the geometry itself, pipelined with the level-0 prefix: training mode
+    (a level of < 2 points is an error there, as in the reference; eval mode takes such batches through the python path,
+    which has to see the sizes first), no activation checkpointing (one shared saved region), AO_AMD_PIPELINE != 0."""
+    if os.environ.get("AO_AMD_PIPELINE", "1") == "0" or not model.training:
+        return False
+    rt = runtime(model)
+    return not (torch.is_grad_enabled() and any(b.enable_checkpoint for b in rt.block_modules)) and rt.M.seq[0].depth > 0
+
+
 def forward(model, data_dict, geo):
-    """PointTransformerV2.forward on the native runtime (call `supported` first)."""
+    """PointTransformerV2.forward on the native runtime (call `supported` first).  geo None: the geometry is built inside,
+    pipelined with the network's level-0 prefix (call `pipelined_ok` first)."""
     rt = runtime(model)
     feat = data_dict["feat"]
+    if geo is None:
+        geo = _Pipelined(model, data_dict["coord"], data_dict["offset"].int())
     training = model.training or not rt.has_running
     mode = getattr(model, "native_param_grads", "autograd")
     bf16 = matmul_bf16()

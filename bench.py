@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the kNN / FPS us-per-query lines")
+    ap.add_argument("--no-reference-loop", action="store_true",
+                    help="skip the reference_loop leg (the reference trainer's run_step statements over this build)")
     ap.add_argument("--spawn-timeout", type=float, default=1800.0,
                     help="--gpus N without a launcher: seconds after which the remaining ranks are terminated (exit 124)")
     return ap.parse_args()
@@ -240,6 +242,25 @@ def cgroup_cpu():
     return quota, stat
 
 
+def thread_cpu_snapshot():
+    """{tid: (name, CPU seconds)} of every thread of this process (/proc/self/task/*/stat: utime + stime) -- which threads a
+    rank really runs (launching thread, geometry worker, HIP / RCCL progress threads) and what each costs per step."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK") if hasattr(os, "sysconf") else 100
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                raw = open("/proc/self/task/%s/stat" % tid).read()
+            except OSError:
+                continue
+            name = raw[raw.index("(") + 1: raw.rindex(")")]
+            f = raw[raw.rindex(")") + 2:].split()
+            out[int(tid)] = (name, (int(f[11]) + int(f[12])) / tick)
+    except OSError:
+        pass
+    return out
+
+
 def cpu_quota():
     """CPUs this process may use: the cgroup quota when there is one, else the affinity mask."""
     try:
@@ -382,6 +403,89 @@ def main():
     if args.gpus > 1 and not launched:
         return spawn_ranks(args)
     return child_main(args)
+
+
+def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
+    """ms per step of the REFERENCE trainer's own statements over this build, with nothing of bench.py's accelerations: a fresh
+    segmentor, wrapped as `create_ddp_model` wraps it (pointcept/engines/defaults.py:20-43: DistributedDataParallel with
+    broadcast_buffers=False when world_size > 1, the bare module otherwise), `torch.optim.AdamW` as the reference's
+    `build_optimizer` returns for the config's dict(type="AdamW", lr=0.006, weight_decay=0.05)
+    (pointcept/utils/optimizer.py:20-55, configs/s3dis/semseg-pt-v2m2-0-base.py:42), torch's MultiStepLR, parameter
+    gradients delivered through autograd, the batch handed to `model(input_dict)` as the loader produces it (host tensors, no
+    `geometry=` key, no prefetcher thread): `Trainer.run_step` (pointcept/engines/train_sam_pp2s.py:173-200) statement by
+    statement, followed by what `InformationWriter.after_step` does every iteration (`.item()` of every loss,
+    pointcept/engines/hooks/misc.py:112).  `ms_per_step_no_item`: the same without that per-step read-back."""
+    import torch.distributed as dist
+
+    seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(cfg).to(device).train()
+    model = seg
+    if world > 1:  # create_ddp_model
+        model = torch.nn.parallel.DistributedDataParallel(seg, device_ids=[device.index], output_device=device.index,
+                                                          broadcast_buffers=False, find_unused_parameters=False)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+    total = 1 << 20
+    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[int(0.09 * total), int(0.2 * total)], gamma=0.1)
+    enable_amp = args.dtype != "fp32"
+    scaler = torch.cuda.amp.GradScaler() if enable_amp else None
+    host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "geometry"}
+    comm_info = {}
+
+    def run_step():  # train_sam_pp2s.py:173-200
+        input_dict = dict(host)
+        for key in input_dict.keys():
+            if isinstance(input_dict[key], torch.Tensor):
+                input_dict[key] = input_dict[key].cuda(non_blocking=True)
+        with torch.cuda.amp.autocast(enabled=enable_amp):
+            output_dict = model(input_dict)
+            if isinstance(output_dict, tuple):  # train_sam_real.py:187: (dict(loss), seg_dict)
+                output_dict = output_dict[0]
+            loss = output_dict["loss"]
+        optimizer.zero_grad()
+        if enable_amp:
+            scaler.scale(loss).backward()
+            scaler.step(optimizer)
+            scale = scaler.get_scale()
+            scaler.update()
+            if scale <= scaler.get_scale():
+                scheduler.step()
+        else:
+            loss.backward()
+            optimizer.step()
+            scheduler.step()
+        comm_info["model_output_dict"] = output_dict
+
+    def after_step():  # hooks/misc.py:108-112
+        for key in comm_info["model_output_dict"].keys():
+            if "loss" in key:
+                comm_info[key] = comm_info["model_output_dict"][key].item()
+
+    def timed(n, with_item):
+        if dist.is_initialized() and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            run_step()
+            if with_item:
+                after_step()
+        torch.cuda.synchronize(device)
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    steps = max(5, min(args.steps, 20))
+    timed(max(3, min(args.warmup, 5)), True)
+    with_item = timed(steps, True)
+    no_item = timed(steps, False)
+    return {"ms_per_step": 1e3 * with_item / steps, "points_per_s": points_per_step * steps / with_item,
+            "ms_per_step_no_item": 1e3 * no_item / steps, "steps": steps,
+            "loop": "Trainer.run_step statements (pointcept/engines/train_sam_pp2s.py:173-200) + InformationWriter.after_step's "
+                    "loss.item() (hooks/misc.py:112); batch from pinned host memory via .cuda(non_blocking=True)",
+            "model": "DistributedDataParallel(broadcast_buffers=False)" if world > 1 else "bare module (create_ddp_model at world_size 1)",
+            "optimizer": "torch.optim.AdamW + MultiStepLR", "param_grads": "autograd (.grad through AccumulateGrad)",
+            "geometry": "inside PointTransformerV2.forward (pipelined with the level-0 prefix; no prefetcher, no geometry= key)",
+            "enable_amp": enable_amp, "loss": comm_info.get("loss")}
 
 
 def child_main(args):
@@ -611,6 +715,7 @@ def child_main(args):
 
     _lib.graph_stats(reset=True)
     cg0 = cgroup_cpu()[1]
+    threads0, proc_cpu0 = thread_cpu_snapshot(), time.process_time()
     gc_off()
     reserved0 = torch.cuda.memory_reserved(device)
     try:
@@ -621,10 +726,25 @@ def child_main(args):
     reserved_growth = torch.cuda.memory_reserved(device) - reserved0  # > 0: the caching allocator went to the driver while timed
     graph = _lib.graph_stats()
     cg1 = cgroup_cpu()[1]
+    # what THIS rank's process cost the host inside the timed region (all ranks of a node share one cgroup CPU quota)
+    threads1 = thread_cpu_snapshot()
+    mine = {"rank": rank, "host_cpu_ms": 1e3 * sum(host_cpu) / max(len(host_cpu), 1),
+            "host_issue_ms": 1e3 * sum(host_wall) / max(len(host_wall), 1),
+            "process_cpu_ms_per_step": 1e3 * (time.process_time() - proc_cpu0) / args.steps, "threads": len(threads1),
+            "busy_threads_ms_per_step": sorted(
+                ([n, round(1e3 * (c - threads0.get(t, (n, 0.0))[1]) / args.steps, 3)] for t, (n, c) in threads1.items()
+                 if c - threads0.get(t, (n, 0.0))[1] > 0.0), key=lambda kv: -kv[1])[:6]}
+    per_rank = [mine]
+    if dist.is_initialized() and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if prefetch is not None:
         prefetch.close()  # (thread mode: the geometry of the batch after the last one is still being built)
     if not args.no_roofline:
         _lib.lib().ptv2_profile_enable(0)
+    ref_loop = None
+    if not args.no_reference_loop:  # every rank takes part (DistributedDataParallel at world_size > 1)
+        ref_loop = reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step)
 
     if rank == 0:
         with torch.no_grad():
@@ -681,6 +801,9 @@ def child_main(args):
                       "launch_ms_per_step": 1e-3 * graph["launch_us"] / args.steps,
                       "wait_for_gpu_ms_per_step": 1e-3 * graph["wait_us"] / args.steps},
             "geometry_prefetch": pf_mode,
+            # every rank's host cost inside the timed region: CPU of its launching thread, of its whole process (geometry
+            # worker, HIP / RCCL helper threads included), its busiest threads -- N ranks share the node's cgroup quota
+            "per_rank": per_rank,
             # the cgroup's CPU accounting across the timed region: a throttled period there is a stalled launching thread
             "cgroup_timed_region": ({k: cg1[k] - cg0[k] for k in cg1 if k in cg0} if cg0 and cg1 else None),
             # bytes torch's caching allocator obtained from the driver inside the timed region (hipMalloc blocks the launching thread)
@@ -738,6 +861,8 @@ def child_main(args):
                                                        "ms_per_step": round(v["total_us"] / 1e3 / max(survey_steps, 1), 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
                                                    for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])}}
+        if ref_loop is not None:
+            out["reference_loop"] = ref_loop
         if world == 1 and not args.no_ops:
             out["ops"] = op_microbench(data)
         if world == 1 and not args.no_cpu_baseline:

@@ -634,13 +634,72 @@ typedef struct ptv2_model {
                                         * decoder stage have written their parameter gradients (the tail of the flat
                                         * gradient buffer in module.parameters() order) -- a data-parallel caller starts
                                         * the all-reduce of that half while the encoder's backward still runs */
+    void *saved0;                      /* != NULL: the activations of the PREFIX (patch embedding + seq 0: everything that needs
+                                        * level 0 only) live here, ptv2_model_prefix_saved_bytes() bytes, and `saved` /
+                                        * ptv2_model_saved_bytes() cover the rest alone -- the two halves of a forward issued as
+                                        * prefix + rest (below); not with `checkpoint` */
+    size_t saved0_bytes;
 } ptv2_model;
 size_t ptv2_model_saved_bytes(const ptv2_model *m);
 size_t ptv2_model_workspace_bytes(const ptv2_model *m);
 int ptv2_model_forward_hip_launcher(const ptv2_model *m, void *workspace, size_t workspace_bytes, void *stream);
+/* The forward in two calls, for a caller that learns the sizes of levels 1.. only while level 0 is already computing
+ * (ao_amd/ptv2/native_model.py: the grid poolings' 4-byte read-backs run on a side stream behind the prefix's launches):
+ *   prefix: GVAPatchEmbed (point_transformer_v2m2_base.py:441-444) -- reads level[0], seq[0], embed, block[seq[0] blocks],
+ *           feat, saved0 only; the sizes are functions of those fields
+ *   rest:   encoder stages, decoder stages, head (:560-576) -- the whole struct, saved0 as the prefix left it
+ * Together they enqueue exactly the kernels of ptv2_model_forward_hip_launcher (same results bit for bit). */
+size_t ptv2_model_prefix_saved_bytes(const ptv2_model *m);
+size_t ptv2_model_prefix_workspace_bytes(const ptv2_model *m);
+int ptv2_model_forward_prefix_hip_launcher(const ptv2_model *m, void *workspace, size_t workspace_bytes, void *stream);
+int ptv2_model_forward_rest_hip_launcher(const ptv2_model *m, void *workspace, size_t workspace_bytes, void *stream);
 /* g_logits (n0, num_classes); the gradient with respect to `feat` is not formed (the input needs none) */
 int ptv2_model_backward_hip_launcher(const ptv2_model *m, const float *g_logits, void *workspace, size_t workspace_bytes,
                                      void *stream);
+
+/* ------------------------------------------------ scene geometry, levels 1.. in one call --
+ * Everything of a scene's geometry that lies behind the first grid pooling -- for every stage i: GridPool's clustering of
+ * level i (point_transformer_v2m2_base.py:246-268), the self k-NN tables of level i+1 (:223) with their position moments,
+ * the 3-NN interpolation table back to level i (:311, libs/pointops/functions/interpolation.py:13-21), and at the end the
+ * inverse tables of every table of the scene (level 0's included) -- enqueued by ONE native call instead of ~25 python-level
+ * launcher calls (~2 ms of host time per scene, on the critical path of a forward that builds its own geometry).  The sizes
+ * of levels 1.. are data dependent: the call reads each pooling's cluster count back (one 4-byte copy + stream
+ * synchronisation per stage, on `stream` only) and carves the tables of the next level out of the caller's `arena` as it
+ * learns them; `level[].n` and the byte offsets in the struct are its outputs.
+ *   in:  num_stages, b, interp, grid_size[], coord0 / offset0 (level 0), level[0].n, level[i].nk + knn[].k (the K values wanted
+ *        at every level), knn0[] (level 0's self tables, built by the caller: inputs of the inverse tables)
+ *   out: level[i].n (i >= 1) and every `long long` field: byte offset into `arena` of
+ *        coord (n,3) f32, offset (b) i32, knn[j].idx (n,k) i32, .mu (3) f64, .cov (9) f64, .inv_ptr (n+1) i32, .inv_rows (n k) i32,
+ *        cluster (n) i64, order (n) i32, idx_ptr (n_next + 1) i32, up_idx (n,3) i32, up_w (n,3) f32, up_inv_ptr (n_next + 1),
+ *        up_inv_rows (3 n); -1: not produced
+ *   fwd_ready_event (hipEvent_t, optional): recorded on `stream` once everything the FORWARD needs is enqueued (the inverse
+ *        tables, which only the backward reads, follow); knn0_event (optional): `stream` waits for it in front of the inverse
+ *        tables (the caller built knn0 on another stream).
+ * Returns PTV2_ERR_ARG for a voxel-id overflow (scene extent / grid size beyond the 48-bit sort key). */
+#define PTV2_GEO_MAX_K 2
+typedef struct ptv2_geo_table {
+    int k;
+    long long idx, mu, cov, inv_ptr, inv_rows;
+} ptv2_geo_table;
+typedef struct ptv2_geo_level {
+    int n, nk;
+    ptv2_geo_table knn[PTV2_GEO_MAX_K];
+    long long coord, offset;
+    long long cluster, order, idx_ptr, up_idx, up_w, up_inv_ptr, up_inv_rows;
+} ptv2_geo_level;
+typedef struct ptv2_scene_geo {
+    int num_stages, b, interp;
+    float grid_size[PTV2_MAX_STAGES];
+    const float *coord0;
+    const int *offset0;
+    const int *knn0[PTV2_GEO_MAX_K];
+    void *fwd_ready_event, *knn0_event;
+    ptv2_geo_level level[PTV2_MAX_STAGES + 1];
+} ptv2_scene_geo;
+size_t ptv2_scene_geometry_arena_bytes(const ptv2_scene_geo *g);      /* upper bound, from level[0].n */
+size_t ptv2_scene_geometry_workspace_bytes(const ptv2_scene_geo *g);
+int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *g, void *arena, size_t arena_bytes, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* Operand precision of the matrix products launched by the CALLING THREAD through the stand-alone launchers
  * (rows_gemm_*, linear_wgrad_*): bf16 != 0 -> V_MFMA_F32_16X16X32_BF16 on operands rounded to bf16 (fp32 accumulate,
@@ -648,7 +707,8 @@ int ptv2_model_backward_hip_launcher(const ptv2_model *m, const float *g_logits,
  * launchers take the choice from their `matmul_bf16` field instead. */
 int ptv2_matmul_precision(int bf16);
 
-/* sizeof(ptv2_block) [0], sizeof(ptv2_block_grads) [1], sizeof(ptv2_model) [2] as this library was compiled: bindings
+/* sizeof(ptv2_block) [0], sizeof(ptv2_block_grads) [1], sizeof(ptv2_model) [2], sizeof(ptv2_gva_block) [3], sizeof(ptv2_scene_geo) [4]
+ * as this library was compiled: bindings
  * that mirror the structs (ctypes) compare it with their own at load time. */
 long long ptv2_struct_bytes(int which);
 

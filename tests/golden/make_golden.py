@@ -316,6 +316,52 @@ def gen_gva(ref):
     save("gva_block.npz", **out)
 
 
+def gen_gva_pe(ref):
+    """GroupedVectorAttention with the two positional-encoding switches away from the configs' values
+    (point_transformer_v2m2_base.py:80-86,113-115): (pe_multiplier, pe_bias) = (True, True) and (False, False), train & eval,
+    the module's own initialisation (the state travels in the fixture: the extra Sequential has no slot in init_state)."""
+    n, c, g, k = 512, 48, 6, 16
+    pts = torch.from_numpy(synth.room_cloud(n, seed=9))
+    off = torch.tensor([200, n], dtype=torch.int32)
+    import pointops
+    idx, _ = pointops.knn_query(k, pts, off)
+    idx[3::11, 14:] = -1
+    feat0 = torch.randn(n, c, generator=torch.Generator().manual_seed(2))
+    ga = torch.randn(n, c, generator=torch.Generator().manual_seed(6))
+    out = dict(xyz=pts, offset=off, idx=idx, feat=feat0, gout=ga)
+    for tag, (mult, bias) in (("mult_bias", (True, True)), ("plain", (False, False))):
+        torch.manual_seed(31)
+        attn = ref.GroupedVectorAttention(embed_channels=c, groups=g, pe_multiplier=mult, pe_bias=bias)
+        with torch.no_grad():  # BatchNorm affine / running statistics away from their defaults
+            gen = torch.Generator().manual_seed(32)
+            for nm, p_ in attn.named_parameters():
+                if "norm" in nm or nm.endswith(".1.norm.weight") or nm.endswith(".1.norm.bias"):
+                    p_.add_(0.2 * torch.randn(p_.shape, generator=gen))
+            for nm, b_ in attn.named_buffers():
+                if nm.endswith("running_mean"):
+                    b_.copy_(0.3 * torch.randn(b_.shape, generator=gen))
+                if nm.endswith("running_var"):
+                    b_.copy_(0.5 + torch.rand(b_.shape, generator=gen))
+        st = {k_: v.clone() for k_, v in attn.state_dict().items()}
+        for k_, v in st.items():
+            out["%s_state_%s" % (tag, k_)] = v
+        for mode in ("train", "eval"):
+            attn.load_state_dict(st, strict=True)
+            attn.train(mode == "train")
+            feat = feat0.clone().requires_grad_(True)
+            a = attn(feat, pts, idx)
+            grads = torch.autograd.grad(a, [feat] + list(attn.parameters()), ga)
+            out["%s_out_%s" % (tag, mode)] = a
+            out["%s_gfeat_%s" % (tag, mode)] = grads[0]
+            for (nm, _), gr in zip(attn.named_parameters(), grads[1:]):
+                out["%s_g_%s_%s" % (tag, mode, nm)] = gr
+            if mode == "train":
+                for nm, b_ in attn.named_buffers():
+                    if nm.endswith("running_mean") or nm.endswith("running_var"):
+                        out["%s_buf_%s" % (tag, nm)] = b_.clone()
+    save("gva_pe.npz", **out)
+
+
 def gen_model(ref):
     """Full PT-v2m2, S3DIS config (drop_path 0) on 2 small room clouds; plus a 4-stage / 'map' variant."""
     manifest = {}
@@ -450,9 +496,13 @@ def main():
     install_stubs()
     pointops = sys.modules["pointops"]  # the reference's own python package
     assert pointops.__file__.startswith(REF)
+    if os.environ.get("AO_GOLDEN_ONLY") == "gva_pe":  # (adds the round-5 fixture without rewriting the others)
+        gen_gva_pe(load_reference_model_module())
+        return
     gen_ops(pointops)
     ref = load_reference_model_module()
     gen_gva(ref)
+    gen_gva_pe(ref)
     gen_model(ref)
     gen_segmentor()
 

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "ptv2_hip.h")
 def declared_symbols():
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs|_stamp_us|_graph_mode|_graph_stats|_graph_reset|_defer_mode))\s*\(", txt)))
+    return sorted(set(re.findall(r"\b([a-z_0-9]+(?:_launcher|_workspace_bytes|_saved_bytes|_arena_bytes|_tiles_floats|_param_layout|_version|_info|_enable|_select|_stride|_is_on|_kernel_count|_read|_host|_struct_bytes|_precision|_count_pairs|_stamp_us|_graph_mode|_graph_stats|_graph_reset|_defer_mode))\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 9
+    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 10
     assert b"gfx950" in L.ptv2_build_info()
     a = L.knn_query_hip_workspace_bytes(80000, 80000, 1)
     b = L.knn_query_hip_workspace_bytes(240000, 240000, 3)
@@ -89,6 +89,8 @@ def test_model_runtime_rejects_an_invalid_description(lib):
     assert L.ptv2_struct_bytes(0) == ctypes.sizeof(block._Blk)
     assert L.ptv2_struct_bytes(1) == ctypes.sizeof(block._BlkGrads)
     assert L.ptv2_struct_bytes(2) == ctypes.sizeof(native_model._Model)
+    from ao_amd.ptv2 import gva
+    assert L.ptv2_struct_bytes(3) == ctypes.sizeof(gva._BlockArgs)
     assert L.ptv2_struct_bytes(99) == -1
     M = native_model._Model()
     assert L.ptv2_model_saved_bytes(ctypes.addressof(M)) == 0

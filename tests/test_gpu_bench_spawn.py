@@ -40,3 +40,29 @@ def test_two_ranks_spawned_by_bench_py_on_one_device():
     assert one["n_gpus"] == 1 and one["config"]["launcher"] == "single"
     # weak scaling bookkeeping: points per step summed over the ranks
     assert abs(two["value"] * two["ms_per_step"] - 2 * one["value"] * one["ms_per_step"]) <= 0.02 * one["value"] * one["ms_per_step"]
+
+
+def test_eight_ranks_on_one_device_under_the_cpu_quota():
+    """the only rehearsal of the 8-GPU launch obtainable on a one-GPU box -- eight rank processes (each with its
+    launching thread, the HIP runtime's helper threads and a gloo progress thread) on ONE MI355X under the box's cgroup CPU quota
+    (16 CPUs on the pool's hosts: 2 per rank).  The ranks must come up, train and agree, nobody may be throttled inside the timed
+    region, and every rank reports what it cost the host.  Reference launch: pointcept/engines/launch.py:74-135."""
+    out = _bench(["--gpus", "8", "--steps", "5", "--warmup", "3", "--points", "20000", "--no-cpu-baseline", "--no-ops", "--no-roofline",
+                  "--no-reference-loop"], AO_AMD_BENCH_ONE_DEVICE="1", AO_AMD_BENCH_BACKEND="gloo")
+    assert out["n_gpus"] == 8 and out["config"]["rccl_ranks"] == 8 and out["config"]["comm_backend"] == "gloo"
+    assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"]  # finite
+    host = out["host"]
+    ranks = host["per_rank"]
+    assert sorted(r["rank"] for r in ranks) == list(range(8))
+    for r in ranks:
+        assert r["host_cpu_ms"] > 0 and r["process_cpu_ms_per_step"] >= r["host_cpu_ms"] * 0.5 and r["threads"] >= 1, r
+    cg = host["cgroup_timed_region"]
+    if cg and "nr_throttled" in cg:  # (a box without a cgroup-v2 CPU controller reports nothing)
+        assert cg["nr_throttled"] == 0, (cg, host["cgroup_cpu_max"])
+    # the ranks' processes together must fit the quota with room to spare: CPU per step summed over the ranks against the
+    # quota's CPU time in one step's wall time
+    quota = host.get("cgroup_cpu_max")
+    if quota and quota.split()[0] != "max":
+        cpus = int(quota.split()[0]) / int(quota.split()[1])
+        used = sum(r["process_cpu_ms_per_step"] for r in ranks) / out["ms_per_step"]
+        assert used < 0.8 * cpus, (used, cpus)

@@ -51,9 +51,15 @@ def graph_mode():
     L.ptv2_graph_reset()
 
 
+@pytest.mark.parametrize("pipeline", ["1", "0"])
 @pytest.mark.parametrize("tag", ["s3dis", "scannet"])
-def test_graph_issue_is_bit_identical_to_eager_over_changing_scene_sizes(graph_mode, tag):
+def test_graph_issue_is_bit_identical_to_eager_over_changing_scene_sizes(graph_mode, monkeypatch, tag, pipeline):
+    """pipeline 1 (default): the forward is two graphs -- the level-0 prefix, and the rest behind the geometry's read-backs
+    (ao_amd/ptv2/native_model.py) -- plus the backward's; 0: one graph per direction."""
     from ao_amd import _lib
+
+    monkeypatch.setenv("AO_AMD_PIPELINE", pipeline)
+    per_call = 3 if pipeline == "1" else 2
 
     cfg = dict(M.S3DIS_CFG if tag == "s3dis" else M.SCANNET_CFG, drop_path_rate=0.0)
     # six batches, every one with other level sizes (the sizes of the coarse levels are data dependent)
@@ -67,7 +73,7 @@ def test_graph_issue_is_bit_identical_to_eager_over_changing_scene_sizes(graph_m
     _lib.graph_stats(reset=True)
     got, got_state = _run(_model(cfg, seed=3), scenes)
     st = _lib.graph_stats()
-    assert st["scopes"] == 2 * len(scenes) and st["declined"] == 0, st
+    assert st["scopes"] == per_call * len(scenes) and st["declined"] == 0, st
     # a ring of three executable graphs per direction: from the fourth call on an existing graph is reused -- updated in
     # place when the node count is unchanged, rebuilt otherwise; both must have happened without an error
     assert st["updated"] + st["instantiated"] == st["scopes"], st
@@ -95,7 +101,8 @@ def test_graph_update_in_place_for_a_repeated_shape_and_on_a_side_stream(graph_m
     st = _lib.graph_stats()
     # an executable graph is created only when every existing one of the slot is still in flight: at least one per direction,
     # at most the ring; every other call updates one in place (same shape, same node count)
-    assert st["scopes"] == 14 and st["declined"] == 0 and 2 <= st["instantiated"] <= 14 and st["updated"] == 14 - st["instantiated"], st
+    # (three graphs per call: forward prefix, forward rest, backward)
+    assert st["scopes"] == 21 and st["declined"] == 0 and 3 <= st["instantiated"] <= 21 and st["updated"] == 21 - st["instantiated"], st
     # (running statistics differ between the 7 identical calls, the logits therefore too: compared call by call)
     for (lw, gw), (lg, gg) in zip(want, got):
         assert torch.equal(lw, lg)
@@ -115,7 +122,7 @@ def test_sampled_kernel_timer_brackets_inside_the_graph(graph_mode):
     _lib.kernel_timer(True)
     _lib.graph_stats(reset=True)
     _run(model, scenes[:1])
-    assert _lib.graph_stats()["declined"] == 2  # HIP-event survey: eager
+    assert _lib.graph_stats()["declined"] == 3  # HIP-event survey: eager (forward prefix, forward rest, backward)
     _lib.kernel_timer(False)
     survey = _lib.kernel_timer_read()
     name = "bn_bwd_apply_kernel"  # (a family with tens of launches per step; the weight gradients are two batched launches)
@@ -126,8 +133,8 @@ def test_sampled_kernel_timer_brackets_inside_the_graph(graph_mode):
     want, _ = _run(model, scenes[1:])
     st = _lib.graph_stats()
     _lib.kernel_timer(False)
-    assert st["declined"] == 0 and st["scopes"] == 14, st
-    assert st["updated"] >= 6, st  # the brackets of a ring entry keep their positions: graphs are updated, not rebuilt
+    assert st["declined"] == 0 and st["scopes"] == 21, st
+    assert st["updated"] >= 9, st  # the brackets of a ring entry keep their positions: graphs are updated, not rebuilt
     rec = _lib.kernel_timer_read()[name]
     assert rec["launches"] >= 7 * (per_step // 5)
     # stamps and events time the same kernel: within a factor (the survey's mean is over all launches, the sample's over a few)

@@ -66,6 +66,41 @@ def test_block_matches_reference_module(ptv2, golden, gva_mode, mode):
                 np.testing.assert_allclose(sd[k[len("block_buf_"):]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("tag,mult,bias", [("mult_bias", True, True), ("plain", False, False)])
+def test_attention_with_the_other_positional_encoding_switches(ptv2, golden, tag, mult, bias, mode):
+    """VERDICT r4 #8 / missing #3: `pe_multiplier=True` and `pe_bias=False` (point_transformer_v2m2_base.py:80-86,113-115) are
+    constructor arguments of the boundary that no configuration of the reference sets; they run the literal op sequence
+    (model.py: gva_unfused, on the HIP gather kernel).  Fixture: the reference's own GroupedVectorAttention with its state
+    (tests/golden/make_golden.py::gen_gva_pe) -- output, input gradient, every parameter gradient, running statistics."""
+    g = golden("gva_pe.npz")
+    attn = ptv2.GroupedVectorAttention(48, 6, pe_multiplier=mult, pe_bias=bias).cuda()
+    pre = tag + "_state_"
+    state = {k[len(pre):]: dev(g[k]) for k in g.files if k.startswith(pre)}
+    attn.load_state_dict(state, strict=True)
+    assert hasattr(attn, "linear_p_multiplier") == mult and hasattr(attn, "linear_p_bias") == bias
+    attn.train(mode == "train")
+    xyz, idx = dev(g["xyz"]), dev(g["idx"])
+    feat = dev(g["feat"]).requires_grad_(True)
+    out = attn(feat, xyz, idx)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["%s_out_%s" % (tag, mode)], rtol=1e-4, atol=1e-4)
+    names = [n for n, _ in attn.named_parameters()]
+    grads = torch.autograd.grad(out, [feat] + list(attn.parameters()), dev(g["gout"]))
+    np.testing.assert_allclose(grads[0].cpu().numpy(), g["%s_gfeat_%s" % (tag, mode)], rtol=1e-3, atol=1e-4)
+    for n, gr in zip(names, grads[1:]):
+        ref = g["%s_g_%s_%s" % (tag, mode, n)]
+        if mode == "train" and n.endswith(".0.bias"):  # exactly-zero true gradient (bias in front of a BatchNorm)
+            wref = g["%s_g_%s_%s" % (tag, mode, n[:-4] + "weight")]
+            assert np.linalg.norm(gr.cpu().numpy()) <= 2e-3 * np.linalg.norm(wref) + 1e-4, n
+            continue
+        assert_grad_close(gr.cpu().numpy(), ref, n)
+    if mode == "train":
+        sd = attn.state_dict()
+        for k in g.files:
+            if k.startswith(tag + "_buf_"):
+                np.testing.assert_allclose(sd[k[len(tag) + 5:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 @pytest.mark.parametrize("tag", ["s3dis", "scannet"])
 def test_full_model_matches_reference_module(ptv2, golden, gva_mode, tag):
     g = golden("ptv2_%s.npz" % tag)
@@ -129,6 +164,40 @@ def test_grid_pool_dense_table_equals_the_sort_path(monkeypatch, points, grid):
     monkeypatch.setenv("AO_AMD_GRIDPOOL", "hip")
     got = grid_pool_geometry(coord, offset, grid)
     assert got[0].shape[0] == want[0].shape[0] > 0
+    for a, w, name in zip(got, want, ("new_coord", "new_offset", "cluster", "order", "idx_ptr")):
+        assert torch.equal(a, w), name
+
+
+@pytest.mark.parametrize("kind", ["one_voxel", "duplicates", "two_clouds_one_crowded"])
+def test_grid_pool_crowded_voxels_take_the_sort_path(monkeypatch, kind):
+    """the dense path orders a voxel's members with a one-thread insertion sort -- quadratic in the
+    occupancy.  A voxel with more than 64 members hands the call back (*n_out = -2) and the wrapper repeats it on the
+    radix-sort path: a whole cloud inside ONE voxel (20 000 members), a duplicate-heavy cloud, one crowded cloud beside a
+    normal one.  Same outputs as the sort path, and the call returns at once instead of spinning for 10^8 serial steps."""
+    import time
+
+    from ao_amd.ptv2.geometry import grid_pool_geometry
+
+    g = torch.Generator().manual_seed(3)
+    if kind == "one_voxel":
+        coord = torch.rand(20000, 3, generator=g) * 0.01 + 0.02
+        offset = torch.tensor([20000], dtype=torch.int32)
+    elif kind == "duplicates":
+        base = torch.rand(40, 3, generator=g) * 4.0
+        coord = base[torch.randint(0, 40, (30000,), generator=g)]
+        offset = torch.tensor([30000], dtype=torch.int32)
+    else:
+        coord = torch.cat([torch.rand(8000, 3, generator=g) * 3.0, torch.rand(9000, 3, generator=g) * 0.02 + 1.0])
+        offset = torch.tensor([8000, 17000], dtype=torch.int32)
+    coord, offset = coord.cuda().contiguous(), offset.cuda()
+    monkeypatch.setenv("AO_AMD_GRIDPOOL", "sort")
+    want = grid_pool_geometry(coord, offset, 0.06)
+    monkeypatch.setenv("AO_AMD_GRIDPOOL", "hip")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = grid_pool_geometry(coord, offset, 0.06)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 2.0
     for a, w, name in zip(got, want, ("new_coord", "new_offset", "cluster", "order", "idx_ptr")):
         assert torch.equal(a, w), name
 

@@ -155,3 +155,64 @@ def test_gradients_after_unscale_are_the_unscaled_gradients(monkeypatch):
     assert len(got[True]) == len(got[False]) > 400
     for a, b in zip(got[True], got[False]):
         assert torch.equal(a, b)
+
+
+def test_run_step_statements_against_the_cpu_oracle(monkeypatch):
+    """ONE oracle-side run of the same statement sequence.  The CPU oracle (oracle/ptv2_ref.RefModule, the
+    reference network restated on CPU torch) under `torch.optim.AdamW` + torch's own MultiStepLR, and the HIP path under
+    FlatAdamW + StepSchedule, both driven by train_sam_pp2s.py:173-200 with enable_amp=False (a GradScaler on CPU tensors is a
+    no-op, and fp32 on both sides is the comparison that pins arithmetic): same loss at step 0, the loss curves together over
+    10 optimizer steps of lr 0.006, the same learning-rate sequence, every step taken."""
+    import torch.nn.functional as F
+
+    import ao_amd.ptv2 as ptv2
+    from ao_amd.ptv2.schedule import build_optimizer, build_scheduler
+
+    monkeypatch.setenv("AO_AMD_MODEL", "native")
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    host = _batch(cfg)
+    # labels that are a function of position: something to learn (random labels give a flat curve)
+    z = host["coord"][:, 2]
+    host["segment"] = ((z - z.min()) / (z.max() - z.min() + 1e-6) * 12.99).long()
+
+    class OracleSegmentor(torch.nn.Module):  # DefaultSegmentor (pointcept/models/default.py:232-251) over the oracle backbone
+        def __init__(self):
+            super().__init__()
+            self.backbone = M.RefModule(cfg, seed=23, randomize_bn=False)
+
+        def forward(self, input_dict):
+            return dict(loss=F.cross_entropy(self.backbone(input_dict), input_dict["segment"], ignore_index=-1))
+
+    def run(model, optimizer, scheduler, move):
+        log = []
+        for _ in range(STEPS):
+            input_dict = dict(host)
+            for key in input_dict.keys():  # :175-177
+                if isinstance(input_dict[key], torch.Tensor):
+                    input_dict[key] = move(input_dict[key])
+            output_dict = model(input_dict)  # enable_amp False: :178-180 without the autocast
+            loss = output_dict["loss"]
+            optimizer.zero_grad()
+            loss.backward()      # :193
+            optimizer.step()     # :194
+            scheduler.step()     # :195
+            log.append((float(loss.detach()), optimizer.param_groups[0]["lr"]))
+        return log
+
+    oracle = OracleSegmentor().train()
+    opt_o = torch.optim.AdamW(oracle.parameters(), lr=0.006, weight_decay=0.05)
+    sch_o = torch.optim.lr_scheduler.MultiStepLR(opt_o, milestones=[6, 8], gamma=0.1)  # (0.6, 0.8) of 10 steps
+    log_o = run(oracle, opt_o, sch_o, lambda t: t)
+
+    model = ptv2.DefaultSegmentor(dict(cfg)).cuda().train()
+    model.backbone.load_state_dict(M.init_state(cfg, seed=23, randomize_bn=False), strict=True)
+    opt = build_optimizer(dict(type="AdamW", lr=0.006, weight_decay=0.05), model, flat=True)
+    sch = build_scheduler(dict(type="MultiStepLR", milestones=[0.6, 0.8], gamma=0.1), opt, total_steps=STEPS)
+    log_h = run(model, opt, sch, lambda t: t.cuda(non_blocking=True))
+
+    lo, lh = np.asarray([l for l, _ in log_o]), np.asarray([l for l, _ in log_h])
+    print("loss oracle", np.round(lo, 5), "\nloss hip   ", np.round(lh, 5))
+    assert abs(lo[0] - lh[0]) < 2e-5                      # the same forward
+    np.testing.assert_allclose([r for _, r in log_h], [r for _, r in log_o], rtol=1e-6)  # the same schedule
+    assert lh[-1] < 0.8 * lh[0] and lo[-1] < 0.8 * lo[0]  # both learn
+    assert np.max(np.abs(lh - lo) / lo) < 0.06, (lo, lh)  # the curves stay together (trajectory test: 2.4 % observed)

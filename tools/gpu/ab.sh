@@ -2,10 +2,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=$1; A="$2"; B="$3"; R=${4:-3}; X="$5"
 mkdir -p $O
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ops --no-roofline $X > /dev/null 2>&1   # warm the box up
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ops --no-roofline --no-reference-loop $X > /dev/null 2>&1   # warm the box up
 for i in $(seq 1 $R); do
-  env $A python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline $X > $O/a$i.json 2> $O/a$i.err
-  env $B python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline $X > $O/b$i.json 2> $O/b$i.err
+  env $A python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline --no-reference-loop $X > $O/a$i.json 2> $O/a$i.err
+  env $B python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops --no-roofline --no-reference-loop $X > $O/b$i.json 2> $O/b$i.err
 done
 python - $O $R <<'PY'
 import json,sys

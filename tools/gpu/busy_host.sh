@@ -9,7 +9,7 @@ for B in $BURN; do
   sleep 1
   for m in $ORDER; do
     if [ $m = g ]; then E="AO_AMD_GRAPH=1"; else E="AO_AMD_GRAPH=0"; fi
-    env $E $EXTRA_ENV python bench.py --no-cpu-baseline --no-ops --no-roofline > gpurun_out/busy/${T}_b${B}_${m}.json 2> gpurun_out/busy/${T}_b${B}_${m}.err
+    env $E $EXTRA_ENV python bench.py --no-cpu-baseline --no-ops --no-roofline --no-reference-loop > gpurun_out/busy/${T}_b${B}_${m}.json 2> gpurun_out/busy/${T}_b${B}_${m}.err
     python - gpurun_out/busy/${T}_b${B}_${m}.json $m $B <<'PY'
 import json, sys
 try:

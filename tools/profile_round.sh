@@ -6,7 +6,7 @@ set -u
 O=${1:-gpurun_out/profile}
 mkdir -p "$O"
 export TMPDIR=/tmp
-B="python3 bench.py --no-cpu-baseline --no-ops --no-roofline"
+B="python3 bench.py --no-cpu-baseline --no-ops --no-roofline --no-reference-loop"
 rocprofv3 --kernel-trace --stats -d "$O/trace" -o run --output-format csv -- $B --steps 20 --warmup 5 > "$O/trace.log" 2>&1
 cp "$O"/trace/run_kernel_stats.csv "$O/kernel_stats.csv" 2>/dev/null || cp "$O"/trace/*/run_kernel_stats.csv "$O/kernel_stats.csv"
 python tools/prof_summary.py "$O/trace" 25 60 > "$O/kernel_summary.txt" 2>&1 || python - "$O" <<'PY'
