@@ -43,8 +43,12 @@ __global__ __launch_bounds__(TPB) void small_linear_fwd_kernel(long long n, int 
                                                                const float *__restrict__ W, const float *__restrict__ b,
                                                                float *__restrict__ y) {
     extern __shared__ float lds[];
-    float *w = lds, *bias = lds + (size_t)cout * cin;
-    for (int e = threadIdx.x; e < cout * cin; e += TPB) w[e] = W[e];
+    // W rows at an ODD pitch: the lanes of a wavefront hold consecutive outputs o and read w[o * pitch + i] -- with the natural
+    // pitch cin = 6 (the S3DIS patch embedding) the 64 lanes fell on 32 banks, two each (SQ_LDS_BANK_CONFLICT 0.47 of this
+    // kernel's LDS cycles, profiles/r04_final_sq_counters.jsonl); an odd pitch is co-prime with the 64 banks
+    const int pitch = cin | 1;
+    float *w = lds, *bias = lds + (size_t)cout * pitch;
+    for (int e = threadIdx.x; e < cout * cin; e += TPB) { const int o = e / cin; w[o * pitch + (e - o * cin)] = W[e]; }
     for (int e = threadIdx.x; e < cout; e += TPB) bias[e] = b ? b[e] : 0.f;
     __syncthreads();
     const long long total = n * cout;
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(TPB) void small_linear_fwd_kernel(long long n, int 
     for (long long e = (long long)blockIdx.x * TPB + threadIdx.x; e < total; e += (long long)gridDim.x * TPB) {
         const long long r = narrow ? (long long)((unsigned)e / (unsigned)cout) : e / cout;
         const int o = (int)(e - r * cout);
-        const float *xr = x + r * cin, *wr = w + (size_t)o * cin;
+        const float *xr = x + r * cin, *wr = w + (size_t)o * pitch;
         float acc = bias[o];
         for (int i = 0; i < cin; ++i) acc = __builtin_fmaf(xr[i], wr[i], acc);
         y[e] = acc;
@@ -384,7 +388,7 @@ int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S,
     if (L.cin % 4 == 0 && L.cout % 4 == 0) {
         RUN(rows_gemm_hip_launcher(n, L.cout, L.cin, x, L.w, 0, L.b, S.h, 0, stream));
     } else {
-        const size_t lds = sizeof(float) * ((size_t)L.cout * L.cin + L.cout);
+        const size_t lds = sizeof(float) * ((size_t)L.cout * (L.cin | 1) + L.cout);
         hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(grid_for((long long)n * L.cout)), dim3(TPB), lds, st, (long long)n, L.cin,
                            L.cout, x, L.w, L.b, S.h);
     }
@@ -621,7 +625,7 @@ int model_forward(const ptv2_model *M, void *workspace, size_t workspace_bytes, 
     RUN(linbn_forward(M, M->head, A.head, M->level[0].n, x, A.head.y, W, stream));
     {
         const int c0 = M->head.cout, nc = M->num_classes;
-        const size_t lds = sizeof(float) * ((size_t)nc * c0 + nc);
+        const size_t lds = sizeof(float) * ((size_t)nc * (c0 | 1) + nc);  // (covers small_linear_fwd's odd row pitch)
         const int gr = grid_for(M->level[0].n);
         if (c0 % 4 == 0 && nc == 13)
             hipLaunchKernelGGL(classifier_fwd_kernel<13>, dim3(gr), dim3(TPB), lds, st, (long long)M->level[0].n, c0,

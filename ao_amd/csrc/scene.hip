@@ -118,8 +118,19 @@ extern "C" size_t ptv2_scene_geometry_workspace_bytes(const ptv2_scene_geo *G) {
         if (rc_ != PTV2_OK) return rc_;  \
     } while (0)
 
+static int scene_geometry(ptv2_scene_geo *G, void *arena, size_t arena_bytes, void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, size_t arena_bytes, void *workspace,
                                                 size_t workspace_bytes, void *stream) {
+    if (!G) return PTV2_ERR_ARG;
+    G->sizes_ready = 0;
+    G->fwd_recorded = 0;
+    const int rc = scene_geometry(G, arena, arena_bytes, workspace, workspace_bytes, stream);
+    if (rc != PTV2_OK) __atomic_store_n(&G->sizes_ready, -1, __ATOMIC_RELEASE);  // (a polling thread must not wait for ever)
+    return rc;
+}
+
+static int scene_geometry(ptv2_scene_geo *G, void *arena, size_t arena_bytes, void *workspace, size_t workspace_bytes, void *stream) {
     if (!geo_ok(G) || !arena) return PTV2_ERR_ARG;
     const Ws W = carve_ws(G, workspace);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
@@ -143,12 +154,18 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
     std::lock_guard<std::mutex> lk(g_pin_mu);
     if (!g_pinned && hipHostMalloc((void **)&g_pinned, 64, hipHostMallocDefault) != hipSuccess) return PTV2_ERR_LAUNCH;
 
-    const float *coord = G->coord0;
-    const int *offset = G->offset0;
-    int n = G->level[0].n;
+    // ---- phase 1: the chain of grid poolings alone -- each needs only the coordinates of the level above it, and their cluster
+    // counts are the only data-dependent sizes of a scene.  With all S read-backs at the front, a second host thread (the one
+    // that issues the network: ao_amd/ptv2/native_model.py) learns every size ~0.3 ms into the call and prepares the rest of the
+    // forward while the tables below are still being computed.
+    const float *coords[PTV2_MAX_STAGES + 1];
+    const int *offsets[PTV2_MAX_STAGES + 1];
+    coords[0] = G->coord0;
+    offsets[0] = G->offset0;
     for (int i = 0; i < S; ++i) {
         ptv2_geo_level &L = G->level[i], &N = G->level[i + 1];
-        // ---- GridPool's clustering of level i: cluster / order exact, idx_ptr / pooled coordinates for at most n clusters
+        const int n = L.n;
+        // GridPool's clustering of level i: cluster / order exact, idx_ptr / pooled coordinates for at most n clusters
         L.cluster = take(8 * (size_t)n);
         L.order = take(4 * (size_t)n);
         L.idx_ptr = take(4 * ((size_t)n + 1));
@@ -158,7 +175,7 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
         if (grid_pool_hip_workspace_bytes(n, b) > W.pool_bytes) return PTV2_ERR_WORKSPACE;
         int m = -2;
         for (int sort_path = 0; sort_path < 2 && m == -2; ++sort_path) {  // the dense table first; -2 asks for the radix sort
-            RUN(grid_pool_hip_launcher(n, b, coord, offset, G->grid_size[i], (long long *)at(L.cluster), (int *)at(L.order),
+            RUN(grid_pool_hip_launcher(n, b, coords[i], offsets[i], G->grid_size[i], (long long *)at(L.cluster), (int *)at(L.order),
                                        (int *)at(L.idx_ptr), (float *)at(N.coord), (int *)at(N.offset), W.n_out, sort_path, W.pool,
                                        W.pool_bytes, stream));
             if (hipMemcpyAsync(g_pinned, W.n_out, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return PTV2_ERR_LAUNCH;
@@ -168,15 +185,47 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
         if (m < 1) return PTV2_ERR_ARG;  // voxel ids beyond the sort key (or an empty level)
         N.n = m;
         off = (size_t)N.coord + al(12 * (size_t)m);  // the pooled coordinates were the last item: give the unused rows back
-        const float *ncoord = (const float *)at(N.coord);
-        const int *noffset = (const int *)at(N.offset);
+        coords[i + 1] = (const float *)at(N.coord);
+        offsets[i + 1] = (const int *)at(N.offset);
         if (knn_query_hip_workspace_bytes(std::max(n, m), m, b) > W.knn_bytes) return PTV2_ERR_WORKSPACE;
-        // ---- tables over the points of level i + 1: ONE cell grid serves the interpolation query from level i and the self tables
+    }
+    // ---- every size is known: carve all the tables; from here on every n and offset of the struct is final
+    for (int i = 0; i <= S; ++i) {
+        ptv2_geo_level &L = G->level[i];
+        if (i < S && G->interp) {
+            L.up_idx = take(12 * (size_t)L.n);
+            L.up_w = take(12 * (size_t)L.n);
+        }
+        if (i > 0)
+            for (int j = 0; j < L.nk; ++j) {
+                ptv2_geo_table &T = L.knn[j];
+                T.idx = take(4 * (size_t)L.n * T.k);
+                T.mu = take(24);
+                T.cov = take(72);
+            }
+    }
+    for (int l = 0; l <= S; ++l) {
+        ptv2_geo_level &Q = G->level[l];
+        for (int j = 0; j < Q.nk; ++j) {
+            Q.knn[j].inv_ptr = take(4 * ((size_t)Q.n + 1));
+            Q.knn[j].inv_rows = take(4 * (size_t)Q.n * Q.knn[j].k);
+        }
+        if (l < S && G->interp) {
+            Q.up_inv_ptr = take(4 * ((size_t)Q.n + 1));
+            Q.up_inv_rows = take(4 * (size_t)Q.n * 3);
+        }
+    }
+    if (full) return PTV2_ERR_WORKSPACE;
+    __atomic_store_n(&G->sizes_ready, 1, __ATOMIC_RELEASE);
+    // ---- phase 2: the tables over the points of every pooled level; ONE cell grid per level serves the interpolation query from
+    // the finer level and the level's self tables
+    for (int i = 0; i < S; ++i) {
+        ptv2_geo_level &L = G->level[i], &N = G->level[i + 1];
+        const int n = L.n, m = N.n;
+        const float *coord = coords[i], *ncoord = coords[i + 1];
+        const int *offset = offsets[i], *noffset = offsets[i + 1];
         int used = 0;
         if (G->interp) {
-            L.up_idx = take(12 * (size_t)n);
-            L.up_w = take(12 * (size_t)n);
-            if (full) return PTV2_ERR_WORKSPACE;
             RUN(knn_query_grid_hip_launcher(n, 3, ncoord, coord, noffset, offset, (int *)at(L.up_idx), W.dist2, m, b, 0, 0, 0, W.knn,
                                             W.knn_bytes, stream));
             used = 1;
@@ -184,10 +233,6 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
         }
         for (int j = 0; j < N.nk; ++j) {
             ptv2_geo_table &T = N.knn[j];
-            T.idx = take(4 * (size_t)m * T.k);
-            T.mu = take(24);
-            T.cov = take(72);
-            if (full) return PTV2_ERR_WORKSPACE;
             if (used > 3) used = 0;  // (more queries than re-run counters: rebuild)
             RUN(knn_query_grid_hip_launcher(m, T.k, ncoord, ncoord, noffset, noffset, (int *)at(T.idx), W.dist2, m, b, 0, used ? 1 : 0,
                                             used, W.knn, W.knn_bytes, stream));
@@ -195,11 +240,9 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
             RUN(gva_pos_moments_hip_launcher(m, T.k, ncoord, (const int *)at(T.idx), (double *)at(T.mu), (double *)at(T.cov), W.pos,
                                              W.pos_bytes, stream));
         }
-        coord = ncoord;
-        offset = noffset;
-        n = m;
     }
     if (G->fwd_ready_event && hipEventRecord((hipEvent_t)G->fwd_ready_event, st) != hipSuccess) return PTV2_ERR_LAUNCH;
+    __atomic_store_n(&G->fwd_recorded, 1, __ATOMIC_RELEASE);
     if (G->knn0_event && hipStreamWaitEvent(st, (hipEvent_t)G->knn0_event, 0) != hipSuccess) return PTV2_ERR_LAUNCH;
     // ---- inverse tables of every table of the scene, PTV2_INVERSE_MAX_JOBS per call (four launches each)
     ptv2_inverse_job jobs[PTV2_INVERSE_MAX_JOBS];
@@ -212,9 +255,7 @@ extern "C" int ptv2_scene_geometry_hip_launcher(ptv2_scene_geo *G, void *arena, 
         return rc;
     };
     auto add = [&](int rows, int k, const int *idx, int targets, long long *inv_ptr, long long *inv_rows) -> int {
-        *inv_ptr = take(4 * ((size_t)targets + 1));
-        *inv_rows = take(4 * (size_t)rows * k);
-        if (full) return PTV2_ERR_WORKSPACE;
+        (void)targets;  // (carved behind the last read-back, above)
         ptv2_inverse_job &J = jobs[cnt++];
         J.n = rows; J.k = k; J.idx = idx; J.inv_ptr = (int *)at(*inv_ptr); J.inv_rows = (int *)at(*inv_rows);
         if (cnt == PTV2_INVERSE_MAX_JOBS) return flush();

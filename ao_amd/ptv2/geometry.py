@@ -219,7 +219,8 @@ class _GeoLevel(ctypes.Structure):  # mirrors ptv2_geo_level
 class _SceneGeo(ctypes.Structure):  # mirrors ptv2_scene_geo
     _fields_ = [("num_stages", ctypes.c_int), ("b", ctypes.c_int), ("interp", ctypes.c_int), ("grid_size", ctypes.c_float * _MAX_STAGES),
                 ("coord0", ctypes.c_void_p), ("offset0", ctypes.c_void_p), ("knn0", ctypes.c_void_p * _GEO_MAX_K),
-                ("fwd_ready_event", ctypes.c_void_p), ("knn0_event", ctypes.c_void_p), ("level", _GeoLevel * (_MAX_STAGES + 1))]
+                ("fwd_ready_event", ctypes.c_void_p), ("knn0_event", ctypes.c_void_p), ("level", _GeoLevel * (_MAX_STAGES + 1)),
+                ("sizes_ready", ctypes.c_int), ("fwd_recorded", ctypes.c_int)]
 
 
 _lib.register({
@@ -237,77 +238,167 @@ def native_finish_supported(st):
             and os.environ.get("AO_AMD_GRIDPOOL", "hip") == "hip")
 
 
+class NativeGeometryJob:
+    """One ptv2_scene_geometry_hip_launcher call, split so that the native call itself can run on a helper thread: `prepare`
+    (struct, arena, workspace: on the thread and stream the tensors are to be allocated on), `run` (the ctypes call alone --
+    it releases the interpreter lock and blocks in the poolings' read-backs), `wait_sizes` / `wait_fwd_recorded` (another
+    thread polls the struct's progress flags), `geometry` (the RawSceneGeometry once the sizes are in)."""
+
+    def __init__(self, st, fwd_ready_event=None, knn0_event=None):
+        lv0 = st.cur
+        dev = lv0.coord.device
+        S = len(st.grid_sizes)
+        G = _SceneGeo()
+        G.num_stages, G.b, G.interp = S, lv0.offset.numel(), 1 if st.interp else 0
+        for i, g in enumerate(st.grid_sizes):
+            G.grid_size[i] = float(g)
+        G.coord0, G.offset0 = lv0.coord.data_ptr(), lv0.offset.data_ptr()
+        G.level[0].n = lv0.coord.shape[0]
+        for i, ks in enumerate(st.neighbours):
+            G.level[i].nk = len(ks)
+            for j, k in enumerate(ks):
+                G.level[i].knn[j].k = int(k)
+        for j, k in enumerate(st.neighbours[0]):
+            G.knn0[j] = lv0.knn[k].data_ptr()
+        G.fwd_ready_event = fwd_ready_event.cuda_event if fwd_ready_event is not None else None
+        G.knn0_event = knn0_event.cuda_event if knn0_event is not None else None
+        L = _lib.lib()
+        addr = ctypes.addressof(G)
+        self.st, self.G, self.lv0, self.L = st, G, lv0, L
+        self.arena = torch.empty(L.ptv2_scene_geometry_arena_bytes(addr), dtype=torch.uint8, device=dev)
+        self.ws = _lib.workspace(L.ptv2_scene_geometry_workspace_bytes(addr), dev)
+        self.stream = _lib.stream_ptr()
+        self.rc = None
+
+    def run(self):
+        G = self.G
+        self.rc = self.L.ptv2_scene_geometry_hip_launcher(ctypes.addressof(G), self.arena.data_ptr(), self.arena.numel(),
+                                                          self.ws.data_ptr(), self.ws.numel(), self.stream)
+        return self.rc
+
+    def check(self):
+        rc, G = self.rc, self.G
+        if rc == 1 and any(G.level[i + 1].n < 1 for i in range(G.num_stages)):
+            raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
+        _lib.check(rc, "ptv2_scene_geometry_hip_launcher")
+
+    def _poll(self, field, fut):
+        import time
+        G = self.G
+        while getattr(G, field) == 0:
+            if fut is not None and fut.done():
+                break
+            time.sleep(0)  # (hands the interpreter lock over; the helper thread is inside the native call almost all the time)
+        if getattr(G, field) != 1:
+            if fut is not None:
+                fut.result()
+            self.check()
+            raise RuntimeError("ptv2_scene_geometry_hip_launcher ended without reporting its sizes")
+
+    def wait_sizes(self, fut=None):
+        self._poll("sizes_ready", fut)
+
+    def wait_fwd_recorded(self, fut=None):
+        self._poll("fwd_recorded", fut)
+
+    def geometry(self):
+        return RawSceneGeometry(self.st, self.G, self.arena, self.lv0)
+
+
 @torch.no_grad()
 def finish_geometry_native(st, fwd_ready_event=None, knn0_event=None):
     """finish_geometry as one native call (ptv2_scene_geometry_hip_launcher): the same launchers in the same order, enqueued
-    from native code; the tables of levels 1.. are views of ONE arena tensor, carved as the poolings' sizes are read back.
+    from native code; the tables of levels 1.. live in ONE arena tensor, carved as the poolings' sizes are read back.
     Runs on the current stream (and synchronises it once per stage).  The events are torch.cuda.Event objects that have been
     recorded at least once (their handle exists): `fwd_ready_event` is recorded once everything the forward needs is enqueued,
     `knn0_event` is waited for in front of the inverse tables."""
-    from . import gva
+    job = NativeGeometryJob(st, fwd_ready_event, knn0_event)
+    job.run()
+    job.check()
+    return job.geometry()
 
-    geo, lv0 = st.geo, st.cur
-    dev = lv0.coord.device
-    S = len(st.grid_sizes)
-    G = _SceneGeo()
-    G.num_stages, G.b, G.interp = S, lv0.offset.numel(), 1 if st.interp else 0
-    for i, g in enumerate(st.grid_sizes):
-        G.grid_size[i] = float(g)
-    G.coord0, G.offset0 = lv0.coord.data_ptr(), lv0.offset.data_ptr()
-    G.level[0].n = lv0.coord.shape[0]
-    for i, ks in enumerate(st.neighbours):
-        G.level[i].nk = len(ks)
-        for j, k in enumerate(ks):
-            G.level[i].knn[j].k = int(k)
-    for j, k in enumerate(st.neighbours[0]):
-        G.knn0[j] = lv0.knn[k].data_ptr()
-    G.fwd_ready_event = fwd_ready_event.cuda_event if fwd_ready_event is not None else None
-    G.knn0_event = knn0_event.cuda_event if knn0_event is not None else None
-    L = _lib.lib()
-    addr = ctypes.addressof(G)
-    arena = torch.empty(L.ptv2_scene_geometry_arena_bytes(addr), dtype=torch.uint8, device=dev)
-    ws = _lib.workspace(L.ptv2_scene_geometry_workspace_bytes(addr), dev)
-    rc = L.ptv2_scene_geometry_hip_launcher(addr, arena.data_ptr(), arena.numel(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-    if rc == 1 and any(G.level[i + 1].n < 1 for i in range(S)):
-        raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
-    _lib.check(rc, "ptv2_scene_geometry_hip_launcher")
 
-    def view(off, dtype, *shape):
-        if off < 0:
-            return None
-        count = 1
-        for d in shape:
-            count *= d
-        nbytes = count * torch.empty((), dtype=dtype).element_size()
-        return arena[off:off + nbytes].view(dtype).view(*shape)
+class RawSceneGeometry(SceneGeometry):
+    """The result of ptv2_scene_geometry_hip_launcher: level 0's tensors, one arena tensor and the struct of byte offsets into
+    it.  The native model runtime takes sizes and addresses straight from here (native_model._Runtime.fill_geometry: no tensor
+    objects on the launching thread's critical path -- ~60 views cost 0.3 ms of host time per step); `levels`, the list of
+    Level objects every other consumer reads, is built on first use."""
 
-    def attach(idx, coord, T):
-        inv_ptr, inv_rows = view(T.inv_ptr, torch.int32, idx.shape[0] + 1), view(T.inv_rows, torch.int32, idx.numel())
-        idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
-        if T.mu >= 0:
-            idx._ao_pos_moments = ((coord.data_ptr(), idx._version), view(T.mu, torch.float64, 3), view(T.cov, torch.float64, 3, 3))
+    def __init__(self, st, G, arena, lv0):
+        self.G, self.arena, self.lv0 = G, arena, lv0
+        self.neighbours, self.interp = st.neighbours, st.interp
+        self.sizes = [G.level[i].n for i in range(G.num_stages + 1)]
+        self.base = arena.data_ptr()
+        self._levels = None
 
-    b = G.b
-    levels = [lv0]
-    for i in range(1, S + 1):
-        Li = G.level[i]
-        lv = Level(coord=view(Li.coord, torch.float32, Li.n, 3), offset=view(Li.offset, torch.int32, b))
-        for j, k in enumerate(st.neighbours[i]):
-            lv.knn[k] = view(Li.knn[j].idx, torch.int32, Li.n, k)
-            attach(lv.knn[k], lv.coord, Li.knn[j])
-        levels.append(lv)
-    for j, k in enumerate(st.neighbours[0]):
-        attach(lv0.knn[k], lv0.coord, G.level[0].knn[j])
-    for i in range(S):
-        Li, lv = G.level[i], levels[i]
-        n, m = Li.n, G.level[i + 1].n
-        lv.cluster, lv.order32 = view(Li.cluster, torch.int64, n), view(Li.order, torch.int32, n)
-        lv.idx_ptr32 = view(Li.idx_ptr, torch.int32, m + 1)
-        if st.interp:
-            lv.up_idx, lv.up_weight = view(Li.up_idx, torch.int32, n, 3), view(Li.up_w, torch.float32, n, 3)
-            lv.up_idx._ao_inverse = (lv.up_idx._version, view(Li.up_inv_ptr, torch.int32, n + 1), view(Li.up_inv_rows, torch.int32, 3 * n))
-    for lv in levels:
-        lv.grid = None
-    geo.levels = levels
-    geo.arena = arena  # (the views keep it alive as well)
-    return geo
+    def addr(self, off):
+        return self.base + off if off >= 0 else None
+
+    def table(self, level, k):
+        """(idx, mu, cov, inv_ptr, inv_rows) addresses of the level's K = k self table."""
+        j = self.neighbours[level].index(k)
+        T = self.G.level[level].knn[j]
+        if level == 0:
+            idx = self.lv0.knn[k]
+            _, mu, cov = idx._ao_pos_moments
+            return idx.data_ptr(), mu.data_ptr(), cov.data_ptr(), self.addr(T.inv_ptr), self.addr(T.inv_rows)
+        return self.addr(T.idx), self.addr(T.mu), self.addr(T.cov), self.addr(T.inv_ptr), self.addr(T.inv_rows)
+
+    def tensors(self):
+        """what has to stay alive (and be marked for the consuming stream) while kernels read the geometry"""
+        out = [self.arena, self.lv0.coord, self.lv0.offset]
+        for idx in self.lv0.knn.values():
+            out.append(idx)
+            out.extend(t for t in getattr(idx, "_ao_pos_moments", ())[1:] if torch.is_tensor(t))
+        return out
+
+    @property
+    def levels(self):
+        if self._levels is None:
+            self._levels = self._build_levels()
+        return self._levels
+
+    @levels.setter
+    def levels(self, value):  # (SceneGeometry's dataclass __init__ is not used; kept assignable)
+        self._levels = value
+
+    def _build_levels(self):
+        G, arena, lv0, S = self.G, self.arena, self.lv0, self.G.num_stages
+
+        def view(off, dtype, *shape):
+            if off < 0:
+                return None
+            count = 1
+            for d in shape:
+                count *= d
+            nbytes = count * torch.empty((), dtype=dtype).element_size()
+            return arena[off:off + nbytes].view(dtype).view(*shape)
+
+        def attach(idx, coord, T):
+            inv_ptr, inv_rows = view(T.inv_ptr, torch.int32, idx.shape[0] + 1), view(T.inv_rows, torch.int32, idx.numel())
+            idx._ao_inverse = (idx._version, inv_ptr, inv_rows)
+            if T.mu >= 0:
+                idx._ao_pos_moments = ((coord.data_ptr(), idx._version), view(T.mu, torch.float64, 3), view(T.cov, torch.float64, 3, 3))
+
+        b = G.b
+        levels = [lv0]
+        for i in range(1, S + 1):
+            Li = G.level[i]
+            lv = Level(coord=view(Li.coord, torch.float32, Li.n, 3), offset=view(Li.offset, torch.int32, b))
+            for j, k in enumerate(self.neighbours[i]):
+                lv.knn[k] = view(Li.knn[j].idx, torch.int32, Li.n, k)
+                attach(lv.knn[k], lv.coord, Li.knn[j])
+            levels.append(lv)
+        for j, k in enumerate(self.neighbours[0]):
+            attach(lv0.knn[k], lv0.coord, G.level[0].knn[j])
+        for i in range(S):
+            Li, lv = G.level[i], levels[i]
+            n, m = Li.n, G.level[i + 1].n
+            lv.cluster, lv.order32 = view(Li.cluster, torch.int64, n), view(Li.order, torch.int32, n)
+            lv.idx_ptr32 = view(Li.idx_ptr, torch.int32, m + 1)
+            if self.interp:
+                lv.up_idx, lv.up_weight = view(Li.up_idx, torch.int32, n, 3), view(Li.up_w, torch.float32, n, 3)
+                lv.up_idx._ao_inverse = (lv.up_idx._version, view(Li.up_inv_ptr, torch.int32, n + 1), view(Li.up_inv_rows, torch.int32, 3 * n))
+        for lv in levels:
+            lv.grid = None
+        return levels

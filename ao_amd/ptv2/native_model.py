@@ -203,15 +203,48 @@ class _Runtime:
         sq.idx, sq.mu, sq.cov, sq.inv_ptr, sq.inv_rows = idx.data_ptr(), mu.data_ptr(), cov.data_ptr(), None, None
         return [idx, mu, cov]
 
+    def geometry_worker(self, device):
+        """The helper thread the pipelined forward runs its native geometry call on (one per runtime; the call releases the
+        interpreter lock and spends most of its time blocked in the poolings' read-backs)."""
+        ex = self.__dict__.get("_geo_worker")
+        if ex is None or self.__dict__.get("_geo_worker_device") != device:
+            from concurrent.futures import ThreadPoolExecutor
+
+            ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ao_amd-geometry",
+                                    initializer=torch.cuda.set_device, initargs=(device,))
+            self.__dict__["_geo_worker"], self.__dict__["_geo_worker_device"] = ex, device
+        return ex
+
     def side_stream(self, device):
         """The stream the pipelined forward builds the deeper levels' geometry on (one per runtime and device)."""
         st = self.__dict__.get("_side")
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device)
+            st = torch.cuda.Stream(device, priority=-1 if os.environ.get("AO_AMD_SIDE_PRIORITY") == "high" else 0)
             self.__dict__["_side"] = st
         return st
 
+    def fill_geometry_raw(self, geo):
+        """fill_geometry from a geometry.RawSceneGeometry: sizes and addresses straight from the native call's struct."""
+        M, S, G = self.M, self.S, geo.G
+        lv0 = geo.lv0
+        for i in range(S + 1):
+            L, Gi = M.level[i], G.level[i]
+            L.n, L.b = Gi.n, G.b
+            if i == 0:
+                L.coord, L.offset = lv0.coord.data_ptr(), lv0.offset.data_ptr()
+            else:
+                L.coord, L.offset = geo.addr(Gi.coord), geo.addr(Gi.offset)
+            L.order, L.idx_ptr, L.cluster = geo.addr(Gi.order), geo.addr(Gi.idx_ptr), geo.addr(Gi.cluster)
+            L.up_idx, L.up_w = geo.addr(Gi.up_idx), geo.addr(Gi.up_w)
+            L.up_inv_ptr, L.up_inv_rows = geo.addr(Gi.up_inv_ptr), geo.addr(Gi.up_inv_rows)
+        for q in range(len(self.sequences)):
+            sq = M.seq[q]
+            sq.idx, sq.mu, sq.cov, sq.inv_ptr, sq.inv_rows = geo.table(sq.level, sq.k)
+        return geo.tensors()
+
     def fill_geometry(self, geo):
+        if hasattr(geo, "G"):
+            return self.fill_geometry_raw(geo)
         M, S = self.M, self.S
         for i, lv in enumerate(geo.levels):
             L = M.level[i]
@@ -244,7 +277,7 @@ class _Runtime:
         blocks skipped.  (The pipelined forward draws for seq 0 first and for the others once their levels' sizes are known.)"""
         if q_to is None:
             q_to = len(self.droppath) - 1
-        sizes = tuple(lv.coord.shape[0] for lv in geo.levels)
+        sizes = tuple(geo.sizes) if hasattr(geo, "sizes") else tuple(lv.coord.shape[0] for lv in geo.levels)
         key = (sizes[: 1 + max(self.M.seq[q].level for q in range(q_from, q_to + 1))], q_from, q_to)
         entry = self._keep_cache.get(key)
         if entry is None:
@@ -274,6 +307,35 @@ class _Runtime:
         base = scales.data_ptr()
         for nb, off, n in spans:
             self.M.block[nb].rowscale = base + 4 * off
+        return scales
+
+    def draw_droppath_bound(self, n0, device):
+        """draw_droppath for all blocks before the deeper levels' sizes are known: every dropping block gets n0 factors (its
+        level has at most n0 rows and reads the first n of them)."""
+        key = ("bound", n0)
+        entry = self._keep_cache.get(key)
+        if entry is None:
+            slots, probs = [], []
+            nb = 0
+            for rates in self.droppath:
+                for r in rates:
+                    if r > 0.0:
+                        slots.append(nb)
+                        probs.append(1.0 - r)
+                    nb += 1
+            keep = (torch.tensor(probs, dtype=torch.float32, device=device).repeat_interleave(n0) if probs else None)
+            entry = (slots, keep)
+            self._keep_cache = {k: v for k, v in self._keep_cache.items() if k[0] != "bound"}
+            self._keep_cache[key] = entry
+        slots, keep = entry
+        for mb in self.M.block[: self.M.num_blocks]:
+            mb.rowscale = None
+        if keep is None:
+            return None
+        scales = torch.bernoulli(keep).div_(keep)
+        base = scales.data_ptr()
+        for slot, nb in enumerate(slots):
+            self.M.block[nb].rowscale = base + 4 * slot * n0
         return scales
 
     def grad_buffer(self, device, fresh):
@@ -336,6 +398,8 @@ def supported(model, feat):
 
 def geometry_supported(geo):
     """every level needs >= 2 rows (training-mode BatchNorm, ptv2_block args_ok): tiny clouds take the python path"""
+    if hasattr(geo, "sizes"):
+        return all(n >= 2 for n in geo.sizes)
     return all(int(lv.coord.shape[0]) >= 2 for lv in geo.levels)
 
 
@@ -370,7 +434,7 @@ class _NativeModel(torch.autograd.Function):
         n0 = feat.shape[0]
         M.feat, M.logits = feat.data_ptr(), None
         M.saved, M.saved_bytes, M.saved0, M.saved0_bytes = None, 0, None, 0
-        saved0, scales0, ev_all = None, None, None
+        saved0, scales0, ev_all, fut, job = None, None, None, None, None
         if isinstance(geo, _Pipelined):
             # The geometry is built HERE, pipelined with the network (no prefetcher thread, no `geometry=` batch key: the
             # reference trainer's `model(input_dict)`, pointcept/engines/train_sam_pp2s.py:181).  Only the grid poolings have
@@ -379,7 +443,7 @@ class _NativeModel(torch.autograd.Function):
             # caller's stream; the poolings, the deeper levels' tables and the inverse tables follow on a side stream, where
             # their read-backs wait for the geometry kernels only -- the host blocks there while the GPU is busy with the
             # prefix; then the rest of the network is enqueued behind an event.
-            from .geometry import begin_geometry, finish_geometry, finish_geometry_native, native_finish_supported
+            from .geometry import NativeGeometryJob, begin_geometry, finish_geometry, native_finish_supported
             req, model = geo, geo.model
             main = torch.cuda.current_stream(dev)
             side = rt.side_stream(dev)
@@ -390,8 +454,25 @@ class _NativeModel(torch.autograd.Function):
             ev_l0 = torch.cuda.Event()
             ev_l0.record(main)  # the level-0 tables exist (the inverse tables on the side stream read them)
             lv0 = st.geo.levels[0]
+            ev_fwd, ev_all = torch.cuda.Event(), torch.cuda.Event()
+            native = native_finish_supported(st)
+            for t in (lv0.coord, lv0.offset, *lv0.knn.values()):  # made on the caller's stream, read on the side stream
+                t.record_stream(side)
+            if native:
+                # one native call for everything behind the first pooling (csrc/scene.hip), on a helper thread of the runtime: it
+                # blocks in the poolings' read-backs while THIS thread captures and launches the prefix; the struct's progress
+                # flags tell this thread when the sizes are in
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_in)
+                    ev_fwd.record(side)  # (creates the handle the launcher re-records)
+                    job = NativeGeometryJob(st, fwd_ready_event=ev_fwd, knn0_event=ev_l0)
+                fut = rt.geometry_worker(dev).submit(job.run)
             keep0 = rt.fill_prefix(lv0)
-            scales0 = rt.draw_droppath(st.geo, dev, 0, 0) if training else None
+            for t in keep0:
+                t.record_stream(side)
+            # DropPath factors of EVERY block in one draw, now: rows sized by level 0 (no level has more), so that no random-number
+            # launch sits between the geometry's last read-back and the rest of the network
+            scales0 = rt.draw_droppath_bound(lv0.coord.shape[0], dev) if training else None
             need0 = L.ptv2_model_prefix_saved_bytes(ctypes.addressof(M))
             if need0 == 0:
                 raise RuntimeError("ao_amd: ptv2_model prefix rejected by the native runtime")
@@ -400,30 +481,23 @@ class _NativeModel(torch.autograd.Function):
             ws = _lib.workspace(L.ptv2_model_prefix_workspace_bytes(ctypes.addressof(M)), dev)
             rc = L.ptv2_model_forward_prefix_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "ptv2_model_forward_prefix_hip_launcher")
-            ev_fwd, ev_all = torch.cuda.Event(), torch.cuda.Event()
+            if native:
+                job.wait_sizes(fut)          # the last read-back is in: every size and address is final
+                geo = job.geometry()
+            else:
+                def before_inverse():
+                    ev_fwd.record(side)      # everything the forward's rest needs is enqueued
+                    side.wait_event(ev_l0)
 
-            def before_inverse():
-                ev_fwd.record(side)      # everything the forward's rest needs is enqueued
-                side.wait_event(ev_l0)
-
-            for t in (lv0.coord, lv0.offset, *lv0.knn.values(), *keep0):  # made on the caller's stream, read on the side stream
-                t.record_stream(side)
-            with torch.cuda.stream(side):
-                side.wait_event(ev_in)
-                if native_finish_supported(st):  # one native call (csrc/scene.hip): ~0.3 ms of host time instead of ~2
-                    ev_fwd.record(side)  # (creates the handle the launcher re-records)
-                    geo = finish_geometry_native(st, fwd_ready_event=ev_fwd, knn0_event=ev_l0)
-                else:
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_in)
                     geo = finish_geometry(st, before_inverse=before_inverse)
-                ev_all.record(side)
-            main.wait_event(ev_fwd)
-            for t in _side_tensors(geo):  # allocated on the side stream, consumed on the caller's
-                t.record_stream(main)
+                    ev_all.record(side)
             if not geometry_supported(geo):
                 raise RuntimeError("ao_amd: a level of this batch has fewer than 2 points; training-mode BatchNorm needs 2 "
                                    "(the reference's nn.BatchNorm1d raises here as well)")
             keep = rt.fill_geometry(geo)
-            scales = rt.draw_droppath(geo, dev, 1) if (training and len(rt.droppath) > 1) else None
+            scales = None
         else:
             keep = rt.fill_geometry(geo)
             scales = rt.draw_droppath(geo, dev) if training else None
@@ -436,8 +510,17 @@ class _NativeModel(torch.autograd.Function):
         M.saved, M.saved_bytes = saved.data_ptr(), saved.numel()
         ws = _lib.workspace(L.ptv2_model_workspace_bytes(ctypes.addressof(M)), dev)
         if saved0 is not None:
+            if fut is not None:
+                job.wait_fwd_recorded(fut)   # (the deeper levels' tables are enqueued, the event re-recorded: usually long since)
+            main.wait_event(ev_fwd)
+            for t in _side_tensors(geo):  # allocated on the side stream, consumed on the caller's
+                t.record_stream(main)
             rc = L.ptv2_model_forward_rest_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "ptv2_model_forward_rest_hip_launcher")
+            if fut is not None:  # the helper thread's call has enqueued the inverse tables by now (the backward waits for them)
+                fut.result()
+                job.check()
+                ev_all.record(side)
         else:
             rc = L.ptv2_model_forward_hip_launcher(ctypes.addressof(M), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
             _lib.check(rc, "ptv2_model_forward_hip_launcher")

@@ -132,6 +132,9 @@ def timed_steps(step_fn, steps, device, points_this_rank, finish=None):
 
 
 def _geometry_tensors(geo):
+    if hasattr(geo, "tensors"):  # geometry.RawSceneGeometry: one arena + level 0's tensors
+        yield from geo.tensors()
+        return
     for lv in geo.levels:
         for v in vars(lv).values():
             if torch.is_tensor(v):

@@ -672,6 +672,7 @@ int ptv2_model_backward_hip_launcher(const ptv2_model *m, const float *g_logits,
  *        coord (n,3) f32, offset (b) i32, knn[j].idx (n,k) i32, .mu (3) f64, .cov (9) f64, .inv_ptr (n+1) i32, .inv_rows (n k) i32,
  *        cluster (n) i64, order (n) i32, idx_ptr (n_next + 1) i32, up_idx (n,3) i32, up_w (n,3) f32, up_inv_ptr (n_next + 1),
  *        up_inv_rows (3 n); -1: not produced
+ *   sizes_ready / fwd_recorded: progress flags for a caller that runs this call on a helper thread (see the struct).
  *   fwd_ready_event (hipEvent_t, optional): recorded on `stream` once everything the FORWARD needs is enqueued (the inverse
  *        tables, which only the backward reads, follow); knn0_event (optional): `stream` waits for it in front of the inverse
  *        tables (the caller built knn0 on another stream).
@@ -695,6 +696,10 @@ typedef struct ptv2_scene_geo {
     const int *knn0[PTV2_GEO_MAX_K];
     void *fwd_ready_event, *knn0_event;
     ptv2_geo_level level[PTV2_MAX_STAGES + 1];
+    /* progress, written by the call for a second host thread that polls the struct while the call is still enqueueing:
+     * sizes_ready = 1 once the last read-back is in and EVERY n and offset of the struct is final (-1: the call failed);
+     * fwd_recorded = 1 once fwd_ready_event has been recorded */
+    volatile int sizes_ready, fwd_recorded;
 } ptv2_scene_geo;
 size_t ptv2_scene_geometry_arena_bytes(const ptv2_scene_geo *g);      /* upper bound, from level[0].n */
 size_t ptv2_scene_geometry_workspace_bytes(const ptv2_scene_geo *g);

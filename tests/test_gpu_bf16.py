@@ -111,14 +111,20 @@ def test_model_under_autocast_tracks_the_fp32_path(tag, points):
     cos = float(fa @ fb / (fa.norm() * fb.norm()))
     print("%s: logits rel L2 %.2e, loss %.5f vs %.5f, gradient cosine %.5f, weight-matrix gradients rel L2 median %.2e worst %.2e (%s)"
           % (tag, r, loss_b, loss_f, cos, median, *worst))
-    # differs from fp32 (bf16 products really ran) and stays within the budget: measured 2-4e-2 (S3DIS cfg), 5.7-6.1e-2
-    # (ScanNet cfg at 8 000 points, whose deepest levels hold a handful of points); torch.autocast on the CPU oracle: 7.7e-2
-    assert 1e-5 < r < 8e-2
+    # differs from fp32 (bf16 products really ran) and stays within what this build shows (round 5, both sizes of each cfg):
+    #   S3DIS cfg   logits 3.9-4.2e-2, gradient cosine 0.969-0.977, weight-matrix gradients median 0.22-0.25 / worst 0.32-0.38
+    #   ScanNet cfg logits 5.9-6.8e-2, gradient cosine 0.928-0.938, median 0.35-0.39 / worst 0.50-0.52 (its deepest levels hold
+    #               a handful of points)
+    # bounds: S3DIS cfg twice the observed deviation for the logits and 1 - cosine, 1.3 x for the per-matrix figures; ScanNet cfg
+    # 1.2-1.5 x (its observed figures leave no room for a factor of two below "unrelated") (the old
+    # `worst < 0.65` for both would have passed a badly broken layer of the S3DIS cfg; what pins a product is the operand-level
+    # test above, 2e-6).  Context: torch.autocast(bfloat16) itself on the CPU oracle of this network (6 000 points, same seed)
+    # deviates from its fp32 run by MORE -- logits 7.7e-2, cosine 0.87, matrices 0.49 median / 0.64 worst -- because it also
+    # stores every Linear output in bf16.
+    lim = dict(s3dis=dict(r=8.4e-2, cos=0.938, median=0.33, worst=0.50), scannet=dict(r=1.0e-1, cos=0.90, median=0.45, worst=0.65))[tag]
+    assert 1e-5 < r < lim["r"], r
     assert abs(loss_b - loss_f) < 2e-2
-    # context: torch.autocast(bfloat16) itself on the CPU oracle of this network (6 000 points, same seed) deviates from
-    # its fp32 run by MORE -- logits 7.7e-2, gradient cosine 0.87, weight matrices 0.49 median / 0.64 worst (random labels
-    # at random init: a small, noisy gradient) -- because it also stores every Linear output in bf16
-    assert cos > 0.9 and median < 0.45 and worst[0] < 0.65, (cos, median, worst)
+    assert cos > lim["cos"] and median < lim["median"] and worst[0] < lim["worst"], (cos, median, worst)
 
 
 def test_training_under_autocast_learns():
