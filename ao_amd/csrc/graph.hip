@@ -88,6 +88,9 @@ std::unordered_map<StreamKey, hipStream_t, StreamKeyHash> g_capture_streams;  //
 
 std::mutex g_mu;
 std::unordered_map<SlotKey, Slot, SlotKeyHash> g_slots;
+// the fence event of the most recent graph launched on a caller stream (owned by its ring entry): completed = that stream has
+// run dry of this library's graphs, i.e. the host is NOT ahead of the GPU (a training loop that synchronises every step)
+std::unordered_map<StreamKey, hipEvent_t, StreamKeyHash> g_last_done;
 std::atomic<int> g_mode{-1};  // -1: read AO_AMD_GRAPH on first use; 0 off; 1 on
 thread_local int g_inside = 0;  // this thread's launches are being captured (the kernel timer stamps instead of recording events)
 
@@ -169,6 +172,7 @@ extern "C" int ptv2_graph_reset(void) {
             if (e.done) (void)hipEventDestroy(e.done);
         }
     g_slots.clear();
+    g_last_done.clear();
     for (auto &kv : g_capture_streams) (void)hipStreamDestroy(kv.second);
     g_capture_streams.clear();
     return PTV2_OK;
@@ -186,6 +190,23 @@ PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow)
     }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { g_stats.declined++; return; }
+    if (which == GRAPH_MODEL_FWD_PREFIX) {
+        // The first launches of a step behind an idle GPU: capturing, updating and launching the prefix's graph keeps the GPU
+        // waiting for ~0.3 ms of host work; issued eagerly its first kernel starts microseconds after the call (a loop that
+        // reads the loss back every iteration -- pointcept's InformationWriter -- pays that at every step).  Same kernels,
+        // same arguments, same order either way.  AO_AMD_GRAPH_IDLE_EAGER=0: always the graph.
+        const char *e = getenv("AO_AMD_GRAPH_IDLE_EAGER");
+        if (!(e && e[0] == '0')) {
+            hipEvent_t last = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_mu);
+                auto it = g_last_done.find(StreamKey{device, s});
+                if (it != g_last_done.end()) last = it->second;
+            }
+            if (last && hipEventQuery(last) == hipSuccess) return;  // (not counted as declined: a choice, not a refusal)
+            (void)hipGetLastError();
+        }
+    }
     hipStream_t c = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -286,7 +307,11 @@ int PtvGraphScope::finish(int rc) {
         g_stats.update_ns += t2 - t1b;
         if (out == PTV2_OK) {
             if (hipGraphLaunch(slot.exec, s) != hipSuccess) { (void)hipGetLastError(); out = PTV2_ERR_LAUNCH; }
-            else if (slot.done && hipEventRecord(slot.done, s) == hipSuccess) slot.in_flight = true;
+            else if (slot.done && hipEventRecord(slot.done, s) == hipSuccess) {
+                slot.in_flight = true;
+                std::lock_guard<std::mutex> lk(g_mu);
+                g_last_done[StreamKey{device, s}] = slot.done;
+            }
             else if (hipStreamSynchronize(s) != hipSuccess) out = PTV2_ERR_LAUNCH;  // no fence: wait here instead
             g_stats.launch_ns += now_ns() - t2;
             g_stats.nodes += (long long)nodes;

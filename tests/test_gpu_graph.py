@@ -41,8 +41,11 @@ def _run(model, scenes):
 
 
 @pytest.fixture
-def graph_mode():
+def graph_mode(monkeypatch):
     from ao_amd import _lib
+
+    # (the counts below expect every forward prefix as a graph; by default it is issued eagerly when the stream has run dry)
+    monkeypatch.setenv("AO_AMD_GRAPH_IDLE_EAGER", "0")
 
     L = _lib.lib()
     prev = L.ptv2_graph_mode(-1)
