@@ -774,6 +774,12 @@ def child_main(args):
                                                              "backward)" if (sync is not None and sync.split is not None)
                                                             else "flat all-reduce"),
                        "optimizer": "FlatAdamW (one kernel)" if flat_opt else "torch.optim.AdamW(fused)",
+                       # what this line's loop uses that the reference trainer's own loop does not (INTEGRATION.md section 3b':
+                       # optional accelerations; `reference_loop` below is the number without any of them)
+                       "trainer_side": ([] if prefetch is None else ["GeometryPrefetcher (%s): the next batch's geometry on a side stream, "
+                                                                      "handed over as batch['geometry']" % pf_mode])
+                                       + (["FlatAdamW", "native_param_grads=%s" % seg.backbone.native_param_grads] if flat_opt else [])
+                                       + (["FlatGradSync (one flat all-reduce)"] if sync is not None else []),
                        "segmentor": "DefaultSegmentorSAM_Image + LogitBasket (%d puts, %d waits for a staging slot)"
                                     % (basket.puts, basket.waits) if basket is not None else "DefaultSegmentor",
                        "loss": float(loss.detach()), "library_build": "src " + str(src_hash(build_info))},
