@@ -4,7 +4,7 @@
 // (libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104) with
 //
 //   1. a per-call uniform grid over each batch segment of xyz (counting sort by cell:
-//      bbox -> grid setup -> count+rank -> 2-launch exclusive scan -> scatter),
+//      bbox -> grid set-up + count + rank (one launch) -> one chained exclusive scan -> scatter),
 //      everything on device, no host sync;
 //   2. a grid query: one lane per query, neighbour cells visited in Chebyshev rings,
 //      candidates read as float4 (x,y,z,id) from the cell-sorted copy, the KC = k+1
@@ -141,12 +141,16 @@ __global__ __launch_bounds__(256) void knn_bbox_kernel(int n, const float *__res
     }
 }
 
-// One thread per segment: choose the cell size so that cells <= points (then the cell tables
-// of all segments fit CELLS_PER_POINT * n + b + 1 entries and segment s owns [CELLS_PER_POINT * start_s + s, ...)).
-__global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, const int *bbox_lo,
-                                      const int *bbox_hi, SegGrid *seg, float occupancy) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= b) return;
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h, int g) {
+    float c = floorf((v - lo) * inv_h);
+    c = fminf(fmaxf(c, 0.f), (float)(g - 1));
+    return (int)c;
+}
+
+// The grid of one segment: the cell size is chosen so that cells <= CELLS_PER_POINT * points (then the cell tables of all
+// segments fit CELLS_PER_POINT * n + b + 1 entries and segment s owns [CELLS_PER_POINT * start_s + s, ...)).
+__device__ __forceinline__ SegGrid seg_grid_of(int s, const int *__restrict__ offset, const int *bbox_lo, const int *bbox_hi,
+                                               float occupancy) {
     int start = s == 0 ? 0 : offset[s - 1];
     int cnt = offset[s] - start;
     SegGrid g;
@@ -184,24 +188,38 @@ __global__ void knn_grid_setup_kernel(int b, const int *__restrict__ offset, con
         g.inv_h = 1.f / h;
         g.minx = lo[0]; g.miny = lo[1]; g.minz = lo[2];
     }
-    seg[s] = g;
+    return g;
 }
 
-__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h, int g) {
-    float c = floorf((v - lo) * inv_h);
-    c = fminf(fmaxf(c, 0.f), (float)(g - 1));
-    return (int)c;
-}
-
+// Grid set-up + count in one launch (round 5: the set-up was a one-thread-per-segment launch of its own, 5 us of boundary in
+// front of this one).  The bounding boxes are final when this kernel starts; a workgroup derives the grids of the segments
+// ITS 256 points lie in (one thread per segment: usually one or two) into LDS, every thread then bins its point.  The grid a
+// segment's queries read later (seg[s]) is stored by the workgroup that holds the segment's first point; workgroup 0 stores
+// the grids of the empty segments (a cross query may still name them).
+constexpr int COUNT_SEGS = 64;  // segments of one workgroup's points held in LDS; more (clouds of < 4 points) fall back to global
 __global__ __launch_bounds__(256) void knn_cell_count_kernel(int n, const float *__restrict__ xyz,
                                                              const int *__restrict__ offset, int b,
-                                                             const SegGrid *__restrict__ seg,
-                                                             int *cell_count, int *point_cell,
+                                                             const int *bbox_lo, const int *bbox_hi, float occupancy,
+                                                             SegGrid *seg, int *cell_count, int *point_cell,
                                                              int *point_rank) {
-    int t = blockIdx.x * 256 + threadIdx.x;
+    __shared__ SegGrid s_grid[COUNT_SEGS];
+    const int first = blockIdx.x * 256, last = min(first + 255, n - 1);
+    const int s0 = seg_of(first, offset, b), s1 = seg_of(last, offset, b);
+    for (int s = s0 + (int)threadIdx.x; s <= s1; s += 256) {
+        const SegGrid g = seg_grid_of(s, offset, bbox_lo, bbox_hi, occupancy);
+        if (s - s0 < COUNT_SEGS) s_grid[s - s0] = g;
+        if (g.n_pts > 0 && g.start >= first) seg[s] = g;  // (exactly one workgroup holds a non-empty segment's first point)
+    }
+    if (blockIdx.x == 0)  // the empty segments hold no point: workgroup 0 stores their (trivial) grids
+        for (int s = (int)threadIdx.x; s < b; s += 256) {
+            const int start = s == 0 ? 0 : offset[s - 1];
+            if (offset[s] - start <= 0) seg[s] = seg_grid_of(s, offset, bbox_lo, bbox_hi, occupancy);
+        }
+    __syncthreads();
+    int t = first + threadIdx.x;
     if (t >= n) return;
     int s = seg_of(t, offset, b);
-    SegGrid g = seg[s];
+    const SegGrid g = (s - s0 < COUNT_SEGS) ? s_grid[s - s0] : seg_grid_of(s, offset, bbox_lo, bbox_hi, occupancy);
     int cx = cell_coord(xyz[3 * t], g.minx, g.inv_h, g.gx);
     int cy = cell_coord(xyz[3 * t + 1], g.miny, g.inv_h, g.gy);
     int cz = cell_coord(xyz[3 * t + 2], g.minz, g.inv_h, g.gz);
@@ -971,10 +989,8 @@ extern "C" int knn_query_grid_hip_launcher(int m, int nsample, const float *xyz,
     // target points per cell of the bounding volume (surface clouds fill a fraction of their cells: several times as many per
     // occupied one).  Swept at 120 k points with the 16-lane query: 2.0 -> 86 us, 1.0 -> 73, 0.5 -> 73, 0.25 -> 78 (k = 16)
     static const float occupancy = [] { const char *e = getenv("AO_AMD_KNN_OCC"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : 0.7f; }();
-    hipLaunchKernelGGL(knn_grid_setup_kernel, dim3(divup(b, 64)), dim3(64), 0, st, b, offset, w.bbox_lo, w.bbox_hi,
-                       w.seg, occupancy);
-    hipLaunchKernelGGL(knn_cell_count_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, w.seg,
-                       w.cell_count, w.point_cell, w.point_rank);
+    hipLaunchKernelGGL(knn_cell_count_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, offset, b, (const int *)w.bbox_lo,
+                       (const int *)w.bbox_hi, occupancy, w.seg, w.cell_count, w.point_cell, w.point_rank);
     hipLaunchKernelGGL(knn_scan_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, st, (const int *)w.cell_count, w.block_sums,
                        w.cell_start, ntiles);
     hipLaunchKernelGGL(knn_scatter_kernel, dim3(divup(n, 256)), dim3(256), 0, st, n, xyz, w.cell_start, w.point_cell,

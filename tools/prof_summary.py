@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 --kernel-trace --stats run: tools/prof_summary.py <dir> [steps] [top]"""
 import csv, glob, sys
 d = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1; top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-f = glob.glob(d + '/*/*_kernel_stats.csv')[0]
+f = (glob.glob(d + '/*/*_kernel_stats.csv') + glob.glob(d + '/*_kernel_stats.csv') + glob.glob(d + '/**/*_kernel_stats.csv', recursive=True))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print("kernel time total %.2f ms, per step %.2f ms over %d steps; %d distinct kernels, %d launches/step" % (
