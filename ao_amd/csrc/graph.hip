@@ -268,7 +268,9 @@ int PtvGraphScope::finish(int rc) {
     }
     {
         Exec &slot = *slot_p;
-        if (!slot.done && hipEventCreateWithFlags(&slot.done, hipEventDisableTiming) != hipSuccess) slot.done = nullptr;
+        // (blocking: the wait for a ring entry -- the host eight steps ahead of the GPU -- sleeps instead of spinning; eight
+        // ranks of a node share one CPU quota, and a spinning launching thread was a whole CPU per rank)
+        if (!slot.done && hipEventCreateWithFlags(&slot.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) slot.done = nullptr;
         if (slot.in_flight && slot.done) {
             const long long w0 = now_ns();
             (void)hipEventSynchronize(slot.done);  // (the host is RING steps ahead of the GPU)

@@ -25,6 +25,8 @@ python tools/trace_grids.py "$O/trace" 25 > "$O/trace_grids.txt" 2>&1
 python tools/trace_step.py "$O/trace" 12 > "$O/step_sequence.txt" 2>&1
 # one S2 Block's backward (192 channels): the launches around the 4th-from-last attention_bwd_point_kernel<24, 192, 2> of a step
 python tools/trace_block.py "$O/trace" "attention_bwd_point_kernel<24, 192, 2" 60 7 12 > "$O/blockS2.txt" 2>&1
+# one S3 Block's forward (384 channels, ~1 074 points): the launches around a mid-run logits_fwd_mfma_kernel<48, 384, 4>
+python tools/trace_block.py "$O/trace" "logits_fwd_mfma_kernel<48, 384, 4" 30 5 8 > "$O/blockS3_fwd.txt" 2>&1
 rm -rf "$O/trace"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f" -- $B --steps 5 --warmup 2 > "$O/pmc_f.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w" -- $B --steps 5 --warmup 2 > "$O/pmc_w.log" 2>&1
@@ -38,14 +40,16 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python tools/pmc_sq.py "$O/pmc_sq" > "$O/sq_counters.jsonl" 2> "$O/sq.err"
 rm -rf "$O/pmc_sq"
 # the bench line takes roofline.traffic from the PMC profile of THIS build under profiles/ (matched by source digest)
-cp "$O/pmc_traffic_per_launch.jsonl" profiles/${ROUND:-r03}_final_pmc_traffic_per_launch.jsonl
+cp "$O/pmc_traffic_per_launch.jsonl" profiles/${ROUND:-r05}_final_pmc_traffic_per_launch.jsonl
 python bench.py --steps 30 --warmup 5 > "$O/bench_fp32.json" 2> "$O/bench_fp32.err"
 python bench.py --steps 30 --warmup 5 --dtype bf16 --no-cpu-baseline --no-ops > "$O/bench_bf16.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 --cfg scannet --scenes 2 --points 100000 --no-cpu-baseline --no-ops > "$O/bench_scannet.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 --cfg scannet --scenes 2 --points 100000 --dtype bf16 --no-cpu-baseline --no-ops > "$O/bench_scannet_bf16.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 --segmentor sam_image --no-cpu-baseline --no-ops > "$O/bench_sam.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 --scenes 4 --points 80000 --no-cpu-baseline --no-ops > "$O/bench_4x80k.json" 2>/dev/null
-for f in fp32 bf16 scannet scannet_bf16 sam 4x80k; do python - "$O/bench_$f.json" "$f" <<'PY'
+# the same loop without the prefetcher: the forward builds its own geometry, pipelined with the level-0 prefix
+AO_AMD_PREFETCH=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-ops > "$O/bench_fp32_no_prefetcher.json" 2>/dev/null
+for f in fp32 fp32_no_prefetcher bf16 scannet scannet_bf16 sam 4x80k; do python - "$O/bench_$f.json" "$f" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read()); print(sys.argv[2], d["ms_per_step"], d["value"])
