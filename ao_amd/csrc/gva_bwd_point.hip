@@ -57,6 +57,27 @@ __host__ __device__ constexpr int ww_pitch(int G) {  // >= G, = 4 mod 16: the 4 
     return p;
 }
 
+// Which group a register of a (g, s) tile holds.  An MFMA result tile leaves row 4 q + r in register r of lane quarter q, and
+// that register is the contraction step r of the next product.  With group = row, G = 6 occupies quarter 0 fully and half
+// of quarter 1: all four registers are live in every lane, three quarters of the lanes compute padding, and every
+// contraction over the groups is four matrix instructions.  With the groups dealt round-robin over the quarters instead
+// (row 4 q + r holds group q + 4 r) G <= 8 needs registers 0..1 only (G <= 12: 0..2): the softmax and its backward -- DPP
+// ladders per register -- and every product that contracts over the groups do half the work.  The kernel works on row
+// numbers ("virtual" groups) throughout; the parameter tables in LDS are laid out by row, and gof / vof translate where a
+// row number meets global memory (W1, gW1, g_A, g_sw rows, the parameter-gradient records).
+#ifndef GVA_BWD_PERM
+#define GVA_BWD_PERM 1
+#endif
+template <int G>
+struct GroupRows {
+    static constexpr bool PERM = GVA_BWD_PERM && G <= 12;
+    static constexpr int RN = PERM ? (G + 3) / 4 : 4;  // registers of a quarter that can hold a group
+    __host__ __device__ static constexpr int gof(int v) {  // row -> group, -1 for padding
+        return PERM ? (((v & 3) < RN && v < 16 && (v >> 2) + 4 * (v & 3) < G) ? (v >> 2) + 4 * (v & 3) : -1) : (v < G ? v : -1);
+    }
+    __host__ __device__ static constexpr int vof(int g) { return PERM ? 4 * (g & 3) + (g >> 2) : g; }  // group -> row
+};
+
 template <int G, int C, int NW>
 struct BwdPointCfg {
     static constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = ww_pitch(G), PW = 4 / NW, CW = C / NW, CS = CW / 4,
@@ -90,6 +111,9 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     static_assert(!LOCAL || NW == 1, "the local form needs the point's g_out row in one wavefront");
     constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PW = K::PW, CW = K::CW, CS = K::CS, UT = K::UT, I = K::I,
                   PF = K::PF, LT = K::LT, NTW = K::NTW;
+    using GR = GroupRows<G>;
+    constexpr int RN = GR::RN;
+    static_assert(!GR::PERM || GT == 1, "the dealt layout is for one-tile group counts");
     extern __shared__ float4 lds4[];
     float4 *sAB = lds4;                                   // [C]  (a.xyz, b)
     float *sWw = (float *)(sAB + C);                      // [G16][GPW]  Ww2, zero padded
@@ -113,16 +137,21 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     const int c0 = sub * CW;
 
     for (int ch = tid; ch < C; ch += 256) sAB[ch] = make_float4(a[3 * ch], a[3 * ch + 1], a[3 * ch + 2], b[ch]);
-    for (int e = tid; e < G16 * GPW; e += 256) {
-        const int g = e / GPW, j = e - g * GPW;
-        sWw[e] = (g < G && j < G) ? Ww2[g * G + j] : 0.f;
+    for (int e = tid; e < G16 * GPW; e += 256) {  // (by row: see GroupRows)
+        const int gv = e / GPW, jv = e - gv * GPW;
+        const int g = GR::gof(gv), j = jv < G16 ? GR::gof(jv) : -1;
+        sWw[e] = (g >= 0 && j >= 0) ? Ww2[g * G + j] : 0.f;
     }
-    for (int g = tid; g < G16; g += 256) {
-        sBw[g] = g < G ? bw2[g] : 0.f;
-        sSc[g] = g < G ? sc[g] : 0.f;
-        sSh[g] = g < G ? sh[g] : 0.f;
+    for (int gv = tid; gv < G16; gv += 256) {
+        const int g = GR::gof(gv);
+        sBw[gv] = g >= 0 ? bw2[g] : 0.f;
+        sSc[gv] = g >= 0 ? sc[g] : 0.f;
+        sSh[gv] = g >= 0 ? sh[g] : 0.f;
     }
     for (int e = tid; e < PF; e += 256) sFin[e] = 0.f;
+    if (GR::PERM) {  // the rows no register writes are operands of the last product all the same
+        for (int e = tid; e < 2 * PW * G16 * 17; e += 256) sGz[e] = 0.f;
+    }
     if (local) {
         for (int e = tid; e < C * C; e += 256) sWp2[e] = Wp2[e];
         for (int e = tid; e < C; e += 256) sWp2[C * C + e] = bp2[e];
@@ -163,7 +192,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     struct Stage { float sx, sy, sz, px, py, pz; int src; float go[GOV]; float gsw; };  // raw; masked by stage_store
     const long long lastp = (long long)n - 1;
     const int lk = l15 < k ? l15 : 0;
-    const int lg = lane % G16 < G ? lane % G16 : 0;
+    const int lgv = GR::gof(lane % G16), lg = lgv >= 0 ? lgv : 0;
     const float *gswp = g_sw ? g_sw : g_out;  // (a valid address either way)
     const float *zpad = ptv2_zero_pad;  // (common.h)
     auto load_ids = [&](long long ptn) -> int { return idx[(ptn < n ? ptn : lastp) * k + lk]; };  // (raw: slot l15 < k ? l15 : 0)
@@ -185,7 +214,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         sSrc[(buf * PW + p) * 16 + l15] = mysrc;
 #pragma unroll
         for (int i = 0; i < GOV; ++i) sGo[(buf * PW + p) * C + (lane + WAVE * i) % C] = actn ? S.go[i] : 0.f;
-        sGsw[(buf * PW + p) * G16 + lane % G16] = (actn && g_sw && lane % G16 < G) ? S.gsw : 0.f;
+        sGsw[(buf * PW + p) * G16 + lane % G16] = (actn && g_sw && lgv >= 0) ? S.gsw : 0.f;
     };
     auto load_w1 = [&](long long ptn, float (&u)[GT][4]) {
         const long long pn = ptn < n ? ptn : lastp;
@@ -193,7 +222,13 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int t = 0; t < GT; ++t) {
             const int j0 = 16 * t + 4 * q;
-            if (G % 4 == 0) {
+            if (GR::PERM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = GR::gof(j0 + r);
+                    u[t][r] = r < RN ? row[j >= 0 ? j : 0] : 0.f;
+                }
+            } else if (G % 4 == 0) {
                 const float4 uu = *(const float4 *)(row + (j0 < G ? j0 : 0));
                 u[t][0] = uu.x; u[t][1] = uu.y; u[t][2] = uu.z; u[t][3] = uu.w;
             } else {
@@ -220,7 +255,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int ci = 0; ci < PD; ++ci) rvvn[ci] = *(const float4 *)(vr + 16 * ci);
         if constexpr (!LOCAL) {
-            const float *gr = (actn && l15 < G) ? g_A + ((ptn * G + l15) * C + chq) : zpad;
+            const float *gr = (actn && GR::gof(l15) >= 0) ? g_A + ((ptn * G + GR::gof(l15)) * C + chq) : zpad;
 #pragma unroll
             for (int ci = 0; ci < PD; ++ci) rgan[ci] = *(const float4 *)(gr + 16 * ci);
         }
@@ -286,13 +321,13 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < I; ++i) acc = __builtin_fmaf(go[g * I + i], wp2c[g * I + i], acc);
-                if (lane < C) myGA[g * C + lane] = acc;
+                if (lane < C) myGA[GR::vof(g) * C + lane] = acc;
             }
             if (lane < G) {
                 float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < I; ++i) acc = __builtin_fmaf(cGo[lane * I + i], sWp2[C * C + lane * I + i], acc);
-                myGsw[lane] = acc;
+                myGsw[GR::vof(lane)] = acc;
             }
             point_sync();
         }
@@ -305,8 +340,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         const float *garow[GT];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) {
-            const int g = 16 * tg + l15;
-            garow[tg] = (act && g < G) ? g_A + ((pt * G + g) * C + chq) : zpad;
+            const int g = GR::gof(16 * tg + l15);
+            garow[tg] = (act && g >= 0) ? g_A + ((pt * G + g) * C + chq) : zpad;
         }
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
@@ -332,7 +367,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int t = 0; t < GT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u1[t][r] = (rowok && 16 * t + 4 * q + r < G) ? u1n[t][r] : 0.f;
+            for (int r = 0; r < 4; ++r) u1[t][r] = (rowok && GR::gof(16 * t + 4 * q + r) >= 0) ? u1n[t][r] : 0.f;
         stage_load(pt + stride, src_n, S);
         if constexpr (XPF) prefetch_chunks(pt + stride, src_n);
         src_n = load_ids(pt + 2 * stride);
@@ -358,13 +393,15 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 const float4 w4 = *(const float4 *)(sWw + (16 * tg + l15) * GPW + 16 * t + 4 * q);
                 z = mfma4(w4.x, y[t][0], z);
                 z = mfma4(w4.y, y[t][1], z);
-                z = mfma4(w4.z, y[t][2], z);
-                z = mfma4(w4.w, y[t][3], z);
+                if (RN > 2) z = mfma4(w4.z, y[t][2], z);
+                if (RN > 3) z = mfma4(w4.w, y[t][3], z);
             }
             const float4 b4 = *(const float4 *)(sBw + 16 * tg + 4 * q);
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = RN; r < 4; ++r) sm[tg][r] = wm[tg][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
                 const float zz = l15 < k ? z[r] + bb[r] : -3.0e38f;
                 const float mx = row16_max(zz);
                 // (the backward's re-evaluation of the softmax: hardware exp2 / reciprocal, ~1e-6 relative -- the correctly rounded
@@ -373,7 +410,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 const float den = row16_sum(e);
                 sm[tg][r] = e * __builtin_amdgcn_rcpf(den);
                 wm[tg][r] = valid ? sm[tg][r] : 0.f;
-                if (DROP) wm[tg][r] *= ptv2_drop_factor(drop, (unsigned long long)row * G + (16 * tg + 4 * q + r));
+                if (DROP) wm[tg][r] *= ptv2_drop_factor(drop, (unsigned long long)row * G + (GR::gof(16 * tg + 4 * q + r) & 0xffff));
             }
         }
         // ---- gw^T (g,s) partial over my channels: g_A P^T + Gm v[idx]^T
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 for (int tg = 0; tg < GT; ++tg) {
                     const float gav = e == 0 ? ga4[tg].x : (e == 1 ? ga4[tg].y : (e == 2 ? ga4[tg].z : ga4[tg].w));
                     gwT[tg] = mfma4(gav, P, gwT[tg]);
-                    gwT[tg] = mfma4(gi == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
+                    gwT[tg] = mfma4(GR::vof(gi) == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
                 }
             }
         }
@@ -413,14 +450,14 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int g = 16 * tg + 4 * q + r;
-                bvrow[tg][r] = local ? myGA + g * C + c0 + l15 : ((act && g < G) ? g_A + (pt * G + g) * C + c0 + l15 : zpad);
+                const int gv = 16 * tg + 4 * q + r, g = GR::gof(gv);
+                bvrow[tg][r] = local ? myGA + gv * C + c0 + l15 : ((act && g >= 0) ? g_A + (pt * G + g) * C + c0 + l15 : zpad);
             }
         float bvn[GT][4];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bvn[tg][r] = bvrow[tg][r][0];
+            for (int r = 0; r < RN; ++r) bvn[tg][r] = bvrow[tg][r][0];
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
             const int ch = c0 + 16 * u + l15;
@@ -428,18 +465,18 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bv[tg][r] = bvn[tg][r];
+                for (int r = 0; r < RN; ++r) bv[tg][r] = bvn[tg][r];
             if (u + 1 < UT) {
 #pragma unroll
                 for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bvn[tg][r] = bvrow[tg][r][16 * (u + 1)];
+                    for (int r = 0; r < RN; ++r) bvn[tg][r] = bvrow[tg][r][16 * (u + 1)];
             }
             v4f d = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d = mfma4(wm[tg][r], bv[tg][r], d);
+                for (int r = 0; r < RN; ++r) d = mfma4(wm[tg][r], bv[tg][r], d);
             const float4 ab = sAB[ch];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -481,10 +518,12 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
             const float4 s4 = *(const float4 *)((local ? myGsw : cGsw) + 16 * tg + 4 * q);
             const float gs[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = RN; r < 4; ++r) gz[tg][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
                 float gm = valid ? gw[tg][r] + gs[r] : 0.f;
                 // (attention dropout: the weight that reached the aggregation was sm * D, so d loss / d sm = D * d loss / d w)
-                if (DROP) gm *= ptv2_drop_factor(drop, (unsigned long long)row * G + (16 * tg + 4 * q + r));
+                if (DROP) gm *= ptv2_drop_factor(drop, (unsigned long long)row * G + (GR::gof(16 * tg + 4 * q + r) & 0xffff));
                 const float dot = row16_sum(sm[tg][r] * gm);
                 gz[tg][r] = rowok ? sm[tg][r] * (gm - dot) : 0.f;
             }
@@ -498,14 +537,14 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
                 for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < RN; ++r)
                         gy = mfma4(sWw[(16 * tg + 4 * q + r) * GPW + 16 * tj + l15], gz[tg][r], gy);
                 const int j0 = 16 * tj + 4 * q;
                 const float4 s4 = *(const float4 *)(sSc + j0);
                 const float scv[4] = {s4.x, s4.y, s4.z, s4.w};
-                float o[4];
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RN; ++r) {
                     // y / u1 of tile tj (tj is a compile-time function of lt only when NW == 1; select by value)
                     float yv = 0.f, uv = 0.f;
 #pragma unroll
@@ -517,7 +556,13 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                     o[r] = gu * scv[r];
                 }
                 if (rowok) {
-                    if (G % 4 == 0) {
+                    if (GR::PERM) {
+#pragma unroll
+                        for (int r = 0; r < RN; ++r) {
+                            const int j = GR::gof(j0 + r);
+                            if (j >= 0) gW1[row * G + j] = o[r];
+                        }
+                    } else if (G % 4 == 0) {
                         if (j0 < G) *(float4 *)(gW1 + row * G + j0) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
                         if (j0 < G) *(float2 *)(gW1 + row * G + j0) = make_float2(o[0], o[1]);
@@ -531,7 +576,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
             for (int t = 0; t < GT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < RN; ++r) {
                     sGz[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = gz[t][r];
                     sY[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = y[t][r];
                     gbw[t][r] += gz[t][r];
@@ -583,8 +628,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                     const int tj = lt * NW + sub;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * tj + 4 * q + r;
-                        if (tj < GT && j < G) { sFin[4 * C + j] += tsc[lt][r]; sFin[4 * C + G + j] += tsh[lt][r]; }
+                        const int j = GR::gof(16 * tj + 4 * q + r);
+                        if (tj < GT && j >= 0) { sFin[4 * C + j] += tsc[lt][r]; sFin[4 * C + G + j] += tsh[lt][r]; }
                     }
                 }
                 if (sub == 0) {
@@ -592,8 +637,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                     for (int t = 0; t < GT; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int g = 16 * t + 4 * q + r;
-                            if (g < G) sFin[4 * C + 2 * G + G * G + g] += gbw[t][r];
+                            const int g = GR::gof(16 * t + 4 * q + r);
+                            if (g >= 0) sFin[4 * C + 2 * G + G * G + g] += gbw[t][r];
                         }
                 }
             }
@@ -602,11 +647,11 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 const int te = e * NW + sub;
                 if (te < GT * GT) {
                     const int tg = te / GT, tj = te - tg * GT;
-                    const int j = 16 * tj + l15;
+                    const int j = GR::gof(16 * tj + l15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int g = 16 * tg + 4 * q + r;
-                        if (g < G && j < G) sFin[4 * C + 2 * G + g * G + j] += accW[e][r];
+                        const int g = GR::gof(16 * tg + 4 * q + r);
+                        if (g >= 0 && j >= 0) sFin[4 * C + 2 * G + g * G + j] += accW[e][r];
                     }
                 }
             }
