@@ -303,6 +303,12 @@ int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, 
                                const float *const *xsh, float *const *y, void *stream);
 int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_bwd_point_local(int k, int c, int g);
+int gva_fwd_point_supported(int k, int c, int g);
+int gva_fwd_point_max_n();
+int gva_fwd_point_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                         const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
+                         const float *Wp2, const float *bp2, float *w, float *sw, float *A, float *out, float *stats,
+                         void *stream);
 int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
                               const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
                               const gva::FoldWBwdArgs &F, const int *inv_ptr, const int *inv_rows, float *gkW, float *gqW, float *ga,
@@ -474,9 +480,17 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
                                 FoldWFwdArgs{B->gamma_w, B->beta_w, B->run_mean_w, B->run_var_w, B->batches_w, B->training, rows,
                                              B->eps_w, B->momentum_w, B->sc, B->sh, B->mean_w, B->rstd_w},
                                 W.stage, W.stage_bytes, stream));
-    RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
-                                           B->idx, W.out_v, B->A, B->sw, B->w, stream));
-    RUN(gva_peb_forward_stats(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, out_stats, stats_done, stream));
+    // softmax, aggregation and the grouped projection: one launch at the full-resolution level (gva_fwd_point.hip), else three
+    if (gva_fwd_point_supported(k, c, g) && n <= gva_fwd_point_max_n() && !gva::ptv2_attn_drop_current().thresh &&
+        !getenv("AO_AMD_FWD_STAGED")) {
+        RUN(gva_fwd_point_launch(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx, B->Wp2, B->bp2,
+                                 B->w, B->sw, B->A, B->out, out_stats, stream));
+        if (out_stats && stats_done) *stats_done = 1;
+    } else {
+        RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
+                                               B->idx, W.out_v, B->A, B->sw, B->w, stream));
+        RUN(gva_peb_forward_stats(n, c, g, B->A, B->Wp2, B->bp2, B->sw, W.out_v, B->out, out_stats, stats_done, stream));
+    }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -57,27 +57,6 @@ __host__ __device__ constexpr int ww_pitch(int G) {  // >= G, = 4 mod 16: the 4 
     return p;
 }
 
-// Which group a register of a (g, s) tile holds.  An MFMA result tile leaves row 4 q + r in register r of lane quarter q, and
-// that register is the contraction step r of the next product.  With group = row, G = 6 occupies quarter 0 fully and half
-// of quarter 1: all four registers are live in every lane, three quarters of the lanes compute padding, and every
-// contraction over the groups is four matrix instructions.  With the groups dealt round-robin over the quarters instead
-// (row 4 q + r holds group q + 4 r) G <= 8 needs registers 0..1 only (G <= 12: 0..2): the softmax and its backward -- DPP
-// ladders per register -- and every product that contracts over the groups do half the work.  The kernel works on row
-// numbers ("virtual" groups) throughout; the parameter tables in LDS are laid out by row, and gof / vof translate where a
-// row number meets global memory (W1, gW1, g_A, g_sw rows, the parameter-gradient records).
-#ifndef GVA_BWD_PERM
-#define GVA_BWD_PERM 1
-#endif
-template <int G>
-struct GroupRows {
-    static constexpr bool PERM = GVA_BWD_PERM && G <= 12;
-    static constexpr int RN = PERM ? (G + 3) / 4 : 4;  // registers of a quarter that can hold a group
-    __host__ __device__ static constexpr int gof(int v) {  // row -> group, -1 for padding
-        return PERM ? (((v & 3) < RN && v < 16 && (v >> 2) + 4 * (v & 3) < G) ? (v >> 2) + 4 * (v & 3) : -1) : (v < G ? v : -1);
-    }
-    __host__ __device__ static constexpr int vof(int g) { return PERM ? 4 * (g & 3) + (g >> 2) : g; }  // group -> row
-};
-
 template <int G, int C, int NW>
 struct BwdPointCfg {
     static constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = ww_pitch(G), PW = 4 / NW, CW = C / NW, CS = CW / 4,
@@ -93,13 +72,13 @@ struct BwdPointCfg {
 // DROP (attention dropout) is a template parameter: as a run-time branch the factor's registers cost every instance 18-24
 // VGPRs (the (24, 192) one went to 256 + scratch) and 8 % of its time with dropout OFF
 template <int G, int C, int NW, bool LOCAL, bool DROP>
-__global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bwd_point_kernel(
+__global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kernel(
     int n, int k, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh,
     const float *__restrict__ Ww2, const float *__restrict__ bw2, const float *__restrict__ v,
     const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ coord,
     const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ g_A,
     const float *__restrict__ g_sw, float *__restrict__ gW1, float *__restrict__ part, const float *__restrict__ Wp2,
-    const float *__restrict__ bp2, PtvDrop drop) {
+    const float *__restrict__ bp2, PtvDrop drop, float *__restrict__ dump) {
     using K = BwdPointCfg<G, C, NW>;
     // Wp2 != NULL (narrow instances, one wavefront per point): g_A (g,ch) = sum_i g_out[gI+i] Wp2[gI+i,ch] and
     // g_sw = <g_out, bp2>_group -- the backward of the grouped projection -- are formed per point in LDS instead of
@@ -248,12 +227,29 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
     constexpr int PD = GT == 1 ? (NCH < 3 ? NCH : 3) : (NCH < 2 ? NCH : 2);  // chunks in flight (registers: GT >= 2 is near the limit)
     constexpr bool XPF = GT == 1;
     const int chq = c0 + 4 * q;
-    float4 rvvn[XPF ? PD : 1], rgan[XPF && !LOCAL ? PD : 1];
+    // VFMA (dealt layout, 8 channels per group): the product Gm v[idx]^T -- the group-masked g_out row against the gathered
+    // v rows, an A operand with one non-zero row per channel -- leaves the matrix core.  Its only other input is v, so the
+    // lane of (slot s, quarter q) simply gathers the channels of ITS groups (rows 4 q + r of the tile: 8 contiguous floats
+    // each) and the sum over a group's channels is eight in-lane FMAs, already in the result layout of gw^T: 16 FMAs instead
+    // of 12 matrix instructions (384 matrix-pipe cycles) and their 12 operand selects per point at (6, 48).
+    constexpr bool VFMA = GR::PERM && RN <= 3 && I == 8 && XPF;  // (G = 12: six more float4 a trip ahead cost the second wavefront per SIMD)
+    constexpr int NVQ = 2 * RN;                                   // float4 of v per lane (VFMA)
+    float4 rvvn[XPF ? (VFMA ? NVQ : PD) : 1], rgan[XPF && !LOCAL ? PD : 1];
     auto prefetch_chunks = [&](long long ptn, int srcv) {  // first PD chunks of point ptn (XPF only)
         const bool actn = ptn < n;
-        const float *vr = (actn && l15 < k && srcv >= 0) ? v + (long long)srcv * C + chq : zpad;
+        if constexpr (VFMA) {
 #pragma unroll
-        for (int ci = 0; ci < PD; ++ci) rvvn[ci] = *(const float4 *)(vr + 16 * ci);
+            for (int r = 0; r < RN; ++r) {
+                const int g = GR::gof(4 * q + r);
+                const float *vr = (actn && l15 < k && srcv >= 0 && g >= 0) ? v + (long long)srcv * C + 8 * g : zpad;
+                rvvn[2 * r] = *(const float4 *)vr;
+                rvvn[2 * r + 1] = *(const float4 *)(vr + 4);
+            }
+        } else {
+            const float *vr = (actn && l15 < k && srcv >= 0) ? v + (long long)srcv * C + chq : zpad;
+#pragma unroll
+            for (int ci = 0; ci < PD; ++ci) rvvn[ci] = *(const float4 *)(vr + 16 * ci);
+        }
         if constexpr (!LOCAL) {
             const float *gr = (actn && GR::gof(l15) >= 0) ? g_A + ((ptn * G + GR::gof(l15)) * C + chq) : zpad;
 #pragma unroll
@@ -345,17 +341,22 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         }
         float4 rvv[PD], rga[PD][GT];
         auto fetch_chunk = [&](int ci, int slot) {
-            rvv[slot] = *(const float4 *)(vrow + 16 * ci);
+            if constexpr (!VFMA) rvv[slot] = *(const float4 *)(vrow + 16 * ci);
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) {
                 if (local) rga[slot][tg] = *(const float4 *)(myGA + (16 * tg + l15) * C + chq + 16 * ci);
                 else rga[slot][tg] = *(const float4 *)(garow[tg] + 16 * ci);
             }
         };
+        float4 vq[VFMA ? NVQ : 1];
+        if constexpr (VFMA) {
+#pragma unroll
+            for (int i = 0; i < NVQ; ++i) vq[i] = rvvn[i];
+        }
         if constexpr (XPF) {  // requested a trip ago
 #pragma unroll
             for (int ci = 0; ci < PD; ++ci) {
-                rvv[ci] = rvvn[ci];
+                if constexpr (!VFMA) rvv[ci] = rvvn[ci];
                 if (local) rga[ci][0] = *(const float4 *)(myGA + l15 * C + chq + 16 * ci);
                 else rga[ci][0] = rgan[ci];
             }
@@ -417,15 +418,29 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
         v4f gwT[GT];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg) gwT[tg] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (VFMA) {  // <g_out, v[idx[s]]> over the channels of my groups: the accumulators start from it
+#pragma unroll
+            for (int r = 0; r < RN; ++r) {
+                const int g = GR::gof(4 * q + r);
+                const float *gop = cGo + 8 * (g >= 0 ? g : 0);  // (a padding row: v came from the zero pad)
+                const float4 g0 = *(const float4 *)gop, g1 = *(const float4 *)(gop + 4);
+                const float4 v0 = vq[2 * r], v1 = vq[2 * r + 1];
+                float t = g0.x * v0.x;
+                t = __builtin_fmaf(g0.y, v0.y, t); t = __builtin_fmaf(g0.z, v0.z, t); t = __builtin_fmaf(g0.w, v0.w, t);
+                t = __builtin_fmaf(g1.x, v1.x, t); t = __builtin_fmaf(g1.y, v1.y, t);
+                t = __builtin_fmaf(g1.z, v1.z, t); t = __builtin_fmaf(g1.w, v1.w, t);
+                gwT[0][r] = t;
+            }
+        }
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
             const int slot = ci % PD;
-            const float4 vv = rvv[slot];
+            const float4 vv = VFMA ? make_float4(0.f, 0.f, 0.f, 0.f) : rvv[slot];
             float4 ga4[GT];
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) ga4[tg] = rga[slot][tg];
             if (ci + PD < NCH) fetch_chunk(ci + PD, slot);
-            const float4 go = *(const float4 *)(cGo + chq + 16 * ci);
+            const float4 go = VFMA ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4 *)(cGo + chq + 16 * ci);
             const float vve[4] = {vv.x, vv.y, vv.z, vv.w}, goe[4] = {go.x, go.y, go.z, go.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                 for (int tg = 0; tg < GT; ++tg) {
                     const float gav = e == 0 ? ga4[tg].x : (e == 1 ? ga4[tg].y : (e == 2 ? ga4[tg].z : ga4[tg].w));
                     gwT[tg] = mfma4(gav, P, gwT[tg]);
-                    gwT[tg] = mfma4(GR::vof(gi) == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
+                    if constexpr (!VFMA) gwT[tg] = mfma4(GR::vof(gi) == 16 * tg + l15 ? goe[e] : 0.f, vve[e], gwT[tg]);
                 }
             }
         }
@@ -532,6 +547,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
         for (int lt = 0; lt < LT; ++lt) {
             const int tj = lt * NW + sub;
+            const int j0 = 16 * tj + 4 * q;
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
             if (tj < GT) {  // wave-uniform
                 v4f gy = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -539,10 +556,8 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
 #pragma unroll
                     for (int r = 0; r < RN; ++r)
                         gy = mfma4(sWw[(16 * tg + 4 * q + r) * GPW + 16 * tj + l15], gz[tg][r], gy);
-                const int j0 = 16 * tj + 4 * q;
                 const float4 s4 = *(const float4 *)(sSc + j0);
                 const float scv[4] = {s4.x, s4.y, s4.z, s4.w};
-                float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < RN; ++r) {
                     // y / u1 of tile tj (tj is a compile-time function of lt only when NW == 1; select by value)
@@ -555,20 +570,27 @@ __global__ __launch_bounds__(256, (G > 16 && G <= 32) ? 2 : 1) void attention_bw
                     tsh[lt][r] += gu;
                     o[r] = gu * scv[r];
                 }
-                if (rowok) {
-                    if (GR::PERM) {
+            }
+            // The gW1 stores are UNCONDITIONAL: a lane with nothing to store (a row past the end, a slot >= k, a padding
+            // tile) stores to a dump row behind the records, a register that holds no group repeats the store of register 0.
+            // Under a condition each store sits behind a branch, and the wait-count pass -- which must be right on the path
+            // that skips them -- waited for the next point's prefetched rows with vmcnt(0) at the bottom of every trip, i.e. for
+            // the write acknowledgement of this trip's own stores.
+            if (GR::PERM || G % 4 == 0) {
+                float *dst = (rowok && tj < GT) ? gW1 + row * G : dump + l15 * G16;
+                if (GR::PERM) {
 #pragma unroll
-                        for (int r = 0; r < RN; ++r) {
-                            const int j = GR::gof(j0 + r);
-                            if (j >= 0) gW1[row * G + j] = o[r];
-                        }
-                    } else if (G % 4 == 0) {
-                        if (j0 < G) *(float4 *)(gW1 + row * G + j0) = make_float4(o[0], o[1], o[2], o[3]);
-                    } else {
-                        if (j0 < G) *(float2 *)(gW1 + row * G + j0) = make_float2(o[0], o[1]);
-                        if (j0 + 2 < G) *(float2 *)(gW1 + row * G + j0 + 2) = make_float2(o[2], o[3]);
+                    for (int r = 0; r < RN; ++r) {
+                        const int j = GR::gof(j0 + r);
+                        dst[j >= 0 ? j : GR::gof(j0)] = j >= 0 ? o[r] : o[0];
                     }
+                } else {
+                    const bool ok = rowok && tj < GT && j0 < G;
+                    *(float4 *)(ok ? dst + j0 : dump + l15 * G16 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
                 }
+            } else if (rowok && tj < GT) {
+                if (j0 < G) *(float2 *)(gW1 + row * G + j0) = make_float2(o[0], o[1]);
+                if (j0 + 2 < G) *(float2 *)(gW1 + row * G + j0 + 2) = make_float2(o[2], o[3]);
             }
         }
         // ---- gWw2 (g,j) += gz^T y, gbw2 += sum_s gz: contraction over s needs the (g,s) tiles transposed
@@ -1065,9 +1087,10 @@ int launch_bwd_point(int n, int k, const float *W1, const float *sc, const float
     const long long cap = resident[local];
     const long long groups = ((long long)n + K::PW - 1) / K::PW;
     const int nblk = (int)std::max<long long>(1, std::min<long long>(groups, cap));
-    if ((size_t)nblk * K::PF > part_floats_avail) return PTV2_ERR_WORKSPACE;
+    const size_t dump_at = ((size_t)nblk * K::PF + 3) & ~(size_t)3;  // 16 dump rows of G16 floats behind the records
+    if (dump_at + 16 * K::G16 > part_floats_avail) return PTV2_ERR_WORKSPACE;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, k, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw,
-                       gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr, drop);
+                       gW1, part, local ? Wp2 : (const float *)nullptr, local ? bp2 : (const float *)nullptr, drop, part + dump_at);
     launch_finalize(st, (const float *)part, nblk, K::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
     return PTV2_OK;
 }

@@ -50,6 +50,27 @@ __device__ __forceinline__ float pe_act(float ax, float ay, float az, float b, f
     return fmaxf(__builtin_fmaf(az, pz, __builtin_fmaf(ay, py, __builtin_fmaf(ax, px, b))), 0.f);
 }
 
+// Which group a register of a (g, s) tile holds.  An MFMA result tile leaves row 4 q + r in register r of lane quarter q, and
+// that register is the contraction step r of the next product.  With group = row, G = 6 occupies quarter 0 fully and half
+// of quarter 1: all four registers are live in every lane, three quarters of the lanes compute padding, and every
+// contraction over the groups is four matrix instructions.  With the groups dealt round-robin over the quarters instead
+// (row 4 q + r holds group q + 4 r) G <= 8 needs registers 0..1 only (G <= 12: 0..2): the softmax and its backward -- DPP
+// ladders per register -- and every product that contracts over the groups do half the work.  The kernel works on row
+// numbers ("virtual" groups) throughout; the parameter tables in LDS are laid out by row, and gof / vof translate where a
+// row number meets global memory (W1, gW1, g_A, g_sw rows, the parameter-gradient records).
+#ifndef GVA_BWD_PERM
+#define GVA_BWD_PERM 1
+#endif
+template <int G>
+struct GroupRows {
+    static constexpr bool PERM = GVA_BWD_PERM && G <= 12;
+    static constexpr int RN = PERM ? (G + 3) / 4 : 4;  // registers of a quarter that can hold a group
+    __host__ __device__ static constexpr int gof(int v) {  // row -> group, -1 for padding
+        return PERM ? (((v & 3) < RN && v < 16 && (v >> 2) + 4 * (v & 3) < G) ? (v >> 2) + 4 * (v & 3) : -1) : (v < G ? v : -1);
+    }
+    __host__ __device__ static constexpr int vof(int g) { return PERM ? 4 * (g & 3) + (g >> 2) : g; }  // group -> row
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
