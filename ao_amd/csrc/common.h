@@ -22,6 +22,7 @@ enum PtvKernelId {
     KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD_REDUCE, KID_BN_BWD_APPLY, KID_SKINNY_FWD, KID_SKINNY_BWD, KID_ROWS_GEMM, /* + 0..7: (BN 48|64) x (W (n,k)|(k,n)) x (KC 32|64) */ KID_BWD_POINT = KID_ROWS_GEMM + 8,
     /* + 0..4 for G = 6, 12, 24, 48, 64 */ KID_WGRAD_LDS = KID_BWD_POINT + 5 /* the LDS-staged fp32 weight gradient */,
     KID_WGRAD_GROUPED /* the grouped projection's weight gradient on the vector ALUs */,
+    KID_FWD_POINT /* softmax + aggregation + grouped projection of the forward in one launch (gva_fwd_point.hip) */,
     KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);

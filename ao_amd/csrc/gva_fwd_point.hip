@@ -327,7 +327,7 @@ int gva_fwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
     const int rounds = (nblk + resident - 1) / resident;
     const int grid = (nblk + rounds - 1) / rounds;
     // W1 + idx + coord + v rows (each unique row once) in; w, sw, A, out out
-    PtvScopedTimer t(KID_AGG_TILE, st, 4.0 * ((double)n * k * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
+    PtvScopedTimer t(KID_FWD_POINT, st, 4.0 * ((double)n * k * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
     if (stats)
         hipLaunchKernelGGL(attention_fwd_point6_kernel<true>, dim3(grid), dim3(256), 0, st, n, nblk, W1, sc, sh, Ww2, bw2, v, a, b, coord,
                            idx, Wp2, bp2, w, sw, A, out, stats);
