@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     }
     for (int e = tid; e < 4 * 16 * 17; e += 256) (&sWt[0][0])[e] = 0.f;  // (the rows no register writes are operand rows too)
     const int o = lane < C ? lane : 0;                                  // my output channel in the projection phase
+    // (measured: the row in LDS instead -- 144 registers, three wavefronts per SIMD -- is 152 us against 146; so is a
+    // register cap of 168 with four spilled values, 167 us)
     float wp2r[C];
 #pragma unroll
     for (int j = 0; j < C / 4; ++j) {
@@ -145,14 +147,17 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
         }
     };
 
-    Ids idn, idnn;
-    Rows Rn;
-    int idc_mine;
+    // The pipeline state lives in two register sets that swap roles every trip (the trip body is instantiated twice): as
+    // one loop-carried set, every prefetched register was copied into its "current" twin at the top of each trip -- 23 of the
+    // trip's ~300 vector instructions.
+    struct Pipe { Rows R; int mine; };   // rows of a point and the id of its slot l15
+    Pipe P0, P1;
+    Ids idA, idB;                         // ids of the point after the one in flight
     {
         const Ids id0 = load_ids(point_of(0));
-        idn = load_ids(point_of(1));
-        load_rows(point_of(0), id0, Rn);
-        idc_mine = id0.mine;
+        idA = load_ids(point_of(1));
+        load_rows(point_of(0), id0, P0.R);
+        P0.mine = id0.mine;
     }
     // (everything requested so far has landed before the loop is entered: otherwise the wait-count pass, merging the loop's
     // entry with its back edge, takes the prologue's "the newest requests are the ones I need" for every trip and drains
@@ -160,17 +165,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     __builtin_amdgcn_s_waitcnt(0);
     // running column statistics of my output channel over the wavefront's points of the current block (about the first value)
     float st_c = 0.f, st_s1 = 0.f, st_s2 = 0.f;
-#pragma unroll 2
-    for (int t = 0; t < trips; ++t) {
+    auto trip = [&](const int t, const Pipe &cur, Pipe &nxt, const Ids &id_in, Ids &id_out) __attribute__((always_inline)) {
         const unsigned pt = point_of(t);
         const bool act = pt < (unsigned)n;
-        const Rows R = Rn;
-        const int mysrc = idc_mine;
+        const Rows &R = cur.R;
+        const int mysrc = cur.mine;
         // requests for the next points
-        idnn = load_ids(point_of(t + 2));
-        load_rows(point_of(t + 1), idn, Rn);
-        idc_mine = idn.mine;
-        idn = idnn;
+        id_out = load_ids(point_of(t + 2));
+        load_rows(point_of(t + 1), id_in, nxt.R);
+        nxt.mine = id_in.mine;
 
         // Stores are UNCONDITIONAL.  A point past the end was loaded as the last point (clamped indices), computes the last
         // point's values and stores them to the last point's rows again; a lane whose second register holds no group repeats
@@ -296,6 +299,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
             }
             __syncthreads();
         }
+    };
+    for (int t = 0; t < trips; t += 2) {  // (trips is a multiple of 16)
+        trip(t, P0, P1, idA, idB);
+        trip(t + 1, P1, P0, idB, idA);
     }
 }
 
