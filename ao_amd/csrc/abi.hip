@@ -165,7 +165,10 @@ const char *kNames[KID_COUNT] = {
     "attention_bwd_point_kernel<12, 96, 1, false>", "attention_bwd_point_kernel<24, 192, 2, false>",
     "attention_bwd_point_kernel<48, 384, 4, false>", "attention_bwd_point_kernel<64, 512, 4, false>",
     "linear_wgrad_lds_kernel",  // (both instances and their batched form: the family)
-    "grouped_wgrad_kernel", "attention_fwd_point6_kernel"};
+    "grouped_wgrad_kernel", "attention_fwd_point6_kernel",
+    "logits_bwd_fused6_kernel<48>", "logits_bwd_fused_kernel<12, 96, 1>", "logits_bwd_fused_kernel<24, 192, 4>",
+    "logits_bwd_fused_kernel<48, 384, 4>", "logits_bwd_fused_kernel<64, 512, 4>",
+    "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;

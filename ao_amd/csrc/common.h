@@ -23,6 +23,9 @@ enum PtvKernelId {
     /* + 0..4 for G = 6, 12, 24, 48, 64 */ KID_WGRAD_LDS = KID_BWD_POINT + 5 /* the LDS-staged fp32 weight gradient */,
     KID_WGRAD_GROUPED /* the grouped projection's weight gradient on the vector ALUs */,
     KID_FWD_POINT /* softmax + aggregation + grouped projection of the forward in one launch (gva_fwd_point.hip) */,
+    KID_LOGITS_BWD_FUSED /* + 0..4 for G = 6, 12, 24, 48, 64: rows + parameter gradients of the logits stage in one launch */,
+    KID_BN_BWD_APPLY_RES = KID_LOGITS_BWD_FUSED + 5 /* bn_bwd_apply_residual_kernel */,
+    KID_BN_BWD_FINAPPLY /* bn_bwd_finapply_kernel<...>: record sum + apply in one launch */,
     KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);

@@ -1589,7 +1589,7 @@ extern "C" int bn_backward_residual_hip_launcher(int n, int c, const float *x, c
                            rowscale, mean, rstd, part);
     }
     if (finapply_ok(n, nblk)) {
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 20.0 * n * c);
+        PtvScopedTimer t(KID_BN_BWD_FINAPPLY, st, 20.0 * n * c);
         const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, nullptr, gx, dbeta, dgamma, y, rowscale, g_residual};
         launch_finapply(st, n, c, 1, training, true, 1, A, A);
         PTV2_CHECK_LAUNCH();
@@ -1599,7 +1599,7 @@ extern "C" int bn_backward_residual_hip_launcher(int n, int c, const float *x, c
     const long long total4 = (long long)n * (c >> 2);
     const int nb2 = (int)std::min<long long>((total4 + TPB - 1) / TPB, 256 * 16);
     {
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 20.0 * n * c);
+        PtvScopedTimer t(KID_BN_BWD_APPLY_RES, st, 20.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_apply_residual_kernel, dim3(nb2), dim3(TPB), 0, st, total4, c >> 2, 1.0f / (float)n, x, gy, y,
                            rowscale, mean, rstd, gamma, (const float *)dbeta, (const float *)dgamma, training, gx, g_residual);
     }
@@ -1622,7 +1622,7 @@ extern "C" int bn_backward_hip_launcher(int n, int c, const float *x, const floa
                            rstd, gamma, beta, relu, part, BnSecond{});
     }
     if (finapply_ok(n, nblk)) {
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        PtvScopedTimer t(KID_BN_BWD_FINAPPLY, st, 12.0 * n * c);
         const BnFinApply A{part, nblk, 2 * c, 0, x, gy, mean, rstd, gamma, beta, gx, dbeta, dgamma, nullptr, nullptr, nullptr};
         launch_finapply(st, n, c, relu, training, false, 1, A, A);
         PTV2_CHECK_LAUNCH();
@@ -1649,7 +1649,7 @@ extern "C" int bn_backward_records_hip_launcher(int n, int c, const float *x, co
     if (n < 1 || c < 4 || c % 4 != 0 || c > 1024 || !records || nrec < 1) return PTV2_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (finapply_ok(n, nrec)) {
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 12.0 * n * c);
+        PtvScopedTimer t(KID_BN_BWD_FINAPPLY, st, 12.0 * n * c);
         const BnFinApply A{records, nrec, 2 * c, 0, x, gy, mean, rstd, gamma, beta, gx, dbeta, dgamma, nullptr, nullptr, nullptr};
         launch_finapply(st, n, c, relu, training, false, 1, A, A);
         PTV2_CHECK_LAUNCH();
@@ -1696,7 +1696,7 @@ extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x
                            rstd[0], gamma[0], beta[0], relu, part, sec);
     }
     if (finapply_ok(n, nblk)) {  // record of a block: [set 0: dbeta c | dgamma c][set 1: ...]
-        PtvScopedTimer t(KID_BN_BWD_APPLY, st, 24.0 * n * c);
+        PtvScopedTimer t(KID_BN_BWD_FINAPPLY, st, 24.0 * n * c);
         const BnFinApply A0{part, nblk, 4 * c, 0, x[0], gy[0], mean[0], rstd[0], gamma[0], beta[0], gx[0], dbeta[0], dgamma[0], nullptr,
                             nullptr, nullptr};
         const BnFinApply A1{part, nblk, 4 * c, 2 * c, x[1], gy[1], mean[1], rstd[1], gamma[1], beta[1], gx[1], dbeta[1], dgamma[1],

@@ -310,7 +310,8 @@ int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const 
     if (inv_ptr && gva_logits_bwd_fused_supported(k, c, g) && !fused_off && !getenv("AO_AMD_BWD_STAGED")) {
         {
             // W1, gW1 in, gWt out, idx, coord; parameter-sized outputs
-            PtvScopedTimer t(KID_LOGITS_BWD_PARAMS, st, 4.0 * ((double)rows * (3 * g + 1) + 3.0 * n));
+            PtvScopedTimer t(KID_LOGITS_BWD_FUSED + (g == 6 ? 0 : g == 12 ? 1 : g == 24 ? 2 : g == 48 ? 3 : 4), st,
+                             4.0 * ((double)rows * (3 * g + 1) + 3.0 * n));
             const int rc = gva_logits_bwd_fused_launch(n, k, c, g, a, b, M, coord, idx, W1, gW1, gT1, gT2, F, gWt, part,
                                                        part_floats(c, g), gM, ga, gb, gcW, st);
             if (rc != PTV2_OK) return rc;
