@@ -190,11 +190,12 @@ PtvGraphScope::PtvGraphScope(void *stream, int which_, bool allow)
     }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) { g_stats.declined++; return; }
-    if (which == GRAPH_MODEL_FWD_PREFIX) {
-        // The first launches of a step behind an idle GPU: capturing, updating and launching the prefix's graph keeps the GPU
-        // waiting for ~0.3 ms of host work; issued eagerly its first kernel starts microseconds after the call (a loop that
-        // reads the loss back every iteration -- pointcept's InformationWriter -- pays that at every step).  Same kernels,
-        // same arguments, same order either way.  AO_AMD_GRAPH_IDLE_EAGER=0: always the graph.
+    if (which == GRAPH_MODEL_FWD_PREFIX || which == GRAPH_MODEL_FWD) {
+        // The first launches of a step behind an idle GPU: capturing, updating and launching the forward's (or its prefix's)
+        // graph keeps the GPU waiting for 0.3-0.8 ms of host work; issued eagerly its first kernel starts microseconds after
+        // the call (a loop that reads the loss back every iteration -- pointcept's InformationWriter -- pays that at every
+        // step, any loop at its first step behind a synchronisation: the first timed step of the bench was 11.6 ms against
+        // 9.85).  Same kernels, same arguments, same order either way.  AO_AMD_GRAPH_IDLE_EAGER=0: always the graph.
         const char *e = getenv("AO_AMD_GRAPH_IDLE_EAGER");
         if (!(e && e[0] == '0')) {
             hipEvent_t last = nullptr;

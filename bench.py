@@ -785,7 +785,8 @@ def child_main(args):
                        "loss": float(loss.detach()), "library_build": "src " + str(src_hash(build_info))},
         }
         first_step_ms = marks[0].elapsed_time(marks[1])
-        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        step_ms_in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        step_ms = sorted(step_ms_in_order)
         pick = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
         out["host"] = host_facts()
         out["host"].update({
@@ -796,7 +797,8 @@ def child_main(args):
             # per-step durations between events recorded on the compute stream at the end of every step
             # (`first`: the step behind the synchronisation that opens the timed region -- the GPU idles while the host captures,
             # updates and launches the forward's graph, and runs the step's first milliseconds from a cold start)
-            "step_ms": {"min": step_ms[0], "median": pick(0.5), "p90": pick(0.9), "max": step_ms[-1], "first": first_step_ms},
+            "step_ms": {"min": step_ms[0], "median": pick(0.5), "p90": pick(0.9), "max": step_ms[-1], "first": first_step_ms,
+                        "in_order": [round(x, 2) for x in step_ms_in_order[:64]]},
             "issue": ("hipGraph: each direction of the model captured and launched as one graph (ao_amd/csrc/graph.hip)"
                       if graph["scopes"] > 0 else "eager (hipLaunchKernelGGL per kernel)"),
             "graph": {"launches_per_step": graph["scopes"] / args.steps, "nodes_per_step": graph["nodes"] / args.steps,
