@@ -57,6 +57,9 @@ struct MapPosStats {  // columns: x y z xx xy xz yy yz zz -> s1[3], symmetric s2
 // latency (104 / 244 us at 72 k / 17 k rows, profiles/r01_*_v8).  SPLIT > 1 spreads the channel loop of one
 // 64-row group over the SPLIT waves of the workgroup (partial logits summed through LDS), which gives the small
 // deep-stage launches SPLIT x more waves to hide latency with.
+#ifndef FWD_RPL
+#define FWD_RPL 2
+#endif
 template <int G, int SPLIT>
 __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, const float *__restrict__ kW,
                                                          const float *__restrict__ qW, const float *__restrict__ a,
@@ -67,7 +70,13 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
                                                          double *__restrict__ T2, FoldWFwdArgs F) {
     extern __shared__ float4 lds4[];
     constexpr int G4 = (G + 3) & ~3;
-    constexpr int RPB = TPB / SPLIT;  // rows per workgroup iteration
+    // rows per lane (SPLIT == 1): the wave-uniform operands of a channel -- (a, b) and the M row, four LDS reads -- serve
+    // RPL rows of the lane.  With one row per lane the full-resolution launch was bound by LDS instruction issue (192 broadcast
+    // reads per row against 480 vector instructions: `share_active_inst_any` 0.17, `share_wait_inst_any` 0.48 in
+    // profiles/r05_final_sq_counters.jsonl, 60 us at 120 k points).  Measured: 60.1 us with one row, 56-57 with two, 58.5
+    // with four (142 registers) -- the rest is the row's own chain idx -> coord -> W1 store.
+    constexpr int RPL = SPLIT == 1 ? (G <= 8 ? FWD_RPL : 2) : 1;
+    constexpr int RPB = TPB / SPLIT * RPL;  // rows per workgroup iteration
     float4 *sAB = lds4;                        // [c]  (a.x, a.y, a.z, b)
     float *sM = (float *)(sAB + c);            // [c][G4]
     float *sRed = sM + (size_t)c * G4;         // [SPLIT][64][G + 1]   (SPLIT > 1 only)
@@ -85,46 +94,64 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
 #pragma unroll
     for (int g = 0; g < G; ++g) t1[g] = t2[g] = 0.f;
     for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
-        const long long row = it * RPB + (SPLIT == 1 ? threadIdx.x : lane);
-        const bool act = row < rows;
-        const int nn = act ? (int)(row / k) : 0;
-        Rel r;
-        r.x = r.y = r.z = 0.f; r.src = -1;
-        if (act) r = rel_pos(coord, idx, row, nn);
+        long long row[RPL];
+        bool act[RPL];
+        int nn[RPL];
+        Rel r[RPL];
+        float kq[RPL][G], acc[RPL][G];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            row[j] = it * RPB + (SPLIT == 1 ? j * TPB + (int)threadIdx.x : lane);
+            act[j] = row[j] < rows;
+            nn[j] = act[j] ? (int)(row[j] / k) : 0;
+            r[j].x = r[j].y = r[j].z = 0.f; r[j].src = -1;
+            if (act[j]) r[j] = rel_pos(coord, idx, row[j], nn[j]);
+        }
         // the neighbour's kW row and the point's qW row are requested before the channel loop, not after it (they need only
         // the neighbour id: one exposed memory round trip less per row)
-        float kq[G];
         if (finisher) {
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-                kq[g] = ptv2_ld_or_zero(kW + (long long)r.src * G + g, act && r.src >= 0) - ptv2_ld_or_zero(qW + (long long)nn * G + g, act);
-        }
-        float acc[G];
+            for (int j = 0; j < RPL; ++j)
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = 0.f;
+                for (int g = 0; g < G; ++g)
+                    kq[j][g] = ptv2_ld_or_zero(kW + (long long)r[j].src * G + g, act[j] && r[j].src >= 0) -
+                               ptv2_ld_or_zero(qW + (long long)nn[j] * G + g, act[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; ++j)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[j][g] = 0.f;
         for (int ci = c0; ci < c1; ++ci) {
             const float4 ab = sAB[ci];
-            const float p = pe_act(ab.x, ab.y, ab.z, ab.w, r.x, r.y, r.z);
+            float p[RPL];
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) p[j] = pe_act(ab.x, ab.y, ab.z, ab.w, r[j].x, r[j].y, r[j].z);
             const float *mr = sM + (size_t)ci * G4;
             if (G % 4 == 0) {
 #pragma unroll
                 for (int g = 0; g < G; g += 4) {
                     const float4 m4 = *(const float4 *)(mr + g);
-                    acc[g] = __builtin_fmaf(p, m4.x, acc[g]); acc[g + 1] = __builtin_fmaf(p, m4.y, acc[g + 1]);
-                    acc[g + 2] = __builtin_fmaf(p, m4.z, acc[g + 2]); acc[g + 3] = __builtin_fmaf(p, m4.w, acc[g + 3]);
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) {
+                        acc[j][g] = __builtin_fmaf(p[j], m4.x, acc[j][g]); acc[j][g + 1] = __builtin_fmaf(p[j], m4.y, acc[j][g + 1]);
+                        acc[j][g + 2] = __builtin_fmaf(p[j], m4.z, acc[j][g + 2]); acc[j][g + 3] = __builtin_fmaf(p[j], m4.w, acc[j][g + 3]);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int g = 0; g < G; g += 2) {
                     const float2 m2 = *(const float2 *)(mr + g);
-                    acc[g] = __builtin_fmaf(p, m2.x, acc[g]); acc[g + 1] = __builtin_fmaf(p, m2.y, acc[g + 1]);
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) {
+                        acc[j][g] = __builtin_fmaf(p[j], m2.x, acc[j][g]); acc[j][g + 1] = __builtin_fmaf(p[j], m2.y, acc[j][g + 1]);
+                    }
                 }
             }
         }
         if (SPLIT > 1) {
             float *mine = sRed + ((size_t)wid * WAVE + lane) * (G + 1);
 #pragma unroll
-            for (int g = 0; g < G; ++g) mine[g] = acc[g];
+            for (int g = 0; g < G; ++g) mine[g] = acc[0][g];
             __syncthreads();
             if (wid == 0) {
 #pragma unroll
@@ -132,24 +159,27 @@ __global__ __launch_bounds__(TPB) void logits_fwd_kernel(int n, int k, int c, co
                     float t = 0.f;
 #pragma unroll
                     for (int w = 0; w < SPLIT; ++w) t += sRed[((size_t)w * WAVE + lane) * (G + 1) + g];
-                    acc[g] = t;
+                    acc[0][g] = t;
                 }
             }
         }
-        if (finisher && act) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                acc[g] += kq[g] + cW[g];
-                t1[g] += acc[g];
-                t2[g] = __builtin_fmaf(acc[g], acc[g], t2[g]);
-            }
-            float *o = W1 + row * G;
-            if (G % 4 == 0) {
+        for (int j = 0; j < RPL; ++j) {
+            if (finisher && act[j]) {
 #pragma unroll
-                for (int g = 0; g < G; g += 4) *(float4 *)(o + g) = make_float4(acc[g], acc[g + 1], acc[g + 2], acc[g + 3]);
-            } else {
+                for (int g = 0; g < G; ++g) {
+                    acc[j][g] += kq[j][g] + cW[g];
+                    t1[g] += acc[j][g];
+                    t2[g] = __builtin_fmaf(acc[j][g], acc[j][g], t2[g]);
+                }
+                float *o = W1 + row[j] * G;
+                if (G % 4 == 0) {
 #pragma unroll
-                for (int g = 0; g < G; g += 2) *(float2 *)(o + g) = make_float2(acc[g], acc[g + 1]);
+                    for (int g = 0; g < G; g += 4) *(float4 *)(o + g) = make_float4(acc[j][g], acc[j][g + 1], acc[j][g + 2], acc[j][g + 3]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; g += 2) *(float2 *)(o + g) = make_float2(acc[j][g], acc[j][g + 1]);
+                }
             }
         }
         if (SPLIT > 1) __syncthreads();  // sRed is rewritten by the next iteration
@@ -296,7 +326,7 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
     const bool split = rows < 400000 && lds_base + lds_red <= 96 * 1024;
     const size_t lds = lds_base + (split ? lds_red : 0);
     if (lds > 150 * 1024 || g % 2 != 0) return PTV2_ERR_ARG;
-    const int nblk = stage_grid(rows, split ? WAVE : TPB);
+    const int nblk = stage_grid(rows, split ? WAVE : (g <= 8 ? FWD_RPL : 2) * TPB);  // (the unsplit kernel takes several rows per lane)
     const bool own_final = (size_t)nblk * 2 * g <= FUSED_FINAL_MAX;
     unsigned *cnt = own_final ? ptv2_stream_counters(st) : nullptr;
     if (own_final && !cnt) return PTV2_ERR_LAUNCH;
