@@ -3,7 +3,7 @@
 branch) that holds global loads, global stores AND an `s_waitcnt vmcnt(0)`.  On gfx9 stores count in vmcnt like loads, so a
 full drain inside a software-pipelined loop also waits for the write acknowledgements of the trip's own stores (~2 us); the
 usual cause is a store behind a divergent condition (the wait-count pass must be right on the path that skips it).
-Usage: python tools/isa_loop_drains.py ao_amd/csrc/gva_bwd_point.hip [name filter]"""
+Usage: python tools/isa_loop_drains.py ao_amd/csrc/gva_bwd_point.hip [name filter] [--all]   (--all: enclosing loops too)"""
 import re
 import subprocess
 import sys
@@ -18,7 +18,7 @@ def demangle(n):
 
 def main():
     src = sys.argv[1]
-    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+    flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else ""
     asm = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [src, "-o", "-"], capture_output=True, text=True).stdout
     cur, body, kernels = None, [], []
     for line in asm.splitlines():
@@ -44,6 +44,15 @@ def main():
             if not (m and m.group(1) in labels and labels[m.group(1)] < n):
                 continue
             blk = body[labels[m.group(1)]:n]
+            # innermost loops only: a loop that contains another backward branch is reported through that one
+            inner = False
+            for k, x in enumerate(blk):
+                mm = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", x)
+                if mm and mm.group(1) in labels and labels[m.group(1)] < labels[mm.group(1)] <= labels[m.group(1)] + k:
+                    inner = True
+                    break
+            if inner and "--all" not in sys.argv:
+                continue
             loads = sum(1 for x in blk if re.match(r"(global|buffer|flat)_load", x))
             stores = sum(1 for x in blk if re.match(r"(global|buffer|flat)_(store|atomic)", x))
             drains = [i for i, x in enumerate(blk) if re.match(r"s_waitcnt vmcnt\(0\)", x)]
