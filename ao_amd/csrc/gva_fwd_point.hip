@@ -132,8 +132,12 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     auto load_rows = [&](unsigned pt, const Ids &id, Rows &R) {
         const unsigned pp = pt < (unsigned)n ? pt : last;
         const unsigned ss = 12u * (unsigned)(id.mine >= 0 ? id.mine : 0);
-        R.sx = ldf(coord, ss); R.sy = ldf(coord, ss + 4); R.sz = ldf(coord, ss + 8);
-        R.px = ldf(coord, 12u * pp); R.py = ldf(coord, 12u * pp + 4); R.pz = ldf(coord, 12u * pp + 8);
+        {   // (12-byte loads: three dword loads per coordinate triple are three passes of 64 lanes through the address unit)
+            struct __attribute__((aligned(4))) F3 { float x, y, z; };
+            const F3 cs = *(const F3 *)((const char *)coord + ss), cp = *(const F3 *)((const char *)coord + 12u * pp);
+            R.sx = cs.x; R.sy = cs.y; R.sz = cs.z;
+            R.px = cp.x; R.py = cp.y; R.pz = cp.z;
+        }
         const unsigned row = (pp * K + l15) * (4u * G);
         R.u0 = ldf(W1, row + u0off);
         R.u1 = ldf(W1, row + u1off);
