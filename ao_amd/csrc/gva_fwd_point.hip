@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     __shared__ float sOv[4][C];
     __shared__ float sSw[4][16];
     __shared__ float sS[3][4][C];                                     // statistics exchange
+    constexpr int PV = 52;                                            // (4 PV = 16 mod 64: the four quarters read disjoint banks)
+    __shared__ __attribute__((aligned(16))) float sV[4][K * PV];      // v rows of the point's neighbours (slot, channel)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
 
     for (int e = tid; e < 16 * GPW; e += 256) {  // parameter tables by tile row
@@ -119,15 +121,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     auto point_of = [&](int t) -> unsigned {
         return ((unsigned)blockIdx.x + (unsigned)(t >> 4) * gridDim.x) * 64u + (unsigned)(wid * 16 + (t & 15));
     };
-    struct Ids { int mine; int4 quad; };                      // neighbour id of slot l15; of the slots 4 q + (0..3)
+    // The v rows of a point's 16 neighbours arrive as 16-byte pieces -- lane = (slot lane >> 2, pieces (lane & 3) + 4 i):
+    // three loads per lane, 16 rows x 64 contiguous bytes each -- and reach the B-operand layout (slot 4 q + st, channel
+    // 16 u + l15) through a wave-private LDS tile.  As twelve dword gathers in the operand layout they were twelve passes of
+    // 64 lanes through the CU's address unit, which bounds this kernel (the coordinate triples as 12-byte loads: 143 -> 136 us).
+    struct Ids { int mine, vs; };                             // neighbour id of slot l15; of slot lane >> 2
     auto load_ids = [&](unsigned pt) -> Ids {
         const unsigned pp = pt < (unsigned)n ? pt : last;
         Ids r;
         r.mine = *(const int *)((const char *)idx + (pp * K + l15) * 4u);
-        r.quad = *(const int4 *)((const char *)idx + (pp * K + 4 * q) * 4u);
+        r.vs = *(const int *)((const char *)idx + (pp * K + (lane >> 2)) * 4u);
         return r;
     };
-    struct Rows { float sx, sy, sz, px, py, pz, u0, u1; float vb[UT][4]; };
+    struct Rows { float sx, sy, sz, px, py, pz, u0, u1; float4 vq[UT]; };
     const unsigned u0off = 4u * g0, u1off = 4u * (g1 >= 0 ? g1 : g0);
     auto load_rows = [&](unsigned pt, const Ids &id, Rows &R) {
         const unsigned pp = pt < (unsigned)n ? pt : last;
@@ -141,14 +147,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
         const unsigned row = (pp * K + l15) * (4u * G);
         R.u0 = ldf(W1, row + u0off);
         R.u1 = ldf(W1, row + u1off);
-        const int qs[4] = {id.quad.x, id.quad.y, id.quad.z, id.quad.w};
+        // (a masked slot reads row 0: its weight -- the other operand -- is zero)
+        const unsigned vo = (unsigned)(id.vs >= 0 ? id.vs : 0) * (4u * C) + 16u * (lane & 3);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            // (a masked slot reads row 0: its weight -- the other operand -- is zero)
-            const unsigned vo = (unsigned)(qs[st] >= 0 ? qs[st] : 0) * (4u * C) + 4u * l15;
-#pragma unroll
-            for (int u = 0; u < UT; ++u) R.vb[u][st] = ldf(v, vo + 64u * u);
-        }
+        for (int i = 0; i < UT; ++i) R.vq[i] = *(const float4 *)((const char *)v + vo + 64u * i);
     };
 
     // The pipeline state lives in two register sets that swap roles every trip (the trip body is instantiated twice): as
@@ -188,6 +190,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
         const bool valid = mysrc >= 0;
         const float4 mypos = valid ? make_float4(R.sx - R.px, R.sy - R.py, R.sz - R.pz, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         sPos[wid][l15] = mypos;  // (every quarter writes the same record)
+#pragma unroll
+        for (int i = 0; i < UT; ++i) *(float4 *)(&sV[wid][(lane >> 2) * PV + 4 * (lane & 3) + 16 * i]) = R.vq[i];
         // ---- logits -> softmax over the 16 slots (= the lanes of a DPP row)
         const float y0 = fmaxf(__builtin_fmaf(scr0, g0 >= 0 ? R.u0 : 0.f, shr0), 0.f);
         const float y1 = fmaxf(__builtin_fmaf(scr1, g1 >= 0 ? R.u1 : 0.f, shr1), 0.f);
@@ -209,14 +213,6 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
                 so[r] = fp_row16_sum(wv[r]);
             }
         }
-        {
-            char *wrow = (char *)w + (ps * K + l15) * (4u * G);
-            *(float *)(wrow + u0off) = wv[0];                       // (4 q is a group in every quarter)
-            *(float *)(wrow + u1off) = g1 >= 0 ? wv[1] : wv[0];     // (u1off = u0off where 4 q + 1 is padding)
-            char *srow = (char *)sw + ps * (4u * G);                // (the 16 lanes of a quarter hold the same sums)
-            *(float *)(srow + u0off) = so[0];
-            *(float *)(srow + u1off) = g1 >= 0 ? so[1] : so[0];
-        }
         sWt[wid][(4 * q) * 17 + l15] = wv[0];
         sWt[wid][(4 * q + 1) * 17 + l15] = wv[1];
         if (l15 == 0) { sSw[wid][4 * q] = so[0]; sSw[wid][4 * q + 1] = so[1]; }
@@ -233,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
             for (int st = 0; st < 4; ++st) {
                 const float P = pe_act(abr[u].x, abr[u].y, abr[u].z, abr[u].w, pq[st].x, pq[st].y, pq[st].z);
                 accA = fp_mfma(wA[st], P, accA);
-                accV = fp_mfma(wA[st], R.vb[u][st], accV);
+                accV = fp_mfma(wA[st], sV[wid][(4 * q + st) * PV + 16 * u + l15], accV);
             }
             const int ch = 16 * u + l15;
             if (g0 >= 0) sA[wid][g0 * AP + ch] = accA[0];
@@ -243,6 +239,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
             if (q == (grp & 3)) sOv[wid][ch] = (2 * u >= 4) ? accV[1] : accV[0];
         }
         fp_wave_sync();
+        // ---- w (16 x 6 floats, contiguous per point) leaves as 24 16-byte pieces gathered from the transposed tile, sw as one
+        //      dword per lane (lane % 6): one store instruction each instead of two
+        {
+            const int pc = lane % 24;
+            float wq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * pc + i, sl = e / G, gg = e - sl * G;
+                wq[i] = sWt[wid][GR::vof(gg) * 17 + sl];
+            }
+            *(float4 *)((char *)w + ps * (4u * K * G) + 16u * pc) = make_float4(wq[0], wq[1], wq[2], wq[3]);
+            const int gs = lane % G;
+            *(float *)((char *)sw + ps * (4u * G) + 4u * gs) = sSw[wid][GR::vof(gs)];
+        }
         // ---- A (6 x 48 floats, contiguous per point) leaves from the LDS tile in 16-byte pieces: 72 of them
         {
             char *ap = (char *)A + ps * (4u * G * C);
