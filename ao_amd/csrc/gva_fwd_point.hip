@@ -12,7 +12,9 @@
 //   w          = mask softmax_s z         DPP row reductions; w and sw = sum_s w leave for the backward
 //   A (g,c')   = w^T (g,s) P (s,c'),  P = ReLU(a . pos + b)                12 matrix instructions; A leaves for the backward
 //                                                                          (operand of the Wp2 weight gradient)
-//   V (g,ch)   = w^T (g,s) v[idx] (s,ch)                                   12 matrix instructions; out_v[ch] = V (ch / 8, ch)
+//   out_v[o]   = sum_s w[s, o / 8] v[idx[s], o]                            lane = o, 16 FMAs from the two LDS tiles (as the
+//                                                                          product w^T v it was 12 more matrix instructions for
+//                                                                          a six-fold redundant tile: 135 -> 125 us)
 //   out[o]     = out_v[o] + <A (o / 8, :), Wp2 (o, :)> + bp2[o] sw[o / 8]  lane = o, its Wp2 row in 48 registers
 // w^T is the one transpose (through a wave-private LDS tile, as in the backward).  A workgroup owns whole 64-row blocks (a
 // wavefront 16 consecutive points of each), so the column statistics of `out` for the BatchNorm behind the attention
@@ -68,7 +70,6 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
     __shared__ float4 sPos[4][K];                                     // (pos.xyz, neighbour id) of the wavefront's point
     __shared__ float sWt[4][16 * 17];                                 // w^T (row, slot)
     __shared__ __attribute__((aligned(16))) float sA[4][G * AP];      // A (g, c')
-    __shared__ float sOv[4][C];
     __shared__ float sSw[4][16];
     __shared__ float sS[3][4][C];                                     // statistics exchange
     constexpr int PV = 52;                                            // (4 PV = 16 mod 64: the four quarters read disjoint banks)
@@ -224,19 +225,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
         for (int st = 0; st < 4; ++st) { wA[st] = sWt[wid][l15 * 17 + 4 * q + st]; pq[st] = sPos[wid][4 * q + st]; }
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
-            fp_v4f accA = (fp_v4f){0.f, 0.f, 0.f, 0.f}, accV = (fp_v4f){0.f, 0.f, 0.f, 0.f};
+            fp_v4f accA = (fp_v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const float P = pe_act(abr[u].x, abr[u].y, abr[u].z, abr[u].w, pq[st].x, pq[st].y, pq[st].z);
                 accA = fp_mfma(wA[st], P, accA);
-                accV = fp_mfma(wA[st], sV[wid][(4 * q + st) * PV + 16 * u + l15], accV);
             }
             const int ch = 16 * u + l15;
             if (g0 >= 0) sA[wid][g0 * AP + ch] = accA[0];
             if (g1 >= 0) sA[wid][g1 * AP + ch] = accA[1];
-            // out_v[ch] is V (ch / 8, ch): group 2 u + (l15 >> 3) lives in quarter (group & 3), register group >> 2
-            const int grp = 2 * u + (l15 >> 3);
-            if (q == (grp & 3)) sOv[wid][ch] = (2 * u >= 4) ? accV[1] : accV[0];
         }
         fp_wave_sync();
         // ---- w (16 x 6 floats, contiguous per point) leaves as 24 16-byte pieces gathered from the transposed tile, sw as one
@@ -274,7 +271,14 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_point6_kernel(
                 acc = __builtin_fmaf(t4.z, wp2r[4 * j + 2], acc);
                 acc = __builtin_fmaf(t4.w, wp2r[4 * j + 3], acc);
             }
-            const float val = sOv[wid][o] + acc + bpo * sSw[wid][GR::vof(go)];
+            // out_v[o] = sum_s w[s, o / 8] v[idx[s], o] on the vector ALU, in the layout the projection wants it: as a matrix
+            // product (w^T v, twelve instructions for the six-fold redundant (g, ch) tile) it cost 384 cycles of a matrix pipe
+            // this kernel does not overlap with anything (profiles/HISTORY.md)
+            const float *wt = &sWt[wid][GR::vof(go) * 17], *vc = &sV[wid][o];
+            float ov = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < K; ++sl) ov = __builtin_fmaf(wt[sl], vc[sl * PV], ov);
+            const float val = ov + acc + bpo * sSw[wid][GR::vof(go)];
             *(float *)((char *)out + ps * (4u * C) + 4u * o) = val;  // (lanes 48..63 repeat lane 0)
             if (STATS) {
                 if ((t & 15) == 0) { st_c = val; st_s1 = 0.f; st_s2 = 0.f; }
