@@ -432,9 +432,28 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                 gwT[0][r] = t;
             }
         }
+        // (a, b) of a chunk's four channels are requested from LDS a whole chunk ahead (one-tile instances): read one channel
+        // ahead, as the compiler arranges it, every product waited ~60 cycles for its LDS read -- the chain ran at twice the
+        // matrix pipe's period (timing-only builds: 3.6 us per matrix instruction and launch)
+        constexpr bool AB_AHEAD = GT == 1;
+        float4 abn[4];
+        if constexpr (AB_AHEAD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) abn[e] = sAB[chq + e];
+        }
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
             const int slot = ci % PD;
+            float4 abc[4];
+            if constexpr (AB_AHEAD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) abc[e] = abn[e];
+                if (ci + 1 < NCH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) abn[e] = sAB[chq + 16 * (ci + 1) + e];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the four reads back to their uses)
+            }
             const float4 vv = VFMA ? make_float4(0.f, 0.f, 0.f, 0.f) : rvv[slot];
             float4 ga4[GT];
 #pragma unroll
@@ -445,7 +464,7 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = chq + 16 * ci + e;
-                const float4 ab = sAB[ch];
+                const float4 ab = AB_AHEAD ? abc[e] : sAB[ch];
                 const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
                 const int gi = ch / I;
 #pragma unroll
