@@ -487,11 +487,26 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                 const int gv = 16 * tg + 4 * q + r, g = GR::gof(gv);
                 bvrow[tg][r] = local ? myGA + gv * C + c0 + l15 : ((act && g >= 0) ? g_A + (pt * G + g) * C + c0 + l15 : zpad);
             }
+        // One-tile local instances: all UT * RN operands (and the tiles' (a, b)) are read from LDS up front, behind a scheduling
+        // barrier -- the scheduler otherwise sinks each read to the matrix instruction that uses it, which then waits an LDS
+        // latency: six instructions cost 17.6 us per launch at (6, 48) (timing-only build)
+        constexpr bool BV_UPFRONT = LOCAL && GT == 1 && UT <= 3;
+        float bvall[BV_UPFRONT ? UT : 1][4];
+        float4 abt[BV_UPFRONT ? UT : 1];
+        if constexpr (BV_UPFRONT) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+#pragma unroll
+                for (int r = 0; r < RN; ++r) bvall[u][r] = bvrow[0][r][16 * u];
+                abt[u] = sAB[c0 + 16 * u + l15];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float bvn[GT][4];
 #pragma unroll
         for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-            for (int r = 0; r < RN; ++r) bvn[tg][r] = bvrow[tg][r][0];
+            for (int r = 0; r < RN; ++r) bvn[tg][r] = BV_UPFRONT ? 0.f : bvrow[tg][r][0];
 #pragma unroll
         for (int u = 0; u < UT; ++u) {
             const int ch = c0 + 16 * u + l15;
@@ -499,8 +514,8 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
-                for (int r = 0; r < RN; ++r) bv[tg][r] = bvn[tg][r];
-            if (u + 1 < UT) {
+                for (int r = 0; r < RN; ++r) bv[tg][r] = BV_UPFRONT ? bvall[BV_UPFRONT ? u : 0][r] : bvn[tg][r];
+            if (!BV_UPFRONT && u + 1 < UT) {
 #pragma unroll
                 for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
@@ -511,7 +526,7 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
             for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
                 for (int r = 0; r < RN; ++r) d = mfma4(wm[tg][r], bv[tg][r], d);
-            const float4 ab = sAB[ch];
+            const float4 ab = BV_UPFRONT ? abt[BV_UPFRONT ? u : 0] : sAB[ch];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float P = pe_act(ab.x, ab.y, ab.z, ab.w, rp[r].x, rp[r].y, rp[r].z);
