@@ -577,6 +577,18 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                 gz[tg][r] = rowok ? sm[tg][r] * (gm - dot) : 0.f;
             }
         }
+        // ---- the (g,s) tiles of gz and y go to LDS here, transposed, for the gWw2 product at the end of the trip (written
+        //      right in front of it, its reads waited a whole LDS round trip for them); gbw2 += sum_s gz
+        if (sub == 0) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int r = 0; r < RN; ++r) {
+                    sGz[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = gz[t][r];
+                    sY[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = y[t][r];
+                    gbw[t][r] += gz[t][r];
+                }
+        }
         // ---- gy^T (j,s) = Ww2^T gz^T for my j tiles -> gW1, gsc, gsh
 #pragma unroll
         for (int lt = 0; lt < LT; ++lt) {
@@ -627,17 +639,7 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                 if (j0 + 2 < G) *(float2 *)(gW1 + row * G + j0 + 2) = make_float2(o[2], o[3]);
             }
         }
-        // ---- gWw2 (g,j) += gz^T y, gbw2 += sum_s gz: contraction over s needs the (g,s) tiles transposed
-        if (sub == 0) {
-#pragma unroll
-            for (int t = 0; t < GT; ++t)
-#pragma unroll
-                for (int r = 0; r < RN; ++r) {
-                    sGz[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = gz[t][r];
-                    sY[(p * G16 + 16 * t + 4 * q + r) * 17 + l15] = y[t][r];
-                    gbw[t][r] += gz[t][r];
-                }
-        }
+        // ---- gWw2 (g,j) += gz^T y: contraction over s, from the (g,s) tiles transposed through LDS (written above)
         point_sync();
 #pragma unroll
         for (int e = 0; e < NTW; ++e) {
