@@ -287,6 +287,20 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
 #pragma unroll
         for (int j = 0; j < C; ++j) wp2c[j] = sWp2[j * C + (lane < C ? lane : 0)];
     }
+    // one-tile instances: the parameter operands of the logits re-evaluation (scale / shift / bias of my rows, my Ww2 row, the
+    // Ww2 column pieces of the gy product) are loop-invariant per lane: registers instead of five LDS reads per point
+    constexpr bool PAR_REGS = GT == 1 && RN <= 2;  // (G = 12: the DROP instance spills at 256 registers)
+    float pSc[4], pSh[4], pBw[4], pW[4], pWg[4];
+    if constexpr (PAR_REGS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pSc[r] = r < RN ? sSc[4 * q + r] : 0.f;
+            pSh[r] = r < RN ? sSh[4 * q + r] : 0.f;
+            pBw[r] = r < RN ? sBw[4 * q + r] : 0.f;
+            pW[r] = r < RN ? sWw[l15 * GPW + 4 * q + r] : 0.f;
+            pWg[r] = r < RN ? sWw[(4 * q + r) * GPW + l15] : 0.f;
+        }
+    }
     int cur = 0;
     for (long long base = (long long)blockIdx.x * PW; base < n; base += stride, cur ^= 1) {
         const long long pt = base + p;
@@ -378,7 +392,8 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
 #pragma unroll
         for (int t = 0; t < GT; ++t) {
             const int j0 = 16 * t + 4 * q;
-            const float4 s4 = *(const float4 *)(sSc + j0), h4 = *(const float4 *)(sSh + j0);
+            const float4 s4 = PAR_REGS ? make_float4(pSc[0], pSc[1], pSc[2], pSc[3]) : *(const float4 *)(sSc + j0);
+            const float4 h4 = PAR_REGS ? make_float4(pSh[0], pSh[1], pSh[2], pSh[3]) : *(const float4 *)(sSh + j0);
             y[t][0] = fmaxf(__builtin_fmaf(s4.x, u1[t][0], h4.x), 0.f);
             y[t][1] = fmaxf(__builtin_fmaf(s4.y, u1[t][1], h4.y), 0.f);
             y[t][2] = fmaxf(__builtin_fmaf(s4.z, u1[t][2], h4.z), 0.f);
@@ -391,13 +406,13 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
             v4f z = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < GT; ++t) {
-                const float4 w4 = *(const float4 *)(sWw + (16 * tg + l15) * GPW + 16 * t + 4 * q);
+                const float4 w4 = PAR_REGS ? make_float4(pW[0], pW[1], pW[2], pW[3]) : *(const float4 *)(sWw + (16 * tg + l15) * GPW + 16 * t + 4 * q);
                 z = mfma4(w4.x, y[t][0], z);
                 z = mfma4(w4.y, y[t][1], z);
                 if (RN > 2) z = mfma4(w4.z, y[t][2], z);
                 if (RN > 3) z = mfma4(w4.w, y[t][3], z);
             }
-            const float4 b4 = *(const float4 *)(sBw + 16 * tg + 4 * q);
+            const float4 b4 = PAR_REGS ? make_float4(pBw[0], pBw[1], pBw[2], pBw[3]) : *(const float4 *)(sBw + 16 * tg + 4 * q);
             const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int r = RN; r < 4; ++r) sm[tg][r] = wm[tg][r] = 0.f;
@@ -601,8 +616,8 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                 for (int tg = 0; tg < GT; ++tg)
 #pragma unroll
                     for (int r = 0; r < RN; ++r)
-                        gy = mfma4(sWw[(16 * tg + 4 * q + r) * GPW + 16 * tj + l15], gz[tg][r], gy);
-                const float4 s4 = *(const float4 *)(sSc + j0);
+                        gy = mfma4(PAR_REGS ? pWg[r] : sWw[(16 * tg + 4 * q + r) * GPW + 16 * tj + l15], gz[tg][r], gy);
+                const float4 s4 = PAR_REGS ? make_float4(pSc[0], pSc[1], pSc[2], pSc[3]) : *(const float4 *)(sSc + j0);
                 const float scv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
                 for (int r = 0; r < RN; ++r) {
