@@ -451,6 +451,10 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
         // ahead, as the compiler arranges it, every product waited ~60 cycles for its LDS read -- the chain ran at twice the
         // matrix pipe's period (timing-only builds: 3.6 us per matrix instruction and launch)
         constexpr bool AB_AHEAD = GT == 1;
+#ifndef GVA_AB_BATCH
+#define GVA_AB_BATCH 1
+#endif
+        constexpr bool AB_BATCH = GVA_AB_BATCH && GT > 1;
         float4 abn[4];
         if constexpr (AB_AHEAD) {
 #pragma unroll
@@ -468,6 +472,12 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
                     for (int e = 0; e < 4; ++e) abn[e] = sAB[chq + 16 * (ci + 1) + e];
                 }
                 __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the four reads back to their uses)
+            } else if constexpr (AB_BATCH) {
+                // the wide instances have no registers for a chunk ahead: the chunk's own four reads as one batch at its top
+                // (one exposed LDS latency per chunk instead of one per channel)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) abc[e] = sAB[chq + 16 * ci + e];
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float4 vv = VFMA ? make_float4(0.f, 0.f, 0.f, 0.f) : rvv[slot];
             float4 ga4[GT];
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(256, G <= 32 ? 2 : 1) void attention_bwd_point_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ch = chq + 16 * ci + e;
-                const float4 ab = AB_AHEAD ? abc[e] : sAB[ch];
+                const float4 ab = (AB_AHEAD || AB_BATCH) ? abc[e] : sAB[ch];
                 const float P = pe_act(ab.x, ab.y, ab.z, ab.w, myp.x, myp.y, myp.z);
                 const int gi = ch / I;
 #pragma unroll
