@@ -18,6 +18,8 @@ for n, l in enumerate(body):
         sp = (labels[m.group(1)], n)
         if best is None or sp[1] - sp[0] > best[1] - best[0]: best = sp
 print('loop', best)
+if best is None:
+    sys.exit(0)  # (no loop in this kernel)
 last = None
 for n in range(best[0], best[1]):
     l = body[n]
