@@ -672,12 +672,13 @@ def child_main(args):
         _lib.kernel_timer(False)
         survey = _lib.kernel_timer_read()
         if survey:
-            # the timer id with the largest total time; ids within 20 % of it count as ties, broken in favour of the fewest
-            # launches -- the largest single kernel.  (Some ids bracket a family of kernel symbols -- the row GEMMs of one
+            # the largest single kernel: the timer id with the largest total time among those with at most 8 launches per step
+            # (and at least half the largest total).  Some ids bracket a family of kernel symbols -- the row GEMMs of one
             # column-block width, the BatchNorm reduce kernels -- whose 24-47 launches together reach the 0.52 ms of the three
-            # launches of the level-0 attention backward; rocprofv3's per-symbol table has that kernel first, and so has this.)
+            # launches of the level-0 attention backward; rocprofv3's per-symbol table has that kernel first, and so has this.
             top = max(v["total_us"] for v in survey.values())
-            dominant = min((kv for kv in survey.items() if kv[1]["total_us"] >= 0.80 * top), key=lambda kv: kv[1]["launches"])[0]
+            few = {k: v for k, v in survey.items() if v["launches"] <= 8 * survey_steps and v["total_us"] >= 0.5 * top}
+            dominant = max((few or survey).items(), key=lambda kv: kv[1]["total_us"])[0]
             # every stride-th launch of it: a uniform sample over the timed region.  ~6 bracketed launches per step (a bracket
             # costs ~3 us of queue time: bracketing all 52 weight-gradient launches of a step was 0.1 ms of it); the stride is
             # co-prime with the launches per step so that the sampled positions spread over all Blocks
