@@ -168,7 +168,9 @@ const char *kNames[KID_COUNT] = {
     "grouped_wgrad_kernel", "attention_fwd_point6_kernel",
     "logits_bwd_fused6_kernel<48>", "logits_bwd_fused_kernel<12, 96, 1>", "logits_bwd_fused_kernel<24, 192, 4>",
     "logits_bwd_fused_kernel<48, 384, 4>", "logits_bwd_fused_kernel<64, 512, 4>",
-    "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel"};
+    "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel",
+    "attention_fwd_tile_kernel<12, 96, 12>", "attention_fwd_tile_kernel<24, 192, 12>", "attention_fwd_tile_kernel<48, 384, 12>",
+    "attention_fwd_tile_kernel<64, 512, 16>"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;
@@ -212,7 +214,7 @@ __global__ void stamp_kernel(unsigned long long *p) {
 extern "C" int ptv2_profile_is_on(void) { return g_on; }
 int ptv2_profile_stamps(void) { return g_on && g_only >= 0 && g_stamp_buf != nullptr; }
 void ptv2_profile_scope(int which, int end, int ring_entry, int ring_size) {  // graph.hip: a captured body begins / ends on this thread
-    if (which < 0 || which > 1) return;
+    if (which < 0 || which >= GRAPH_SLOTS) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!end) {
         for (int k = 0; k < KID_COUNT; ++k) t_scope_seen[k] = 0;

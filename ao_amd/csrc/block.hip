@@ -17,6 +17,8 @@
 
 #include "common.h"
 
+size_t bn_tiles_floats_rb(int n, int c, int rb);  // dense.hip: statistics records of rb rows each
+
 namespace {
 
 inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -74,7 +76,8 @@ Work carve_work(void *base, int n, int k, int c, int g) {
     w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
     w.gva = take(w.gva_bytes);
     for (int i = 0; i < 7; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
-    for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * bn_tiles_floats(n, c));
+    // (stat[0] also takes the attention output's records, which the deep levels' tile kernel leaves per 16 rows)
+    for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * (i == 0 ? bn_tiles_floats_rb(n, c, 16) : bn_tiles_floats(n, c)));
     w.bytes = off;
     return w;
 }
@@ -171,17 +174,23 @@ static bool use_batch(const ptv2_block *B, int i) { return B->training || !B->ru
 
 // statistics of BatchNorm `i` (input h, (n,c)) -> S.mean / S.rstd / S.sc / S.sh: from the producing GEMM's epilogue
 // records (`part` != NULL), from a pass over h (`part` == NULL, batch statistics), or from the running buffers (eval)
+int bn_tiles_finalize_rb(int n, int c, int rb, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
+                         float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                         void *stream);
 int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
                            float *const *mean, float *const *rstd, float *const *sc, float *const *sh, float *const *running_mean,
                            float *const *running_var, long long *const *num_batches_tracked, float eps, float momentum,
                            void *stream);
 
 static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, const float *gamma, const float *beta,
-                      const Saved &S, const Work &W, void *stream) {
+                      const Saved &S, const Work &W, void *stream, int rb = 64) {
     if (use_batch(B, i)) {
         const bool track = B->training && B->run_mean[i] && B->run_var[i];
         float *rm = track ? B->run_mean[i] : nullptr, *rv = track ? B->run_var[i] : nullptr;
         long long *nb = track ? B->batches[i] : nullptr;
+        if (part && rb != 64)
+            return bn_tiles_finalize_rb(B->n, B->c, rb, part, gamma, beta, S.mean[i], S.rstd[i], S.bsc[i], S.bsh[i], rm, rv, nb, B->eps,
+                                        B->momentum, stream);
         if (part)
             return bn_tiles_finalize_hip_launcher(B->n, B->c, part, gamma, beta, S.mean[i], S.rstd[i], S.bsc[i], S.bsh[i], rm, rv,
                                                   nb, B->eps, B->momentum, stream);
@@ -258,12 +267,13 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     ptv2_gva_block V;
     fill_gva(B, S, &V);
     // (the attention's last stage leaves the tile statistics of its output where the matrix-core form of it runs: h1's
-    // record buffer is free by now)
+    // record buffer is free by now; attn_stats = rows per record, 0: none)
     int attn_stats = 0;
     RUN(gva_block_forward_stats(&V, use_batch(B, 5) ? W.stat[0] : nullptr, &attn_stats, W.gva, W.gva_bytes, stream));
     // norm2 (statistics from those records, else by a pass over attn) -> fc3 on f2 = ReLU(BN2(attn)) (+ statistics of h3)
     // -> norm3 -> tail
-    RUN(bn_prepare(B, 5, S.attn, attn_stats ? W.stat[0] : nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream));
+    RUN(bn_prepare(B, 5, S.attn, attn_stats ? W.stat[0] : nullptr, P[PTV2_BLK_N2_G], P[PTV2_BLK_N2_B], S, W, stream,
+                   attn_stats ? attn_stats : 64));
     {
         const float *xs[1] = {S.attn}, *ws[1] = {P[PTV2_BLK_FC3_W]};
         float *ys[1] = {S.h3}, *sts[1] = {st_h3};

@@ -26,7 +26,8 @@ enum PtvKernelId {
     KID_LOGITS_BWD_FUSED /* + 0..4 for G = 6, 12, 24, 48, 64: rows + parameter gradients of the logits stage in one launch */,
     KID_BN_BWD_APPLY_RES = KID_LOGITS_BWD_FUSED + 5 /* bn_bwd_apply_residual_kernel */,
     KID_BN_BWD_FINAPPLY /* bn_bwd_finapply_kernel<...>: record sum + apply in one launch */,
-    KID_COUNT
+    KID_FWD_TILE /* + 0..3 for G = 12, 24, 48, 64: softmax + aggregation + grouped projection per 16-point tile (gva_fwd_tile.hip) */,
+    KID_COUNT = KID_FWD_TILE + 4
 };
 extern "C" int ptv2_profile_is_on(void);
 int ptv2_profile_wants(int kid);

@@ -126,7 +126,12 @@ struct BnTileSet {
     const float *gamma, *beta;
     float *sc, *sh;
     double *fold;  // two-level scratch (bn_fold_tiles_kernel)
+    int rb;        // rows per record: 64 (the row GEMM's epilogue, the projection kernels) or 16 (gva_fwd_tile.hip); 0 = 64
 };
+__device__ __forceinline__ int bn_tile_rows(const BnTileSet &S, int k, int n) {  // rows of record k
+    const int rb = S.rb ? S.rb : 64;
+    return (n - k * rb) < rb ? (n - k * rb) : rb;
+}
 
 __device__ __forceinline__ void bn_tiles_emit(const BnTileSet &S, int ch, double t1, double t2, int n, float eps, float momentum) {
     const double m = t1 / n;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, Bn
     double a = 0.0, b = 0.0, a2 = 0.0, b2 = 0.0;
     if (ch < c) {
         auto rec = [&](int k, double &sa, double &sq) {
-            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const int cnt = bn_tile_rows(S, k, n);
             const double sb = (double)part[(size_t)k * 2 * c + ch];
             sa += sb;
             sq += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_kernel(BnTileSet A, Bn
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int kk = k + u * SLICES;
-                const int cnt = (n - kk * 64) < 64 ? (n - kk * 64) : 64;
+                const int cnt = bn_tile_rows(S, kk, n);
                 const double sb = (double)s[u];
                 if (u & 1) { a2 += sb; b2 += (double)m[u] + sb * sb / (double)cnt; }
                 else { a += sb; b += (double)m[u] + sb * sb / (double)cnt; }
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_tiles_split_kernel(BnTileSet
     double a = 0.0, b = 0.0;
     if (ch < c) {
         for (int k = blockIdx.y * SLICES + sl; k < nrb; k += BNT_NS * SLICES) {
-            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const int cnt = bn_tile_rows(S, k, n);
             const double sb = (double)part[(size_t)k * 2 * c + ch];
             a += sb;
             b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
@@ -1416,7 +1421,7 @@ __global__ __launch_bounds__(gva::FIN_COLS *gva::FIN_SLICES) void bn_fold_tiles_
     double a = 0.0, b = 0.0;
     if (ch < c) {
         for (int k = blockIdx.y * gva::FIN_SLICES + sl; k < nrb; k += gridDim.y * gva::FIN_SLICES) {
-            const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+            const int cnt = bn_tile_rows(S, k, n);
             const double sb = (double)part[(size_t)k * 2 * c + ch];
             a += sb;
             b += (double)part[(size_t)k * 2 * c + c + ch] + sb * sb / (double)cnt;
@@ -1449,12 +1454,16 @@ __global__ void bn_finalize_folded_kernel(BnTileSet A, BnTileSet B, int nrec, in
 extern "C" size_t bn_tiles_floats(int n, int c) {  // floats of a statistics record buffer (incl. the folding scratch)
     return (size_t)((n + 63) / 64) * 2 * c + 2 + 2 * (size_t)16 * 2 * c;
 }
+size_t bn_tiles_floats_rb(int n, int c, int rb) {  // the same for records of rb rows
+    return (size_t)((n + rb - 1) / rb) * 2 * c + 2 + 2 * (size_t)16 * 2 * c;
+}
 
 // count (1 or 2) tensors of one shape in one launch (two for > 512 records: fold, then finish)
-static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, float eps, float momentum, void *stream) {
-    const int nrb_all = (n + 63) / 64;
+static int bn_tiles_finalize_sets(int n, int c, int count, BnTileSet *sets, float eps, float momentum, void *stream, int rb = 64) {
+    const int nrb_all = (n + rb - 1) / rb;
     for (int i = 0; i < count; ++i) {
         BnTileSet &S = sets[i];
+        S.rb = rb;
         if (!S.part || !S.mean || !S.rstd || ((S.sc != nullptr) && (!S.gamma || !S.beta || !S.sh))) return PTV2_ERR_ARG;
         // the folded records live behind the tile records (the GEMM wrote nrb * 2c floats; 16 * 2c doubles more are reserved)
         S.fold = (double *)(const_cast<float *>(S.part) + (((size_t)nrb_all * 2 * c + 1) & ~(size_t)1));
@@ -1493,8 +1502,16 @@ extern "C" int bn_tiles_finalize_hip_launcher(int n, int c, float *part, const f
                                               float *running_var, long long *num_batches_tracked, float eps, float momentum,
                                               void *stream) {
     if (n < 1 || c < 4) return PTV2_ERR_ARG;
-    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr};
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr, 64};
     return bn_tiles_finalize_sets(n, c, 1, &S, eps, momentum, stream);
+}
+// internal (block.hip): records of rb rows each (bn_tiles_floats_rb floats) -- the attention's tile kernel leaves 16-row records
+int bn_tiles_finalize_rb(int n, int c, int rb, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
+                         float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                         void *stream) {
+    if (n < 1 || c < 4 || (rb != 16 && rb != 64)) return PTV2_ERR_ARG;
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr, rb};
+    return bn_tiles_finalize_sets(n, c, 1, &S, eps, momentum, stream, rb);
 }
 
 // two tensors of one shape (internal to the block runtime: the q / k BatchNorms); arrays of 2
@@ -1506,7 +1523,7 @@ int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const 
     BnTileSet S[2];
     for (int i = 0; i < 2; ++i)
         S[i] = BnTileSet{part[i], mean[i], rstd[i], running_mean[i], running_var[i], num_batches_tracked[i], gamma[i], beta[i], sc[i],
-                         sh[i], nullptr};
+                         sh[i], nullptr, 64};
     return bn_tiles_finalize_sets(n, c, 2, S, eps, momentum, stream);
 }
 

@@ -309,6 +309,10 @@ int gva_fwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                          const float *Wp2, const float *bp2, float *w, float *sw, float *A, float *out, float *stats,
                          void *stream);
+int gva_fwd_tile_supported(int k, int c, int g);
+int gva_fwd_tile_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                        const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
+                        const float *Wp2, const float *bp2, float *w, float *sw, float *out, float *stats, float *a_out, void *stream);
 int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const float *b, const float *M, const float *coord,
                               const int *idx, const float *W1, const float *gW1, const double *gT1, const double *gT2,
                               const gva::FoldWBwdArgs &F, const int *inv_ptr, const int *inv_rows, float *gkW, float *gqW, float *ga,
@@ -450,8 +454,9 @@ extern "C" int gva_block_forward_hip_launcher(const ptv2_gva_block *B, void *wor
     return gva_block_forward_stats(B, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
-// internal (block.hip): out_stats != NULL asks the last stage for the per-64-row-block column statistics of `out` (the
-// BatchNorm behind the attention then needs no statistics pass); *stats_done says whether they were produced
+// internal (block.hip): out_stats != NULL asks the last stage for the column statistics of `out` per block of rows (the
+// BatchNorm behind the attention then needs no statistics pass); *stats_done = rows per record (64, or 16 from the tile
+// kernel: the buffer holds bn_tiles_floats_rb(n, c, 16) floats), 0 when none were produced
 int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
                             void *stream) {
     if (stats_done) *stats_done = 0;
@@ -485,7 +490,12 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
         !getenv("AO_AMD_FWD_STAGED")) {
         RUN(gva_fwd_point_launch(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx, B->Wp2, B->bp2,
                                  B->w, B->sw, B->A, B->out, out_stats, stream));
-        if (out_stats && stats_done) *stats_done = 1;
+        if (out_stats && stats_done) *stats_done = 64;
+    } else if (gva_fwd_tile_supported(k, c, g) && !gva::ptv2_attn_drop_current().thresh && !getenv("AO_AMD_FWD_STAGED")) {
+        // the deep levels: one launch per 16-point tile x group block (gva_fwd_tile.hip); no out_v, no A
+        RUN(gva_fwd_tile_launch(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx, B->Wp2, B->bp2,
+                                B->w, B->sw, B->out, out_stats, B->A, stream));
+        if (out_stats && stats_done) *stats_done = 16;
     } else {
         RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
                                                B->idx, W.out_v, B->A, B->sw, B->w, stream));

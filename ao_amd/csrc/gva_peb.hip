@@ -414,7 +414,7 @@ int gva_peb_forward_stats(int n, int c, int g, const float *A, const float *Wp2,
             case 384: launch_peb_mfma<384>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
             default: launch_peb_mfma<512>(n, g, A, Wp2, bp2, sw, out_v, out, stats, st); break;
         }
-        if (stats && stats_done) *stats_done = 1;
+        if (stats && stats_done) *stats_done = 64;
         PTV2_CHECK_LAUNCH();
         return PTV2_OK;
     }

@@ -54,6 +54,7 @@ _SIG = {
     "gva_block_backward_hip_launcher": (_lib._c_int, [_lib._vp, _lib._vp, _lib._vp, _lib._c_size, _lib._vp]),
     "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
     "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
+    "gva_attention_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 17),
 }
 _lib.register(_SIG)
 

@@ -290,6 +290,15 @@ int gva_peb_forward_hip_launcher(int n, int c, int g, const float *A, const floa
                                  const float *sw, const float *out_v, float *out, void *stream);
 int gva_peb_backward_hip_launcher(int n, int c, int g, const float *g_out, const float *Wp2,
                                   const float *bp2, float *g_A, float *g_sw, void *stream);
+/* The two stages above and the projection as ONE launch (ao_amd/csrc/gva_fwd_tile.hip; k = 16 and (g, c) one of (12, 96),
+ * (24, 192), (48, 384), (64, 512) -- the deep levels of PT-v2m2; PTV2_ERR_ARG otherwise): a workgroup owns 16 points x a block
+ * of groups, A = w^T P lives in LDS per 16-channel chunk, Wp2 is streamed once per tile.  Writes w (n,k,g), sw (n,g) and
+ * out (n,c) = sum_s w v[idx] + A Wp2^T (grouped) + bp2 sw -- GroupedVectorAttention.forward :122-129 behind the folded
+ * positional encoding.  A (n,g,c) is written only when A != NULL (the staged backward reads it). */
+int gva_attention_forward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                       const float *Ww2, const float *bw2, const float *v, const float *a,
+                                       const float *b, const float *coord, const int *idx, const float *Wp2,
+                                       const float *bp2, float *w, float *sw, float *out, float *A, void *stream);
 
 /* ------------------------------------------ whole attention block, one call --
  * GroupedVectorAttention.forward / backward (point_transformer_v2m2_base.py:103-129) behind ONE launcher each:

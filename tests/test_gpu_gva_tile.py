@@ -1,0 +1,99 @@
+"""GPU: the deep-level fused attention forward (ao_amd/csrc/gva_fwd_tile.hip) against the three staged launches it replaces.
+
+Reference op: GroupedVectorAttention.forward, point_transformer_v2m2_base.py:103-129.  The staged launchers
+(gva_aggregate_forward: softmax + aggregation, gva_peb_forward: grouped projection) are pinned by the reference-module
+fixtures (tests/test_gpu_model.py); here the one-launch form must reproduce their w, sw, A and out on the same inputs,
+including clouds shorter than K (masked -1 slots) and point counts that are not multiples of the 16-point tile."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(n, c, g, seed):
+    from ao_amd import pointops, synth
+
+    k = 16
+    sizes = [n] if n < 40 else [n - 30, 9, 21]
+    coord = torch.from_numpy(np.concatenate([synth.room_cloud(max(m, 64), seed=seed + i)[:m] for i, m in enumerate(sizes)])).cuda()
+    offset = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device="cuda")
+    idx, _ = pointops.knn_query(k, coord, offset)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=gen)
+    return dict(k=k, coord=coord, idx=idx.contiguous(), W1=r(n, k, g), sc=0.5 + r(g).abs(), sh=0.3 * r(g), Ww2=r(g, g) / g ** 0.5,
+                bw2=0.1 * r(g), v=r(n, c), a=2.0 * r(c, 3), b=0.2 * r(c), Wp2=r(c, c) / c ** 0.5, bp2=0.1 * r(c))
+
+
+def _staged(t, n, c, g):
+    from ao_amd import _lib
+    import ao_amd.ptv2.gva  # noqa: F401
+
+    L = _lib.lib()
+    k = t["k"]
+    dev = t["v"].device
+    out_v = torch.empty(n, c, device=dev)
+    A = torch.empty(n, g, c, device=dev)
+    sw = torch.empty(n, g, device=dev)
+    w = torch.empty(n, k, g, device=dev)
+    out = torch.empty(n, c, device=dev)
+    _lib.check(L.gva_aggregate_forward_hip_launcher(
+        n, k, c, g, t["W1"].data_ptr(), t["sc"].data_ptr(), t["sh"].data_ptr(), t["Ww2"].data_ptr(), t["bw2"].data_ptr(),
+        t["v"].data_ptr(), t["a"].data_ptr(), t["b"].data_ptr(), t["coord"].data_ptr(), t["idx"].data_ptr(), out_v.data_ptr(),
+        A.data_ptr(), sw.data_ptr(), w.data_ptr(), _lib.stream_ptr()), "gva_aggregate_forward_hip_launcher")
+    _lib.check(L.gva_peb_forward_hip_launcher(n, c, g, A.data_ptr(), t["Wp2"].data_ptr(), t["bp2"].data_ptr(), sw.data_ptr(),
+                                              out_v.data_ptr(), out.data_ptr(), _lib.stream_ptr()), "gva_peb_forward_hip_launcher")
+    return w, sw, A, out
+
+
+def _fused(t, n, c, g, want_a):
+    from ao_amd import _lib
+    import ao_amd.ptv2.gva  # noqa: F401
+
+    L = _lib.lib()
+    k = t["k"]
+    dev = t["v"].device
+    A = torch.full((n, g, c), float("nan"), device=dev) if want_a else None
+    sw = torch.full((n, g), float("nan"), device=dev)
+    w = torch.full((n, k, g), float("nan"), device=dev)
+    out = torch.full((n, c), float("nan"), device=dev)
+    _lib.check(L.gva_attention_forward_hip_launcher(
+        n, k, c, g, t["W1"].data_ptr(), t["sc"].data_ptr(), t["sh"].data_ptr(), t["Ww2"].data_ptr(), t["bw2"].data_ptr(),
+        t["v"].data_ptr(), t["a"].data_ptr(), t["b"].data_ptr(), t["coord"].data_ptr(), t["idx"].data_ptr(), t["Wp2"].data_ptr(),
+        t["bp2"].data_ptr(), w.data_ptr(), sw.data_ptr(), out.data_ptr(), A.data_ptr() if want_a else 0, _lib.stream_ptr()),
+        "gva_attention_forward_hip_launcher")
+    return w, sw, A, out
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("c,g", [(96, 12), (192, 24), (384, 48), (512, 64)])
+@pytest.mark.parametrize("n", [4501, 1074, 129, 48, 17, 16, 5])
+def test_tile_forward_equals_the_staged_launches(n, c, g):
+    t = _inputs(n, c, g, seed=11 + n % 7)
+    if n < 40:
+        assert int((t["idx"] < 0).sum()) > 0 or n >= 16  # clouds shorter than K carry -1 slots
+    ws, sws, As, outs = _staged(t, n, c, g)
+    for want_a in (True, False):
+        wf, swf, Af, outf = _fused(t, n, c, g, want_a)
+        torch.cuda.synchronize()
+        assert torch.isfinite(wf).all() and torch.isfinite(swf).all() and torch.isfinite(outf).all()
+        # the fused softmax uses the hardware exp2 / reciprocal (1e-6 relative) and sums in another order
+        assert float((wf - ws).abs().max()) < 5e-6, float((wf - ws).abs().max())
+        assert float((swf - sws).abs().max()) < 1e-5
+        assert _rel(outf, outs) < 5e-6, _rel(outf, outs)
+        assert float((outf - outs).abs().max()) < 2e-4 * float(outs.abs().max())
+        if want_a:
+            assert torch.isfinite(Af).all()
+            assert _rel(Af, As) < 5e-6, _rel(Af, As)
+
+
+def test_tile_forward_rejects_other_shapes():
+    from ao_amd import _lib
+
+    t = _inputs(64, 48, 6, seed=3)
+    with pytest.raises(RuntimeError, match="PTV2_ERR_ARG"):
+        _fused(t, 64, 48, 6, False)
+    assert _lib.lib().gva_attention_forward_hip_launcher(0, 16, 96, 12, *([1] * 15), 0, 0) == 0  # n = 0: nothing to do
