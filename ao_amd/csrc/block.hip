@@ -18,6 +18,7 @@
 #include "common.h"
 
 size_t bn_tiles_floats_rb(int n, int c, int rb);  // dense.hip: statistics records of rb rows each
+int gva_block_keeps_A(int k, int c, int g);        // gva_block.hip
 
 namespace {
 
@@ -51,7 +52,9 @@ Saved carve_saved(void *base, int n, int k, int c, int g) {
     s.a = (float *)take(sizeof(float) * 3 * c); s.b = (float *)take(sizeof(float) * c);
     s.rstd_p = (float *)take(sizeof(float) * c); s.M = (float *)take(sizeof(float) * (size_t)c * g);
     s.cW = (float *)take(sizeof(float) * g); s.kW = (float *)take(ng); s.qW = (float *)take(ng);
-    s.W1 = (float *)take(rows); s.w = (float *)take(rows); s.A = (float *)take(sizeof(float) * (size_t)n * g * c);
+    // (A (n,g,c) only where the attention forward of this shape writes it: not at the deep levels' tile path)
+    s.W1 = (float *)take(rows); s.w = (float *)take(rows);
+    s.A = gva_block_keeps_A(k, c, g) ? (float *)take(sizeof(float) * (size_t)n * g * c) : nullptr;
     s.sw = (float *)take(ng); s.sc = (float *)take(sizeof(float) * g); s.sh = (float *)take(sizeof(float) * g);
     s.mean_w = (double *)take(sizeof(double) * g); s.rstd_w = (double *)take(sizeof(double) * g);
     s.bytes = off;

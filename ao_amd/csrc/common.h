@@ -27,7 +27,8 @@ enum PtvKernelId {
     KID_BN_BWD_APPLY_RES = KID_LOGITS_BWD_FUSED + 5 /* bn_bwd_apply_residual_kernel */,
     KID_BN_BWD_FINAPPLY /* bn_bwd_finapply_kernel<...>: record sum + apply in one launch */,
     KID_FWD_TILE /* + 0..3 for G = 12, 24, 48, 64: softmax + aggregation + grouped projection per 16-point tile (gva_fwd_tile.hip) */,
-    KID_COUNT = KID_FWD_TILE + 4
+    KID_WGRAD_TILE = KID_FWD_TILE + 4 /* the grouped projection's weight gradient with A recomputed (gva_wgrad_tile.hip) */,
+    KID_COUNT
 };
 extern "C" int ptv2_profile_is_on(void);
 int ptv2_profile_wants(int kid);

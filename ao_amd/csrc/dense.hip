@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "gva_common.h"
+#include "wgrad_job.h"
 
 namespace dense {
 
@@ -995,19 +996,6 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_lds_kernel(int n, int cout, 
 // all, workgroup -> (job, chunk, tile, product) through a job table in device memory, followed by ONE finalize over the
 // records of all jobs.  Kernels, tile order and record layout are those of the per-call launch; a filed job's row chunks are
 // longer (wg_chunk: the other jobs fill the GPU), so its sums agree with the per-call launch's to ~2e-6 of the gradient's norm.
-struct WgradJob {
-    int n, cout, cin, tiles_i, tiles, batch, chunk, chunks;
-    int wg0;          // first workgroup of the job in the batched launch
-    int has_pb, count;  // bias sums behind the weight records; > 0: the multi form (operand pairs per product)
-    int rec, fin0;    // floats per chunk record; first element of the job in the batched finalize
-    int wgs, gw;      // workgroups of the job; (grouped form) groups per workgroup
-    int fin_lanes;    // record groups per output element in the batched finalize (1, or 4: the wavefronts of a workgroup)
-    long long ldy, sy, ldx, sx, lds_s;
-    const float *gY, *X, *rowscale;
-    float *part;
-    const float *mgY[6], *mX[6], *mxsc[6], *mxsh[6];
-    float *dW, *db, *mdW[6], *mdb[6];  // finalize: strided form -> dW (batch * cout * cin) then db; multi form -> per product
-};
 constexpr int WGRAD_PACK = 8;  // jobs per table-writer launch (by value: the kernarg block holds 4 KB)
 struct WgradJobPack { WgradJob j[WGRAD_PACK]; };
 static_assert(sizeof(WgradJobPack) + 16 <= 4096, "the table writer's argument block must fit the 4 KB kernarg segment");
@@ -1814,15 +1802,22 @@ int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy
 }
 
 // ---- deferred weight-gradient launches (see WgradJob) ----------------------------------------------------------------------
+// gva_wgrad_tile.hip
+int gva_wgrad_tile_supported(int k, int c, int g);
+size_t gva_wgrad_tile_plan(dense::WgradJob *J, int max_splits);
+int gva_wgrad_tile_launch_one(const dense::WgradJob &J, hipStream_t st);
+int gva_wgrad_tile_launch_jobs(const dense::WgradJob *table, int njobs, int wgs, hipStream_t st);
 namespace {
+constexpr int WGRAD_FORMS = 6;
 struct WgradDefer {
     bool active = false;
     bool armed = false;          // the call in progress may be filed (set by the call sites whose operands outlive their Block)
     bool armed_rs = false;       // ... the row-scaled strided form (the grouped projection's weight gradient inside the attention)
     char *arena = nullptr;       // [job table RS = 0 | job table RS = 1 | kept operands and chunk records]
     size_t cap = 0, used = 0;
-    std::vector<WgradJob> jobs[5];  // filed since the last flush, per kernel form: LDS-staged (RS = 0 / 1), direct fp32, direct bf16, grouped
-    double bytes[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // their algorithmic bytes (kernel timer)
+    // filed since the last flush, per kernel form: LDS-staged (RS = 0 / 1), direct fp32, direct bf16, grouped, grouped with A recomputed
+    std::vector<WgradJob> jobs[WGRAD_FORMS];
+    double bytes[WGRAD_FORMS] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // their algorithmic bytes (kernel timer)
 };
 thread_local WgradDefer g_wdefer;
 constexpr int WGRAD_MAX_JOBS = 64;
@@ -1831,12 +1826,12 @@ constexpr size_t WGRAD_TABLE_BYTES = (sizeof(WgradJob) * WGRAD_MAX_JOBS + 255) &
 
 void ptv2_wgrad_defer_begin(void *arena, size_t bytes) {
     WgradDefer &D = g_wdefer;
-    for (int f = 0; f < 5; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
+    for (int f = 0; f < WGRAD_FORMS; ++f) { D.jobs[f].clear(); D.bytes[f] = 0.0; }
     D.armed = D.armed_rs = false;
-    D.active = arena != nullptr && bytes > 5 * WGRAD_TABLE_BYTES;
+    D.active = arena != nullptr && bytes > WGRAD_FORMS * WGRAD_TABLE_BYTES;
     D.arena = (char *)arena;
     D.cap = bytes;
-    D.used = 5 * WGRAD_TABLE_BYTES;
+    D.used = WGRAD_FORMS * WGRAD_TABLE_BYTES;
 }
 bool ptv2_wgrad_defer_active() { return g_wdefer.active; }
 void ptv2_wgrad_defer_end() {
@@ -1846,7 +1841,7 @@ void ptv2_wgrad_defer_end() {
 void ptv2_wgrad_defer_arm(bool on) { g_wdefer.armed = on && g_wdefer.active; }
 void ptv2_wgrad_defer_arm_rs(bool on) { g_wdefer.armed_rs = on && g_wdefer.active; }
 bool ptv2_wgrad_defer_armed_rs() { return g_wdefer.active && g_wdefer.armed_rs; }
-size_t ptv2_wgrad_defer_table_bytes() { return 5 * WGRAD_TABLE_BYTES; }
+size_t ptv2_wgrad_defer_table_bytes() { return WGRAD_FORMS * WGRAD_TABLE_BYTES; }
 // a slice of the arena that lives until the backward ends (operands a deferred job reads, its records); NULL: no room
 float *ptv2_wgrad_defer_alloc(size_t floats) {
     WgradDefer &D = g_wdefer;
@@ -1868,7 +1863,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
                                    (int)WL_LDS_BYTES) == hipSuccess;
     }();
     if (!once) return PTV2_ERR_LAUNCH;
-    for (int form = 0; form < 5; ++form) {
+    for (int form = 0; form < WGRAD_FORMS; ++form) {
         std::vector<WgradJob> &jobs = D.jobs[form];
         if (jobs.empty()) continue;
         WgradJob *table = (WgradJob *)(D.arena + (size_t)form * WGRAD_TABLE_BYTES);
@@ -1877,7 +1872,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
         // full-resolution patch-embedding Block LAST, and its 150 us workgroups starting at the end of the launch were its tail
         // (bench step 10.53 -> 10.49 ms)
         std::stable_sort(jobs.begin(), jobs.end(), [form](const WgradJob &a, const WgradJob &b) {
-            const long long wa = (long long)a.chunk * (form == 4 ? a.gw * a.cin : 1), wb = (long long)b.chunk * (form == 4 ? b.gw * b.cin : 1);
+            const long long wa = (long long)a.chunk * (form >= 4 ? a.gw * a.cin : 1), wb = (long long)b.chunk * (form >= 4 ? b.gw * b.cin : 1);
             return wa > wb;
         });
         int wgs = 0, fin = 0;
@@ -1894,7 +1889,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
             hipLaunchKernelGGL(wgrad_jobs_write_kernel, dim3(1), dim3(64), 0, st, pack, cnt, table + at);
         }
         {
-            PtvScopedTimer t(form == 4 ? KID_WGRAD_GROUPED : (form < 2 ? KID_WGRAD_LDS : KID_WGRAD), st, D.bytes[form]);
+            PtvScopedTimer t(form == 5 ? KID_WGRAD_TILE : form == 4 ? KID_WGRAD_GROUPED : (form < 2 ? KID_WGRAD_LDS : KID_WGRAD), st, D.bytes[form]);
             if (form == 0)
                 hipLaunchKernelGGL(linear_wgrad_lds_kernel_jobs<0>, dim3((unsigned)wgs), dim3(TPB), WL_LDS_BYTES, st,
                                    (const WgradJob *)table, njobs);
@@ -1907,7 +1902,9 @@ int ptv2_wgrad_defer_flush(void *stream) {
             else if (form == 3)
                 hipLaunchKernelGGL(linear_wgrad_kernel_jobs<true>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
                                    njobs);
-            else {
+            else if (form == 5) {
+                if (gva_wgrad_tile_launch_jobs((const WgradJob *)table, njobs, wgs, st) != PTV2_OK) return PTV2_ERR_LAUNCH;
+            } else {
                 size_t lds = 0;
                 for (const WgradJob &J : jobs) lds = std::max(lds, grouped_lds_bytes(J.cin, J.gw));
                 hipLaunchKernelGGL(grouped_wgrad_kernel_jobs, dim3((unsigned)wgs), dim3(TPB), lds, st, (const WgradJob *)table, njobs);
@@ -1918,6 +1915,43 @@ int ptv2_wgrad_defer_flush(void *stream) {
         jobs.clear();
         D.bytes[form] = 0.0;
     }
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
+// internal (gva_block.hip): the grouped projection's weight gradient with A recomputed from the saved softmax weights
+// (gva_wgrad_tile.hip): dW (g, 8, c) and db (g, 8) = sum_n g_out sw.  Filed when the caller's backward defers (the operands
+// outlive the Block), else launched here with its finalize; PTV2_ERR_ARG for shapes without an instance
+int gva_wp2_wgrad_recompute(int n, int k, int c, int g, const float *g_out, const float *w, const float *sw, const float *a,
+                            const float *b, const float *coord, const int *idx, float *dW, float *db, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    if (!gva_wgrad_tile_supported(k, c, g) || n < 1 || !g_out || !w || !sw || !a || !b || !coord || !idx || !dW || !db) return PTV2_ERR_ARG;
+    WgradJob J{};
+    J.n = n; J.cin = c; J.batch = g;
+    J.gY = g_out; J.X = w; J.rowscale = sw; J.dW = dW; J.db = db;
+    J.aux[0] = coord; J.aux[1] = idx; J.aux[2] = a; J.aux[3] = b;
+    const double algo = 4.0 * ((double)n * (c + 16.0 * g + g + 16 + 3) + (double)c * c + c);  // g_out, w, sw, idx, coord in; dW, db out
+    if (g_wdefer.active && g_wdefer.armed_rs && (int)g_wdefer.jobs[5].size() < WGRAD_MAX_JOBS) {
+        const size_t floats = gva_wgrad_tile_plan(&J, n / 128 + 1);
+        float *keep = ptv2_wgrad_defer_alloc(floats);
+        if (keep) {
+            J.part = keep;
+            g_wdefer.jobs[5].push_back(J);
+            g_wdefer.bytes[5] += algo;
+            return PTV2_OK;
+        }
+    }
+    const size_t rec = (size_t)g * (8 * (size_t)c + 8);
+    const int fit = (int)std::min<size_t>(1 << 20, workspace_bytes / (sizeof(float) * rec));
+    if (!workspace || fit < 1) return PTV2_ERR_WORKSPACE;
+    (void)gva_wgrad_tile_plan(&J, std::min(fit, n / 128 + 1));  // (the same split as a filed job: the same bits either way)
+    J.part = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        PtvScopedTimer t(KID_WGRAD_TILE, st, algo);
+        if (gva_wgrad_tile_launch_one(J, st) != PTV2_OK) return PTV2_ERR_LAUNCH;
+    }
+    launch_finalize(st, (const float *)J.part, J.chunks, (int)rec, gva::MapSplit2<float>{dW, db, g * 8 * c});
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
 }

@@ -310,6 +310,14 @@ int gva_fwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          const float *Wp2, const float *bp2, float *w, float *sw, float *A, float *out, float *stats,
                          void *stream);
 int gva_fwd_tile_supported(int k, int c, int g);
+int gva_wp2_wgrad_recompute(int n, int k, int c, int g, const float *g_out, const float *w, const float *sw, const float *a,
+                            const float *b, const float *coord, const int *idx, float *dW, float *db, void *workspace,
+                            size_t workspace_bytes, void *stream);
+// the deep levels' one-launch forward (gva_fwd_tile.hip) is the path of this shape; AO_AMD_FWD_STAGED: the three staged launches
+static bool gva_tile_path(int k, int c, int g) { return gva_fwd_tile_supported(k, c, g) && !getenv("AO_AMD_FWD_STAGED"); }
+// 1 when the forward of this shape writes A (n, g, c) for the backward (block.hip sizes the saved buffer with it): the
+// staged launches, the full-resolution point kernel, or the tile path with AO_AMD_TILE_KEEP_A (the A-reading weight gradient)
+int gva_block_keeps_A(int k, int c, int g) { return !gva_tile_path(k, c, g) || getenv("AO_AMD_TILE_KEEP_A") != nullptr; }
 int gva_fwd_tile_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
                         const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
                         const float *Wp2, const float *bp2, float *w, float *sw, float *out, float *stats, float *a_out, void *stream);
@@ -491,10 +499,10 @@ int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stat
         RUN(gva_fwd_point_launch(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx, B->Wp2, B->bp2,
                                  B->w, B->sw, B->A, B->out, out_stats, stream));
         if (out_stats && stats_done) *stats_done = 64;
-    } else if (gva_fwd_tile_supported(k, c, g) && !gva::ptv2_attn_drop_current().thresh && !getenv("AO_AMD_FWD_STAGED")) {
+    } else if (gva_tile_path(k, c, g)) {
         // the deep levels: one launch per 16-point tile x group block (gva_fwd_tile.hip); no out_v, no A
         RUN(gva_fwd_tile_launch(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx, B->Wp2, B->bp2,
-                                B->w, B->sw, B->out, out_stats, B->A, stream));
+                                B->w, B->sw, B->out, out_stats, gva_block_keeps_A(k, c, g) ? B->A : nullptr, stream));
         if (out_stats && stats_done) *stats_done = 16;
     } else {
         RUN(gva_aggregate_forward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
@@ -547,6 +555,11 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
         // grad bp2 = sum_n g_out[n, ch] sw[n, group(ch)] as its weighted bias sums (it reads g_out anyway; that sum was a launch
         // of its own per Block, bp2_grad_kernel: 15 x 6 us); where the weight gradient cannot (bf16 operands), the kernel below
         const PtvDeferScope defer;
+        if (!gva_block_keeps_A(k, c, g)) {  // A = w^T P is formed again inside the weight gradient (gva_wgrad_tile.hip)
+            RUN(gva_wp2_wgrad_recompute(n, k, c, g, G->g_out, B->w, B->sw, B->a, B->b, B->coord, B->idx, G->gWp2, G->gbp2, W.wp2_part,
+                                        W.wp2_bytes, stream));
+            bp2_done = 1;
+        } else
         RUN(linear_wgrad_strided_rowscale(n, I, c, g, G->g_out, c, I, B->A, (long long)g * c, c, G->gWp2, G->gbp2, B->sw, g, &bp2_done,
                                           W.wp2_part, W.wp2_bytes, stream));
     }

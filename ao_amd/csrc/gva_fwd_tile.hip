@@ -71,17 +71,18 @@ struct FwdTileCfg {
     static constexpr int GTF = (G + 15) / 16, G16 = GTF * 16, GPW = ft_ww_pitch(G), QB = GB / 4, NGW = GB / 4, OB = 8 * GB,
                          NCH = C / 16, GP = 20, PP = ft_point_pitch(GB, GP), OP = OB + 4, WT = 16 * 17;
     static_assert(GB % 4 == 0 && GB <= 16 && G % GB == 0 && C == 8 * G && GPW >= G16, "group blocks of 4 q groups");
-    static constexpr size_t lds_floats = 4 * (size_t)C + 4 * 256 + 16 * GPW + 16 + 2 * G16 + 16 * WT + 256 + 256 + 2 * 16 * PP + 16 * OP;
+    static constexpr size_t lds_floats = 4 * (size_t)C + 4 * 256 + 16 * GPW + 16 + 2 * G16 + 16 * WT + 256 + 2 * 16 * PP + 16 * OP;
 };
 
 // stats != NULL: record [tile][2 C] = column sums of `out` over the tile's rows, sums of squares about the tile mean
 // a_out != NULL: A (n, G, C) is written as well (the staged backward reads it)
-template <int G, int C, int GB>
+template <int G, int C, int GB, bool WRITE_A, bool DROP>
 __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
     int n, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh, const float *__restrict__ Ww2,
     const float *__restrict__ bw2, const float *__restrict__ v, const float *__restrict__ a, const float *__restrict__ b,
     const float *__restrict__ coord, const int *__restrict__ idx, const float *__restrict__ Wp2, const float *__restrict__ bp2,
-    float *__restrict__ w, float *__restrict__ sw, float *__restrict__ out, float *__restrict__ stats, float *__restrict__ a_out) {
+    float *__restrict__ w, float *__restrict__ sw, float *__restrict__ out, float *__restrict__ stats, float *__restrict__ a_out,
+    PtvDrop drop) {
     using K = FwdTileCfg<G, C, GB>;
     constexpr int GTF = K::GTF, G16 = K::G16, GPW = K::GPW, QB = K::QB, NGW = K::NGW, OB = K::OB, NCH = K::NCH, GP = K::GP, PP = K::PP,
                   OP = K::OP, WT = K::WT;
@@ -94,8 +95,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
     float *sSh = sSc + G16;                    // [G16]
     float *sWt = sSh + G16;                    // [16][16 x 17]  w^T (point; row, slot)
     float *sSw = sWt + 16 * WT;                // [16][16]
-    int *sSrc = (int *)(sSw + 256);            // [16][16]
-    float *sA = (float *)(sSrc + 256);         // [2][16][PP]    A chunk (point; group, 16 c' + pad)
+    float *sA = sSw + 256;                     // [2][16][PP]    A chunk (point; group, 16 c' + pad)
     float *sOut = sA + 2 * 16 * PP;            // [16][OP]       out_v (point, channel of the block)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -135,35 +135,80 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
         cy[i] = coord[3 * ss + 1] - coord[3 * pts[i] + 1];
         cz[i] = coord[3 * ss + 2] - coord[3 * pts[i] + 2];
     }
+    // ---- the v rows of out_v are requested now and consumed behind the softmax: lane = (slot parity lane >> 5, 16-byte piece
+    //      lane & 31 of the block's 8 GB channels), eight rows per point.  The neighbour id of (point, slot) is wave-uniform
+    //      (lane `slot` holds it): a scalar read, no LDS round trip in front of the gather
+    const int of = lane & 31, par = lane >> 5;
+    const bool fa = of < OB / 4;
+    auto request_rows = [&](int i, float4 (&rows)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = __builtin_amdgcn_readlane(srcv[i], 2 * j), s1 = __builtin_amdgcn_readlane(srcv[i], 2 * j + 1);
+            const int src = par ? s1 : s0;
+            const float *vp = (fa && src >= 0) ? v + (long long)src * C + o0 + 4 * of : ptv2_zero_pad;
+            rows[j] = *(const float4 *)vp;
+        }
+    };
+    auto reduce_rows = [&](int i, const float4 (&rows)[8]) {  // out_v of point i -> sOut
+        const int p = 4 * wid + i, gl = fa ? of >> 1 : 0;
+        float wg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wg[j] = sWt[p * WT + gl * 17 + 2 * j + par];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc.x = __builtin_fmaf(wg[j], rows[j].x, acc.x); acc.y = __builtin_fmaf(wg[j], rows[j].y, acc.y);
+            acc.z = __builtin_fmaf(wg[j], rows[j].z, acc.z); acc.w = __builtin_fmaf(wg[j], rows[j].w, acc.w);
+        }
+        acc.x += __shfl_xor(acc.x, 32, WAVE); acc.y += __shfl_xor(acc.y, 32, WAVE);
+        acc.z += __shfl_xor(acc.z, 32, WAVE); acc.w += __shfl_xor(acc.w, 32, WAVE);
+        if (par == 0 && fa) *(float4 *)(sOut + p * OP + 4 * of) = acc;
+    };
+    // (two points' rows at a time: all four are 128 registers, more than the softmax leaves at two wavefronts per SIMD)
+    float4 vv0[8], vv1[8];
+#ifndef FT_SKIP_OUTV
+    request_rows(0, vv0);
+    request_rows(1, vv1);
+#endif
     __syncthreads();
 
-    // ---- phase 1: logits -> softmax over the 16 slots (= the lanes of a DPP row) for the rows of this block
+    // ---- phase 1: logits -> softmax over the 16 slots (= the lanes of a DPP row) for the rows of this block; the four
+    //      points' matrix-instruction chains are interleaved
+    ft_v4f z[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = (ft_v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < GTF; ++t) {
+        const float4 s4 = *(const float4 *)(sSc + 16 * t + 4 * q), h4 = *(const float4 *)(sSh + 16 * t + 4 * q);
+        const float4 w4 = *(const float4 *)(sWw + l15 * GPW + 16 * t + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ft_mfma(w4.x, fmaxf(__builtin_fmaf(s4.x, u[i][t][0], h4.x), 0.f), z[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ft_mfma(w4.y, fmaxf(__builtin_fmaf(s4.y, u[i][t][1], h4.y), 0.f), z[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ft_mfma(w4.z, fmaxf(__builtin_fmaf(s4.z, u[i][t][2], h4.z), 0.f), z[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ft_mfma(w4.w, fmaxf(__builtin_fmaf(s4.w, u[i][t][3], h4.w), 0.f), z[i]);
+    }
+    const float4 b4 = *(const float4 *)(sBw + 4 * q);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = 4 * wid + i;
         const bool valid = srcv[i] >= 0;
-        ft_v4f z = (ft_v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < GTF; ++t) {
-            const float4 s4 = *(const float4 *)(sSc + 16 * t + 4 * q), h4 = *(const float4 *)(sSh + 16 * t + 4 * q);
-            const float4 w4 = *(const float4 *)(sWw + l15 * GPW + 16 * t + 4 * q);
-            z = ft_mfma(w4.x, fmaxf(__builtin_fmaf(s4.x, u[i][t][0], h4.x), 0.f), z);
-            z = ft_mfma(w4.y, fmaxf(__builtin_fmaf(s4.y, u[i][t][1], h4.y), 0.f), z);
-            z = ft_mfma(w4.z, fmaxf(__builtin_fmaf(s4.z, u[i][t][2], h4.z), 0.f), z);
-            z = ft_mfma(w4.w, fmaxf(__builtin_fmaf(s4.w, u[i][t][3], h4.w), 0.f), z);
-        }
-        const float4 b4 = *(const float4 *)(sBw + 4 * q);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
         float wv[4], so[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float zz = z[r] + bb[r];
+            const float zz = z[i][r] + bb[r];
             const float mx = ft_row16_max(zz);
             // (the correctly rounded expf and division of the staged softmax kernel, in its order: w is bit-identical to it; the
             // ~25 vector instructions per weight do not matter at the deep levels)
             const float e = expf(zz - mx);
             const float den = ft_row16_sum(e);
             wv[r] = (valid && q < QB) ? e / den : 0.f;
+            // attention dropout on the softmax output (gva_common.h: the factor is a hash of the element index, evaluated again
+            // by the backward)
+            if (DROP) wv[r] *= ptv2_drop_factor(drop, ((unsigned long long)pts[i] * 16 + l15) * G + (g0 + 4 * q + r));
             so[r] = ft_row16_sum(wv[r]);
             sWt[p * WT + (4 * q + r) * 17 + l15] = wv[r];
         }
@@ -175,37 +220,16 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
             }
         }
         sPos[p * 16 + l15] = valid ? make_float4(cx[i], cy[i], cz[i], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sSrc[p * 16 + l15] = srcv[i];
     }
     ft_wave_sync();  // the records of my 4 points are wave-private until the first chunk barrier
 
-    // ---- out_v of my 4 points: lane = (slot parity lane >> 5, 16-byte piece lane & 31 of the block's 8 GB channels)
-    {
-        const int f = lane & 31, par = lane >> 5;
-        const bool fa = f < OB / 4;
-        const int gl = fa ? f >> 1 : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = 4 * wid + i;
-            float4 vv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int src = sSrc[p * 16 + 2 * j + par];
-                const float *vp = (fa && src >= 0) ? v + (long long)src * C + o0 + 4 * f : ptv2_zero_pad;
-                vv[j] = *(const float4 *)vp;
-            }
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float wg = sWt[p * WT + gl * 17 + 2 * j + par];
-                acc.x = __builtin_fmaf(wg, vv[j].x, acc.x); acc.y = __builtin_fmaf(wg, vv[j].y, acc.y);
-                acc.z = __builtin_fmaf(wg, vv[j].z, acc.z); acc.w = __builtin_fmaf(wg, vv[j].w, acc.w);
-            }
-            acc.x += __shfl_xor(acc.x, 32, WAVE); acc.y += __shfl_xor(acc.y, 32, WAVE);
-            acc.z += __shfl_xor(acc.z, 32, WAVE); acc.w += __shfl_xor(acc.w, 32, WAVE);
-            if (par == 0 && fa) *(float4 *)(sOut + p * OP + 4 * f) = acc;
-        }
-    }
+    // ---- out_v of my first two points from the rows requested above; the other two points' rows travel through the chunk loop
+#ifndef FT_SKIP_OUTV
+    reduce_rows(0, vv0);
+    reduce_rows(1, vv1);
+    request_rows(2, vv0);
+    request_rows(3, vv1);
+#endif
 
     // ---- chunks of 16 channels c'
     float wA[4][4];     // A operand of phase A: w^T (row l15, slot 4 st + q) of my 4 points
@@ -228,6 +252,9 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
         wpn[gi] = *(const float4 *)wp2row[gi];
         acc[gi] = (ft_v4f){0.f, 0.f, 0.f, 0.f};
     }
+#ifdef FT_SKIP_CHUNKS
+    __syncthreads();
+#else
 #pragma unroll 2
     for (int ck = 0; ck < NCH; ++ck) {
         float *buf = sA + (ck & 1) * 16 * PP;
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) buf[(4 * wid + i) * PP + (4 * q + r) * GP + l15] = d[i][r];
-            if (a_out) {
+            if constexpr (WRITE_A) {  // (a template parameter: a branch in this loop costs every trip a drained memory queue)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -266,7 +293,13 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
             acc[gi] = ft_mfma(wpc[gi].w, bx.w, acc[gi]);
         }
     }
+#endif
 
+#ifndef FT_SKIP_OUTV
+    reduce_rows(2, vv0);
+    reduce_rows(3, vv1);
+#endif
+    __syncthreads();
     // ---- epilogue: D[i][p]: output 4 q + reg of the group (q < 2), point l15
     const long long ptl = (long long)tile * 16 + l15;
     const bool rv = ptl < n;
@@ -303,17 +336,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_tile_kernel(
 template <int G, int C, int GB>
 static int launch_fwd_tile(int n, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2, const float *v,
                            const float *a, const float *b, const float *coord, const int *idx, const float *Wp2, const float *bp2,
-                           float *w, float *sw, float *out, float *stats, float *a_out, hipStream_t st) {
+                           float *w, float *sw, float *out, float *stats, float *a_out, PtvDrop drop, hipStream_t st) {
     using K = FwdTileCfg<G, C, GB>;
     const size_t lds = sizeof(float) * K::lds_floats;
-    auto kern = attention_fwd_tile_kernel<G, C, GB>;
-    static bool configured = false;
-    if (!configured) {
+    const bool dropping = drop.thresh != 0;
+    auto kern = a_out ? (dropping ? attention_fwd_tile_kernel<G, C, GB, true, true> : attention_fwd_tile_kernel<G, C, GB, true, false>)
+                      : (dropping ? attention_fwd_tile_kernel<G, C, GB, false, true> : attention_fwd_tile_kernel<G, C, GB, false, false>);
+    static bool configured[2][2] = {{false, false}, {false, false}};
+    if (!configured[a_out != nullptr][dropping]) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV2_ERR_LAUNCH;
-        configured = true;
+        configured[a_out != nullptr][dropping] = true;
     }
     hipLaunchKernelGGL(kern, dim3((n + 15) / 16, G / GB), dim3(256), lds, st, n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, Wp2, bp2, w,
-                       sw, out, stats, a_out);
+                       sw, out, stats, a_out, drop);
     return PTV2_OK;
 }
 
@@ -338,7 +373,8 @@ int gva_fwd_tile_launch(int n, int k, int c, int g, const float *W1, const float
     PtvScopedTimer t(KID_FWD_TILE + (g == 12 ? 0 : g == 24 ? 1 : g == 48 ? 2 : 3), st,
                      4.0 * ((double)n * k * (2 * g + 1) + (double)n * (3 + 2 * c + g)));
     int rc;
-#define ARGS n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, Wp2, bp2, w, sw, out, stats, a_out, st
+    const PtvDrop drop = ptv2_attn_drop_current();  // (0 outside a gva_block call with attention dropout)
+#define ARGS n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, Wp2, bp2, w, sw, out, stats, a_out, drop, st
     if (g == 12) rc = launch_fwd_tile<12, 96, 12>(ARGS);
     else if (g == 24) rc = launch_fwd_tile<24, 192, 12>(ARGS);
     else if (g == 48) rc = launch_fwd_tile<48, 384, 12>(ARGS);
