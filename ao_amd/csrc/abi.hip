@@ -170,7 +170,9 @@ const char *kNames[KID_COUNT] = {
     "logits_bwd_fused_kernel<48, 384, 4>", "logits_bwd_fused_kernel<64, 512, 4>",
     "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel",
     "attention_fwd_tile_kernel<12, 96, 12>", "attention_fwd_tile_kernel<24, 192, 12>", "attention_fwd_tile_kernel<48, 384, 12>",
-    "attention_fwd_tile_kernel<64, 512, 16>", "wp2_wgrad_tile_kernel"};
+    "attention_fwd_tile_kernel<64, 512, 16>", "wp2_wgrad_tile_kernel",
+    "attention_bwd_tile_kernel<12, 96, 8>", "attention_bwd_tile_kernel<24, 192, 8>", "attention_bwd_tile_kernel<48, 384, 8>",
+    "attention_bwd_tile_kernel<64, 512, 8>"};
 struct Rec { hipEvent_t a, b; double bytes; };
 std::mutex g_mu;
 int g_on = 0;

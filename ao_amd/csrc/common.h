@@ -28,7 +28,8 @@ enum PtvKernelId {
     KID_BN_BWD_FINAPPLY /* bn_bwd_finapply_kernel<...>: record sum + apply in one launch */,
     KID_FWD_TILE /* + 0..3 for G = 12, 24, 48, 64: softmax + aggregation + grouped projection per 16-point tile (gva_fwd_tile.hip) */,
     KID_WGRAD_TILE = KID_FWD_TILE + 4 /* the grouped projection's weight gradient with A recomputed (gva_wgrad_tile.hip) */,
-    KID_COUNT
+    KID_BWD_TILE_K /* + 0..3 for G = 12, 24, 48, 64: the deep levels' attention backward per tile of points (gva_bwd_tile.hip) */,
+    KID_COUNT = KID_BWD_TILE_K + 4
 };
 extern "C" int ptv2_profile_is_on(void);
 int ptv2_profile_wants(int kid);

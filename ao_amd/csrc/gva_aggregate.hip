@@ -522,19 +522,30 @@ int gva_bwd_point_launch(int n, int k, int c, int g, const float *W1, const floa
                          float *gWw2, float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail,
                          hipStream_t st, const float *Wp2, const float *bp2, PtvDrop drop);
 int gva_bwd_point_local(int k, int c, int g);
+// gva_bwd_tile.hip: the deep levels' backward per tile of points, g_A formed in the kernel
+int gva_bwd_tile_supported(int k, int c, int g);
+size_t gva_bwd_tile_part_floats(int n, int c, int g);
+int gva_bwd_tile_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
+                        const float *bw2, const float *v, const float *a, const float *b, const float *coord, const int *idx,
+                        const float *g_out, const float *Wp2, const float *bp2, float *gW1, float *gsc, float *gsh, float *gWw2,
+                        float *gbw2, float *ga, float *gb, float *part, size_t part_floats_avail, gva::PtvDrop drop, hipStream_t st);
+// 1 when the backward of this shape runs the tile kernel (AO_AMD_BWD_POINT: the point kernel behind a peb_bwd launch instead)
+int gva_bwd_tile_path(int k, int c, int g) {
+    return gva_bwd_tile_supported(k, c, g) && !getenv("AO_AMD_BWD_STAGED") && !getenv("AO_AMD_BWD_POINT");
+}
 
 int gva_softmax_point_launch(int n, int k, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
                              const float *bw2, const int *idx, float *w, float *sw, hipStream_t st, PtvDrop drop);
 
-static size_t agg_part_bytes(int c, int g) {
-    return align_up(sizeof(float) * std::max({(size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g,
-                                              gva_bwd_point_part_floats(c, g)}));
+static size_t agg_part_bytes(int n, int k, int c, int g) {
+    return align_up(sizeof(float) * std::max({(size_t)BWD_TILE_BLOCKS * 4 * c, (size_t)MAX_BLOCKS * 2 * g, gva_bwd_point_part_floats(c, g),
+                                              gva_bwd_tile_supported(k, c, g) ? gva_bwd_tile_part_floats(n, c, g) : (size_t)0}));
 }
 
 extern "C" size_t gva_aggregate_workspace_bytes(int n, int k, int c, int g) {
     if (n < 0 || k < 1 || c < 1 || g < 1) return 0;
     const size_t rows = (size_t)n * k;
-    const size_t part = agg_part_bytes(c, g);
+    const size_t part = agg_part_bytes(n, k, c, g);
     return part + 3 * align_up(sizeof(float) * rows * g) + dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g) + 1024;
 }
 
@@ -592,10 +603,28 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
     if (n == 0) return PTV2_OK;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)n * k;
-    const size_t part_bytes = agg_part_bytes(c, g);
+    const size_t part_bytes = agg_part_bytes(n, k, c, g);
     const size_t rows_bytes = align_up(sizeof(float) * (size_t)rows * g);
     char *base = (char *)workspace;
     float *part = (float *)base;
+    if (inv_ptr && g_fused_Wp2 && g_fused_bp2 && gva_bwd_tile_path(k, c, g)) {
+        // the deep levels: one launch per tile of points (gva_bwd_tile.hip), g_A = g_out Wp2 formed per 16-channel chunk in LDS
+        {
+            // W1, idx, coord, g_out, v rows (unique once) in; gW1 out
+            PtvScopedTimer t(KID_BWD_TILE_K + (g == 12 ? 0 : g == 24 ? 1 : g == 48 ? 2 : 3), st,
+                             4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c)));
+            const PtvDeferScope defer;  // its record sums ride on the gv launch below (which needs none of them)
+            const int rc = gva_bwd_tile_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_fused_Wp2, g_fused_bp2, gW1,
+                                               gsc, gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), ptv2_attn_drop_current(), st);
+            if (rc != PTV2_OK) return rc;
+        }
+        {
+            PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
+            launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
+        }
+        PTV2_CHECK_LAUNCH();
+        return PTV2_OK;
+    }
     if (inv_ptr && gva_bwd_point_supported(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) {
         // one fused MFMA launch (+ its finalize) instead of tile / rows / finalizes / the G x G weight-gradient GEMM
         {
@@ -670,9 +699,22 @@ int gva_aggregate_backward_fused_peb(int n, int k, int c, int g, const float *W1
                                      const float *bp2, const int *inv_ptr, const int *inv_rows, float *gW1, float *gsc,
                                      float *gsh, float *gWw2, float *gbw2, float *gv, float *ga, float *gb, void *workspace,
                                      size_t workspace_bytes, void *stream) {
-    if (!inv_ptr || !gva_bwd_point_local(k, c, g) || !Wp2 || !bp2) return PTV2_ERR_ARG;
+    if (!inv_ptr || !(gva_bwd_point_local(k, c, g) || gva_bwd_tile_path(k, c, g)) || !Wp2 || !bp2) return PTV2_ERR_ARG;
     return aggregate_backward_impl(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, nullptr, nullptr, Wp2, bp2,
                                    inv_ptr, inv_rows, gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace, workspace_bytes, stream);
+}
+
+// the public form of the above: backward of gva_attention_forward_hip_launcher (the grouped projection's backward folded in)
+extern "C" int gva_attention_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                                   const float *Ww2, const float *bw2, const float *v, const float *a,
+                                                   const float *b, const float *coord, const int *idx, const float *w,
+                                                   const float *g_out, const float *Wp2, const float *bp2, const int *inv_ptr,
+                                                   const int *inv_rows, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2,
+                                                   float *gv, float *ga, float *gb, void *workspace, size_t workspace_bytes,
+                                                   void *stream) {
+    if (!gva_bwd_tile_supported(k, c, g)) return PTV2_ERR_ARG;
+    return gva_aggregate_backward_fused_peb(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, w, g_out, Wp2, bp2, inv_ptr, inv_rows,
+                                            gW1, gsc, gsh, gWw2, gbw2, gv, ga, gb, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gva_aggregate_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc,

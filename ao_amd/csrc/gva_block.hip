@@ -303,6 +303,7 @@ int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, 
                                const float *const *xsh, float *const *y, void *stream);
 int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_bwd_point_local(int k, int c, int g);
+int gva_bwd_tile_path(int k, int c, int g);
 int gva_fwd_point_supported(int k, int c, int g);
 int gva_fwd_point_max_n();
 int gva_fwd_point_launch(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh, const float *Ww2,
@@ -546,7 +547,7 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     PtvRiderGuard riders;  // an error return below must not leave queued sums (pointers into this call's workspace) behind
     // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
     //    grad Wp2 (direct part), grad bp2 (direct part)
-    const bool fused_peb = G->inv_ptr && gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED");
+    const bool fused_peb = G->inv_ptr && ((gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) || gva_bwd_tile_path(k, c, g));
     if (!fused_peb) RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
     int bp2_done = 0;
     {

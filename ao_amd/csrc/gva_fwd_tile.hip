@@ -50,8 +50,9 @@ __device__ __forceinline__ float ft_row16_max(float v) {
     v = fmaxf(v, ft_dpp<0x140>(v));
     return v;
 }
+// (LDS hand-off inside a wavefront; a wavefront-scope fence would also wait for the global stores of w / sw: gva_bwd_tile.hip)
 __device__ __forceinline__ void ft_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 

@@ -55,6 +55,7 @@ _SIG = {
     "gva_peb_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 7),
     "gva_peb_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 3 + [_lib._vp] * 6),
     "gva_attention_forward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 17),
+    "gva_attention_backward_hip_launcher": (_lib._c_int, [_lib._c_int] * 4 + [_lib._vp] * 25 + [_lib._c_size, _lib._vp]),
 }
 _lib.register(_SIG)
 

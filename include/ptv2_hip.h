@@ -299,6 +299,18 @@ int gva_attention_forward_hip_launcher(int n, int k, int c, int g, const float *
                                        const float *Ww2, const float *bw2, const float *v, const float *a,
                                        const float *b, const float *coord, const int *idx, const float *Wp2,
                                        const float *bp2, float *w, float *sw, float *out, float *A, void *stream);
+/* Its backward as one launch per tile of points + the inverse-table gather of grad v (ao_amd/csrc/gva_bwd_tile.hip; the same
+ * shapes): given w (n,k,g) of the forward and g_out (n,c) -- g_A = g_out Wp2 per group is formed in LDS per 16-channel chunk,
+ * never in memory -- writes gW1 (n,k,g), gsc, gsh (g), gWw2 (g,g), gbw2 (g), gv (n,c), ga (c,3), gb (c) (the gradients of the
+ * folded positional encoding P = ReLU(a . pos + b)).  inv_ptr / inv_rows: the inverse neighbour table (inverse_table);
+ * workspace: gva_aggregate_workspace_bytes(n,k,c,g).  grad Wp2 / bp2 (direct parts) are the caller's (a weight gradient). */
+int gva_attention_backward_hip_launcher(int n, int k, int c, int g, const float *W1, const float *sc, const float *sh,
+                                        const float *Ww2, const float *bw2, const float *v, const float *a,
+                                        const float *b, const float *coord, const int *idx, const float *w,
+                                        const float *g_out, const float *Wp2, const float *bp2, const int *inv_ptr,
+                                        const int *inv_rows, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2,
+                                        float *gv, float *ga, float *gb, void *workspace, size_t workspace_bytes,
+                                        void *stream);
 
 /* ------------------------------------------ whole attention block, one call --
  * GroupedVectorAttention.forward / backward (point_transformer_v2m2_base.py:103-129) behind ONE launcher each:

@@ -283,7 +283,8 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
             np.testing.assert_allclose(ck.cpu().numpy(), expect.cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
             twice += 1
     assert twice == 2 * 4 * 15  # mean and variance of four norms in each of the 15 Blocks
-    assert saved[True] < 0.45 * saved[False], saved
+    # (the deep levels no longer save an (N,G,C) tensor: the full arena shrank, the shared region is still the level-0 Block's)
+    assert saved[True] < 0.6 * saved[False], saved
 
 
 @pytest.mark.parametrize("tag,points,bf16", [("s3dis", 9000, False), ("scannet", 7000, False), ("s3dis", 9000, True)])
