@@ -353,8 +353,11 @@ BlockWs carve(void *base, int n, int k, int c, int g) {
                               dense_workspace_bytes((int)std::min<size_t>(rows, 2147483647), g, g)});
     w.stage = take(w.stage_bytes);
     w.out_v = (float *)take(sizeof(float) * (size_t)n * c);
-    w.gA = (float *)take(sizeof(float) * (size_t)n * g * c);
-    w.g_sw = (float *)take(sizeof(float) * (size_t)n * g);
+    // (g_A (n,g,c) / g_sw only where a peb_bwd launch hands them to the aggregation backward: not at the full-resolution level's
+    // point kernel nor on the deep levels' tile path, which form them on chip)
+    const bool fused_peb = (gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) || gva_bwd_tile_path(k, c, g);
+    w.gA = fused_peb ? nullptr : (float *)take(sizeof(float) * (size_t)n * g * c);
+    w.g_sw = fused_peb ? nullptr : (float *)take(sizeof(float) * (size_t)n * g);
     w.gW1 = (float *)take(sizeof(float) * rows * g);
     w.gkW = (float *)take(sizeof(float) * (size_t)n * g);
     w.gqW = (float *)take(sizeof(float) * (size_t)n * g);
@@ -547,7 +550,8 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     PtvRiderGuard riders;  // an error return below must not leave queued sums (pointers into this call's workspace) behind
     // 1. projection after the neighbour sum: g_A, g_sw (formed inside the point kernel for the narrow instances),
     //    grad Wp2 (direct part), grad bp2 (direct part)
-    const bool fused_peb = G->inv_ptr && ((gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) || gva_bwd_tile_path(k, c, g));
+    const bool fused_peb = (gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) || gva_bwd_tile_path(k, c, g);
+    if (fused_peb && !G->inv_ptr) return PTV2_ERR_ARG;  // (the fused forms gather grad v through the inverse neighbour table)
     if (!fused_peb) RUN(gva_peb_backward_hip_launcher(n, c, g, G->g_out, B->Wp2, B->bp2, W.gA, W.g_sw, stream));
     int bp2_done = 0;
     {

@@ -444,6 +444,18 @@ class PointTransformerV2(nn.Module):
     def geometry(self, coord, offset):
         return build_geometry(coord, offset, self.grid_sizes, self.geometry_neighbours(), interp=self.unpool_backend == "interp")
 
+    # ---- DistributedDataParallel (what the reference's create_ddp_model wraps every rank's model in, engines/defaults.py:20-43)
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """DistributedDataParallel reads this attribute of the module it wraps (torch/nn/parallel/distributed.py) and leaves
+        the named parameters alone: no per-parameter hook, no bucket copy, no all-reduce of its own.  The native backward
+        writes all 840 gradients into ONE flat buffer, so it averages that buffer over the ranks with one RCCL all-reduce
+        itself (native_model._NativeModel.backward) -- DDP's 840 AccumulateGrad hooks and bucket copies cost 3.9 ms of a 10.7 ms
+        step on one MI355X (bench.py `reference_loop.ddp`).  The trainer does not change: it still wraps the model, and the
+        wrapper still does its start-up checks on the one parameter left to it (DDP refuses a module without any).
+        AO_AMD_DDP_SYNC=ddp: hand every parameter to DDP as any other module does."""
+        return parallel_ddp_ignore(self, "")
+
     def forward(self, data_dict, geometry=None):
         coord, feat = data_dict["coord"], data_dict["feat"]
         offset = data_dict["offset"].int()
@@ -459,6 +471,10 @@ class PointTransformerV2(nn.Module):
 
         if native_model.supported(self, feat) and native_model.geometry_supported(geo):  # the whole network behind one native call per direction
             return native_model.forward(self, data_dict, geo)
+        if self.__dict__.get("_ao_ddp_native_sync") and self.training and torch.is_grad_enabled():
+            raise RuntimeError("ao_amd: this batch takes the stage-wise python path, whose gradients the native flat all-reduce "
+                               "does not see, under a DistributedDataParallel wrapper that was told to leave the parameters "
+                               "alone; set AO_AMD_DDP_SYNC=ddp (DDP then synchronises every parameter itself)")
         lv = geo.levels
         pe = self.patch_embed
         feat = pe.blocks([lv[0].coord, pe.proj(feat), lv[0].offset], lv[0].neighbours(pe.blocks.neighbours))[1]
@@ -475,6 +491,40 @@ class PointTransformerV2(nn.Module):
         if isinstance(self.seg_head, nn.Sequential):
             return self.seg_head[3](lin_bn_relu(self.seg_head[0], self.seg_head[1].norm, feat))
         return self.seg_head(feat)
+
+
+def parallel_ddp_ignore(module, prefix):
+    """The `_ddp_params_and_buffers_to_ignore` list of `module` (PointTransformerV2 itself, prefix "", or a segmentor that holds
+    it as `backbone`, prefix "backbone."): every backbone parameter but the smallest one, when the native runtime will average
+    the flat gradient buffer itself -- a process group exists, the network is in the native runtime's shape, AO_AMD_DDP_SYNC
+    is not "ddp".  DDP asks for it while it is being constructed, which is also when it broadcasts rank 0's parameters to the
+    others: the parameters it is told to ignore are broadcast here instead."""
+    import torch.distributed as dist
+
+    from . import native_model
+
+    backbone = module if prefix == "" else module.backbone
+    if os.environ.get("AO_AMD_DDP_SYNC", "native") == "ddp" or not (dist.is_available() and dist.is_initialized()):
+        return []
+    if os.environ.get("AO_AMD_MODEL", "native") != "native" or os.environ.get("AO_AMD_BLOCK", "native") != "native" \
+            or os.environ.get("AO_AMD_GVA", "fused") != "fused":
+        return []
+    named = list(backbone.named_parameters())
+    if not named or not all(p.is_cuda and p.dtype == torch.float32 and p.requires_grad for _, p in named):
+        return []
+    if not native_model.runtime(backbone).static_ok:
+        return []
+    keep = min(range(len(named)), key=lambda i: (named[i][1].numel(), i))  # DDP needs at least one parameter of its own
+    names = [prefix + n for i, (n, _) in enumerate(named) if i != keep]
+    if not backbone.__dict__.get("_ao_ddp_native_sync"):
+        backbone.__dict__["_ao_ddp_native_sync"] = True
+        if dist.get_world_size() > 1:  # what DDP's _sync_module_states does for the parameters it owns
+            with torch.no_grad():
+                ps = [p.data for i, (_, p) in enumerate(named) if i != keep]
+                flat = torch.cat([t.reshape(-1) for t in ps])
+                dist.broadcast(flat, 0)
+                torch._foreach_copy_(ps, [c.view_as(t) for c, t in zip(flat.split([t.numel() for t in ps]), ps)])
+    return names
 
 
 MODEL_TYPE = "PT-v2m2"

@@ -572,6 +572,17 @@ class _NativeModel(torch.autograd.Function):
         # graph is dropped -- a training loop keeps the previous step's loss / output dict alive into the next forward, which
         # then needed a SECOND arena (and the allocator a multi-gigabyte hipMalloc in the middle of the second step)
         ctx.keep = ctx.geo = None
+        if owner is not None and owner.__dict__.get("_ao_ddp_native_sync"):
+            # under a DistributedDataParallel wrapper that leaves the parameters to us (model.parallel_ddp_ignore): the average
+            # over the ranks as ONE all-reduce of the flat buffer, enqueued behind the backward; the caller's stream waits for it
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                if dist.get_backend() == "nccl":  # RCCL averages in the collective
+                    dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True).wait()
+                else:  # (gloo, the two-ranks-on-one-device tests: no AVG)
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                    flat.mul_(1.0 / dist.get_world_size())
         if direct:
             if accumulate:
                 torch._foreach_add_([p.grad for p in rt.params], views)

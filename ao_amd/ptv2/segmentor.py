@@ -102,6 +102,13 @@ class DefaultSegmentor(nn.Module):
     (pointcept/models/default.py:232-251): `DefaultSegmentor(backbone=dict(type="PT-v2m2", ...), criteria=[dict(
     type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)])`."""
 
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """DistributedDataParallel wraps the segmentor (engines/train_sam_pp2s.py:207-213): see PointTransformerV2's property"""
+        from .model import parallel_ddp_ignore
+
+        return parallel_ddp_ignore(self, "backbone.") if isinstance(self.backbone, PointTransformerV2) else []
+
     def __init__(self, backbone=None, criteria=None, ignore_index=-1):
         super().__init__()
         self.backbone = backbone if isinstance(backbone, nn.Module) else PointTransformerV2(

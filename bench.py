@@ -414,78 +414,131 @@ def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
     gradients delivered through autograd, the batch handed to `model(input_dict)` as the loader produces it (host tensors, no
     `geometry=` key, no prefetcher thread): `Trainer.run_step` (pointcept/engines/train_sam_pp2s.py:173-200) statement by
     statement, followed by what `InformationWriter.after_step` does every iteration (`.item()` of every loss,
-    pointcept/engines/hooks/misc.py:112).  `ms_per_step_no_item`: the same without that per-step read-back."""
+    pointcept/engines/hooks/misc.py:112).  `ms_per_step_no_item`: the same without that per-step read-back.
+
+    `variants`: the same loop under CONFIG-ONLY changes of the optimizer line -- `OPTIMIZERS.build` passes every key of the
+    dict to the constructor (pointcept/utils/optimizer.py:55), so `dict(type="AdamW", ..., fused=True)` and, with the registry
+    file of INTEGRATION.md section 2, `dict(type="FlatAdamW", ...)` need no trainer code.
+    `ddp`: the loop with the `DistributedDataParallel(broadcast_buffers=False)` wrap forced in a one-rank RCCL group (what
+    every rank of the reference's multi-GPU recipe runs: 840 parameters -> AccumulateGrad hooks, bucket copies, one
+    all-reduce per bucket): its cost on this build, measurable on one GPU."""
     import torch.distributed as dist
 
-    seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(cfg).to(device).train()
-    model = seg
-    if world > 1:  # create_ddp_model
-        model = torch.nn.parallel.DistributedDataParallel(seg, device_ids=[device.index], output_device=device.index,
-                                                          broadcast_buffers=False, find_unused_parameters=False)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
-    total = 1 << 20
-    scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[int(0.09 * total), int(0.2 * total)], gamma=0.1)
     enable_amp = args.dtype != "fp32"
-    scaler = torch.cuda.amp.GradScaler() if enable_amp else None
     host = {k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "geometry"}
-    comm_info = {}
-
-    def run_step():  # train_sam_pp2s.py:173-200
-        input_dict = dict(host)
-        for key in input_dict.keys():
-            if isinstance(input_dict[key], torch.Tensor):
-                input_dict[key] = input_dict[key].cuda(non_blocking=True)
-        with torch.cuda.amp.autocast(enabled=enable_amp):
-            output_dict = model(input_dict)
-            if isinstance(output_dict, tuple):  # train_sam_real.py:187: (dict(loss), seg_dict)
-                output_dict = output_dict[0]
-            loss = output_dict["loss"]
-        optimizer.zero_grad()
-        if enable_amp:
-            scaler.scale(loss).backward()
-            scaler.step(optimizer)
-            scale = scaler.get_scale()
-            scaler.update()
-            if scale <= scaler.get_scale():
-                scheduler.step()
-        else:
-            loss.backward()
-            optimizer.step()
-            scheduler.step()
-        comm_info["model_output_dict"] = output_dict
-
-    def after_step():  # hooks/misc.py:108-112
-        for key in comm_info["model_output_dict"].keys():
-            if "loss" in key:
-                comm_info[key] = comm_info["model_output_dict"][key].item()
-
-    def timed(n, with_item):
-        if dist.is_initialized() and world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            run_step()
-            if with_item:
-                after_step()
-        torch.cuda.synchronize(device)
-        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
-        if dist.is_initialized() and world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
     steps = max(5, min(args.steps, 20))
-    timed(max(3, min(args.warmup, 5)), True)
-    with_item = timed(steps, True)
-    no_item = timed(steps, False)
-    return {"ms_per_step": 1e3 * with_item / steps, "points_per_s": points_per_step * steps / with_item,
-            "ms_per_step_no_item": 1e3 * no_item / steps, "steps": steps,
-            "loop": "Trainer.run_step statements (pointcept/engines/train_sam_pp2s.py:173-200) + InformationWriter.after_step's "
-                    "loss.item() (hooks/misc.py:112); batch from pinned host memory via .cuda(non_blocking=True)",
-            "model": "DistributedDataParallel(broadcast_buffers=False)" if world > 1 else "bare module (create_ddp_model at world_size 1)",
-            "optimizer": "torch.optim.AdamW + MultiStepLR", "param_grads": "autograd (.grad through AccumulateGrad)",
-            "geometry": "inside PointTransformerV2.forward (pipelined with the level-0 prefix; no prefetcher, no geometry= key)",
-            "enable_amp": enable_amp, "loss": comm_info.get("loss")}
+    warm = max(3, min(args.warmup, 5))
+
+    def build(optim_kind, force_ddp):
+        seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(cfg).to(device).train()
+        model, wrapped = seg, False
+        if world > 1 or force_ddp:  # create_ddp_model
+            if not dist.is_initialized():  # a one-rank group of its own (the bench's exchange is not in use at world 1)
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                dist.init_process_group("nccl", rank=0, world_size=1)
+            model = torch.nn.parallel.DistributedDataParallel(seg, device_ids=[device.index], output_device=device.index,
+                                                              broadcast_buffers=False, find_unused_parameters=False)
+            wrapped = True
+        if optim_kind == "AdamW":
+            optimizer = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05)
+        elif optim_kind == "AdamW(fused=True)":
+            optimizer = torch.optim.AdamW(model.parameters(), lr=0.006, weight_decay=0.05, fused=True)
+        else:  # dict(type="FlatAdamW", lr=0.006, weight_decay=0.05) through the registry (ao_amd/ptv2/registry.py)
+            from ao_amd.ptv2.optim import FlatAdamW
+
+            optimizer = FlatAdamW(params=model.parameters(), lr=0.006, weight_decay=0.05)
+        total = 1 << 20
+        scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=[int(0.09 * total), int(0.2 * total)], gamma=0.1)
+        scaler = torch.cuda.amp.GradScaler() if enable_amp else None
+        return model, optimizer, scheduler, scaler, wrapped
+
+    def measure(optim_kind, force_ddp, with_item_too):
+        model, optimizer, scheduler, scaler, wrapped = build(optim_kind, force_ddp)
+        comm_info = {}
+
+        def run_step():  # train_sam_pp2s.py:173-200
+            input_dict = dict(host)
+            for key in input_dict.keys():
+                if isinstance(input_dict[key], torch.Tensor):
+                    input_dict[key] = input_dict[key].cuda(non_blocking=True)
+            with torch.cuda.amp.autocast(enabled=enable_amp):
+                output_dict = model(input_dict)
+                if isinstance(output_dict, tuple):  # train_sam_real.py:187: (dict(loss), seg_dict)
+                    output_dict = output_dict[0]
+                loss = output_dict["loss"]
+            optimizer.zero_grad()
+            if enable_amp:
+                scaler.scale(loss).backward()
+                scaler.step(optimizer)
+                scale = scaler.get_scale()
+                scaler.update()
+                if scale <= scaler.get_scale():
+                    scheduler.step()
+            else:
+                loss.backward()
+                optimizer.step()
+                scheduler.step()
+            comm_info["model_output_dict"] = output_dict
+
+        def after_step():  # hooks/misc.py:108-112
+            for key in comm_info["model_output_dict"].keys():
+                if "loss" in key:
+                    comm_info[key] = comm_info["model_output_dict"][key].item()
+
+        def timed(n, with_item):
+            if dist.is_initialized() and world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run_step()
+                if with_item:
+                    after_step()
+            torch.cuda.synchronize(device)
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            if dist.is_initialized() and world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        timed(warm, True)
+        with_item = timed(steps, True) if with_item_too else None
+        no_item = timed(steps, False)
+        after_step()
+        del model, optimizer
+        return with_item, no_item, comm_info.get("loss"), wrapped
+
+    with_item, no_item, loss, wrapped = measure("AdamW", False, True)
+    out = {"ms_per_step": 1e3 * with_item / steps, "points_per_s": points_per_step * steps / with_item,
+           "ms_per_step_no_item": 1e3 * no_item / steps, "steps": steps,
+           "loop": "Trainer.run_step statements (pointcept/engines/train_sam_pp2s.py:173-200) + InformationWriter.after_step's "
+                   "loss.item() (hooks/misc.py:112); batch from pinned host memory via .cuda(non_blocking=True)",
+           "model": "DistributedDataParallel(broadcast_buffers=False)" if wrapped else "bare module (create_ddp_model at world_size 1)",
+           "optimizer": "torch.optim.AdamW + MultiStepLR", "param_grads": "autograd (.grad through AccumulateGrad)",
+           "geometry": "inside PointTransformerV2.forward (pipelined with the level-0 prefix; no prefetcher, no geometry= key)",
+           "enable_amp": enable_amp, "loss": loss}
+    # config-only changes of the optimizer line; then the reference's DDP wrap forced at one rank
+    variants = {}
+    for kind in ("AdamW(fused=True)", "FlatAdamW"):
+        try:
+            _, t, _, _ = measure(kind, False, False)
+            variants["optimizer = dict(type=%s)" % ('"AdamW", ..., fused=True' if kind != "FlatAdamW" else '"FlatAdamW", ...')] = {
+                "ms_per_step_no_item": 1e3 * t / steps}
+        except Exception as exc:  # a variant must not take the line down
+            variants[kind] = {"error": repr(exc)[:200]}
+    out["variants"] = variants
+    if world == 1:
+        ddp = {}
+        for kind in ("AdamW", "FlatAdamW"):
+            try:
+                _, t, _, w = measure(kind, True, False)
+                ddp[kind] = {"ms_per_step_no_item": 1e3 * t / steps, "wrapped": bool(w)}
+            except Exception as exc:
+                ddp[kind] = {"error": repr(exc)[:200]}
+        ddp["what"] = ("DistributedDataParallel(broadcast_buffers=False) as create_ddp_model wraps (engines/defaults.py:20-43), "
+                       "forced in a one-rank RCCL group: hooks + bucket copies + the all-reduce launch, without another rank to wait for")
+        out["ddp"] = ddp
+    return out
 
 
 def child_main(args):
@@ -747,7 +800,12 @@ def child_main(args):
         _lib.lib().ptv2_profile_enable(0)
     ref_loop = None
     if not args.no_reference_loop:  # every rank takes part (DistributedDataParallel at world_size > 1)
-        ref_loop = reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step)
+        try:
+            ref_loop = reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step)
+        except Exception as exc:  # (after the timed region: a failure here is reported on the line, it does not take the headline down)
+            if world > 1:
+                raise  # (the other ranks are inside its collectives: fail together, loudly)
+            ref_loop = {"error": repr(exc)[:300]}
 
     if rank == 0:
         with torch.no_grad():

@@ -348,7 +348,8 @@ typedef struct ptv2_gva_block {
 
 typedef struct ptv2_gva_block_grads {
     const float *g_out;                           /* (n,c) */
-    const int *inv_ptr, *inv_rows;                /* inverse neighbour table (may be NULL) */
+    const int *inv_ptr, *inv_rows;                /* inverse neighbour table (NULL only for shapes without a fused backward:
+                                                   * (6,48) and the deep-level instances (12,96) (24,192) (48,384) need it) */
     float *gq, *gk, *gv;                          /* (n,c) each; gv [zeroed] when inv_ptr == NULL */
     float *gWp1, *gbp1, *ggamma_p, *gbeta_p, *gWp2, *gbp2, *gWw1, *gbw1, *ggamma_w, *gbeta_w, *gWw2, *gbw2;
 } ptv2_gva_block_grads;

@@ -284,7 +284,7 @@ def test_native_activation_checkpointing_gives_the_same_bits_with_less_memory():
             twice += 1
     assert twice == 2 * 4 * 15  # mean and variance of four norms in each of the 15 Blocks
     # (the deep levels no longer save an (N,G,C) tensor: the full arena shrank, the shared region is still the level-0 Block's)
-    assert saved[True] < 0.6 * saved[False], saved
+    assert saved[True] < 0.8 * saved[False], saved
 
 
 @pytest.mark.parametrize("tag,points,bf16", [("s3dis", 9000, False), ("scannet", 7000, False), ("s3dis", 9000, True)])
