@@ -10,6 +10,7 @@
 // the next level's tables -- carved from the caller's arena as the sizes become known.
 #include <algorithm>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -94,8 +95,28 @@ size_t level_bytes(const ptv2_scene_geo *G, int i, size_t n, bool first, bool la
     return t;
 }
 
-int *g_pinned = nullptr;  // one pinned word per read-back in flight; a call holds the mutex for its duration
+// Pinned read-back words, one per call in flight (a pool: the mutex covers taking / returning a word only -- a geometry build
+// that waits for its GPU stage no longer keeps every other build of the process, on whatever device or stream, waiting behind
+// it; hipHostMallocPortable: the word is usable from every device of the process)
 std::mutex g_pin_mu;
+std::vector<int *> g_pin_free;
+struct PinnedWord {
+    int *p = nullptr;
+    PinnedWord() {
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            if (!g_pin_free.empty()) { p = g_pin_free.back(); g_pin_free.pop_back(); }
+        }
+        if (!p && hipHostMalloc((void **)&p, 64, hipHostMallocPortable) != hipSuccess) p = nullptr;
+    }
+    ~PinnedWord() {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        g_pin_free.push_back(p);
+    }
+    PinnedWord(const PinnedWord &) = delete;
+    PinnedWord &operator=(const PinnedWord &) = delete;
+};
 
 }  // namespace
 
@@ -151,8 +172,9 @@ static int scene_geometry(ptv2_scene_geo *G, void *arena, size_t arena_bytes, vo
         L.coord = L.offset = L.cluster = L.order = L.idx_ptr = L.up_idx = L.up_w = L.up_inv_ptr = L.up_inv_rows = -1;
         for (int j = 0; j < PTV2_GEO_MAX_K; ++j) L.knn[j].idx = L.knn[j].mu = L.knn[j].cov = L.knn[j].inv_ptr = L.knn[j].inv_rows = -1;
     }
-    std::lock_guard<std::mutex> lk(g_pin_mu);
-    if (!g_pinned && hipHostMalloc((void **)&g_pinned, 64, hipHostMallocDefault) != hipSuccess) return PTV2_ERR_LAUNCH;
+    const PinnedWord pinned;
+    if (!pinned.p) return PTV2_ERR_LAUNCH;
+    int *const g_pinned = pinned.p;
 
     // ---- phase 1: the chain of grid poolings alone -- each needs only the coordinates of the level above it, and their cluster
     // counts are the only data-dependent sizes of a scene.  With all S read-backs at the front, a second host thread (the one
@@ -182,7 +204,10 @@ static int scene_geometry(ptv2_scene_geo *G, void *arena, size_t arena_bytes, vo
             if (hipStreamSynchronize(st) != hipSuccess) return PTV2_ERR_LAUNCH;  // the one host wait of a stage
             m = *g_pinned;
         }
-        if (m < 1) return PTV2_ERR_ARG;  // voxel ids beyond the sort key (or an empty level)
+        if (m < 1) {  // voxel ids beyond the sort key (m == -1, reported as such: the caller tells it from other argument errors)
+            N.n = m == -1 ? -1 : 0;
+            return PTV2_ERR_ARG;
+        }
         N.n = m;
         off = (size_t)N.coord + al(12 * (size_t)m);  // the pooled coordinates were the last item: give the unused rows back
         coords[i + 1] = (const float *)at(N.coord);

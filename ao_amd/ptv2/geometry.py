@@ -278,7 +278,7 @@ class NativeGeometryJob:
 
     def check(self):
         rc, G = self.rc, self.G
-        if rc == 1 and any(G.level[i + 1].n < 1 for i in range(G.num_stages)):
+        if rc == 1 and any(G.level[i + 1].n == -1 for i in range(G.num_stages)):  # (the launcher marks exactly this case)
             raise RuntimeError("grid_pool: voxel ids exceed the 48-bit sort key (scene extent / grid_size too large)")
         _lib.check(rc, "ptv2_scene_geometry_hip_launcher")
 

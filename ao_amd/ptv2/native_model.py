@@ -417,7 +417,23 @@ def _side_tensors(geo):
 
 class _NativeModel(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, anchor, rt, geo, training, mode, bf16, *params):
+    def forward(ctx, *args):
+        try:
+            return _NativeModel._forward(ctx, *args)
+        except BaseException:
+            # the helper thread may still be inside the native geometry call, enqueuing on the side stream: let it finish (its
+            # error, if any, is the consequence, not the cause) before the exception unwinds -- the next forward would queue
+            # behind it on the single-worker executor and find the side stream in an unknown state
+            fut = ctx.__dict__.pop("_geo_fut", None) if hasattr(ctx, "__dict__") else None
+            if fut is not None:
+                try:
+                    fut.result()
+                except Exception:
+                    pass
+            raise
+
+    @staticmethod
+    def _forward(ctx, feat, anchor, rt, geo, training, mode, bf16, *params):
         feat = feat.contiguous()
         dev = feat.device
         L = _lib.lib()
@@ -447,9 +463,12 @@ class _NativeModel(torch.autograd.Function):
             req, model = geo, geo.model
             main = torch.cuda.current_stream(dev)
             side = rt.side_stream(dev)
+            # (materialised BEFORE the event: a non-contiguous coord view -- feat[:, :3] -- or an int64 offset becomes a copy kernel
+            # on this stream, which the side stream's first pooling must not overtake)
+            coord0, offset0 = req.coord.contiguous(), req.offset.int().contiguous()
             ev_in = torch.cuda.Event()
             ev_in.record(main)  # coord / offset may have been produced on this stream (the trainer's H2D copies)
-            st = begin_geometry(req.coord, req.offset, model.grid_sizes, model.geometry_neighbours(),
+            st = begin_geometry(coord0, offset0, model.grid_sizes, model.geometry_neighbours(),
                                 interp=model.unpool_backend == "interp")
             ev_l0 = torch.cuda.Event()
             ev_l0.record(main)  # the level-0 tables exist (the inverse tables on the side stream read them)
@@ -467,6 +486,7 @@ class _NativeModel(torch.autograd.Function):
                     ev_fwd.record(side)  # (creates the handle the launcher re-records)
                     job = NativeGeometryJob(st, fwd_ready_event=ev_fwd, knn0_event=ev_l0)
                 fut = rt.geometry_worker(dev).submit(job.run)
+                ctx._geo_fut = fut
             keep0 = rt.fill_prefix(lv0)
             for t in keep0:
                 t.record_stream(side)

@@ -167,3 +167,25 @@ def test_prefix_issued_eagerly_behind_an_idle_stream_gives_the_same_bits(monkeyp
     for (la, ga, sa), (lb, gb, sb) in zip(a, b):
         assert torch.equal(la, lb)
         assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+
+
+def test_pipelined_forward_takes_a_coord_view_and_an_int64_offset():
+    """`coord` handed over as a non-contiguous view (feat[:, :3], how a loader that keeps one (N, 6) tensor would
+    pass it) and an int64 `offset` become copy kernels on the caller's stream; the side stream's first pooling has to wait for
+    them (the input event is recorded behind the materialisation), so the result equals the contiguous / int32 call's bits."""
+    from ao_amd.ptv2 import native_model
+
+    cfg = dict(M.S3DIS_CFG, drop_path_rate=0.0)
+    data = _data([7, 8], 20000, cfg)
+    wide = torch.cat([data["coord"], torch.randn_like(data["coord"])], dim=1)  # (N, 6): coord = a strided view of it
+    view = dict(data, coord=wide[:, :3], offset=data["offset"].long())
+    assert not view["coord"].is_contiguous() and view["offset"].dtype == torch.int64
+    res = {}
+    for tag, d in (("plain", data), ("view", view)):
+        model = _model(cfg, seed=29)
+        assert native_model.supported(model, d["feat"]) and native_model.pipelined_ok(model)
+        for _ in range(3):
+            res[tag] = _run(model, d)
+    assert torch.equal(res["plain"][0], res["view"][0])
+    for a, b in zip(res["plain"][1], res["view"][1]):
+        assert torch.equal(a, b)
