@@ -153,24 +153,28 @@ unsigned *ptv2_stream_counters(hipStream_t st) {
 // branch beyond one flag read.  Enabled by bench.py for its roofline object (HIP events on the launch
 // stream around ONE named kernel per launcher, so the averages are comparable with rocprofv3 --stats).
 namespace {
+// A name that ends in " [family]" brackets several kernel symbols (instantiations of one template chosen by shape, or the
+// kernels of one BatchNorm pass): bench.py ranks those as families and takes its dominant KERNEL among the others, each of
+// which is one symbol of rocprofv3's table.
 const char *kNames[KID_COUNT] = {
-    "knn_grid_query_kernel", "logits_fwd_kernel", "softmax_rows_kernel", "aggregate_tile_kernel", "peb_fwd_kernel",
-    "peb_bwd_kernel", "aggregate_bwd_tile_kernel", "aggregate_bwd_rows_kernel", "aggregate_bwd_gv_kernel",
-    "logits_bwd_rows_kernel", "logits_bwd_gather_kernel", "logits_bwd_params_kernel", "linear_wgrad_kernel",
-    "bn_stats_kernel", "bn_apply_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "skinny_fwd_kernel",
-    "skinny_bwd_kernel", "rows_gemm_kernel<48, false, 32>", "rows_gemm_kernel<48, false, 64>",
-    "rows_gemm_kernel<48, true, 32>", "rows_gemm_kernel<48, true, 64>", "rows_gemm_kernel<64, false, 32>",
-    "rows_gemm_kernel<64, false, 64>", "rows_gemm_kernel<64, true, 32>", "rows_gemm_kernel<64, true, 64>",
+    "knn_row_query_kernel [family]", "logits_fwd_kernel [family]", "softmax_rows_kernel [family]", "aggregate_tile_kernel [family]",
+    "peb_fwd_kernel [family]", "peb_bwd_kernel<8>", "aggregate_bwd_tile_kernel [family]", "aggregate_bwd_rows_kernel [family]",
+    "aggregate_bwd_gv_kernel<8>", "logits_bwd_rows_kernel [family]", "logits_bwd_gather_kernel", "logits_bwd_params_kernel [family]",
+    "linear_wgrad_kernel [family]", "bn_stats_kernel", "bn_apply_kernel [family]", "bn_bwd_reduce_kernel [family]",
+    "bn_bwd_apply_kernel [family]", "skinny_fwd_kernel", "skinny_bwd_kernel", "rows_gemm_kernel<48, false, 32> [family]",
+    "rows_gemm_kernel<48, false, 64> [family]", "rows_gemm_kernel<48, true, 32> [family]", "rows_gemm_kernel<48, true, 64> [family]",
+    "rows_gemm_kernel<64, false, 32> [family]", "rows_gemm_kernel<64, false, 64> [family]", "rows_gemm_kernel<64, true, 32> [family]",
+    "rows_gemm_kernel<64, true, 64> [family]",
     "attention_bwd_point_kernel<6, 48, 1, true>",
     "attention_bwd_point_kernel<12, 96, 1, false>", "attention_bwd_point_kernel<24, 192, 2, false>",
     "attention_bwd_point_kernel<48, 384, 4, false>", "attention_bwd_point_kernel<64, 512, 4, false>",
-    "linear_wgrad_lds_kernel",  // (both instances and their batched form: the family)
-    "grouped_wgrad_kernel", "attention_fwd_point6_kernel",
+    "linear_wgrad_lds_kernel [family]",  // (both instances and their batched form)
+    "grouped_wgrad_kernel_jobs", "attention_fwd_point6_kernel",
     "logits_bwd_fused6_kernel<48>", "logits_bwd_fused_kernel<12, 96, 1>", "logits_bwd_fused_kernel<24, 192, 4>",
     "logits_bwd_fused_kernel<48, 384, 4>", "logits_bwd_fused_kernel<64, 512, 4>",
-    "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel",
+    "bn_bwd_apply_residual_kernel", "bn_bwd_finapply_kernel [family]",
     "attention_fwd_tile_kernel<12, 96, 12>", "attention_fwd_tile_kernel<24, 192, 12>", "attention_fwd_tile_kernel<48, 384, 12>",
-    "attention_fwd_tile_kernel<64, 512, 16>", "wp2_wgrad_tile_kernel",
+    "attention_fwd_tile_kernel<64, 512, 16>", "wp2_wgrad_tile_kernel_jobs",
     "attention_bwd_tile_kernel<12, 96, 8>", "attention_bwd_tile_kernel<24, 192, 8>", "attention_bwd_tile_kernel<48, 384, 8>",
     "attention_bwd_tile_kernel<64, 512, 8>"};
 struct Rec { hipEvent_t a, b; double bytes; };

@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-ops", action="store_true", help="skip the kNN / FPS us-per-query lines")
     ap.add_argument("--no-reference-loop", action="store_true",
                     help="skip the reference_loop leg (the reference trainer's run_step statements over this build)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip config.also: the reference recipe's per-GPU batch (3 x 80 000 points) timed by a child run")
     ap.add_argument("--spawn-timeout", type=float, default=1800.0,
                     help="--gpus N without a launcher: seconds after which the remaining ranks are terminated (exit 124)")
     return ap.parse_args()
@@ -112,6 +114,7 @@ def pmc_traffic(kernel, build_info):
     profile's first line carries the source digest of THIS build of the library; (None, why) otherwise."""
     import glob
 
+    kernel = kernel.replace(" [family]", "")  # (a family's timer name: matched as the template's instances below)
     want = src_hash(build_info)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_per_launch.jsonl")), reverse=True)
     stale = []
@@ -541,6 +544,64 @@ def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
     return out
 
 
+def block_leg(ptv2, geo, device, reps=10):
+    """One level-0 Block of the scene (C = 48, G = 6, K = 16) on its own, forward and backward timed with HIP events, against
+    SURVEY.md section 8(d)'s COMPULSORY traffic of a fused Block -- forward 4 N (2C + K + 3) bytes (feat in, feat out, idx,
+    coord), backward 4 N (4C + K + 3) (feat, grad_out in; grad_feat out; recompute) -- i.e. the fraction of the HBM roofline
+    the whole Block chain reaches, beside the per-kernel fraction of its dominant kernel (which counts the design's own
+    intermediates as algorithmic bytes).  Standalone: the Block's weight gradients run in the backward here (the model runtime
+    files them and runs all of them at the end of the step)."""
+    lv = geo.levels[0]
+    n, c, g, k = int(lv.coord.shape[0]), 48, 6, 16
+    idx = lv.neighbours(k)
+    blk = ptv2.Block(c, g).to(device).train()
+    x = torch.randn(n, c, device=device).relu_().requires_grad_(True)
+    go = torch.randn(n, c, device=device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf, tb = [], []
+    for it in range(reps + 3):
+        ev[0].record()
+        y = blk([lv.coord, x, lv.offset], idx)[1]
+        ev[1].record()
+        y.backward(go)
+        ev[2].record()
+        torch.cuda.synchronize(device)
+        if it >= 3:
+            tf.append(ev[0].elapsed_time(ev[1]))
+            tb.append(ev[1].elapsed_time(ev[2]))
+        blk.zero_grad(set_to_none=True)
+        x.grad = None
+    tf, tb = sorted(tf)[len(tf) // 2], sorted(tb)[len(tb) // 2]
+    fb, bb = 4.0 * n * (2 * c + k + 3), 4.0 * n * (4 * c + k + 3)
+    return {"level": 0, "n": n, "c": c, "g": g, "k": k,
+            "forward": {"ms": tf, "compulsory_MB": fb / 1e6, "frac": fb / (tf * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+            "backward": {"ms": tb, "compulsory_MB": bb / 1e6, "frac": bb / (tb * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+            "what": "one level-0 Block standalone (median of %d, HIP events; eager issue, weight gradients inside the backward); "
+                    "compulsory bytes per SURVEY.md section 8(d)" % reps}
+
+
+def also_leg(args):
+    """`config.also`: the batch each rank of the reference's 4-GPU recipe runs -- batch_size 12 over 4 GPUs = 3 scenes per GPU
+    (configs/s3dis/semseg-pt-v2m2-0-base.py:3, pointcept/engines/defaults.py:139), 80 000 points each --
+    timed by a child run of this script with the same loop (a fresh process: its own arenas, graphs and prefetcher), so that
+    the driver's line carries that number beside the 1 x 120 000 headline.  Only for the default workload at one GPU."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--scenes", "3", "--points", "80000", "--steps", "10", "--warmup", "5",
+           "--dtype", args.dtype, "--cfg", args.cfg, "--segmentor", args.segmentor, "--no-cpu-baseline", "--no-ops", "--no-roofline",
+           "--no-reference-loop", "--no-also"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or len(lines) != 1:
+            return {"error": "child rc %d: %s" % (out.returncode, out.stderr[-300:])}
+        d = json.loads(lines[0])
+        return {"workload": d["config"]["workload"], "why": "the per-GPU batch of the reference's 4-GPU recipe (batch_size 12 / 4 GPUs, "
+                "configs/s3dis/semseg-pt-v2m2-0-base.py:3)", "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                "steps": d["steps"], "warmup": d["warmup"], "points_per_step": d["config"].get("points_per_step")}
+    except Exception as exc:
+        return {"error": repr(exc)[:300]}
+
+
 def child_main(args):
     _imports()
     # stdout carries exactly ONE line, the JSON result of rank 0: everything else that writes to file descriptor 1 in any
@@ -650,6 +711,8 @@ def child_main(args):
         for _ in range(2 if pf_mode == "thread" else 1):
             prefetch.start(data["coord"], data["offset"])
 
+    ar_events = [] if sync is not None else None  # (event pair, bytes) per step around the gradient all-reduce
+
     def step():
         batch = data if prefetch is None else dict(data, geometry=prefetch.take())
         if prefetch is not None and pf_mode == "thread":
@@ -667,7 +730,14 @@ def child_main(args):
         loss.backward()
         if flat_opt:  # gradients -> one flat buffer -> (all-reduce) -> one update kernel
             flat = opt.flatten_grads()
-            scale = sync.reduce_flat(flat) if sync is not None else 1.0
+            if sync is not None and ar_events is not None:  # the exchange bracketed on the stream that waits for it
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+                scale = sync.reduce_flat(flat)
+                eb.record()
+                ar_events.append((ea, eb, flat.numel() * 4))
+            else:
+                scale = sync.reduce_flat(flat) if sync is not None else 1.0
             if prefetch is not None and pf_mode == "1":
                 prefetch.start(data["coord"], data["offset"])
             opt.step(flat_grad=flat, grad_scale=scale)
@@ -725,13 +795,11 @@ def child_main(args):
         _lib.kernel_timer(False)
         survey = _lib.kernel_timer_read()
         if survey:
-            # the largest single kernel: the timer id with the largest total time among those with at most 8 launches per step
-            # (and at least half the largest total).  Some ids bracket a family of kernel symbols -- the row GEMMs of one
-            # column-block width, the BatchNorm reduce kernels -- whose 24-47 launches together reach the 0.52 ms of the three
-            # launches of the level-0 attention backward; rocprofv3's per-symbol table has that kernel first, and so has this.
-            top = max(v["total_us"] for v in survey.values())
-            few = {k: v for k, v in survey.items() if v["launches"] <= 8 * survey_steps and v["total_us"] >= 0.5 * top}
-            dominant = max((few or survey).items(), key=lambda kv: kv[1]["total_us"])[0]
+            # the dominant KERNEL: the largest total among the timer ids that bracket ONE kernel symbol (an instantiation, as
+            # rocprofv3's per-kernel table lists it).  Ids whose name ends in " [family]" bracket several symbols -- the row GEMMs
+            # of one column-block width, the kernels of a BatchNorm pass -- and are ranked as families in `all_kernels` only.
+            single = {k: v for k, v in survey.items() if not k.endswith("[family]")}
+            dominant = max((single or survey).items(), key=lambda kv: kv[1]["total_us"])[0]
             # every stride-th launch of it: a uniform sample over the timed region.  ~6 bracketed launches per step (a bracket
             # costs ~3 us of queue time: bracketing all 52 weight-gradient launches of a step was 0.1 ms of it); the stride is
             # co-prime with the launches per step so that the sampled positions spread over all Blocks
@@ -769,6 +837,8 @@ def child_main(args):
         marks[i + 1].record()
         return out
 
+    if ar_events is not None:
+        del ar_events[:]  # (the warm-up's)
     _lib.graph_stats(reset=True)
     cg0 = cgroup_cpu()[1]
     threads0, proc_cpu0 = thread_cpu_snapshot(), time.process_time()
@@ -831,6 +901,9 @@ def child_main(args):
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "comm_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": _launcher_name(),
+                       "miou": "not measured: no S3DIS on the box.  The 'mIoU within +-0.2 after equal steps' target of BASELINE.json has "
+                               "a synthetic stand-in only (tests/test_gpu_model.py: 10-step trajectory vs the CPU oracle, 150 steps vs "
+                               "the literal op sequence)",
                        "grad_sync": "ddp" if use_ddp else ("flat all-reduce, two chunks (decoder half overlapped with the encoder "
                                                              "backward)" if (sync is not None and sync.split is not None)
                                                             else "flat all-reduce"),
@@ -930,8 +1003,26 @@ def child_main(args):
                                                        "ms_per_step": round(v["total_us"] / 1e3 / max(survey_steps, 1), 3),
                                                        "GBps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
                                                    for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["total_us"])}}
+        if ar_events:
+            # per-step gradient exchange from events on the stream that waits for it: what the first real N > 1 line needs to
+            # explain itself.  Bus bandwidth as nccl-tests define it for an all-reduce: 2 (N - 1) / N x bytes / time
+            ms_list = sorted(a.elapsed_time(b) for a, b, _ in ar_events)
+            nbytes = ar_events[0][2]
+            med = ms_list[len(ms_list) // 2]
+            out["config"]["all_reduce"] = {"ms_per_step_median": med, "ms_per_step_max": ms_list[-1], "MB": nbytes / 1e6,
+                                           "bus_GBps": (2.0 * (world - 1) / world) * nbytes / (med * 1e-3) / 1e9 if world > 1 and med > 0 else None,
+                                           "ranks": world, "what": "HIP events around FlatGradSync.reduce_flat on rank 0's compute stream "
+                                           "(the collective runs on RCCL's stream; the compute stream waits for it)"}
+        if world == 1 and not args.no_roofline and args.cfg == "s3dis":
+            try:
+                out["roofline"]["block"] = block_leg(ptv2, geo, device)
+                out["roofline"]["block_frac"] = out["roofline"]["block"]["backward"]["frac"]
+            except Exception as exc:
+                out.setdefault("roofline", {})["block"] = {"error": repr(exc)[:200]}
         if ref_loop is not None:
             out["reference_loop"] = ref_loop
+        if world == 1 and not args.no_also and args.cfg == "s3dis" and args.scenes == 1 and args.points == 120000:
+            out["config"]["also"] = also_leg(args)
         if world == 1 and not args.no_ops:
             out["ops"] = op_microbench(data)
         if world == 1 and not args.no_cpu_baseline:

@@ -94,9 +94,13 @@ def test_full_size_block_forward_backward_matches_unfused(monkeypatch, seeds, po
         np.testing.assert_allclose(sd_f[key].cpu().numpy(), sd_u[key].cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=key)
 
 
-@pytest.mark.parametrize("tag,seeds,points", [("s3dis", (0,), 120000), ("s3dis", (4, 5), 80000), ("scannet", (7, 8), 100000)])
+@pytest.mark.parametrize("tag,seeds,points", [("s3dis", (0,), 120000), ("s3dis", (4, 5), 80000), ("scannet", (7, 8), 100000),
+                                              ("s3dis", (4, 5, 6), 80000), ("scannet", (0,), 240000)])
 def test_full_size_model_train_step_matches_unfused(monkeypatch, tag, seeds, points):
-    """("scannet", 2 x 100 000 points): BASELINE.json configs[4]'s shape -- four stages, C up to 512 (G = 64), "map" unpool."""
+    """("scannet", 2 x 100 000 points): BASELINE.json configs[4]'s shape -- four stages, C up to 512 (G = 64), "map" unpool.
+    ("s3dis", 3 x 80 000): the per-GPU batch of the reference's 4-GPU recipe (batch_size 12 over 4 GPUs,
+    configs/s3dis/semseg-pt-v2m2-0-base.py:3).  ("scannet", ONE cloud of 240 000 points): the size BASELINE.json's configs[4]
+    states per scene (the uncropped / validation size; the training crop is 100 000, configs/scannet/semseg-pt-v2m2-0-base.py:111)."""
     import ao_amd.ptv2 as ptv2
     from ao_amd import synth
 
@@ -104,8 +108,10 @@ def test_full_size_model_train_step_matches_unfused(monkeypatch, tag, seeds, poi
     if tag == "s3dis":
         data = _scene(seeds, points)
     else:
-        b = synth.scene_batch(list(seeds), point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"], room=1)
+        b = synth.scene_batch(list(seeds), point_max=points, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"],
+                              room=2 if points > 200000 else 1)
         data = {k: torch.from_numpy(v).cuda() for k, v in b.items()}
+    assert int(data["coord"].shape[0]) >= int(0.95 * points * len(seeds)), data["coord"].shape
     state = M.init_state(cfg, seed=13)
     res = {}
     for tag in ("fused", "unfused"):
@@ -160,3 +166,51 @@ def test_model_train_step_matches_the_oracle_at_24k_points():
     worst = _compare_grads(names, got, list(ref_grads), 2e-2, weights)
     print("oracle 24k: max |dlogit| %.2e, worst gradient %s rel L2 %.2e"
           % (float((logits.detach().cpu() - ref_logits.detach()).abs().max()), *worst))
+
+
+def test_scannet_cfg_geometry_of_one_240k_point_cloud():
+    """BASELINE.json configs[4] at its stated size -- ONE ScanNet-cfg cloud of 240 000 points -- through the scene geometry the
+    model builds (kNN tables, grid poolings, cluster maps; "map" unpooling: no interpolation tables): properties of the WHOLE
+    output (self neighbour first, ascending distances, indices inside the cloud, cluster maps consistent with the pooled
+    coordinates) and the multi-threaded CPU oracle on a 4 000-query subset of every level's kNN table and on the first pooling."""
+    import ao_amd.ptv2 as ptv2
+    from ao_amd import pointops, synth
+    from oracle import pointops_ref as P
+
+    cfg = dict(M.SCANNET_CFG, drop_path_rate=0.0)
+    b = synth.scene_batch([0], point_max=240000, in_channels=cfg["in_channels"], num_classes=cfg["num_classes"], room=2)
+    coord = torch.from_numpy(b["coord"]).cuda()
+    offset = torch.from_numpy(b["offset"]).cuda().int()
+    assert coord.shape[0] == 240000 and offset.tolist() == [240000]
+    model = ptv2.PointTransformerV2(**cfg).cuda()
+    geo = model.geometry(coord, offset)
+    sizes = [int(lv.coord.shape[0]) for lv in geo.levels]
+    assert sizes[0] == 240000 and all(a > b for a, b in zip(sizes, sizes[1:])) and len(sizes) == 5, sizes
+    gen = torch.Generator().manual_seed(5)
+    for li, (lv, ks) in enumerate(zip(geo.levels, model.geometry_neighbours())):
+        n = int(lv.coord.shape[0])
+        for k in ks:
+            idx = lv.neighbours(k)
+            assert idx.shape == (n, k) and idx.dtype == torch.int32
+            kk = min(k, n)
+            assert int(idx[:, :kk].min()) >= 0 and int(idx.max()) < n
+            assert torch.equal(idx[:, 0].long(), torch.arange(n, device="cuda"))  # the query itself, distance 0, first
+            d = (lv.coord[idx[:, :kk].long()] - lv.coord[:, None, :]).pow(2).sum(-1)
+            assert bool((d[:, 1:] >= d[:, :-1] - 1e-6).all())  # ascending
+            # the reference's algorithm (C restatement, all host threads) on a subset of the queries
+            pick = torch.randperm(n, generator=gen)[: min(4000, n)].sort().values
+            q = lv.coord[pick.cuda()].cpu().contiguous()
+            ridx, _ = P.knn_query_raw(k, lv.coord.cpu(), lv.offset.cpu(), q, torch.tensor([q.shape[0]], dtype=torch.int32), mt=True)
+            assert torch.equal(idx[pick.cuda()].cpu(), ridx), (li, k)
+    # cluster maps: every point's cluster exists, every cluster has members, pooled coordinate = mean of its members
+    for lv, nxt in zip(geo.levels, geo.levels[1:]):
+        cl = lv.cluster.long()
+        m = int(nxt.coord.shape[0])
+        assert int(cl.min()) == 0 and int(cl.max()) == m - 1
+        cnt = torch.bincount(cl, minlength=m)
+        assert int(cnt.min()) >= 1 and int(cnt.sum()) == lv.coord.shape[0]
+        mean = torch.zeros(m, 3, device="cuda", dtype=torch.float64).index_add_(0, cl, lv.coord.double()) / cnt[:, None]
+        assert float((mean - nxt.coord.double()).abs().max()) < 1e-5
+    # the first pooling against the oracle's restatement of GridPool's clustering (bit-exact pooled coordinates)
+    ref_c, _, ref_cluster, _, _ = M.grid_pool_geometry(torch.from_numpy(b["coord"]), torch.from_numpy(b["offset"]).int(), cfg["grid_sizes"][0])
+    assert torch.equal(geo.levels[1].coord.cpu(), ref_c) and torch.equal(geo.levels[0].cluster.cpu().long(), ref_cluster.long())
