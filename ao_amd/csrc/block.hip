@@ -79,8 +79,8 @@ Work carve_work(void *base, int n, int k, int c, int g) {
     w.gva_bytes = gva_block_workspace_bytes(n, k, c, g);
     w.gva = take(w.gva_bytes);
     for (int i = 0; i < 7; ++i) w.t[i] = (float *)take(sizeof(float) * (size_t)n * c);
-    // (stat[0] also takes the attention output's records, which the deep levels' tile kernel leaves per 16 rows)
-    for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * (i == 0 ? bn_tiles_floats_rb(n, c, 16) : bn_tiles_floats(n, c)));
+    // (records of 16 rows: the deep levels' k-split GEMM and attention tile kernels leave them per 16-row block)
+    for (int i = 0; i < 4; ++i) w.stat[i] = (float *)take(sizeof(float) * bn_tiles_floats_rb(n, c, 16));
     w.bytes = off;
     return w;
 }
@@ -183,7 +183,17 @@ int bn_tiles_finalize_rb(int n, int c, int rb, float *part, const float *gamma, 
 int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
                            float *const *mean, float *const *rstd, float *const *sc, float *const *sh, float *const *running_mean,
                            float *const *running_var, long long *const *num_batches_tracked, float eps, float momentum,
-                           void *stream);
+                           void *stream, int rb);
+// gemm.hip: rows per statistics / reduce record the fused row GEMMs write for a shape (16: the deep levels' k-split kernel),
+// and the switch that tells them this caller reads either
+int rows_gemm_record_rows(int m, int n, int k);
+void ptv2_gemm_allow_rb16(int on);
+namespace {
+struct GemmRb16Scope {
+    GemmRb16Scope() { ptv2_gemm_allow_rb16(1); }
+    ~GemmRb16Scope() { ptv2_gemm_allow_rb16(0); }
+};
+}  // namespace
 
 static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, const float *gamma, const float *beta,
                       const Saved &S, const Work &W, void *stream, int rb = 64) {
@@ -209,7 +219,8 @@ static int bn_prepare(const ptv2_block *B, int i, const float *h, float *part, c
 int gva_fold_forward_batched(int count, const ptv2_gva_block *blocks, void *stream);
 int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
                             float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
-                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream);
+                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream,
+                            int rb);
 int gva_block_forward_stats(const ptv2_gva_block *B, float *out_stats, int *stats_done, void *workspace, size_t workspace_bytes,
                             void *stream);
 
@@ -237,6 +248,8 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
     const Work W = carve_work(workspace, n, k, c, g);
     if (!workspace || workspace_bytes < W.bytes) return PTV2_ERR_WORKSPACE;
     const float *const *P = B->param;
+    const GemmRb16Scope rb16;                          // this function reads the row GEMMs' records at either granularity
+    const int rb = rows_gemm_record_rows(n, c, c);     // (every Linear of a Block is (n, c) x (c, c))
     float *st_h1 = use_batch(B, 0) ? W.stat[0] : nullptr, *st_hq = use_batch(B, 1) ? W.stat[1] : nullptr;
     float *st_hk = use_batch(B, 2) ? W.stat[2] : nullptr, *st_h3 = use_batch(B, 6) ? W.stat[3] : nullptr;
     // fc1 (+ statistics of h1) -> norm1
@@ -245,7 +258,7 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
         float *ys[1] = {S.h1}, *sts[1] = {st_h1};
         RUN(rows_gemm_fused_hip_launcher(n, c, c, 1, 0, xs, ws, 0, nullptr, ys, 0, nullptr, nullptr, sts, stream));
     }
-    RUN(bn_prepare(B, 0, S.h1, st_h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S, W, stream));
+    RUN(bn_prepare(B, 0, S.h1, st_h1, P[PTV2_BLK_N1_G], P[PTV2_BLK_N1_B], S, W, stream, rb));
     // linear_q / linear_k / linear_v on f1 = ReLU(BN1(h1)) (applied on the operand load), statistics of hq, hk
     {
         const float *xs[3] = {S.h1, S.h1, S.h1}, *ws[3] = {P[PTV2_BLK_Q_W], P[PTV2_BLK_K_W], P[PTV2_BLK_V_W]};
@@ -261,10 +274,10 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
         float *rms[2] = {tq ? B->run_mean[1] : nullptr, tk ? B->run_mean[2] : nullptr};
         float *rvs[2] = {tq ? B->run_var[1] : nullptr, tk ? B->run_var[2] : nullptr};
         long long *nbs[2] = {tq ? B->batches[1] : nullptr, tk ? B->batches[2] : nullptr};
-        RUN(bn_tiles_finalize_pair(n, c, parts, gs, bs, means, rstds, scs, shs, rms, rvs, nbs, B->eps, B->momentum, stream));
+        RUN(bn_tiles_finalize_pair(n, c, parts, gs, bs, means, rstds, scs, shs, rms, rvs, nbs, B->eps, B->momentum, stream, rb));
     } else {
-        RUN(bn_prepare(B, 1, S.hq, st_hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S, W, stream));
-        RUN(bn_prepare(B, 2, S.hk, st_hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S, W, stream));
+        RUN(bn_prepare(B, 1, S.hq, st_hq, P[PTV2_BLK_QN_G], P[PTV2_BLK_QN_B], S, W, stream, rb));
+        RUN(bn_prepare(B, 2, S.hk, st_hk, P[PTV2_BLK_KN_G], P[PTV2_BLK_KN_B], S, W, stream, rb));
     }
     // grouped vector attention (q, k enter as hq, hk + folded affine)
     ptv2_gva_block V;
@@ -288,10 +301,10 @@ extern "C" int ptv2_block_forward_hip_launcher(const ptv2_block *B, void *worksp
         const bool track = B->training && B->run_mean[6] && B->run_var[6];
         tail_done = bn_tiles_apply_residual(n, c, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S.mean[6], S.rstd[6], S.bsc[6], S.bsh[6],
                                             track ? B->run_mean[6] : nullptr, track ? B->run_var[6] : nullptr,
-                                            track ? B->batches[6] : nullptr, B->eps, B->momentum, S.h3, B->x, B->rowscale, B->y, stream);
+                                            track ? B->batches[6] : nullptr, B->eps, B->momentum, S.h3, B->x, B->rowscale, B->y, stream, rb);
     }
     if (!tail_done) {
-        RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream));
+        RUN(bn_prepare(B, 6, S.h3, st_h3, P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], S, W, stream, rb));
         RUN(bn_apply_residual_hip_launcher(n, c, S.h3, S.mean[6], S.rstd[6], P[PTV2_BLK_N3_G], P[PTV2_BLK_N3_B], B->x, B->rowscale,
                                            B->y, stream));
     }
@@ -338,8 +351,10 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
                                           stream));
     // fc3 input gradient -> g_f2 (ta); norm2 + ReLU -> g_attn (tb)
     // (at <= 512 row blocks the GEMM's epilogue leaves the reduce records of the BatchNorm backward that consumes its output)
-    const int nrb = (n + 63) / 64;
-    const bool epi = nrb <= 512;
+    const GemmRb16Scope rb16;
+    const int rb = rows_gemm_record_rows(n, c, c);
+    const int nrb = (n + rb - 1) / rb;   // reduce records the GEMM epilogues leave (per 64 rows, or 16 from the k-split kernel)
+    const bool epi = nrb <= (rb == 16 ? 2048 : 512);
     if (epi) {
         const float *xs[1] = {g_h3}, *ws[1] = {P[PTV2_BLK_FC3_W]};
         RUN(rows_gemm_bnbwd_hip_launcher(n, c, c, 1, xs, ws, 1, ta, S.attn, S.mean[5], S.rstd[5], P[PTV2_BLK_N2_G],

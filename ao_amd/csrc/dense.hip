@@ -505,14 +505,14 @@ __global__ __launch_bounds__(TPB) void bn_tiles_apply_residual_kernel(BnTileSet 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int kk = k + u * SL;
-                    const int cnt = (n - kk * 64) < 64 ? (n - kk * 64) : 64;
+                    const int cnt = bn_tile_rows(S, kk, n);
                     const double sb = (double)sv[u];
                     a += sb;
                     b += (double)mv[u] + sb * sb / (double)cnt;
                 }
             }
             for (; k < nrb; k += SL) {
-                const int cnt = (n - k * 64) < 64 ? (n - k * 64) : 64;
+                const int cnt = bn_tile_rows(S, k, n);
                 const double sb = (double)p[(size_t)k * 2 * c];
                 a += sb;
                 b += (double)p[(size_t)k * 2 * c + c] + sb * sb / (double)cnt;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_finapply_kernel(int n, int c, int 
 // records few enough for the consumer-side sum (and the A/B switch of the tests: AO_AMD_BN_FINAPPLY=0)
 static bool finapply_ok(int n, int nrec) {
     const char *e = getenv("AO_AMD_BN_FINAPPLY");
-    return nrec <= 256 && n <= 16384 && !(e && e[0] == '0');
+    return nrec <= 640 && n <= 16384 && !(e && e[0] == '0');  // (640: the 16-row records of the k-split GEMM at <= 10 k rows)
 }
 
 static void launch_finapply(hipStream_t st, int n, int c, int relu, int training, bool residual, int sets, const BnFinApply &A0,
@@ -1506,24 +1506,25 @@ int bn_tiles_finalize_rb(int n, int c, int rb, float *part, const float *gamma, 
 int bn_tiles_finalize_pair(int n, int c, float *const *part, const float *const *gamma, const float *const *beta,
                            float *const *mean, float *const *rstd, float *const *sc, float *const *sh, float *const *running_mean,
                            float *const *running_var, long long *const *num_batches_tracked, float eps, float momentum,
-                           void *stream) {
-    if (n < 1 || c < 4) return PTV2_ERR_ARG;
+                           void *stream, int rb) {
+    if (n < 1 || c < 4 || (rb != 16 && rb != 64)) return PTV2_ERR_ARG;
     BnTileSet S[2];
     for (int i = 0; i < 2; ++i)
         S[i] = BnTileSet{part[i], mean[i], rstd[i], running_mean[i], running_var[i], num_batches_tracked[i], gamma[i], beta[i], sc[i],
-                         sh[i], nullptr, 64};
-    return bn_tiles_finalize_sets(n, c, 2, S, eps, momentum, stream);
+                         sh[i], nullptr, rb};
+    return bn_tiles_finalize_sets(n, c, 2, S, eps, momentum, stream, rb);
 }
 
 // internal (block.hip): BatchNorm statistics from the producing GEMM's tile records AND the Block tail
 // y = ReLU(residual + rowscale * BN(x)) in one launch when the records are few (deep levels); returns 0 when it declines
 int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *sc,
                             float *sh, float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
-                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream) {
-    const int nrb = (n + 63) / 64;
+                            float momentum, const float *x, const float *residual, const float *rowscale, float *y, void *stream,
+                            int rb) {
+    const int nrb = (n + rb - 1) / rb;
     const char *e = getenv("AO_AMD_BN_FINAPPLY");
-    if (nrb > 256 || c % 4 != 0 || (e && e[0] == '0')) return 0;
-    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr};
+    if (nrb > (rb == 16 ? 512 : 256) || c % 4 != 0 || (e && e[0] == '0') || (rb != 16 && rb != 64)) return 0;
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, sc, sh, nullptr, rb};
     const dim3 grid((unsigned)((c + FA_COLS - 1) / FA_COLS), (unsigned)((n + FA_ROWS - 1) / FA_ROWS));
     {
         PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 12.0 * n * c);
@@ -1806,7 +1807,7 @@ int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy
 int gva_wgrad_tile_supported(int k, int c, int g);
 size_t gva_wgrad_tile_plan(dense::WgradJob *J, int max_splits);
 int gva_wgrad_tile_launch_one(const dense::WgradJob &J, hipStream_t st);
-int gva_wgrad_tile_launch_jobs(const dense::WgradJob *table, int njobs, int wgs, hipStream_t st);
+int gva_wgrad_tile_launch_jobs(const dense::WgradJob *table, int njobs, int wgs, int pos_wgs, hipStream_t st);
 namespace {
 constexpr int WGRAD_FORMS = 6;
 struct WgradDefer {
@@ -1876,7 +1877,14 @@ int ptv2_wgrad_defer_flush(void *stream) {
             return wa > wb;
         });
         int wgs = 0, fin = 0;
+        long long pos_wgs = 0;  // (recompute form: workgroups of the relative-position launch in front of the jobs)
+        bool pos_all = form == 5;
         for (WgradJob &J : jobs) {
+            if (form == 5) {
+                J.ldy = pos_wgs;
+                pos_wgs += ((long long)J.n * 16 + 255) / 256;
+                pos_all = pos_all && J.mX[0] != nullptr;
+            }
             J.wg0 = wgs; J.fin0 = fin;
             J.fin_lanes = J.chunks > 32 ? 4 : 1;
             wgs += J.wgs;
@@ -1903,7 +1911,7 @@ int ptv2_wgrad_defer_flush(void *stream) {
                 hipLaunchKernelGGL(linear_wgrad_kernel_jobs<true>, dim3((unsigned)wgs), dim3(TPB), 0, st, (const WgradJob *)table,
                                    njobs);
             else if (form == 5) {
-                if (gva_wgrad_tile_launch_jobs((const WgradJob *)table, njobs, wgs, st) != PTV2_OK) return PTV2_ERR_LAUNCH;
+                if (gva_wgrad_tile_launch_jobs((const WgradJob *)table, njobs, wgs, pos_all ? (int)pos_wgs : 0, st) != PTV2_OK) return PTV2_ERR_LAUNCH;
             } else {
                 size_t lds = 0;
                 for (const WgradJob &J : jobs) lds = std::max(lds, grouped_lds_bytes(J.cin, J.gw));
@@ -1934,8 +1942,10 @@ int gva_wp2_wgrad_recompute(int n, int k, int c, int g, const float *g_out, cons
     if (g_wdefer.active && g_wdefer.armed_rs && (int)g_wdefer.jobs[5].size() < WGRAD_MAX_JOBS) {
         const size_t floats = gva_wgrad_tile_plan(&J, n / 128 + 1);
         float *keep = ptv2_wgrad_defer_alloc(floats);
-        if (keep) {
+        float *pos = keep ? ptv2_wgrad_defer_alloc((size_t)n * 16 * 4) : nullptr;  // relative positions, written at the flush
+        if (keep && pos) {
             J.part = keep;
+            J.mX[0] = pos;
             g_wdefer.jobs[5].push_back(J);
             g_wdefer.bytes[5] += algo;
             return PTV2_OK;

@@ -488,6 +488,150 @@ __global__ __launch_bounds__(THREADS) void rows_gemm_direct_kernel(int m, int n,
     gemm_epilogue<BN>(acc, row0, rb, n0, z, indep, m, n, bias, Y, accumulate, multi, sW);
 }
 
+// ---- the deep levels' form: 16 rows per workgroup, the contraction split over its four wavefronts ("k-split", round 6) -----------
+// At 1-20 k rows a launch of the kernels above is a few hundred workgroups that all run the same serial chain -- request a
+// chunk, wait a memory round trip, stage it, barrier, 24-32 matrix instructions, again for the next chunk -- in lockstep: 9-23 us
+// for 0.1-0.3 GFLOP (the matrix work itself is 2-3 us), a quarter of every deep Block.  Here a workgroup owns ONE 16-row strip x
+// BN columns and each wavefront a quarter of the reduction indices: every operand of the workgroup -- its rows of X (64
+// contiguous bytes per 4 lanes) and its BN x K / 4 piece of W, straight into the matrix-instruction operand registers, no LDS
+// staging -- is requested at once, one round trip; K / 16 x BN / 16 matrix instructions per wavefront; the four partial tiles meet
+// in LDS (added in wavefront order: fixed association) and each wavefront finishes every fourth column tile: bias, accumulate,
+// store, and -- a wavefront holds all 16 rows of its tile -- the BatchNorm records of the strip without another exchange.  Four
+// times the workgroups of the 64-row form (short ones, whose phases interleave on a compute unit); W (<= 1 MB) comes from L2.
+// Records (forward statistics / backward reduce sums) are per 16-ROW block: rows_gemm_record_rows() tells the caller.
+template <int BN, bool W_KMAJOR, int K>
+__global__ __launch_bounds__(THREADS) void rows_gemm_ksplit_kernel(int m, int n, const float *__restrict__ X0, const float *__restrict__ W0,
+                                                                   const float *__restrict__ bias0, float *__restrict__ Y0, int accumulate,
+                                                                   int ncb, GemmMulti multi) {
+    constexpr int NT = BN / 16, QF = K / 16, JW = (QF + 3) / 4;  // reduction steps of 16 indices: JW per wavefront
+    __shared__ __attribute__((aligned(16))) float sRed[4][NT][64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
+    const long long row0 = (long long)rb * 16;
+    const int n0 = cb * BN;
+    const int z = blockIdx.y;
+    const bool indep = multi.count && !multi.sum;
+    const float *bias = indep ? multi.bias[z] : bias0;
+    float *Y = multi.count ? multi.Y[indep ? z : 0] : Y0;
+    const int npair = (multi.count && multi.sum) ? multi.count : 1;
+    const long long row = row0 + l15;
+    const bool rv = row < m;
+    const int j0 = wid * JW;
+    v4f acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int pair = 0; pair < npair; ++pair) {
+        const float *X = multi.count ? multi.X[indep ? z : pair] : X0;
+        const float *W = multi.count ? multi.W[indep ? z : pair] : W0;
+        // every operand of my quarter of the reduction, requested before anything waits (masked lanes read the zero pad)
+        float4 x[JW], w[JW][NT], s4[JW], h4[JW];
+        const float *xr = rv ? X + row * K + 4 * q : ptv2_zero_pad;
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            const int j = j0 + jj;
+            const bool jok = j < QF;
+            x[jj] = *(const float4 *)((jok && rv) ? xr + 16 * j : ptv2_zero_pad);
+            if (multi.xsc) {
+                s4[jj] = *(const float4 *)(jok ? multi.xsc + 16 * j + 4 * q : ptv2_zero_pad);
+                h4[jj] = *(const float4 *)(jok ? multi.xsh + 16 * j + 4 * q : ptv2_zero_pad);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = n0 + 16 * t + l15;
+                const bool ok = jok && col < n;
+                if (!W_KMAJOR) {
+                    w[jj][t] = *(const float4 *)(ok ? W + (long long)col * K + 16 * j + 4 * q : ptv2_zero_pad);
+                } else {  // W (k, n): four reduction indices of my column, 64 contiguous bytes per quarter and index
+                    const float *wp = ok ? W + (long long)(16 * j + 4 * q) * n + col : ptv2_zero_pad;
+                    const long long st = ok ? n : 0;
+                    w[jj][t] = make_float4(wp[0], wp[st], wp[2 * st], wp[3 * st]);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            if (multi.xsc) {  // ReLU(x * sc + sh): the BatchNorm + ReLU in front of this Linear (zero scale / shift past K: 0)
+                x[jj].x = fmaxf(__builtin_fmaf(x[jj].x, s4[jj].x, h4[jj].x), 0.f); x[jj].y = fmaxf(__builtin_fmaf(x[jj].y, s4[jj].y, h4[jj].y), 0.f);
+                x[jj].z = fmaxf(__builtin_fmaf(x[jj].z, s4[jj].z, h4[jj].z), 0.f); x[jj].w = fmaxf(__builtin_fmaf(x[jj].w, s4[jj].w, h4[jj].w), 0.f);
+                if (!rv) x[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][t].x, x[jj].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][t].y, x[jj].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][t].z, x[jj].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][t].w, x[jj].w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four partial tiles meet in LDS; wavefront w finishes the column tiles t = w, w + 4, ...
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *(float4 *)(&sRed[wid][t][4 * lane]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    float *stats = multi.count ? multi.stats[indep ? z : 0] : nullptr;
+    const int cnt = (int)((m - row0) < 16 ? (m - row0) : 16);
+    const float inv = 1.0f / (float)cnt;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if ((t & 3) != wid) continue;  // (uniform over the wavefront)
+        const float4 a0 = *(const float4 *)(&sRed[0][t][4 * lane]), a1 = *(const float4 *)(&sRed[1][t][4 * lane]);
+        const float4 a2 = *(const float4 *)(&sRed[2][t][4 * lane]), a3 = *(const float4 *)(&sRed[3][t][4 * lane]);
+        // D[i][j]: i = output column within the tile = 4 q + reg, j = row within the strip = l15
+        const int col = n0 + 16 * t + 4 * q;
+        const bool cok = col < n;
+        float4 v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
+                               ((a0.w + a1.w) + a2.w) + a3.w);
+        {
+            const float4 bb = ptv2_ld_or_zero((const float4 *)(bias + col), bias && cok);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        const float4 val = v;
+        if (rv && cok) {
+            float4 *dst = (float4 *)(Y + row * n + col);
+            if (accumulate) {
+                const float4 o = *dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *dst = v;
+        }
+        if (multi.count && multi.brec) {  // reduce records of the BatchNorm (+ ReLU) this gradient enters: sum g', sum g' xhat
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), e = d;
+            if (rv && cok) {
+                const float4 xv = *(const float4 *)(multi.bnx + row * n + col);
+                const float4 mm = *(const float4 *)(multi.bnm + col), rs = *(const float4 *)(multi.bnr + col);
+                float4 h;
+                h.x = (xv.x - mm.x) * rs.x; h.y = (xv.y - mm.y) * rs.y; h.z = (xv.z - mm.z) * rs.z; h.w = (xv.w - mm.w) * rs.w;
+                d = val;
+                if (multi.bnrelu) {
+                    const float4 gg = *(const float4 *)(multi.bng + col), bb = *(const float4 *)(multi.bnb + col);
+                    if (__builtin_fmaf(h.x, gg.x, bb.x) <= 0.f) d.x = 0.f;
+                    if (__builtin_fmaf(h.y, gg.y, bb.y) <= 0.f) d.y = 0.f;
+                    if (__builtin_fmaf(h.z, gg.z, bb.z) <= 0.f) d.z = 0.f;
+                    if (__builtin_fmaf(h.w, gg.w, bb.w) <= 0.f) d.w = 0.f;
+                }
+                e = make_float4(d.x * h.x, d.y * h.y, d.z * h.z, d.w * h.w);
+            }
+            const float ax = row16_sum(d.x), ay = row16_sum(d.y), az = row16_sum(d.z), aw = row16_sum(d.w);
+            const float bx = row16_sum(e.x), by = row16_sum(e.y), bz = row16_sum(e.z), bw = row16_sum(e.w);
+            if (l15 == 0 && cok) {
+                *(float4 *)(multi.brec + (size_t)rb * 2 * n + col) = make_float4(ax, ay, az, aw);
+                *(float4 *)(multi.brec + (size_t)rb * 2 * n + n + col) = make_float4(bx, by, bz, bw);
+            }
+        }
+        if (stats) {  // column statistics of this 16-row block: sum, sum of squares about the block mean
+            const float sx = row16_sum(rv ? val.x : 0.f), sy = row16_sum(rv ? val.y : 0.f);
+            const float sz = row16_sum(rv ? val.z : 0.f), sw = row16_sum(rv ? val.w : 0.f);
+            const float dx = rv ? val.x - sx * inv : 0.f, dy = rv ? val.y - sy * inv : 0.f;
+            const float dz = rv ? val.z - sz * inv : 0.f, dw = rv ? val.w - sw * inv : 0.f;
+            const float qx = row16_sum(dx * dx), qy = row16_sum(dy * dy), qz = row16_sum(dz * dz), qw = row16_sum(dw * dw);
+            if (l15 == 0 && cok) {
+                *(float4 *)(stats + (size_t)rb * 2 * n + col) = make_float4(sx, sy, sz, sw);
+                *(float4 *)(stats + (size_t)rb * 2 * n + n + col) = make_float4(qx, qy, qz, qw);
+            }
+        }
+    }
+}
+
 }  // namespace gemm
 
 template <int BN, bool KM, int K>
@@ -561,6 +705,49 @@ static int column_block(int m, int n, int products = 1) {
     return 16;
 }
 
+// ---- k-split form (deep levels) ------------------------------------------------------------------------------------------
+namespace {
+thread_local int g_rb16_ok = 0;  // the caller understands records of 16 rows (block.hip sets it around its launches)
+}
+void ptv2_gemm_allow_rb16(int on) { g_rb16_ok = on; }
+static bool ksplit_ok(int m, int n, int k, bool has_records) {
+    // measured and rejected as the default (round 6, profiles/r06_rejected/gemm_ksplit.md): 7x the workgroups of the 64-row form
+    // but 16-20 us per launch against 11-14 (4x the weight reads per row, an LDS reduce and a barrier per workgroup), +0.45 ms a
+    // step.  AO_AMD_GEMM_KSPLIT=1 turns it on for A/B runs and keeps it under test.
+    static const bool on = [] { const char *e = getenv("AO_AMD_GEMM_KSPLIT"); return e && e[0] == '1'; }();
+    const char *e = getenv("AO_AMD_GEMM");  // (lds / direct: the A/B switches of the older forms)
+    if (!on || e || ptv2_matmul_bf16()) return false;
+    if (has_records && !g_rb16_ok) return false;  // (the public launchers' records are per 64 rows: include/ptv2_hip.h)
+    return m >= 1 && m <= 32768 && (k == 96 || k == 192 || k == 384) && n % 16 == 0 && n >= 16;
+}
+// rows per statistics / reduce record the fused launchers below will write for this shape (16: the k-split kernel; else 64)
+int rows_gemm_record_rows(int m, int n, int k) { return ksplit_ok(m, n, k, true) ? 16 : 64; }
+
+template <int BN, bool KM>
+static void launch_ksplit_k(int k, dim3 grid, hipStream_t st, int m, int n, const float *X, const float *W, const float *bias, float *Y,
+                            int accumulate, int ncb, const gemm::GemmMulti &gm) {
+    switch (k) {
+        case 96: hipLaunchKernelGGL((gemm::rows_gemm_ksplit_kernel<BN, KM, 96>), grid, dim3(gemm::THREADS), 0, st, m, n, X, W, bias, Y, accumulate, ncb, gm); break;
+        case 192: hipLaunchKernelGGL((gemm::rows_gemm_ksplit_kernel<BN, KM, 192>), grid, dim3(gemm::THREADS), 0, st, m, n, X, W, bias, Y, accumulate, ncb, gm); break;
+        default: hipLaunchKernelGGL((gemm::rows_gemm_ksplit_kernel<BN, KM, 384>), grid, dim3(gemm::THREADS), 0, st, m, n, X, W, bias, Y, accumulate, ncb, gm); break;
+    }
+}
+// launches the k-split kernel when it applies; `products`: grid.y (independent products)
+static bool try_ksplit(int m, int n, int k, bool kmajor, int products, hipStream_t st, const float *X, const float *W, const float *bias,
+                       float *Y, int accumulate, const gemm::GemmMulti &gm, bool has_records) {
+    if (!ksplit_ok(m, n, k, has_records)) return false;
+    const int bn = n % 48 == 0 ? 48 : (n % 64 == 0 ? 64 : (n % 32 == 0 ? 32 : 16));
+    const int ncb = n / bn;
+    const long long wgs = (((long long)m + 15) / 16) * ncb;
+    if (wgs > 2147483647LL) return false;
+    const dim3 grid((unsigned)wgs, (unsigned)products);
+#define KS(BNN) do { if (kmajor) launch_ksplit_k<BNN, true>(k, grid, st, m, n, X, W, bias, Y, accumulate, ncb, gm); \
+                     else launch_ksplit_k<BNN, false>(k, grid, st, m, n, X, W, bias, Y, accumulate, ncb, gm); } while (0)
+    if (bn == 48) KS(48); else if (bn == 64) KS(64); else if (bn == 32) KS(32); else KS(16);
+#undef KS
+    return true;
+}
+
 static void launch_gemm(int bn, bool kmajor, bool wide_k, dim3 grid, hipStream_t st, int m, int n, int k, const float *X,
                         const float *W, const float *bias, float *Y, int accumulate, int ncb, const gemm::GemmMulti &gm) {
     if (launch_gemm_direct(bn, kmajor, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, gm)) return;
@@ -598,7 +785,8 @@ extern "C" int rows_gemm_hip_launcher(int m, int n, int k, const float *X, const
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
                          4.0 * ((double)m * (n + k) + (double)n * k));
-        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
+        if (!try_ksplit(m, n, k, w_kmajor != 0, 1, st, X, W, bias, Y, accumulate, GemmMulti{}, false))
+            launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, X, W, bias, Y, accumulate, ncb, GemmMulti{});
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -638,7 +826,10 @@ extern "C" int rows_gemm_fused_hip_launcher(int m, int n, int k, int count, int 
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
                          4.0 * count * ((double)m * (n + k) + (double)n * k));
-        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
+        bool records = false;
+        for (int i = 0; i < count; ++i) records = records || gm.stats[i] != nullptr;
+        if (!try_ksplit(m, n, k, w_kmajor != 0, sum ? 1 : count, st, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, gm, records))
+            launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], b0, gm.Y[0], accumulate, ncb, gm);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;
@@ -680,7 +871,8 @@ extern "C" int rows_gemm_bnbwd_hip_launcher(int m, int n, int k, int count, cons
     {
         PtvScopedTimer t(KID_ROWS_GEMM + (n48 ? 0 : 4) + (w_kmajor ? 2 : 0) + (k >= 192 ? 1 : 0), st,
                          4.0 * ((double)m * (2 * n + count * k) + (double)count * n * k));
-        launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], nullptr, Y, 0, ncb, gm);
+        if (!try_ksplit(m, n, k, w_kmajor != 0, 1, st, gm.X[0], gm.W[0], nullptr, Y, 0, gm, true))
+            launch_gemm(bn, w_kmajor != 0, k >= 192, grid, st, m, n, k, gm.X[0], gm.W[0], nullptr, Y, 0, ncb, gm);
     }
     PTV2_CHECK_LAUNCH();
     return PTV2_OK;

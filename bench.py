@@ -51,6 +51,7 @@ def _imports():
     np, torch, dist = numpy, _torch, _dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+MFMA_FP32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (V_MFMA_F32_16X16X4_F32, exact fp32; guides/MI355X_MICROARCH.md)
 
 
 def parse():
@@ -99,6 +100,26 @@ def algorithmic_step_bytes(levels, cfg):
     for (nb, c, k), n in zip(per_level, levels):
         total += nb * 4 * n * (6 * c + 2 * k + 6)
     return total
+
+
+def mfma_bound_flops(kernel, levels):
+    """Algorithmic (useful: no tile padding counted) matrix FLOPs per launch of the deep-level attention tile kernels, which are
+    bound by the fp32 matrix pipe, not by HBM: their operands live in LDS / registers and what they read from memory is a few MB
+    (gva_fwd_tile.hip / gva_bwd_tile.hip).  None for every other kernel (HBM roofline).  Per point, K = 16 slots, G groups,
+    C = 8 G channels: forward  z = Ww2 y (2 K G G), A = w^T P (2 K G C), projection (2 C C);  backward  z, gy, gWw2 (3 x 2 K G G),
+    g_A = g_out Wp2 (2 C C), gw = g_A P^T and gP = w g_A (2 x 2 K G C)."""
+    import re
+
+    m = re.match(r"attention_(fwd|bwd)_tile_kernel<(\d+), (\d+),", kernel)
+    if not m:
+        return None
+    g, c, k = int(m.group(2)), int(m.group(3)), 16
+    n = {12: 1, 24: 2, 48: 3, 64: 4}.get(g)
+    if n is None or n >= len(levels):
+        return None
+    n = levels[n]
+    per_point = (2 * k * g * g + 2 * k * g * c + 2 * c * c) if m.group(1) == "fwd" else (6 * k * g * g + 2 * c * c + 4 * k * g * c)
+    return float(n) * per_point
 
 
 def src_hash(build_info):
@@ -982,8 +1003,16 @@ def child_main(args):
                 net_us = max(rec["avg_us"] - empty_us, 0.5 * rec["avg_us"])
                 achieved = rec["bytes_per_launch"] / (net_us * 1e-6) / 1e9
                 traffic, traffic_source = pmc_traffic(name, build_info)
-                out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                flops = mfma_bound_flops(name, levels)
+                head = ({"bound": "mfma", "kernel": name, "achieved": flops / (net_us * 1e-6) / 1e12, "peak": MFMA_FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (net_us * 1e-6) / 1e12 / MFMA_FP32_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": flops, "hbm_achieved_GBps": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "why_mfma": "the deep-level attention tile kernels keep their operands in LDS / registers (a few MB from "
+                                     "memory per launch): the exact-fp32 matrix pipe bounds them"}
+                        if flops else
+                        {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS})
+                out["roofline"] = {**head, "traffic": traffic,
                                    "traffic_source": traffic_source,
                                    "avg_us": net_us, "avg_us_bracket": rec["avg_us"], "empty_bracket_us": empty_us,
                                    "bracket": bracket,
