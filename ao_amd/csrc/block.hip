@@ -354,6 +354,8 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     const GemmRb16Scope rb16;
     const int rb = rows_gemm_record_rows(n, c, c);
     const int nrb = (n + rb - 1) / rb;   // reduce records the GEMM epilogues leave (per 64 rows, or 16 from the k-split kernel)
+    // (the full-resolution level -- 1875 records -- measured the same step with the epilogue records as with the separate reduce:
+    // profiles/r06_rejected/bn_small_levers.md)
     const bool epi = nrb <= (rb == 16 ? 2048 : 512);
     if (epi) {
         const float *xs[1] = {g_h3}, *ws[1] = {P[PTV2_BLK_FC3_W]};

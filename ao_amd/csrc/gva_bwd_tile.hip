@@ -74,10 +74,11 @@ __host__ __device__ constexpr int bt_point_pitch(int G, int GP) {  // >= G GP, =
 template <int G, int C, int TP>
 struct BwdTileCfg {
     static constexpr int GT = (G + 15) / 16, G16 = GT * 16, GPW = bt_ww_pitch(G), PPW = TP / 4, NCH = C / 16, NGW = G / 4, GP = 20,
-                         PPG = bt_point_pitch(G, GP), PF = 4 * C + 3 * G + G * G, TW = 2 * G16 * 17;
-    static_assert((TP == 8 || TP == 16) && G % 4 == 0 && C == 8 * G && GPW >= G16, "tiles of 8 or 16 points");
-    // [sAB 4C] [sWw G16 GPW] [sBw, sSc, sSh 3 G16] [sPos 4 TP 16] [sGo TP C] [sGsw TP G16] [sFinAB 4 x 4C] [sGA 2 TP PPG | sT 4 TW + sFin PF]
-    static constexpr size_t tail = std::max<size_t>(2 * (size_t)TP * PPG, 4 * (size_t)TW + PF);
+                         PPG = bt_point_pitch(G, GP), PF = 4 * C + 3 * G + G * G,
+                         DW = 2 * G16 * 17 > 3 * G + G * G ? 2 * G16 * 17 : 3 * G + G * G;  // a wavefront's transposes, then its record piece
+    static_assert((TP == 4 || TP == 8 || TP == 16) && G % 4 == 0 && C == 8 * G && GPW >= G16, "tiles of 8 or 16 points");
+    // [sAB 4C] [sWw G16 GPW] [sBw, sSc, sSh 3 G16] [sPos 4 TP 16] [sGo TP C] [sGsw TP G16] [sFinAB 4 x 4C] [sGA 2 TP PPG | sT 4 DW]
+    static constexpr size_t tail = std::max<size_t>(2 * (size_t)TP * PPG, 4 * (size_t)DW);
     static constexpr size_t lds_floats = 4 * (size_t)C + (size_t)G16 * GPW + 3 * G16 + 4 * TP * 16 + (size_t)TP * C + TP * G16 + 16 * (size_t)C + tail;
 };
 
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     const float *__restrict__ bp2, float *__restrict__ gW1, float *__restrict__ part, PtvDrop drop) {
     using K = BwdTileCfg<G, C, TP>;
     constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PPW = K::PPW, NCH = K::NCH, NGW = K::NGW, GP = K::GP, PPG = K::PPG, PF = K::PF,
-                  TW = K::TW;
+                  DW = K::DW;
     extern __shared__ float4 lds4[];
     float4 *sAB = lds4;                              // [C]  (a.xyz, b)
     float4 *sPos = sAB + C;                          // [TP][16]
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     float *sGsw = sGo + TP * C;                      // [TP][G16]
     float *sGA = sGsw + TP * G16;                    // [2][TP][PPG]  g_A chunk (point; group, 16 c' + pad)
     float *sT = sGA;                                 // behind the chunk loop: [4 waves][2][G16][17] transposes of gz, y
-    float *sFin = sT + 4 * TW;                       //                        [PF] the workgroup's record
+    //                                                                   then [4 waves][3 G + G G] the wavefronts' record pieces
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     BT_STAMP(7);
 
     // ---- softmax backward, Linear(G,G) backward, the sums over all slots
-    float *mGz = sT + wid * TW, *mY = mGz + G16 * 17;
+    float *mGz = sT + wid * DW, *mY = mGz + G16 * 17;
     float tsc[GT][4], tsh[GT][4], gbw[GT][4];
     bt_v4f accW[GT * GT];
 #pragma unroll
@@ -408,7 +409,6 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
         for (int r = 0; r < 4; ++r) tsc[t][r] = tsh[t][r] = gbw[t][r] = 0.f;
 #pragma unroll
     for (int e = 0; e < GT * GT; ++e) accW[e] = (bt_v4f){0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < PF; e += 256) sFin[e] = 0.f;
 #ifndef BT_SKIP_TAIL
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -476,45 +476,49 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
 #endif
 
     BT_STAMP(8);
-    // ---- the workgroup's record: (ga, gb) from the wavefronts' chunk sums, the rest wavefront after wavefront (fixed order)
+    // ---- the workgroup's record: each wavefront leaves its sums in its own piece of LDS; one barrier; every thread adds the four
+    // pieces of its elements in wavefront order ((w0 + w1) + w2) + w3 and stores them
 #pragma unroll
     for (int t = 0; t < GT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { tsc[t][r] = bt_row16_sum(tsc[t][r]); tsh[t][r] = bt_row16_sum(tsh[t][r]); gbw[t][r] = bt_row16_sum(gbw[t][r]); }
-    __syncthreads();
-    for (int ch = tid; ch < C; ch += 256) {
-        const float4 a0 = sFinAB[ch], a1 = sFinAB[C + ch], a2 = sFinAB[2 * C + ch], a3 = sFinAB[3 * C + ch];
-        sFin[4 * ch] = ((a0.x + a1.x) + a2.x) + a3.x;
-        sFin[4 * ch + 1] = ((a0.y + a1.y) + a2.y) + a3.y;
-        sFin[4 * ch + 2] = ((a0.z + a1.z) + a2.z) + a3.z;
-        sFin[4 * ch + 3] = ((a0.w + a1.w) + a2.w) + a3.w;
-    }
-    for (int turn = 0; turn < 4; ++turn) {
-        if (wid == turn) {
-            if (l15 == 0) {
+    bt_wave_sync();  // (the last point's transposes have been read: the piece is this wavefront's own)
+    {
+        float *mine = sT + wid * DW;  // [gsc G][gsh G][gbw2 G][gWw2 G x G]
+        if (l15 == 0) {
 #pragma unroll
-                for (int t = 0; t < GT; ++t)
+            for (int t = 0; t < GT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * t + 4 * q + r;
-                        if (j < G) { sFin[4 * C + j] += tsc[t][r]; sFin[4 * C + G + j] += tsh[t][r]; sFin[4 * C + 2 * G + G * G + j] += gbw[t][r]; }
-                    }
-            }
-#pragma unroll
-            for (int tg = 0; tg < GT; ++tg)
-#pragma unroll
-                for (int tj = 0; tj < GT; ++tj) {
-                    const int j = 16 * tj + l15;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int g = 16 * tg + 4 * q + r;
-                        if (g < G && j < G) sFin[4 * C + 2 * G + g * G + j] += accW[tg * GT + tj][r];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * q + r;
+                    if (j < G) { mine[j] = tsc[t][r]; mine[G + j] = tsh[t][r]; mine[2 * G + j] = gbw[t][r]; }
                 }
         }
-        __syncthreads();
+#pragma unroll
+        for (int tg = 0; tg < GT; ++tg)
+#pragma unroll
+            for (int tj = 0; tj < GT; ++tj) {
+                const int j = 16 * tj + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int g = 16 * tg + 4 * q + r;
+                    if (g < G && j < G) mine[3 * G + g * G + j] = accW[tg * GT + tj][r];
+                }
+            }
     }
-    for (int e = tid; e < PF; e += 256) part[(size_t)blockIdx.x * PF + e] = sFin[e];
+    __syncthreads();
+    float *rec = part + (size_t)blockIdx.x * PF;
+    for (int ch = tid; ch < C; ch += 256) {
+        const float4 a0 = sFinAB[ch], a1 = sFinAB[C + ch], a2 = sFinAB[2 * C + ch], a3 = sFinAB[3 * C + ch];
+        *(float4 *)(rec + 4 * ch) = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y,
+                                                ((a0.z + a1.z) + a2.z) + a3.z, ((a0.w + a1.w) + a2.w) + a3.w);
+    }
+    for (int e = tid; e < 3 * G + G * G; e += 256) {
+        const float s = ((sT[e] + sT[DW + e]) + sT[2 * DW + e]) + sT[3 * DW + e];
+        // record layout (MapBwdPoint): [ga, gb 4C][gsc G][gsh G][gWw2 G x G][gbw2 G]
+        const int at = e < 2 * G ? e : e < 3 * G ? e + G * G : e - G;
+        rec[4 * C + at] = s;
+    }
     BT_STAMP(9);
 }
 
@@ -549,7 +553,7 @@ int gva_bwd_tile_supported(int k, int c, int g) {
 }
 // floats of partial records gva_bwd_tile_launch writes
 size_t gva_bwd_tile_part_floats(int n, int c, int g) {
-    const int tp = 8;
+    const int tp = g == 48 ? 4 : 8;
     return (size_t)((n + tp - 1) / tp) * (4 * (size_t)c + 3 * (size_t)g + (size_t)g * g) + 64;
 }
 
@@ -564,6 +568,9 @@ int gva_bwd_tile_launch(int n, int k, int c, int g, const float *W1, const float
 #define ARGS n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, drop, st
     if (g == 12) return launch_bwd_tile<12, 96, 8>(ARGS);
     if (g == 24) return launch_bwd_tile<24, 192, 8>(ARGS);
+    // one workgroup per CU at this width: tiles of 4 points while they all fit in ONE round of the 256 CUs (n = 240: 61 us against
+    // 80), tiles of 8 beyond (n = 1074: 135 workgroups, 86 us; 269 tiles of 4 would be two rounds, 120 us)
+    if ((n + 3) / 4 <= 256) return launch_bwd_tile<48, 384, 4>(ARGS);
     return launch_bwd_tile<48, 384, 8>(ARGS);
 #undef ARGS
 }

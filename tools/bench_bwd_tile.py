@@ -16,7 +16,11 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
     L = _lib.lib()
     st = _lib.stream_ptr()
-    for n, c, g in ((19028, 96, 12), (4501, 192, 24), (1074, 384, 48), (1600, 192, 24), (240, 384, 48)):
+    shapes = ((19028, 96, 12), (4501, 192, 24), (1074, 384, 48), (1600, 192, 24), (240, 384, 48))
+    if "--sweep" in sys.argv:  # how the launch scales with the number of workgroups (rounds of 256 CUs x 1 or 2 resident)
+        shapes = tuple((n, 192, 24) for n in (1024, 2048, 3072, 4096, 4501, 6144, 8192)) + tuple((n, 384, 48) for n in (512, 1074, 2048)) + \
+            tuple((n, 96, 12) for n in (4096, 8192, 19028))
+    for n, c, g in shapes:
         t = _inputs(n, c, g, seed=5)
         k, dev = 16, t["v"].device
         w, g_out, inv_ptr, inv_rows = _bwd_inputs(t, n, c, g)

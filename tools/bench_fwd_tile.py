@@ -25,10 +25,14 @@ def timed(fn, reps):
 def main():
     import ao_amd.ptv2.gva  # noqa: F401
 
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
     L = _lib.lib()
     st = _lib.stream_ptr()
-    for n, c, g in ((19028, 96, 12), (4501, 192, 24), (1074, 384, 48), (11000, 96, 12), (1600, 192, 24), (240, 384, 48), (30, 512, 64)):
+    shapes = ((19028, 96, 12), (4501, 192, 24), (1074, 384, 48), (11000, 96, 12), (1600, 192, 24), (240, 384, 48), (30, 512, 64))
+    if "--sweep" in sys.argv:  # how the launch scales with the number of workgroups (rounds of the resident slots)
+        shapes = tuple((n, 192, 24) for n in (2048, 3072, 4096, 4501, 6144, 8192)) + tuple((n, 384, 48) for n in (512, 1024, 1074, 2048)) + \
+            tuple((n, 96, 12) for n in (4096, 8192, 16384, 19028))
+    for n, c, g in shapes:
         t = _inputs(n, c, g, seed=5)
         k = 16
         dev = t["v"].device

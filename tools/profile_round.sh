@@ -23,8 +23,11 @@ PY
 python tools/trace_gaps.py "$O/trace" > "$O/trace_gaps.txt" 2>&1
 python tools/trace_grids.py "$O/trace" 25 > "$O/trace_grids.txt" 2>&1
 python tools/trace_step.py "$O/trace" 12 > "$O/step_sequence.txt" 2>&1
-# one S2 Block's backward (192 channels): the launches around the 4th-from-last attention_bwd_point_kernel<24, 192, 2> of a step
-python tools/trace_block.py "$O/trace" "attention_bwd_point_kernel<24, 192, 2" 60 7 12 > "$O/blockS2.txt" 2>&1
+# one S2 Block's backward (192 channels): the launches around a mid-run attention_bwd_tile_kernel<24, 192, 8> (4 before: the tail's
+# BatchNorm + fc3; 9 behind: gv ... the fc1 input gradient)
+python tools/trace_block.py "$O/trace" "attention_bwd_tile_kernel<24, 192, 8" 60 4 10 > "$O/blockS2.txt" 2>&1
+# one S2 Block's forward: around a mid-run attention_fwd_tile_kernel<24, 192, 12> (7 before: fc1 ... the logit sums; 3 behind)
+python tools/trace_block.py "$O/trace" "attention_fwd_tile_kernel<24, 192, 12" 60 7 4 > "$O/blockS2_fwd.txt" 2>&1
 # one S3 Block's forward (384 channels, ~1 074 points): the launches around a mid-run logits_fwd_mfma_kernel<48, 384, 4>
 python tools/trace_block.py "$O/trace" "logits_fwd_mfma_kernel<48, 384, 4" 30 5 8 > "$O/blockS3_fwd.txt" 2>&1
 rm -rf "$O/trace"
@@ -40,7 +43,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 python tools/pmc_sq.py "$O/pmc_sq" > "$O/sq_counters.jsonl" 2> "$O/sq.err"
 rm -rf "$O/pmc_sq"
 # the bench line takes roofline.traffic from the PMC profile of THIS build under profiles/ (matched by source digest)
-cp "$O/pmc_traffic_per_launch.jsonl" profiles/${ROUND:-r05}_final_pmc_traffic_per_launch.jsonl
+cp "$O/pmc_traffic_per_launch.jsonl" profiles/${ROUND:-r06}_final_pmc_traffic_per_launch.jsonl
 python bench.py --steps 30 --warmup 5 > "$O/bench_fp32.json" 2> "$O/bench_fp32.err"
 python bench.py --steps 30 --warmup 5 --dtype bf16 --no-cpu-baseline --no-ops > "$O/bench_bf16.json" 2>/dev/null
 python bench.py --steps 20 --warmup 5 --cfg scannet --scenes 2 --points 100000 --no-cpu-baseline --no-ops > "$O/bench_scannet.json" 2>/dev/null
