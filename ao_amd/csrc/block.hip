@@ -18,6 +18,9 @@
 #include "common.h"
 
 size_t bn_tiles_floats_rb(int n, int c, int rb);  // dense.hip: statistics records of rb rows each
+void ptv2_skinny_bn_arm(int n, int c, const float *const *x, const float *const *gy, const float *const *mean, const float *const *rstd,
+                        const float *const *gamma, const float *const *beta, int relu, void *workspace, size_t workspace_bytes);
+void ptv2_skinny_bn_disarm(void);
 int gva_block_keeps_A(int k, int c, int g);        // gva_block.hip
 
 namespace {
@@ -379,9 +382,17 @@ extern "C" int ptv2_block_backward_hip_launcher(const ptv2_block *B, const ptv2_
     VG.gWp2 = GP(PTV2_BLK_P2_W); VG.gbp2 = GP(PTV2_BLK_P2_B); VG.gWw1 = GP(PTV2_BLK_W1_W); VG.gbw1 = GP(PTV2_BLK_W1_B);
     VG.ggamma_w = GP(PTV2_BLK_WN_G); VG.gbeta_w = GP(PTV2_BLK_WN_B); VG.gWw2 = GP(PTV2_BLK_W2_W); VG.gbw2 = GP(PTV2_BLK_W2_B);
     if (!G->inv_ptr) (void)ptv2_zero_async(gv, sizeof(float) * (size_t)n * c, (hipStream_t)stream);
+    // the attention backward's last launch (the skinny input gradients gk, gq) also leaves the reduce records of the two
+    // BatchNorm backwards that consume them (dense.hip skinny_bn_bwd_reduce_kernel): one launch fewer per Block
+    if (batch[1] == batch[2]) {
+        const float *xs[2] = {S.hk, S.hq}, *gys[2] = {gk, gq}, *ms[2] = {S.mean[2], S.mean[1]}, *rs[2] = {S.rstd[2], S.rstd[1]};
+        const float *gs[2] = {P[PTV2_BLK_KN_G], P[PTV2_BLK_QN_G]}, *bs[2] = {P[PTV2_BLK_KN_B], P[PTV2_BLK_QN_B]};
+        ptv2_skinny_bn_arm(n, c, xs, gys, ms, rs, gs, bs, 1, W.dense, W.dense_bytes);
+    }
     ptv2_wgrad_defer_arm_rs(kept != nullptr);
     const int grc = gva_block_backward_hip_launcher(&V, &VG, W.gva, W.gva_bytes, stream);
     ptv2_wgrad_defer_arm_rs(false);
+    ptv2_skinny_bn_disarm();
     RUN(grc);
     // linear_k / linear_q BatchNorm + ReLU
     if (batch[1] == batch[2]) {  // one reduce / finalize / apply for both

@@ -437,6 +437,85 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(int n, int c, const 
     }
 }
 
+// The same reduce with its gradient formed in place: gy[row, :] = sg[row, :] W (the input gradient of the skinny Linear(c, G) in
+// front of the logits: kW = k Ww1^T, qW = q Ww1^T) is computed, stored (the apply pass reads it) and summed by the lane that owns
+// the float4 -- skinny_bwd_kernel and the q / k BatchNorms' reduce were two launches over the same (n, c) rows in every Block's
+// backward.  blockIdx.y: the tensor (k, q); trailing workgroups in x: the queued parameter-gradient sums (riders, as skinny_bwd).
+struct SkinnyBn {
+    const float *sg;   // (n, cout) gradient of the projection's output
+    float *gy;         // (n, c) its input gradient = the BatchNorm's output gradient (written)
+    const float *x, *mean, *rstd, *gamma, *beta;
+};
+__global__ __launch_bounds__(TPB) void skinny_bn_bwd_reduce_kernel(int n, int c, int cout, SkinnyBn A, SkinnyBn B,
+                                                                   const float *__restrict__ W, int relu, float *__restrict__ part,
+                                                                   int main_blocks, gva::PtvRiders Rs) {
+    extern __shared__ float4 lds4[];
+    if ((int)blockIdx.x >= main_blocks) {
+        if (blockIdx.y == 0) gva::rider_run(Rs, (int)blockIdx.x - main_blocks);
+        return;
+    }
+    const SkinnyBn &S = blockIdx.y ? B : A;
+    const int cq = c >> 2;
+    const int rl = TPB / cq;
+    const int q = threadIdx.x % cq, r = threadIdx.x / cq;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (r < rl) {
+        const float4 m = ((const float4 *)S.mean)[q], rs = ((const float4 *)S.rstd)[q];
+        const float4 g = ((const float4 *)S.gamma)[q], b = ((const float4 *)S.beta)[q];
+        const float *wc = W + 4 * q;
+        for (long long row = (long long)blockIdx.x * rl + r; row < n; row += (long long)main_blocks * rl) {
+            const float4 v = ((const float4 *)S.x)[row * cq + q];
+            const float *sg = S.sg + row * cout;
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            int o = 0;
+            for (; o + 6 <= cout; o += 6) {  // (six outputs' loads in flight together, as skinny_bwd_kernel)
+                float sv[6];
+                float4 wv[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { sv[u] = sg[o + u]; wv[u] = *(const float4 *)(wc + (size_t)(o + u) * c); }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    d.x = __builtin_fmaf(sv[u], wv[u].x, d.x); d.y = __builtin_fmaf(sv[u], wv[u].y, d.y);
+                    d.z = __builtin_fmaf(sv[u], wv[u].z, d.z); d.w = __builtin_fmaf(sv[u], wv[u].w, d.w);
+                }
+            }
+            for (; o < cout; ++o) {
+                const float sv = sg[o];
+                const float4 w = *(const float4 *)(wc + (size_t)o * c);
+                d.x = __builtin_fmaf(sv, w.x, d.x); d.y = __builtin_fmaf(sv, w.y, d.y);
+                d.z = __builtin_fmaf(sv, w.z, d.z); d.w = __builtin_fmaf(sv, w.w, d.w);
+            }
+            ((float4 *)S.gy)[row * cq + q] = d;
+            float4 h;
+            h.x = (v.x - m.x) * rs.x; h.y = (v.y - m.y) * rs.y; h.z = (v.z - m.z) * rs.z; h.w = (v.w - m.w) * rs.w;
+            if (relu) {
+                if (__builtin_fmaf(h.x, g.x, b.x) <= 0.f) d.x = 0.f;
+                if (__builtin_fmaf(h.y, g.y, b.y) <= 0.f) d.y = 0.f;
+                if (__builtin_fmaf(h.z, g.z, b.z) <= 0.f) d.z = 0.f;
+                if (__builtin_fmaf(h.w, g.w, b.w) <= 0.f) d.w = 0.f;
+            }
+            s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+            s2.x = __builtin_fmaf(d.x, h.x, s2.x); s2.y = __builtin_fmaf(d.y, h.y, s2.y);
+            s2.z = __builtin_fmaf(d.z, h.z, s2.z); s2.w = __builtin_fmaf(d.w, h.w, s2.w);
+        }
+    }
+    float4 *sa = lds4, *sb = lds4 + TPB;
+    sa[threadIdx.x] = s1;
+    sb[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a;
+        for (int k = 0; k < rl; ++k) {
+            const float4 u = sa[k * cq + threadIdx.x], w = sb[k * cq + threadIdx.x];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b2.x += w.x; b2.y += w.y; b2.z += w.z; b2.w += w.w;
+        }
+        float *p = part + ((size_t)blockIdx.x * 2 + blockIdx.y) * 2 * c;  // record of a block: [set 0 | set 1]
+        ((float4 *)p)[threadIdx.x] = a;
+        ((float4 *)(p + c))[threadIdx.x] = b2;
+    }
+}
+
 // gx = gamma * rstd * (gy' - dbeta/n - xhat * dgamma/n)   (training);   gamma * rstd * gy' (eval)
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(long long total4, int cq, float inv_n, const float *x,
                                                            const float *gy, const float *mean, const float *rstd,
@@ -482,7 +561,9 @@ constexpr int FA_COLS = 32, FA_ROWS = 128;  // consumer-side record sums: stripe
 // 128 rows) merge the stripe's tile records of the producing GEMM themselves (parallel-variance identity in float64, as
 // bn_finalize_tiles_kernel) instead of waiting for a finalize launch; the row-chunk-0 workgroups deliver mean / rstd /
 // folded affine / running statistics for the backward and the optimizer.
-template <int DUMMY>
+// RESIDUAL = false: y = ReLU(BN(x)) (`relu` = residual == NULL ... see the launcher) -- the Linear + BatchNorm + ReLU layers
+// between the Blocks (GridPool.fc, UnpoolWithSkip.proj / proj_skip: model.hip linbn_forward)
+template <int PLAIN>
 __global__ __launch_bounds__(TPB) void bn_tiles_apply_residual_kernel(BnTileSet S, int nrb, int n, int c, float eps, float momentum,
                                                                       const float *__restrict__ x,
                                                                       const float *__restrict__ residual,
@@ -545,6 +626,16 @@ __global__ __launch_bounds__(TPB) void bn_tiles_apply_residual_kernel(BnTileSet 
     const long long r1 = (r0 + FA_ROWS) < (long long)n ? (r0 + FA_ROWS) : (long long)n;
     for (long long row = r0 + rl; row < r1; row += RL) {
         const long long e = row * cq + qcol;
+        if (PLAIN) {
+            const float4 v = ((const float4 *)x)[e];
+            float4 o;
+            o.x = fmaxf(__builtin_fmaf((v.x - m.x) * r.x, g.x, b.x), 0.f);
+            o.y = fmaxf(__builtin_fmaf((v.y - m.y) * r.y, g.y, b.y), 0.f);
+            o.z = fmaxf(__builtin_fmaf((v.z - m.z) * r.z, g.z, b.z), 0.f);
+            o.w = fmaxf(__builtin_fmaf((v.w - m.w) * r.w, g.w, b.w), 0.f);
+            ((float4 *)y)[e] = o;
+            continue;
+        }
         const float rsc = rowscale ? rowscale[row] : 1.f;
         const float4 v = ((const float4 *)x)[e], res = ((const float4 *)residual)[e];
         float4 o;
@@ -1536,6 +1627,24 @@ int bn_tiles_apply_residual(int n, int c, float *part, const float *gamma, const
     return 1;
 }
 
+// internal (model.hip): the same for y = ReLU(BN(x)) -- statistics from the producing GEMM's 64-row records and the apply pass in
+// one launch (was bn_stats + bn_finalize + bn_apply); returns 0 when it declines (many records: the three launches stay)
+int bn_tiles_apply_relu(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *running_mean,
+                        float *running_var, long long *num_batches_tracked, float eps, float momentum, const float *x, float *y,
+                        void *stream) {
+    const int nrb = (n + 63) / 64;
+    const char *e = getenv("AO_AMD_BN_FINAPPLY");
+    if (nrb > 512 || c % 4 != 0 || (e && e[0] == '0')) return 0;
+    BnTileSet S{part, mean, rstd, running_mean, running_var, num_batches_tracked, gamma, beta, nullptr, nullptr, nullptr, 64};
+    const dim3 grid((unsigned)((c + FA_COLS - 1) / FA_COLS), (unsigned)((n + FA_ROWS - 1) / FA_ROWS));
+    {
+        PtvScopedTimer t(KID_BN_APPLY, (hipStream_t)stream, 8.0 * n * c);
+        hipLaunchKernelGGL(bn_tiles_apply_residual_kernel<1>, grid, dim3(TPB), 0, (hipStream_t)stream, S, nrb, n, c, eps, momentum, x,
+                           (const float *)nullptr, (const float *)nullptr, y);
+    }
+    return 1;
+}
+
 extern "C" int bn_apply_hip_launcher(int n, int c, const float *x, const float *mean, const float *rstd,
                                      const float *gamma, const float *beta, int relu, float *y, void *stream) {
     if (n < 0 || c < 4 || c % 4 != 0) return PTV2_ERR_ARG;
@@ -1684,6 +1793,61 @@ struct MapBnPair {  // record [dbeta0 c | dgamma0 c | dbeta1 c | dgamma1 c]
     }
 };
 
+// ---- the q / k BatchNorms' reduce inside the launch that forms their output gradients (skinny_bn_bwd_reduce_kernel) ----
+// block.hip arms this with the operands of the bn_backward_pair call that will follow its attention backward; gva_block.hip, at
+// the skinny input-gradient launch, asks skinny_backward_pair_bn_reduce to run the fused kernel instead; the pair launcher finds
+// `done` with matching operands and skips its reduce launch.  Thread-local: one Block backward per thread at a time.
+struct SkinnyBnArm {
+    bool armed = false, done = false;
+    int n = 0, c = 0, nblk = 0, relu = 0;
+    const float *x[2] = {}, *mean[2] = {}, *rstd[2] = {}, *gamma[2] = {}, *beta[2] = {};
+    const float *gy[2] = {};
+    float *part = nullptr;
+};
+static thread_local SkinnyBnArm t_skinny_bn;
+
+void ptv2_skinny_bn_arm(int n, int c, const float *const *x, const float *const *gy, const float *const *mean, const float *const *rstd,
+                        const float *const *gamma, const float *const *beta, int relu, void *workspace, size_t workspace_bytes) {
+    SkinnyBnArm &K = t_skinny_bn;
+    K = SkinnyBnArm{};
+    static const bool off = [] { const char *e = getenv("AO_AMD_SKINNY_BN"); return e && e[0] == '0'; }();  // A/B switch
+    if (off || n < 1 || c < 4 || c % 4 != 0 || (c >> 2) > TPB || !workspace || workspace_bytes < dense_workspace_bytes(n, 2 * c, c)) return;
+    K.armed = true;
+    K.n = n; K.c = c; K.nblk = bn_grid(n, c); K.relu = relu;
+    // (deep levels: two rows per lane up to 256 records -- 128 records of seven rows per lane left the launch at one workgroup per
+    // CU waiting on its own loads: 21.6 us at 4 501 rows x 192 against 15.3)
+    constexpr int cap = 256;
+    if (n <= 16384) {
+        const int rl = std::max(1, TPB / (c >> 2));
+        K.nblk = (int)std::max<long long>(1, std::min<long long>(((long long)n + rl * 2 - 1) / (rl * 2), cap));
+    }
+    for (int i = 0; i < 2; ++i) { K.x[i] = x[i]; K.gy[i] = gy[i]; K.mean[i] = mean[i]; K.rstd[i] = rstd[i]; K.gamma[i] = gamma[i]; K.beta[i] = beta[i]; }
+    K.part = (float *)workspace;
+}
+void ptv2_skinny_bn_disarm(void) { t_skinny_bn.armed = false; }
+
+int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
+// internal (gva_block.hip): gx[i] = gy[i] W as skinny_linear_backward_pair -- and, when armed for exactly these outputs, the
+// reduce records of the BatchNorm backward that consumes them, in the same launch
+int skinny_backward_pair_bn_reduce(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream) {
+    SkinnyBnArm &K = t_skinny_bn;
+    const bool fuse = K.armed && K.n == n && K.c == cin && K.gy[0] == gx[0] && K.gy[1] == gx[1] && n > 0;
+    K.armed = false;
+    if (!fuse) return skinny_linear_backward_pair(n, cin, cout, gy, W, gx, stream);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        PtvScopedTimer t(KID_SKINNY_BWD, st, 8.0 * n * (cin + cout) + 8.0 * n * cin);
+        const gva::PtvRiders Rs = gva::ptv2_rider_take();
+        const SkinnyBn A{gy[0], gx[0], K.x[0], K.mean[0], K.rstd[0], K.gamma[0], K.beta[0]};
+        const SkinnyBn B{gy[1], gx[1], K.x[1], K.mean[1], K.rstd[1], K.gamma[1], K.beta[1]};
+        hipLaunchKernelGGL(skinny_bn_bwd_reduce_kernel, dim3(K.nblk + gva::rider_blocks(Rs), 2), dim3(TPB), sizeof(float4) * 2 * TPB, st,
+                           n, cin, cout, A, B, W, K.relu, K.part, K.nblk, Rs);
+    }
+    K.done = true;
+    PTV2_CHECK_LAUNCH();
+    return PTV2_OK;
+}
+
 // two BatchNorm backwards of one shape (x[i], gy[i], ... i = 0, 1) in the three launches of one
 // (workspace: dense_workspace_bytes(n, 2 * c, c))
 extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x, const float *const *gy,
@@ -1695,10 +1859,14 @@ extern "C" int bn_backward_pair_hip_launcher(int n, int c, const float *const *x
         return PTV2_ERR_ARG;
     if (!workspace || workspace_bytes < dense_workspace_bytes(n, 2 * c, c)) return PTV2_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = bn_grid(n, c);
+    int nblk = bn_grid(n, c);
     float *part = (float *)workspace;
+    SkinnyBnArm &K = t_skinny_bn;
+    const bool reduced = K.done && K.part == part && K.n == n && K.c == c && K.gy[0] == gy[0] && K.gy[1] == gy[1];
+    K.done = false;
+    if (reduced) nblk = K.nblk;
     const BnSecond sec{x[1], gy[1], mean[1], rstd[1], gamma[1], beta[1], gx[1], dgamma[1], dbeta[1]};
-    {
+    if (!reduced) {  // (else: the records are there already, left by the launch that formed gy -- skinny_backward_pair_bn_reduce)
         PtvScopedTimer t(KID_BN_BWD_REDUCE, st, 16.0 * n * c);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, 2), dim3(TPB), sizeof(float4) * 2 * TPB, st, n, c, x[0], gy[0], mean[0],
                            rstd[0], gamma[0], beta[0], relu, part, sec);

@@ -301,7 +301,7 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
                             const gva::FoldWFwdArgs &F, void *workspace, size_t workspace_bytes, void *stream);
 int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
                                const float *const *xsh, float *const *y, void *stream);
-int skinny_linear_backward_pair(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
+int skinny_backward_pair_bn_reduce(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_bwd_point_local(int k, int c, int g);
 int gva_bwd_tile_path(int k, int c, int g);
 int gva_fwd_point_supported(int k, int c, int g);
@@ -612,7 +612,8 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
     {
         const float *gys[2] = {W.gkW, W.gqW};
         float *gxs[2] = {G->gk, G->gq};
-        RUN(skinny_linear_backward_pair(n, c, g, gys, B->Ww1, gxs, stream));
+        // (+ the reduce records of the linear_q / linear_k BatchNorm backward when the Block runtime asked for them: dense.hip)
+        RUN(skinny_backward_pair_bn_reduce(n, c, g, gys, B->Ww1, gxs, stream));
     }
     ptv2_rider_flush(st);  // anything still queued (paths without a carrying launch) before the glue reads the sums
     riders.release();

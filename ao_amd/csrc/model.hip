@@ -378,6 +378,11 @@ bool wgrad_defer_enabled() {
     return m != 0;
 }
 
+}  // namespace
+int bn_tiles_apply_relu(int n, int c, float *part, const float *gamma, const float *beta, float *mean, float *rstd, float *running_mean,
+                        float *running_var, long long *num_batches_tracked, float eps, float momentum, const float *x, float *y,
+                        void *stream);  // dense.hip
+namespace {
 bool use_batch(const ptv2_model *M, const ptv2_linbn &L) { return M->training || !L.run_mean || !L.run_var; }
 
 // h = x W^T + b (row GEMM, or the narrow kernel when cin is not a multiple of 4); y = ReLU(BN(h)).  `y` may differ from
@@ -385,6 +390,23 @@ bool use_batch(const ptv2_model *M, const ptv2_linbn &L) { return M->training ||
 int linbn_forward(const ptv2_model *M, const ptv2_linbn &L, const LinBnSaved &S, int n, const float *x, float *y, const Work &W,
                   void *stream) {
     hipStream_t st = (hipStream_t)stream;
+    // at the pooled levels the GEMM's epilogue leaves the column statistics of h per 64 rows and ONE launch merges them and
+    // applies BatchNorm + ReLU (three launches otherwise: statistics, finalize, apply)
+    if (use_batch(M, L) && L.cin % 4 == 0 && L.cout % 4 == 0 && (n + 63) / 64 <= 512 &&
+        sizeof(float) * bn_tiles_floats(n, L.cout) <= W.dense_bytes) {
+        const bool track = M->training && L.run_mean && L.run_var;
+        const float *xs[1] = {x}, *ws[1] = {L.w}, *bs[1] = {L.b};
+        float *ys[1] = {S.h}, *sts[1] = {(float *)W.dense};
+        RUN(rows_gemm_fused_hip_launcher(n, L.cout, L.cin, 1, 0, xs, ws, 0, L.b ? bs : nullptr, ys, 0, nullptr, nullptr, sts, stream));
+        if (bn_tiles_apply_relu(n, L.cout, (float *)W.dense, L.gamma, L.beta, S.mean, S.rstd, track ? L.run_mean : nullptr,
+                                track ? L.run_var : nullptr, track ? L.batches : nullptr, M->eps, M->momentum, S.h, y, stream))
+            return PTV2_OK;
+        RUN(bn_tiles_finalize_hip_launcher(n, L.cout, (float *)W.dense, L.gamma, L.beta, S.mean, S.rstd, nullptr, nullptr,
+                                           track ? L.run_mean : nullptr, track ? L.run_var : nullptr, track ? L.batches : nullptr,
+                                           M->eps, M->momentum, stream));
+        RUN(bn_apply_hip_launcher(n, L.cout, S.h, S.mean, S.rstd, L.gamma, L.beta, 1, y, stream));
+        return PTV2_OK;
+    }
     if (L.cin % 4 == 0 && L.cout % 4 == 0) {
         RUN(rows_gemm_hip_launcher(n, L.cout, L.cin, x, L.w, 0, L.b, S.h, 0, stream));
     } else {
