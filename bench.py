@@ -618,7 +618,7 @@ def also_leg(args):
         d = json.loads(lines[0])
         return {"workload": d["config"]["workload"], "why": "the per-GPU batch of the reference's 4-GPU recipe (batch_size 12 / 4 GPUs, "
                 "configs/s3dis/semseg-pt-v2m2-0-base.py:3)", "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
-                "steps": d["steps"], "warmup": d["warmup"], "points_per_step": d["config"].get("points_per_step")}
+                "steps": d["steps"], "warmup": d["warmup"], "points_per_step": round(d["value"] * d["ms_per_step"] / 1e3)}
     except Exception as exc:
         return {"error": repr(exc)[:300]}
 
