@@ -92,11 +92,11 @@ struct BwdTileCfg {
 #endif
 
 template <int G, int C, int TP, bool DROP>
-__global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kernel(
+__device__ __forceinline__ void attention_bwd_tile_body(
     int n, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh, const float *__restrict__ Ww2,
     const float *__restrict__ bw2, const float *__restrict__ v, const float *__restrict__ a, const float *__restrict__ b,
     const float *__restrict__ coord, const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ Wp2,
-    const float *__restrict__ bp2, float *__restrict__ gW1, float *__restrict__ part, PtvDrop drop) {
+    const float *__restrict__ bp2, float *__restrict__ gW1, float *__restrict__ part, PtvDrop drop, const long long pt0) {
     using K = BwdTileCfg<G, C, TP>;
     constexpr int GT = K::GT, G16 = K::G16, GPW = K::GPW, PPW = K::PPW, NCH = K::NCH, NGW = K::NGW, GP = K::GP, PPG = K::PPG, PF = K::PF,
                   DW = K::DW;
@@ -115,8 +115,7 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     //                                                                   then [4 waves][3 G + G G] the wavefronts' record pieces
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x;
-    const long long last = (long long)n - 1;
+    const long long last = (long long)n - 1;  // (pt0: the first point of this workgroup's tile)
     BT_STAMP(0);
 
     // ---- requests first: neighbour ids, logits rows, g_out rows of my points
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     float u1[PPW][GT][4];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const long long pt = (long long)tile * TP + PPW * wid + i;
+        const long long pt = pt0 + PPW * wid + i;
         act[i] = pt < n;
         pts[i] = act[i] ? pt : last;
         srcv[i] = idx[pts[i] * 16 + l15];
@@ -522,6 +521,76 @@ __global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kerne
     BT_STAMP(9);
 }
 
+template <int G, int C, int TP, bool DROP>
+__global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_kernel(
+    int n, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh, const float *__restrict__ Ww2,
+    const float *__restrict__ bw2, const float *__restrict__ v, const float *__restrict__ a, const float *__restrict__ b,
+    const float *__restrict__ coord, const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ Wp2,
+    const float *__restrict__ bp2, float *__restrict__ gW1, float *__restrict__ part, PtvDrop drop) {
+    attention_bwd_tile_body<G, C, TP, DROP>(n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, part, drop,
+                                            (long long)blockIdx.x * TP);
+}
+
+// Whole rounds of 8-point tiles, then the remainder as 4-point tiles.  The kernel is throughput-bound per CU (two resident
+// workgroups take 45 us at (24,192), one alone 24), so a last round that fills a fraction of the slots costs a whole lone
+// workgroup's latency: 4 501 points = 512 + 51 tiles of 8 ran 61 -> 85 us against 4 096 points (tools/bench_bwd_tile.py --sweep).
+// With the remainder cut into tiles of 4 the last round's workgroups carry half the matrix work each.
+template <int G, int C, bool DROP>
+__global__ __launch_bounds__(256, G <= 24 ? 2 : 1) void attention_bwd_tile_mixed_kernel(
+    int n, int nfull, const float *__restrict__ W1, const float *__restrict__ sc, const float *__restrict__ sh, const float *__restrict__ Ww2,
+    const float *__restrict__ bw2, const float *__restrict__ v, const float *__restrict__ a, const float *__restrict__ b,
+    const float *__restrict__ coord, const int *__restrict__ idx, const float *__restrict__ g_out, const float *__restrict__ Wp2,
+    const float *__restrict__ bp2, float *__restrict__ gW1, float *__restrict__ part, PtvDrop drop) {
+    if ((int)blockIdx.x < nfull)
+        attention_bwd_tile_body<G, C, 8, DROP>(n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, part, drop,
+                                               (long long)blockIdx.x * 8);
+    else
+        attention_bwd_tile_body<G, C, 4, DROP>(n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, part, drop,
+                                               (long long)nfull * 8 + (long long)((int)blockIdx.x - nfull) * 4);
+}
+
+template <int G, int C>
+static int launch_bwd_tile_mixed(int n, int nfull, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2,
+                                 const float *v, const float *a, const float *b, const float *coord, const int *idx, const float *g_out,
+                                 const float *Wp2, const float *bp2, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2, float *ga,
+                                 float *gb, float *part, size_t part_floats_avail, PtvDrop drop, hipStream_t st) {
+    using K8 = BwdTileCfg<G, C, 8>;
+    using K4 = BwdTileCfg<G, C, 4>;
+    static_assert(K8::PF == K4::PF, "one record format");
+    const size_t lds = sizeof(float) * std::max(K8::lds_floats, K4::lds_floats);
+    const bool dropping = drop.thresh != 0;
+    auto kern = dropping ? attention_bwd_tile_mixed_kernel<G, C, true> : attention_bwd_tile_mixed_kernel<G, C, false>;
+    static bool configured[2] = {false, false};
+    if (!configured[dropping]) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PTV2_ERR_LAUNCH;
+        configured[dropping] = true;
+    }
+    const int ntail = (int)((n - (long long)nfull * 8 + 3) / 4);
+    const int nblk = nfull + ntail;
+    if ((size_t)nblk * K8::PF > part_floats_avail) return PTV2_ERR_WORKSPACE;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, n, nfull, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, part, drop);
+    launch_finalize(st, (const float *)part, nblk, K8::PF, MapBwdPoint{ga, gb, gsc, gsh, gWw2, gbw2, C, G});
+    return PTV2_OK;
+}
+// whole rounds of resident workgroups the 8-point tiles fill, when what is left is at most half a round (else 0: plain launch)
+template <int G, int C>
+static int bwd_tile_full_rounds(int n) {
+    static int slots = 0;
+    if (!slots) {
+        using K8 = BwdTileCfg<G, C, 8>;
+        using K4 = BwdTileCfg<G, C, 4>;
+        const size_t lds = sizeof(float) * std::max(K8::lds_floats, K4::lds_floats);
+        int dev = 0, cus = 0, occ = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipFuncSetAttribute((const void *)attention_bwd_tile_mixed_kernel<G, C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)attention_bwd_tile_mixed_kernel<G, C, false>, 256, lds) != hipSuccess || occ < 1) occ = 2;
+        slots = occ * cus;
+    }
+    static const bool off = [] { const char *e = getenv("AO_AMD_BT_MIXED"); return e && e[0] == '0'; }();
+    const int nt8 = (n + 7) / 8, full = nt8 / slots * slots, tail = nt8 - full;
+    return (!off && full > 0 && tail > 0 && 2 * tail <= slots) ? full : 0;
+}
+
 template <int G, int C, int TP>
 static int launch_bwd_tile(int n, const float *W1, const float *sc, const float *sh, const float *Ww2, const float *bw2, const float *v,
                            const float *a, const float *b, const float *coord, const int *idx, const float *g_out, const float *Wp2,
@@ -553,7 +622,7 @@ int gva_bwd_tile_supported(int k, int c, int g) {
 }
 // floats of partial records gva_bwd_tile_launch writes
 size_t gva_bwd_tile_part_floats(int n, int c, int g) {
-    const int tp = g == 48 ? 4 : 8;
+    const int tp = 4;  // (the most records any of the forms writes: tiles of 4 points)
     return (size_t)((n + tp - 1) / tp) * (4 * (size_t)c + 3 * (size_t)g + (size_t)g * g) + 64;
 }
 
@@ -566,6 +635,12 @@ int gva_bwd_tile_launch(int n, int k, int c, int g, const float *W1, const float
     using namespace gva;
     if (!gva_bwd_tile_supported(k, c, g) || n < 1) return PTV2_ERR_ARG;
 #define ARGS n, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, drop, st
+    if (g == 12 || g == 24) {
+        const int nfull = g == 12 ? bwd_tile_full_rounds<12, 96>(n) : bwd_tile_full_rounds<24, 192>(n);
+#define MARGS n, nfull, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, Wp2, bp2, gW1, gsc, gsh, gWw2, gbw2, ga, gb, part, part_floats_avail, drop, st
+        if (nfull) return g == 12 ? launch_bwd_tile_mixed<12, 96>(MARGS) : launch_bwd_tile_mixed<24, 192>(MARGS);
+#undef MARGS
+    }
     if (g == 12) return launch_bwd_tile<12, 96, 8>(ARGS);
     if (g == 24) return launch_bwd_tile<24, 192, 8>(ARGS);
     // one workgroup per CU at this width: tiles of 4 points while they all fit in ONE round of the 256 CUs (n = 240: 61 us against

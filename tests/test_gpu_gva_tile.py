@@ -155,7 +155,7 @@ def _bwd_fused(t, n, c, g, w, g_out, inv_ptr, inv_rows):
 
 
 @pytest.mark.parametrize("c,g", [(96, 12), (192, 24), (384, 48)])
-@pytest.mark.parametrize("n", [4501, 1074, 129, 17, 8, 5])
+@pytest.mark.parametrize("n", [6500, 4501, 1074, 129, 17, 8, 5])
 def test_tile_backward_equals_the_staged_launches(monkeypatch, n, c, g):
     """gva_bwd_tile.hip (g_A formed in LDS per tile of points and 16-channel chunk) against gva_peb_backward + the point kernel
     that reads g_A (N,G,C) from memory: every output of the stage, on clouds with -1 slots and ragged tiles."""
