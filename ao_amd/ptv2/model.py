@@ -401,8 +401,16 @@ class PointTransformerV2(nn.Module):
                  enc_groups=(12, 24, 48, 64), enc_neighbours=(16, 16, 16, 16), dec_depths=(1, 1, 1, 1),
                  dec_channels=(48, 96, 192, 384), dec_groups=(6, 12, 24, 48), dec_neighbours=(16, 16, 16, 16),
                  grid_sizes=(0.06, 0.12, 0.24, 0.48), attn_qkv_bias=True, pe_multiplier=False, pe_bias=True,
-                 attn_drop_rate=0.0, drop_path_rate=0, enable_checkpoint=False, unpool_backend="map"):
+                 attn_drop_rate=0.0, drop_path_rate=0, enable_checkpoint=False, unpool_backend="map", native_param_grads=None):
+        """The reference's keyword arguments (:448-474) and ONE more, optional: native_param_grads = "autograd" (default: the
+        parameters receive their gradients through AccumulateGrad, as from any module) | "direct" (the native backward
+        assigns `p.grad` itself: 840 AccumulateGrad nodes, ~1.4 ms of host time per step, are not built; parameter hooks do
+        not fire and torch.autograd.grad(loss, parameters) is not available) -- a config key for loops that only call
+        loss.backward(): backbone = dict(type="PT-v2m2", ..., native_param_grads="direct")."""
         super().__init__()
+        if native_param_grads is not None:
+            assert native_param_grads in ("autograd", "direct"), native_param_grads
+            self.native_param_grads = native_param_grads
         self.in_channels, self.num_classes = in_channels, num_classes
         self.num_stages = len(enc_depths)
         for seq in (dec_depths, enc_channels, dec_channels, enc_groups, dec_groups, enc_neighbours, dec_neighbours,

@@ -453,8 +453,10 @@ def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
     steps = max(5, min(args.steps, 20))
     warm = max(3, min(args.warmup, 5))
 
-    def build(optim_kind, force_ddp):
-        seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(cfg).to(device).train()
+    def build(optim_kind, force_ddp, direct=False):
+        # direct: backbone = dict(type="PT-v2m2", ..., native_param_grads="direct") -- the one keyword this build's class adds
+        bcfg = dict(cfg, native_param_grads="direct") if direct else cfg
+        seg = (ptv2.DefaultSegmentorSAM_Image if args.segmentor == "sam_image" else ptv2.DefaultSegmentor)(bcfg).to(device).train()
         model, wrapped = seg, False
         if world > 1 or force_ddp:  # create_ddp_model
             if not dist.is_initialized():  # a one-rank group of its own (the bench's exchange is not in use at world 1)
@@ -477,8 +479,8 @@ def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
         scaler = torch.cuda.amp.GradScaler() if enable_amp else None
         return model, optimizer, scheduler, scaler, wrapped
 
-    def measure(optim_kind, force_ddp, with_item_too):
-        model, optimizer, scheduler, scaler, wrapped = build(optim_kind, force_ddp)
+    def measure(optim_kind, force_ddp, with_item_too, direct=False):
+        model, optimizer, scheduler, scaler, wrapped = build(optim_kind, force_ddp, direct)
         comm_info = {}
 
         def run_step():  # train_sam_pp2s.py:173-200
@@ -550,6 +552,15 @@ def reference_loop_leg(ptv2, args, cfg, device, data, world, points_per_step):
                 "ms_per_step_no_item": 1e3 * t / steps}
         except Exception as exc:  # a variant must not take the line down
             variants[kind] = {"error": repr(exc)[:200]}
+    # ... and of the backbone line: gradients assigned by the native backward instead of 840 AccumulateGrad nodes (a loop that
+    # only calls loss.backward() does not see the difference; not under DDP, whose reducer waits for its parameter's node)
+    for kind in ("AdamW", "FlatAdamW"):
+        try:
+            _, t, _, _ = measure(kind, False, False, direct=True)
+            variants['backbone = dict(..., native_param_grads="direct") + optimizer = dict(type="%s", ...)' % kind] = {
+                "ms_per_step_no_item": 1e3 * t / steps}
+        except Exception as exc:
+            variants["direct+" + kind] = {"error": repr(exc)[:200]}
     out["variants"] = variants
     if world == 1:
         ddp = {}

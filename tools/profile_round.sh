@@ -25,11 +25,11 @@ python tools/trace_grids.py "$O/trace" 25 > "$O/trace_grids.txt" 2>&1
 python tools/trace_step.py "$O/trace" 12 > "$O/step_sequence.txt" 2>&1
 # one S2 Block's backward (192 channels): the launches around a mid-run attention_bwd_tile_kernel<24, 192, 8> (4 before: the tail's
 # BatchNorm + fc3; 9 behind: gv ... the fc1 input gradient)
-python tools/trace_block.py "$O/trace" "attention_bwd_tile_kernel<24, 192, 8" 60 4 10 > "$O/blockS2.txt" 2>&1
+python tools/trace_block.py "$O/trace" "attention_bwd_tile_(mixed_)?kernel<24, 192" 60 4 9 same > "$O/blockS2.txt" 2>&1
 # one S2 Block's forward: around a mid-run attention_fwd_tile_kernel<24, 192, 12> (7 before: fc1 ... the logit sums; 3 behind)
-python tools/trace_block.py "$O/trace" "attention_fwd_tile_kernel<24, 192, 12" 60 7 4 > "$O/blockS2_fwd.txt" 2>&1
+python tools/trace_block.py "$O/trace" "attention_fwd_tile_kernel<24, 192, 12" 60 7 4 same > "$O/blockS2_fwd.txt" 2>&1
 # one S3 Block's forward (384 channels, ~1 074 points): the launches around a mid-run logits_fwd_mfma_kernel<48, 384, 4>
-python tools/trace_block.py "$O/trace" "logits_fwd_mfma_kernel<48, 384, 4" 30 5 8 > "$O/blockS3_fwd.txt" 2>&1
+python tools/trace_block.py "$O/trace" "logits_fwd_mfma_kernel<48, 384, 4" 30 5 8 same > "$O/blockS3_fwd.txt" 2>&1
 rm -rf "$O/trace"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_f" -- $B --steps 5 --warmup 2 > "$O/pmc_f.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_w" -- $B --steps 5 --warmup 2 > "$O/pmc_w.log" 2>&1

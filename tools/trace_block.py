@@ -1,15 +1,24 @@
 #!/usr/bin/env python
 """Print the kernel sequence (duration, gap to the previous kernel) around the n-th launch of a marker kernel in a
-rocprofv3 kernel trace: tools/trace_block.py <dir> <marker substring> [occurrence] [before] [after]"""
-import csv, glob, sys
+rocprofv3 kernel trace: tools/trace_block.py <dir> <marker regex> [occurrence] [before] [after] [queue]
+(queue: only the kernels of the marker's queue when "same")"""
+import csv, glob, re, sys
 d, marker = sys.argv[1], sys.argv[2]
 occ = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 before = int(sys.argv[4]) if len(sys.argv) > 4 else 45
 after = int(sys.argv[5]) if len(sys.argv) > 5 else 40
 f = (glob.glob(d + '/*/*_kernel_trace.csv') + glob.glob(d + '/*_kernel_trace.csv'))[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
+same = len(sys.argv) > 6 and sys.argv[6] == "same"
+idx = [i for i, r in enumerate(rows) if re.search(marker, r['Kernel_Name'])]
+if not idx:
+    sys.exit("no kernel matches %r" % marker)
 i0 = idx[min(occ, len(idx) - 1)]
+if same:  # the marker's queue only (the geometry stream's kernels interleave by time otherwise)
+    qid = rows[i0]['Queue_Id']
+    rows = [r for r in rows if r['Queue_Id'] == qid]
+    idx = [i for i, r in enumerate(rows) if re.search(marker, r['Kernel_Name'])]
+    i0 = idx[min(occ, len(idx) - 1)]
 prev_end = None
 tot = 0
 for r in rows[max(0, i0 - before):i0 + after]:
