@@ -389,8 +389,13 @@ class _Runtime:
                 setattr(obj, field, base + 4 * offs[pi])
 
 
-def runtime(model):
+def runtime(model, check=True):
+    """The model's _Runtime, rebuilt when a parameter or buffer has moved.  check=False: the caller runs right behind a
+    `supported(model, feat)` of the same forward, which has just compared all 841 tensor addresses (0.2 ms of the launching
+    thread per comparison: three per forward before)."""
     rt = model.__dict__.get("_ao_runtime")
+    if rt is not None and not check:
+        return rt
     if rt is not None:
         try:
             fresh = rt.key == _block._pointer_key(rt.tensor_slots)
@@ -645,14 +650,14 @@ def pipelined_ok(model):
     which has to see the sizes first), no activation checkpointing (one shared saved region), AO_AMD_PIPELINE != 0."""
     if os.environ.get("AO_AMD_PIPELINE", "1") == "0" or not model.training:
         return False
-    rt = runtime(model)
+    rt = runtime(model, check=False)
     return not (torch.is_grad_enabled() and any(b.enable_checkpoint for b in rt.block_modules)) and rt.M.seq[0].depth > 0
 
 
 def forward(model, data_dict, geo):
     """PointTransformerV2.forward on the native runtime (call `supported` first).  geo None: the geometry is built inside,
     pipelined with the network's level-0 prefix (call `pipelined_ok` first)."""
-    rt = runtime(model)
+    rt = runtime(model, check=False)
     feat = data_dict["feat"]
     if geo is None:
         geo = _Pipelined(model, data_dict["coord"], data_dict["offset"].int())
