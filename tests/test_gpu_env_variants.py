@@ -6,6 +6,7 @@ Block parity tests (native Block against the op-by-op python Block, forward + ev
   AO_AMD_SKINNY_BN=0     skinny input gradients and the q / k BatchNorm reduce as two launches
   AO_AMD_BWD_POINT=1     deep-level attention backward as peb_bwd + point kernel instead of the tile kernel
   AO_AMD_TILE_KEEP_A=1   the forward tile kernel also writes A; the strided weight gradient reads it
+  AO_AMD_BT_MIXED=0      the backward tile kernel's last round in 8-point tiles (default: the remainder in 4-point tiles)
 """
 import os
 import subprocess
@@ -29,7 +30,7 @@ def test_block_parity_with_the_k_split_gemm_on():
 
 
 @pytest.mark.parametrize("env", [{"AO_AMD_GV_MERGE": "0"}, {"AO_AMD_SKINNY_BN": "0"}, {"AO_AMD_BWD_POINT": "1"},
-                                 {"AO_AMD_TILE_KEEP_A": "1"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
+                                 {"AO_AMD_TILE_KEEP_A": "1"}, {"AO_AMD_BT_MIXED": "0"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_block_parity_with_a_switch_set(env):
     _run(env, "test_native_block_matches_python_block", 12)
 
