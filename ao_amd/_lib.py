@@ -103,7 +103,7 @@ _ERR = {1: "PTV2_ERR_ARG (invalid argument)", 2: "PTV2_ERR_WORKSPACE (workspace 
 _lib = None
 # bumped together with ptv2_abi_version() (ao_amd/csrc/abi.hip) whenever a launcher signature or a struct that ctypes
 # mirrors (block.py::_Blk, _BlkGrads) changes: a stale libptv2_hip.so then refuses to load instead of misreading memory
-EXPECTED_ABI = 10
+EXPECTED_ABI = 11
 
 
 def build(verbose=False):

@@ -8,7 +8,7 @@
 
 #include "gva_common.h"
 
-extern "C" int ptv2_abi_version(void) { return 10; }  // == EXPECTED_ABI in ao_amd/_lib.py
+extern "C" int ptv2_abi_version(void) { return 11; }  // == EXPECTED_ABI in ao_amd/_lib.py
 
 // sizeof() of the structs that ctypes mirrors field by field (block.py, native_model.py): compared at load time, so a
 // layout drift between the header and a python mirror is an import error, not a misread pointer

@@ -43,7 +43,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_host_only_entry_points(lib):
     L = lib.lib()
-    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 10
+    assert L.ptv2_abi_version() == lib.EXPECTED_ABI == 11
     assert b"gfx950" in L.ptv2_build_info()
     a = L.knn_query_hip_workspace_bytes(80000, 80000, 1)
     b = L.knn_query_hip_workspace_bytes(240000, 240000, 3)
