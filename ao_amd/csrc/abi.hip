@@ -84,10 +84,6 @@ void ptv2_rider_flush(hipStream_t st) {
     for (int i = 0; i < g_pending.count; ++i) launch_alone(g_pending.r[i], st);
     g_pending.count = 0;
 }
-PtvGvMerge &ptv2_gv_merge() {
-    static thread_local PtvGvMerge m;
-    return m;
-}
 int ptv2_rider_drop() {
     const int had = g_pending.count;
     g_pending.count = 0;

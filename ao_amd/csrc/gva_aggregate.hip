@@ -408,18 +408,13 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_rows_kernel(long long rows,
 // grad v[j,ch] = sum over slots r that point at j of w[r, g(ch)] * g_out[r / k, ch]
 // one thread per (point j, group, float4 of the group's channels): the slot list and the group weight are read
 // once per 4 channels instead of once per channel
-// gWt != NULL (the Block runtime's merged launch): the thread of a group's FIRST float4 also walks the logits stage's slot
-// gradients along the same list -- grad kW[j,g] = sum over the slots that point at j of gWt[r,g] -- and sums its own point's
-// slots, grad qW[j,g] = -sum_s gWt[j,s,g] (was logits_bwd_gather_kernel: a second walk of the same lists per Block)
 template <int I>
 __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int c, int g,
                                                                const float *__restrict__ w,
                                                                const float *__restrict__ g_out,
                                                                const int *__restrict__ inv_ptr,
                                                                const int *__restrict__ inv_rows,
-                                                               float *__restrict__ gv, int main_blocks, PtvRiders Rs,
-                                                               const float *__restrict__ gWt, float *__restrict__ gkW,
-                                                               float *__restrict__ gqW) {
+                                                               float *__restrict__ gv, int main_blocks, PtvRiders Rs) {
     if ((int)blockIdx.x >= main_blocks) {  // trailing workgroups: deferred parameter-gradient sums (gva_common.h, riders)
         rider_run(Rs, (int)blockIdx.x - main_blocks);
         return;
@@ -433,8 +428,6 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
         float acc[V];
 #pragma unroll
         for (int i = 0; i < V; ++i) acc[i] = 0.f;
-        const bool lead = gWt != nullptr && ch == gl * I;  // (loads of the other lanes go to the zero pad)
-        float acck = 0.f;
         const int p0 = inv_ptr[j], p1 = inv_ptr[j + 1];
         // the list is walked 8 entries at a time: slot ids first, then all weights and gradient rows, then the sums in
         // list order (an entry-by-entry loop pays three dependent memory latencies per entry)
@@ -446,7 +439,7 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
 #pragma unroll
         for (int u = 0; u < UB; ++u) r[u] = inv_rows[p0 + u < p1 ? p0 + u : plast] | (p0 + u < p1 ? 0 : -1);
         for (int p = p0; p < p1; p += UB) {
-            float wv[UB], t[UB][V], tk[UB];
+            float wv[UB], t[UB][V];
             // the slot ids of the NEXT batch travel with this batch's weights and gradient rows (one round trip less per
             // batch after the first)
 #pragma unroll
@@ -455,7 +448,6 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
             for (int u = 0; u < UB; ++u) {
                 const bool ok = r[u] >= 0;
                 wv[u] = ptv2_ld_or_zero(w + (long long)r[u] * g + gl, ok);
-                tk[u] = ptv2_ld_or_zero(gWt + (long long)r[u] * g + gl, ok && lead);
                 const float *go = g_out + (long long)(r[u] / k) * c + ch;
                 if (V == 4) {
                     const float4 q = ptv2_ld_or_zero((const float4 *)go, ok);
@@ -469,7 +461,6 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
             for (int u = 0; u < UB; ++u) {  // (entries past the end add w = 0 times 0)
 #pragma unroll
                 for (int i = 0; i < V; ++i) acc[i] = __builtin_fmaf(wv[u], t[u][i], acc[i]);
-                if (r[u] >= 0) acck += tk[u];
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) r[u] = rn[u];
@@ -478,33 +469,17 @@ __global__ __launch_bounds__(TPB) void aggregate_bwd_gv_kernel(int n, int k, int
         else
 #pragma unroll
             for (int i = 0; i < V; ++i) gv[(long long)j * c + ch + i] = acc[i];
-        if (gWt != nullptr) {  // (launch-uniform)
-            float q = 0.f;
-            if (k == 16) {  // all 16 slot loads in flight before the first add
-                float ts[16];
-#pragma unroll
-                for (int sl = 0; sl < 16; ++sl) ts[sl] = ptv2_ld_or_zero(gWt + ((long long)j * 16 + sl) * g + gl, lead);
-#pragma unroll
-                for (int sl = 0; sl < 16; ++sl) q += ts[sl];
-            } else {
-                for (int sl = 0; sl < k; ++sl) q += ptv2_ld_or_zero(gWt + ((long long)j * k + sl) * g + gl, lead);
-            }
-            if (lead) {
-                gkW[(long long)j * g + gl] = acck;
-                gqW[(long long)j * g + gl] = -q;
-            }
-        }
     }
 }
 
 static void launch_bwd_gv(hipStream_t st, int n, int k, int c, int g, const float *w, const float *g_out, const int *inv_ptr,
-                          const int *inv_rows, float *gv, const float *gWt = nullptr, float *gkW = nullptr, float *gqW = nullptr) {
+                          const int *inv_rows, float *gv) {
     const int I = c / g;
     const int V = I >= 4 ? 4 : I;
     const int main_blocks = (int)std::min<long long>(((long long)n * (c / V) + TPB - 1) / TPB, MAX_BLOCKS * 4);
     const PtvRiders Rs = ptv2_rider_take();  // gv depends on none of the parameter-gradient sums queued before this launch
     const dim3 grid((unsigned)(main_blocks + rider_blocks(Rs)));
-#define GVCASE(II) case II: hipLaunchKernelGGL(aggregate_bwd_gv_kernel<II>, grid, dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv, main_blocks, Rs, gWt, gkW, gqW); break;
+#define GVCASE(II) case II: hipLaunchKernelGGL(aggregate_bwd_gv_kernel<II>, grid, dim3(TPB), 0, st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv, main_blocks, Rs); break;
     switch (I) { GVCASE(1) GVCASE(2) GVCASE(4) GVCASE(8) GVCASE(16) GVCASE(32) GVCASE(64) default: break; }
 #undef GVCASE
 }
@@ -624,18 +599,11 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
                                    const int *inv_rows, float *gW1, float *gsc, float *gsh, float *gWw2, float *gbw2, float *gv,
                                    float *ga, float *gb, void *workspace, size_t workspace_bytes, void *stream) {
     if (n < 0 || !pow2(k) || k > 64 || c < 1 || g < 1 || c % g != 0 || !pow2(c / g) || c / g > 64) return PTV2_ERR_ARG;
-    // (the fused forms -- one launch + its record sums -- need the record region only)
-    const bool fused_form = inv_ptr && !getenv("AO_AMD_BWD_STAGED") &&
-                            ((g_fused_Wp2 && g_fused_bp2 && gva_bwd_tile_path(k, c, g)) || gva_bwd_point_supported(k, c, g));
-    if (!workspace || workspace_bytes < (fused_form ? agg_part_bytes(n, k, c, g) : gva_aggregate_workspace_bytes(n, k, c, g)))
-        return PTV2_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < gva_aggregate_workspace_bytes(n, k, c, g)) return PTV2_ERR_WORKSPACE;
     if (n == 0) return PTV2_OK;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)n * k;
     const size_t part_bytes = agg_part_bytes(n, k, c, g);
-    // the Block runtime takes grad v in a later launch of its own, together with the logits stage's gather (PtvGvMerge)
-    PtvGvMerge &merge = ptv2_gv_merge();
-    const bool later_gv = merge.want && fused_form;
     const size_t rows_bytes = align_up(sizeof(float) * (size_t)rows * g);
     char *base = (char *)workspace;
     float *part = (float *)base;
@@ -645,15 +613,12 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
             // W1, idx, coord, g_out, v rows (unique once) in; gW1 out
             PtvScopedTimer t(KID_BWD_TILE_K + (g == 12 ? 0 : g == 24 ? 1 : g == 48 ? 2 : 3), st,
                              4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c)));
-            // its record sums ride on the gv launch below (which needs none of them) -- unless that launch is left to the caller:
-            // the logits stage in between reads two of the sums (gsc, gsh), so they are finished by a launch of their own
-            const PtvDeferScopeIf defer(!later_gv);
+            const PtvDeferScope defer;  // its record sums ride on the gv launch below (which needs none of them)
             const int rc = gva_bwd_tile_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_fused_Wp2, g_fused_bp2, gW1,
                                                gsc, gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), ptv2_attn_drop_current(), st);
             if (rc != PTV2_OK) return rc;
         }
-        if (later_gv) merge.gv_pending = true;
-        else {
+        {
             PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
             launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
         }
@@ -665,16 +630,13 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
         {
             // W1, idx, coord, g_out, g_sw, v rows (unique once), g_A in; gW1 out
             PtvScopedTimer t(KID_BWD_POINT + (g == 6 ? 0 : g == 12 ? 1 : g == 24 ? 2 : g == 48 ? 3 : 4), st, 4.0 * ((double)rows * (2 * g + 1) + (double)n * (3 + 2 * c + g) + (double)n * g * c));
-            // its record sums ride on the gv launch below (which needs none of them) -- unless that launch is left to the caller:
-            // the logits stage in between reads two of the sums (gsc, gsh), so they are finished by a launch of their own
-            const PtvDeferScopeIf defer(!later_gv);
+            const PtvDeferScope defer;  // its record sums ride on the gv launch below (which needs none of them)
             const int rc = gva_bwd_point_launch(n, k, c, g, W1, sc, sh, Ww2, bw2, v, a, b, coord, idx, g_out, g_A, g_sw, gW1, gsc,
                                                 gsh, gWw2, gbw2, ga, gb, part, part_bytes / sizeof(float), st, g_fused_Wp2,
                                                 g_fused_bp2, ptv2_attn_drop_current());
             if (rc != PTV2_OK) return rc;
         }
-        if (later_gv) merge.gv_pending = true;
-        else {
+        {
             PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n));
             launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv);
         }
@@ -728,19 +690,6 @@ static int aggregate_backward_impl(int n, int k, int c, int g, const float *W1, 
     // grad Ww2[g][g'] = sum_rows gz[r,g] y[r,g'],  grad bw2 = column sums of gz: the Linear weight-gradient reduction
     return linear_wgrad_hip_launcher((int)rows, g, g, gz, yb, gWw2, gbw2, dense_ws, dense_bytes, stream);
 }
-
-// internal (gva_block.hip): grad v, and (gWt != NULL) grad kW / grad qW of the logits stage, in one walk of the inverse lists
-int gva_bwd_gv_gather_launch(int n, int k, int c, int g, const float *w, const float *g_out, const int *inv_ptr, const int *inv_rows,
-                             float *gv, const float *gWt, float *gkW, float *gqW, void *stream) {
-    if (n < 1 || !inv_ptr || !inv_rows || !w || !g_out || !gv || c % g != 0 || (gWt && (!gkW || !gqW))) return PTV2_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const long long rows = (long long)n * k;
-    PtvScopedTimer t(KID_BWD_GV, st, 4.0 * ((double)rows * (g + 1) + 2.0 * n * c + n) + (gWt ? 4.0 * ((double)rows * g + 2.0 * n * g) : 0.0));
-    launch_bwd_gv(st, n, k, c, g, w, g_out, inv_ptr, inv_rows, gv, gWt, gkW, gqW);
-    PTV2_CHECK_LAUNCH();
-    return PTV2_OK;
-}
-size_t gva_aggregate_fused_part_bytes(int n, int k, int c, int g) { return agg_part_bytes(n, k, c, g); }
 
 // gva_aggregate_backward with the backward of the grouped projection (gva_peb_backward) folded into the point kernel:
 // for the instances gva_bwd_point_local() names, g_A (N,G,C) and g_sw are never materialised.  Internal to block runtime.

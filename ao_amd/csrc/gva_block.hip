@@ -301,9 +301,6 @@ int gva_logits_forward_fold(int n, int k, int c, int g, const float *kW, const f
                             const gva::FoldWFwdArgs &F, void *workspace, size_t workspace_bytes, void *stream);
 int skinny_linear_forward_pair(int n, int cin, int cout, const float *const *x, const float *W, const float *const *xsc,
                                const float *const *xsh, float *const *y, void *stream);
-size_t gva_aggregate_fused_part_bytes(int n, int k, int c, int g);
-int gva_bwd_gv_gather_launch(int n, int k, int c, int g, const float *w, const float *g_out, const int *inv_ptr, const int *inv_rows,
-                             float *gv, const float *gWt, float *gkW, float *gqW, void *stream);
 int skinny_backward_pair_bn_reduce(int n, int cin, int cout, const float *const *gy, const float *W, float *const *gx, void *stream);
 int gva_bwd_point_local(int k, int c, int g);
 int gva_bwd_tile_path(int k, int c, int g);
@@ -341,7 +338,6 @@ struct BlockWs {  // carve the block workspace
     char *stage; size_t stage_bytes;       // scratch handed to the stage launchers
     float *out_v, *gA, *g_sw, *gW1, *gkW, *gqW, *ga2, *gb2, *ga1, *gb1, *gM, *gcW, *gsc, *gsh, *gWw1_k, *gWw1_q, *part;
     char *wp2_part, *kq_part; size_t wp2_bytes, kq_bytes;  // split-K records whose sums ride on a later launch (riders)
-    char *agg_part; size_t agg_part_bytes;
     double *T1, *T2, *gT1, *gT2;
     size_t bytes;
 };
@@ -360,9 +356,6 @@ BlockWs carve(void *base, int n, int k, int c, int g) {
     // (g_A (n,g,c) / g_sw only where a peb_bwd launch hands them to the aggregation backward: not at the full-resolution level's
     // point kernel nor on the deep levels' tile path, which form them on chip)
     const bool fused_peb = (gva_bwd_point_local(k, c, g) && !getenv("AO_AMD_BWD_STAGED")) || gva_bwd_tile_path(k, c, g);
-    // (the fused aggregation backward's partial records in a region of their own)
-    w.agg_part_bytes = fused_peb ? gva_aggregate_fused_part_bytes(n, k, c, g) : 0;
-    w.agg_part = fused_peb ? take(w.agg_part_bytes) : nullptr;
     w.gA = fused_peb ? nullptr : (float *)take(sizeof(float) * (size_t)n * g * c);
     w.g_sw = fused_peb ? nullptr : (float *)take(sizeof(float) * (size_t)n * g);
     w.gW1 = (float *)take(sizeof(float) * rows * g);
@@ -586,21 +579,11 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
                            cnt ? cnt + CNT_BP2 : nullptr, G->gbp2);
         if (!own_final) launch_finalize(st, (const float *)W.part, nblk, c, MapVec<float>{G->gbp2});
     }
-    // 2. softmax / aggregation stage.  With the fused forms grad v is left to ONE launch behind the logits stage that also does
-    //    that stage's gather of grad kW / slot sum of grad qW: both walk the inverse neighbour lists (AO_AMD_GV_MERGE=0: two launches)
-    struct MergeScope {
-        PtvGvMerge &m;
-        explicit MergeScope(bool on) : m(ptv2_gv_merge()) { m = PtvGvMerge{}; m.want = on; }
-        ~MergeScope() { m = PtvGvMerge{}; }
-    };
-    static const bool merge_off = [] { const char *e = getenv("AO_AMD_GV_MERGE"); return e && e[0] == '0'; }();
-    // (where the gather is worth more than the launch the aggregation stage's record sums then need for themselves -- they
-    // rode on grad v, and the logits stage reads two of them: the full-resolution level, 43 us of gather against 5.5)
-    const MergeScope merge(fused_peb && !merge_off && n >= 32768);
+    // 2. softmax / aggregation stage
     if (fused_peb)
         RUN(gva_aggregate_backward_fused_peb(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord, B->idx,
                                              B->w, G->g_out, B->Wp2, B->bp2, G->inv_ptr, G->inv_rows, W.gW1, W.gsc, W.gsh,
-                                             G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.agg_part, W.agg_part_bytes, stream));
+                                             G->gWw2, G->gbw2, G->gv, W.ga2, W.gb2, W.stage, W.stage_bytes, stream));
     else
         RUN(gva_aggregate_backward_hip_launcher(n, k, c, g, B->W1, B->sc, B->sh, B->Ww2, B->bw2, B->v, B->a, B->b, B->coord,
                                                 B->idx, B->w, G->g_out, W.gA, W.g_sw, G->inv_ptr, G->inv_rows, W.gW1, W.gsc,
@@ -614,11 +597,6 @@ extern "C" int gva_block_backward_hip_launcher(const ptv2_gva_block *B, const pt
                                   FoldWBwdArgs{B->gamma_w, B->mean_w, B->rstd_w, B->training, rows, W.gsc, W.gsh, G->ggamma_w,
                                                G->gbeta_w},
                                   G->inv_ptr, G->inv_rows, W.gkW, W.gqW, W.ga1, W.gb1, W.gM, W.gcW, W.stage, W.stage_bytes, stream));
-    if (merge.m.gv_pending) {  // grad v (+ grad kW / grad qW); carries the sums queued so far
-        RUN(gva_bwd_gv_gather_launch(n, k, c, g, B->w, G->g_out, G->inv_ptr, G->inv_rows, G->gv, merge.m.gather_pending ? merge.m.gWt : nullptr,
-                                     W.gkW, W.gqW, stream));
-        merge.m.gv_pending = merge.m.gather_pending = false;
-    }
     // 6. projections kW = k Ww1^T, qW = q Ww1^T: weight gradient first (its records in a region of their own), then the
     //    input gradients -- the launch that carries the queued sums
     {

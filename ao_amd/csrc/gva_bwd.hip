@@ -316,11 +316,7 @@ int gva_logits_backward_foldw(int n, int k, int c, int g, const float *a, const 
                                                        part_floats(c, g), gM, ga, gb, gcW, st);
             if (rc != PTV2_OK) return rc;
         }
-        gva::PtvGvMerge &merge = gva::ptv2_gv_merge();
-        if (merge.want && merge.gv_pending) {  // the Block runtime's grad v launch walks the same lists: it gathers (gva_common.h)
-            merge.gather_pending = true;
-            merge.gWt = gWt;
-        } else {
+        {
             PtvScopedTimer t(KID_LOGITS_BWD_GATHER, st, 4.0 * ((double)rows * g + 2.0 * n * g + rows));
             hipLaunchKernelGGL(logits_bwd_gather_kernel, dim3(stage_grid((long long)n * g, TPB)), dim3(TPB), 0, st, n, k, g,
                                (const float *)gWt, idx, inv_ptr, inv_rows, gkW, gqW);

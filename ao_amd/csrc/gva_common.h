@@ -224,21 +224,6 @@ struct PtvRiderGuard {
     ~PtvRiderGuard() { if (armed) (void)ptv2_rider_drop(); }
     void release() { armed = false; }
 };
-// gva_block.hip's backward asks the aggregation stage to leave grad v, and the logits stage to leave its inverse-table gather
-// of grad kW / its slot sum of grad qW, to ONE later launch (gva_bwd_gv_gather_launch: both walk the same inverse neighbour
-// lists).  Per host thread (abi.hip); cleared by the scope that set `want`.
-struct PtvGvMerge {
-    bool want = false;            // set by the Block runtime around its two stage calls
-    bool gv_pending = false;      // the aggregation stage skipped its grad v launch
-    bool gather_pending = false;  // the logits stage skipped its gather
-    const float *gWt = nullptr;   // (n, k, g) slot gradients the gather reads
-};
-PtvGvMerge &ptv2_gv_merge();
-struct PtvDeferScopeIf {
-    const bool on;
-    explicit PtvDeferScopeIf(bool o) : on(o) { if (on) ptv2_rider_defer_depth(1); }
-    ~PtvDeferScopeIf() { if (on) ptv2_rider_defer_depth(-1); }
-};
 struct PtvDeferScope {
     PtvDeferScope() { ptv2_rider_defer_depth(1); }
     ~PtvDeferScope() { ptv2_rider_defer_depth(-1); }
