@@ -60,7 +60,9 @@ def _worker(rank, world, port, backend, q):
         state = torch.cat([p.detach().reshape(-1) for p in seg.parameters()]).cpu()
         loss, grads = _grads(ddp, _scene(seed=rank))
         flat = torch.cat([g.reshape(-1) for g in grads]).cpu()
-        q.put((rank, owned, state, loss, flat, bool(seg.backbone.__dict__.get("_ao_ddp_native_sync"))))
+        # (numpy arrays: pickled by value.  A torch tensor travels as a file descriptor the parent fetches from THIS process's
+        # resource sharer -- an EOFError in the parent's q.get() when this process has exited first: seen once in four suite runs)
+        q.put((rank, owned, state.numpy(), loss, flat.numpy(), bool(seg.backbone.__dict__.get("_ao_ddp_native_sync"))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -74,6 +76,7 @@ def test_ddp_wrap_in_a_one_rank_rccl_group_changes_nothing_but_the_route():
     p = ctx.Process(target=_worker, args=(0, 1, _free_port(), "nccl", q))
     p.start()
     rank, owned, state, loss, flat, native = q.get(timeout=600)
+    state, flat = torch.from_numpy(state), torch.from_numpy(flat)
     p.join(120)
     assert p.exitcode == 0
     assert native and len(owned) == 1, owned  # DDP keeps one (the smallest) parameter, the native all-reduce the other 839
@@ -99,6 +102,7 @@ def _two_ranks():
         p.start()
     try:
         got = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        got = [(r, o, torch.from_numpy(st), l, torch.from_numpy(fl), nat) for r, o, st, l, fl, nat in got]
     except queue.Empty:
         got = None
     for p in procs:
